@@ -1,0 +1,257 @@
+/*
+ * papc_hip.h -- C ABI of libpapc_hip.so: the MI355X (gfx950) hot path of AgentMaker/PAPC.
+ *
+ * The reference has no FFI on this path: every entry point below replaces a plain Python function or
+ * paddle.nn.Layer method (cited per function, paths relative to /root/reference/).  The reference's one
+ * native-plugin precedent (pybind11 .so loaded by load_pb11,
+ * PAPC/models/detect/pointpillars/libs/tools/buildtools/pybind11_build.py:76-115; callee convention
+ * libs/ops/cc/nms/nms.h:17-30: caller pre-allocates outputs, function returns a status/count) is the
+ * model for the conventions here:
+ *
+ *   - every pointer is DEVICE memory owned by the caller (PyTorch tensors); the library allocates
+ *     nothing, keeps no global state besides the optional event profiler, never calls hipSetDevice;
+ *   - every call only enqueues work on `stream` (a hipStream_t passed as void*), never synchronises;
+ *   - returns PAPC_OK (0) or a negative PAPC_E_* code; papc_last_error_string() (thread-local) says why;
+ *   - fp32 everywhere ("f32" suffix), indices int32 unless a function says int64.
+ *
+ * Row layout used by the MLP entry points: activations are row-major [M, C] with rows ordered
+ * (b, s, k) -- i.e. the reference's [B, C, K, S] tensors (pointnet2_basic_layers.py:214) stored
+ * point-major / channel-contiguous.
+ */
+#ifndef PAPC_HIP_H
+#define PAPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAPC_OK 0
+#define PAPC_E_INVALID (-1)     /* bad argument (null pointer, size out of range, misalignment) */
+#define PAPC_E_UNSUPPORTED (-2) /* valid request outside what the kernels were built for        */
+#define PAPC_E_LAUNCH (-3)      /* hipLaunchKernel / runtime error                               */
+
+typedef void *papc_stream_t; /* hipStream_t */
+
+/* library version (major*10000 + minor*100 + patch) */
+int papc_version(void);
+/* text of the last error raised on this thread ("" if none) */
+const char *papc_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampling / grouping (PAPC/models/layers/pointnet2_basic_layers.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* farthest_point_sample(xyz, npoint)  -- pointnet2_basic_layers.py:65-95.
+ * xyz is addressed as xyz[b*sb + n*sn + c*sc] (elements): [B,N,3] -> (3N,3,1); planar [B,3,N] -> (3N,1,N).
+ * start_idx[b] replaces paddle.randint (:76); init_dist is 1.0f for reference parity (:75).
+ * out_idx [B,npoint] int32; out_new_xyz [B,npoint,3] (may be NULL) = index_points(xyz, out_idx) (:144).
+ * Bit-exact contract: dist = (dx*dx+dy*dy)+dz*dz, strict-< update, lowest index on ties.
+ * Supports N <= 16384. */
+int papc_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
+                 const int64_t *start_idx, float init_dist, int32_t *out_idx, float *out_new_xyz,
+                 papc_stream_t stream);
+
+/* query_ball_point(radius, nsample, xyz, new_xyz) for n_radii radii in ONE scan
+ * -- pointnet2_basic_layers.py:98-126 (MSG loop :260-262).
+ * xyz strided as above; new_xyz [B,S,3] contiguous.  thr[r] = (float)((double)radius*radius), computed by
+ * the host (python scalar promoted to fp32, :112).  out_idx[r] -> [B,S,nsample[r]], int64 when idx64 != 0
+ * (the reference's dtype) else int32.  thr/nsample/out_idx are HOST arrays of length n_radii (<= 4).
+ * Semantics: first nsample[r] indices j ascending with !(sqdist > thr[r]), padded with the first hit; N
+ * everywhere when there is no hit.  sqdist = ((-2*fma-chain dot) + |q|^2) + |p|^2 exactly as :36-38. */
+int papc_ball_query_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz, int B,
+                        int N, int S, int n_radii, const float *thr, const int *nsample,
+                        void *const *out_idx, int idx64, papc_stream_t stream);
+
+/* square_distance(src, dst) -- pointnet2_basic_layers.py:26-40. src [B,N,3], dst [B,M,3] -> out [B,N,M]. */
+int papc_square_distance_f32(const float *src, const float *dst, int B, int N, int M, float *out,
+                             papc_stream_t stream);
+
+/* index_points(points, idx) -- pointnet2_basic_layers.py:43-62.  points [B,N,C], idx [B,S] (int32, or
+ * int64 when idx64) -> out [B,S,C].  Indices outside [0,N) write zeros (the reference raises IndexError). */
+int papc_index_points_f32(const float *points, const void *idx, int idx64, int B, int N, int C, int S,
+                          float *out, papc_stream_t stream);
+/* gradient of index_points: grad_points[b, idx[b,s], :] += grad_out[b,s,:]  (grad_points pre-zeroed) */
+int papc_index_points_bwd_f32(const float *grad_out, const void *idx, int idx64, int B, int N, int C, int S,
+                              float *grad_points, papc_stream_t stream);
+
+/* the gather/centre/concat of sample_and_group -- pointnet2_basic_layers.py:146-153 (and the MSG order
+ * :263-269).  xyz strided; new_xyz [B,S,3]; feats [B,N,D] or NULL (D=0); idx [B,S,K] int32.
+ * out [B,S,K,3+D]: xyz_first != 0 -> [xyz[idx]-new_xyz, feats[idx]] (SSG :151) else [feats[idx], xyz-..] (:267). */
+int papc_group_points_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
+                          const float *feats, const int32_t *idx, int B, int N, int S, int K, int D,
+                          int xyz_first, float *out, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Shared pointwise MLP: relu(bn(conv1x1(x))) stacks + max  (pointnet2_basic_layers.py:215-219, :271-276;
+ * PAPC/models/classify/pointnet_base/pointnet_base.py:7-25,44)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* A-operand sources of papc_mlp_gemm_f32 */
+#define PAPC_A_PLAIN 0   /* x[m,k]                                                       */
+#define PAPC_A_BNRELU 1  /* relu(scale[k]*x[m,k] + shift[k])   (previous layer's BN+ReLU folded into the load) */
+#define PAPC_A_GROUP 2   /* rows gathered on the fly: [xyz[idx]-new_xyz, feats[idx]] (see papc_group_points_f32) */
+
+typedef struct papc_group_src {
+    const float *xyz;      /* strided cloud */
+    int64_t sb, sn, sc;
+    const float *new_xyz;  /* [B,S,3] */
+    const float *feats;    /* [B,N,D] or NULL */
+    const int32_t *idx;    /* [B,S,K] */
+    int N, S, K, D;
+    int xyz_first;
+} papc_group_src;
+
+/* One conv1x1 layer on rows with fp32 MFMA: y[M,Cout] = A(x)[M,Cin] . w[Cout,Cin]^T + bias.
+ * a_mode selects how A is produced (above); x is [M,ldx] for PLAIN/BNRELU, `grp` for GROUP.
+ * bn_scale/bn_shift [Cin] fold the previous layer's train-mode BN (from papc_bn_finalize_f32).
+ * stats_partial (may be NULL): [papc_mlp_gemm_parts(M), 2, Cout] per-workgroup column sums and sums of
+ * squares of y (deterministic, no atomics) for this layer's batch statistics. */
+/* rows of stats_partial written by papc_mlp_gemm_f32 for M rows (= its persistent grid size) */
+int papc_mlp_gemm_parts(int64_t M);
+int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
+                      const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
+                      int64_t M, int Cin, int Cout, float *y, float *stats_partial, papc_stream_t stream);
+
+/* Reduce stats_partial [n_tiles,2,C] (n_tiles = papc_mlp_gemm_parts(M)) -> train-mode BatchNorm constants (BatchNorm2D :190; paddle default
+ * eps 1e-5, biased variance): mean, invstd, and the folded affine scale = gamma*invstd,
+ * shift = beta - mean*scale.  running_mean/var (may be NULL) get paddle's momentum update
+ * r = momentum*r + (1-momentum)*batch. */
+int papc_bn_finalize_f32(const float *stats_partial, int n_tiles, int64_t M, int C, const float *gamma,
+                         const float *beta, float eps, float momentum, float *mean, float *invstd,
+                         float *scale, float *shift, float *running_mean, float *running_var,
+                         papc_stream_t stream);
+
+/* out[g,c] = max_{k<K} relu(scale[c]*y[g*K+k, c] + shift[c]); argmax[g,c] = first k attaining it
+ * (paddle.max(new_points, 2) :219).  y [G*K, C] -> out [G,C], argmax [G,C] int32 (may be NULL). */
+int papc_bn_relu_max_f32(const float *y, const float *scale, const float *shift, int64_t G, int K, int C,
+                         float *out, int32_t *argmax, papc_stream_t stream);
+
+/* z = relu(scale*y+shift) materialised ([M,C]); used where the reference returns activations (PFN non-last
+ * layers, PointNet-Basic intermediate checks). */
+int papc_bn_relu_f32(const float *y, const float *scale, const float *shift, int64_t M, int C, float *z,
+                     papc_stream_t stream);
+
+/* ---- backward of the stack ------------------------------------------------------------------ */
+
+/* dZ sources for the backward kernels */
+#define PAPC_DZ_DENSE 0 /* dz[m,c] given densely                                            */
+#define PAPC_DZ_MAX 1   /* dz[m,c] = (m%K == argmax[m/K,c]) ? gout[m/K,c] : 0  (backward of the max over K) */
+
+/* Per-channel reductions of the BN+ReLU backward: with p = dz * (scale*y+shift > 0),
+ * partial[t] = (sum p, sum p*xhat) over the t-th of n_parts contiguous row ranges, xhat = (y-mean)*invstd.
+ * DENSE: dz [M,C]; MAX: gout [M/K,C] + argmax.  red_partial [n_parts,2,C] (caller picks n_parts <= 1024). */
+int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, const int32_t *argmax, int K,
+                           const float *y, const float *mean, const float *invstd, const float *scale,
+                           const float *shift, int64_t M, int C, int n_parts, float *red_partial,
+                           papc_stream_t stream);
+
+/* Reduce red_partial -> dgamma[c] = sum p*xhat, dbeta[c] = sum p, and the two per-channel constants of
+ * dy = scale*(p - c1 - xhat*c2): c1 = dbeta/M, c2 = dgamma/M. */
+int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, int C, float *dgamma,
+                             float *dbeta, float *c1, float *c2, papc_stream_t stream);
+
+typedef struct papc_bwd_dy {
+    int dz_mode;           /* PAPC_DZ_* */
+    const float *dz;       /* [M,C] (DENSE) */
+    const float *gout;     /* [M/K,C] (MAX) */
+    const int32_t *argmax; /* [M/K,C] (MAX) */
+    int K;
+    const float *y;        /* [M,C] pre-BN output of this layer (saved by forward) */
+    const float *mean, *invstd, *scale, *shift, *c1, *c2; /* [C] */
+} papc_bwd_dy;
+
+/* dX[M,Cin] = dY[M,Cout] . w[Cout,Cin], dY produced on the fly from `dy` (never materialised).
+ * wt is w transposed: [Cin,Cout].  If scatter != NULL the result rows are instead accumulated
+ * (atomicAdd) into grad_feats[b, idx[m], :] for the feature columns of a GROUP layer (gradient of
+ * index_points, autograd-correct -- the reference cuts it, pointnet2_basic_layers.py:57-60); xyz columns
+ * carry no gradient.  col0/ncols select the slice of dX columns kept (feature part). */
+typedef struct papc_scatter_dst {
+    float *grad_feats;     /* [B,N,D], pre-zeroed */
+    const int32_t *idx;    /* [B,S,K] or NULL for identity rows (group_all) */
+    int N, S, K, D;
+    int col0;              /* first dX column that maps to feature 0 */
+} papc_scatter_dst;
+int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, float *dx,
+                        const papc_scatter_dst *scatter, papc_stream_t stream);
+
+/* dW partials: dw_partial[t, Cout, Cin] = sum over the rows of chunk t of dY[m,:]^T A(x)[m,:], and
+ * db_partial[t, Cout] = sum dY[m,:].  A(x) as in papc_mlp_gemm_f32 (recomputed, not stored).
+ * rows_per_chunk is a multiple of 128; n_chunks = ceil(M/rows_per_chunk). */
+int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const float *x, int64_t ldx,
+                        const papc_group_src *grp, const float *bn_scale, const float *bn_shift, int64_t M,
+                        int Cin, int Cout, int rows_per_chunk, float *dw_partial, float *db_partial,
+                        papc_stream_t stream);
+
+/* out[i] = sum_t partial[t, i]  (fixed order -> deterministic); n = elements per chunk */
+int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PointPillars PillarFeatureNet (PAPC/models/detect/pointpillars/models/bones/pillars.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* PillarFeatureNet.forward with a single (last) PFNLayer -- pillars.py:79-108 + PFNLayer :29-37 --
+ * the reference's shipped configuration (num_filters [64]).  features [P,T,4], num_voxels [P] i32,
+ * coors [P,4] i32 (batch,z,y,x).  Decoration :82-95 (9 channels), padding mask :99-102,
+ * Linear(9->C, no bias) :30, BatchNorm1D(train, eps) :31, ReLU :32, max over T :34.
+ * pass 1 writes stats_partial [n_blocks,2,C]; papc_bn_finalize_f32 turns them into scale/shift;
+ * pass 2 recomputes the linear layer and writes out [P,C] (+argmax [P,C] or NULL).
+ * w is [C,9] ([out,in]; paddle's Linear stores [in,out]).  C <= 64. */
+/* decoration only (pillars.py:82-102): out [P,T,9] = masked [x,y,z,r, xyz-mean, x-cx, y-cy] rows */
+int papc_pfn_decorate_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                          float vx, float vy, float x_offset, float y_offset, float *out, papc_stream_t stream);
+int papc_pfn_stats_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                       float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                       float *stats_partial, int *n_blocks_out, papc_stream_t stream);
+int papc_pfn_apply_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                       float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                       const float *scale, const float *shift, float *out, int32_t *argmax,
+                       papc_stream_t stream);
+/* number of stats blocks papc_pfn_stats_f32 will write for P pillars */
+int papc_pfn_num_blocks(int P);
+/* backward: given gout [P,C] and argmax, the BN constants and w: dgamma/dbeta partials, dW [C,9].
+ * Two passes like the forward (red pass, then dw pass with c1,c2). */
+int papc_pfn_bwd_reduce_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P,
+                            int T, float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                            const float *gout, const int32_t *argmax, const float *mean, const float *invstd,
+                            const float *scale, const float *shift, float *red_partial, papc_stream_t stream);
+int papc_pfn_bwd_dw_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                        float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                        const float *gout, const int32_t *argmax, const float *mean, const float *invstd,
+                        const float *scale, const float *shift, const float *c1, const float *c2,
+                        float *dw_partial, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Harness helpers (the reference's Adam step, PAPC/train.py:62-65,113-116, on one flat buffer)
+ * ---------------------------------------------------------------------------------------------- */
+/* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params. */
+int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       float grad_scale, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Event profiler (bench.py's live per-kernel durations).  Off by default.
+ * papc_prof_enable(mask): bit i enables event pairs around launches of kernel family i
+ * (PAPC_K_* below).  papc_prof_read: total ms and launch count since the last reset (synchronises the
+ * recorded events).  Uses hipEventRecord on the caller's stream.
+ * ---------------------------------------------------------------------------------------------- */
+#define PAPC_K_FPS 0
+#define PAPC_K_BALL_QUERY 1
+#define PAPC_K_GROUP 2
+#define PAPC_K_MLP_GEMM 3
+#define PAPC_K_BN_RELU_MAX 4
+#define PAPC_K_BWD_REDUCE 5
+#define PAPC_K_BWD_DX 6
+#define PAPC_K_BWD_DW 7
+#define PAPC_K_PFN 8
+#define PAPC_K_MISC 9
+#define PAPC_K_COUNT 10
+int papc_prof_enable(unsigned mask);
+int papc_prof_reset(void);
+int papc_prof_read(int kernel, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAPC_HIP_H */

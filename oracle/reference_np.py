@@ -1,0 +1,360 @@
+"""CPU oracle for the PAPC hot path -- TEST INFRASTRUCTURE ONLY (the checker, never the product).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package.  ``papc_amd`` never does; it fails loudly if its HIP library is missing.
+
+PARITY UNPINNED.  The reference (AgentMaker/PAPC) is pure Python on PaddlePaddle; it holds no
+tests, fixtures or golden vectors for this path, and PaddlePaddle cannot be installed in the build
+container, so this restatement could not be checked against an execution of the reference.  It
+follows the reference source line by line (``file:line`` citations are into
+``/root/reference/PAPC/models/layers/pointnet2_basic_layers.py`` unless another file is named),
+numpy standing in for paddle, with fp32 rounding order fixed to the canonical arithmetic of
+SURVEY.md section 8a (see ``papc_oracle.c``).  Second opinions available here: the same functions
+written literally (``*_literal`` below: tile/mask/sort exactly as the source does) and a torch-CPU
+transliteration (``torch_cpu_reference.py``); the tests check all three agree.
+
+Layout conventions are the reference's: xyz ``[B,N,3]``, features ``[B,N,D]`` inside the free
+functions; layers take ``[B,C,N]``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def _lib():
+    """Load (building with gcc if needed) the C restatement ``liboracle.so``."""
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        src = os.path.join(_HERE, "papc_oracle.c")
+        if (not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        _LIB = ctypes.CDLL(so)
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# square_distance :26-40
+# --------------------------------------------------------------------------------------------
+def _matmul_nt(a, b):
+    """paddle.matmul(a, b.transpose([0,2,1])) with the canonical k-ordered fma chain (C)."""
+    a, b = _f32(a), _f32(b)
+    B, N, C = a.shape
+    M = b.shape[1]
+    out = np.empty((B, N, M), np.float32)
+    _lib().orc_matmul_nt(_fp(a), _fp(b), B, N, M, C, _fp(out))
+    return out
+
+
+def square_distance(src, dst):
+    """:26-40, written as the source writes it (three in-place steps, fp32)."""
+    src, dst = _f32(src), _f32(dst)
+    B, N, _ = src.shape
+    _, M, _ = dst.shape
+    dist = np.float32(-2) * _matmul_nt(src, dst)                                   # :36
+    dist += _sum_last3(src ** 2).reshape(B, N, 1)                                  # :37
+    dist += _sum_last3(dst ** 2).reshape(B, 1, M)                                  # :38
+    return dist
+
+
+def _sum_last3(sq):
+    """paddle.sum(x, axis=-1) over a length-3 axis: canonical left-to-right (a0+a1)+a2."""
+    assert sq.shape[-1] == 3
+    return (sq[..., 0] + sq[..., 1]) + sq[..., 2]
+
+
+def square_distance_c(src, dst):
+    """Same values from the C restatement (one fused loop); used for big inputs."""
+    src, dst = _f32(src), _f32(dst)
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    out = np.empty((B, N, M), np.float32)
+    _lib().orc_square_distance(_fp(src), _fp(dst), B, N, M, _fp(out))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# index_points :43-62
+# --------------------------------------------------------------------------------------------
+def index_points(points, idx):
+    """:43-62 -- numpy fancy indexing exactly as the source (idx may be float, cast to int64 :59)."""
+    points = np.asarray(points)
+    B = points.shape[0]
+    idx = np.asarray(idx)
+    view_shape = list(idx.shape)
+    view_shape[1:] = [1] * (len(view_shape) - 1)
+    repeat_shape = list(idx.shape)
+    repeat_shape[0] = 1
+    batch_indices = np.tile(np.arange(B).reshape(view_shape), repeat_shape)         # :56
+    return points[batch_indices.astype("int64"), idx.astype("int64"), :]            # :57-60
+
+
+# --------------------------------------------------------------------------------------------
+# farthest_point_sample :65-95
+# --------------------------------------------------------------------------------------------
+def farthest_point_sample_literal(xyz, npoint, start_idx, init_dist=1.0):
+    """:65-95 step by step.  ``start_idx`` replaces paddle.randint (:76).  Returns float32
+    centroids like the source (:74)."""
+    xyz = _f32(xyz)
+    B, N, C = xyz.shape
+    centroids = np.zeros((B, npoint), np.float32)                                    # :74
+    distance = np.full((B, N), init_dist, np.float32)                               # :75 (ones)
+    farthest = np.asarray(start_idx, dtype=np.int64).copy()                         # :76
+    batch_indices = np.arange(B)
+    for i in range(npoint):                                                         # :79
+        centroids[:, i] = farthest                                                  # :80
+        centroid = xyz[batch_indices, farthest, :][:, None, :]                      # :81-85
+        dist = _sum_last3((xyz - centroid) ** 2)                                    # :86
+        mask = dist < distance                                                      # :87
+        distance[mask] = dist[mask]                                                 # :88-92
+        farthest = np.argmax(distance, -1)                                          # :93 (first max)
+    return centroids
+
+
+def farthest_point_sample(xyz, npoint, start_idx, init_dist=1.0):
+    """C restatement of the same loop; returns int32 indices ``[B,npoint]``."""
+    xyz = _f32(xyz)
+    B, N, _ = xyz.shape
+    start = np.ascontiguousarray(start_idx, dtype=np.int64)
+    out = np.empty((B, npoint), np.int32)
+    _lib().orc_fps(_fp(xyz), B, N, npoint, _fp(start), ctypes.c_float(init_dist), _fp(out))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# query_ball_point :98-126
+# --------------------------------------------------------------------------------------------
+def radius_threshold(radius):
+    """``radius ** 2`` is a python double; the comparison promotes it to the tensor dtype (:112)."""
+    return np.float32(float(radius) * float(radius))
+
+
+def query_ball_point_literal(radius, nsample, xyz, new_xyz):
+    """:98-126 exactly as written: tile arange, mask -> N, full sort, keep nsample, pad with first."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, N, C = xyz.shape
+    _, S, _ = new_xyz.shape
+    group_idx = np.tile(np.arange(N, dtype=np.int64).reshape(1, 1, N), [B, S, 1])   # :110
+    sqrdists = square_distance(new_xyz, xyz)                                        # :111
+    mask = sqrdists > radius_threshold(radius)                                      # :112
+    group_idx[mask] = N                                                             # :113-116
+    group_idx = np.sort(group_idx, axis=-1)[:, :, :nsample]                         # :117
+    group_first = np.tile(group_idx[:, :, 0].reshape(B, S, 1), [1, 1, nsample])     # :118
+    mask = group_idx == N                                                           # :119
+    group_idx[mask] = group_first[mask]                                             # :120-123
+    return group_idx
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """C restatement (first-``nsample``-hits scan); int64 ``[B,S,nsample]``."""
+    xyz, new_xyz = _f32(xyz), _f32(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    out = np.empty((B, S, nsample), np.int64)
+    _lib().orc_ball_query(_fp(xyz), _fp(new_xyz), B, N, S, ctypes.c_float(radius_threshold(radius)),
+                          nsample, _fp(out))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# sample_and_group :129-157, sample_and_group_all :160-176
+# --------------------------------------------------------------------------------------------
+def sample_and_group(npoint, radius, nsample, xyz, points, start_idx, returnfps=False, init_dist=1.0):
+    xyz = _f32(xyz)
+    B, N, C = xyz.shape
+    S = npoint
+    fps_idx = farthest_point_sample(xyz, npoint, start_idx, init_dist)              # :143
+    new_xyz = index_points(xyz, fps_idx)                                            # :144
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)                           # :145
+    grouped_xyz = index_points(xyz, idx)                                            # :146
+    grouped_xyz_norm = grouped_xyz - new_xyz.reshape(B, S, 1, C)                    # :147
+    if points is not None:
+        grouped_points = index_points(_f32(points), idx)                            # :150
+        new_points = np.concatenate([grouped_xyz_norm, grouped_points], axis=-1)    # :151 xyz first
+    else:
+        new_points = grouped_xyz_norm                                               # :153
+    if returnfps:
+        return new_xyz, new_points, grouped_xyz, fps_idx
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    xyz = _f32(xyz)
+    B, N, C = xyz.shape
+    new_xyz = np.zeros((B, 1, C), np.float32)                                       # :170
+    grouped_xyz = xyz.reshape(B, 1, N, C)                                           # :171
+    if points is not None:
+        new_points = np.concatenate([grouped_xyz, _f32(points).reshape(B, 1, N, -1)], axis=-1)  # :173
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points
+
+
+# --------------------------------------------------------------------------------------------
+# Conv2D(1x1) + BatchNorm2D(train) + ReLU stack and max  :215-219
+# --------------------------------------------------------------------------------------------
+def conv1x1_rows(x, w, bias, f64=False):
+    """nn.Conv2D(cin, cout, 1) on rows: x [M,Cin] . w[Cout,Cin]^T + bias (:189, :217).
+    fp32 path = canonical k-ordered fmaf chain (C); f64 path = numpy double (error bound)."""
+    if f64:
+        y = np.asarray(x, np.float64) @ np.asarray(w, np.float64).T
+        return y + np.asarray(bias, np.float64) if bias is not None else y
+    x, w = _f32(x), _f32(w)
+    M, Cin = x.shape
+    Cout = w.shape[0]
+    y = np.empty((M, Cout), np.float32)
+    b32 = _f32(bias) if bias is not None else None
+    _lib().orc_conv1x1(_fp(x), _fp(w), _fp(b32) if b32 is not None else None,
+                       ctypes.c_int64(M), Cin, Cout, _fp(y))
+    return y
+
+
+def batchnorm_train_rows(y, gamma, beta, eps, f64=False):
+    """BatchNorm (training): per-channel batch mean / biased variance over all rows, then
+    (y-mean)/sqrt(var+eps)*gamma+beta (:190, :217; paddle default eps 1e-5).  Statistics are
+    accumulated in double in both modes; returns (out, mean, var)."""
+    yd = np.asarray(y, np.float64)
+    mean = yd.mean(axis=0)
+    var = yd.var(axis=0)
+    if f64:
+        out = (yd - mean) / np.sqrt(var + eps) * np.asarray(gamma, np.float64) + np.asarray(beta, np.float64)
+        return out, mean, var
+    mean32, var32 = mean.astype(np.float32), var.astype(np.float32)
+    inv = (np.float32(1.0) / np.sqrt(var32 + np.float32(eps))).astype(np.float32)
+    out = (np.asarray(y, np.float32) - mean32) * inv * _f32(gamma) + _f32(beta)
+    return out.astype(np.float32), mean, var
+
+
+def mlp_stack_rows(x, weights, f64=False, eps=1e-5, return_all=False):
+    """relu(bn(conv(x))) for each (w, bias, gamma, beta) in ``weights`` on rows [M,C] (:215-217)."""
+    acts = []
+    for (w, b, g, bt) in weights:
+        y = conv1x1_rows(x, w, b, f64)
+        z, _, _ = batchnorm_train_rows(y, g, bt, eps, f64)
+        x = np.maximum(z, 0)
+        acts.append((y, x))
+    return (x, acts) if return_all else x
+
+
+class PointNetSetAbstraction:
+    """:179-221.  ``weights`` = list of (conv_w [Cout,Cin], conv_b [Cout], bn_gamma, bn_beta)."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, weights):
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.weights = weights
+        assert len(weights) == len(mlp)
+
+    def forward(self, xyz, points, start_idx=None, f64=False, init_dist=1.0, return_all=False):
+        xyz = np.transpose(_f32(xyz), (0, 2, 1))                                    # :203
+        if points is not None:
+            points = np.transpose(_f32(points), (0, 2, 1))                          # :205
+        if self.group_all:
+            new_xyz, new_points = sample_and_group_all(xyz, points)                 # :211
+        else:
+            new_xyz, new_points = sample_and_group(self.npoint, self.radius, self.nsample, xyz, points,
+                                                   start_idx, init_dist=init_dist)  # :213
+        B, S, K, C = new_points.shape
+        # :214-217: [B,C,K,S] conv/bn/relu == the same ops on rows (b,s,k) x C
+        rows = new_points.reshape(B * S * K, C)
+        z, acts = mlp_stack_rows(rows, self.weights, f64, return_all=True)
+        z = z.reshape(B, S, K, -1)
+        out = z.max(axis=2)                                                         # :219 max over nsample
+        out = np.transpose(out, (0, 2, 1))                                          # [B,D',S]
+        new_xyz = np.transpose(new_xyz, (0, 2, 1))                                  # :220
+        if return_all:
+            return new_xyz, out, acts
+        return new_xyz, out
+
+
+class PointNetSetAbstractionMsg:
+    """:224-281.  ``weights[i]`` is the (w,b,gamma,beta) list of radius branch i."""
+
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list, weights):
+        self.npoint, self.radius_list, self.nsample_list = npoint, radius_list, nsample_list
+        self.weights = weights
+
+    def forward(self, xyz, points, start_idx, f64=False, init_dist=1.0):
+        xyz = np.transpose(_f32(xyz), (0, 2, 1))                                    # :252
+        if points is not None:
+            points = np.transpose(_f32(points), (0, 2, 1))
+        B, N, C = xyz.shape
+        S = self.npoint
+        new_xyz = index_points(xyz, farthest_point_sample(xyz, S, start_idx, init_dist))   # :258
+        outs = []
+        for i, radius in enumerate(self.radius_list):
+            K = self.nsample_list[i]
+            group_idx = query_ball_point(radius, K, xyz, new_xyz)                   # :262
+            grouped_xyz = index_points(xyz, group_idx)
+            grouped_xyz = grouped_xyz - new_xyz.reshape(B, S, 1, C)                 # :264
+            if points is not None:
+                grouped_points = index_points(points, group_idx)
+                grouped_points = np.concatenate([grouped_points, grouped_xyz], axis=-1)    # :267 feats first
+            else:
+                grouped_points = grouped_xyz
+            rows = grouped_points.reshape(B * S * K, -1)
+            z = mlp_stack_rows(rows, self.weights[i], f64).reshape(B, S, K, -1)
+            outs.append(np.transpose(z.max(axis=2), (0, 2, 1)))                     # :276
+        return np.transpose(new_xyz, (0, 2, 1)), np.concatenate(outs, axis=1)       # :279-280
+
+
+# --------------------------------------------------------------------------------------------
+# PointPillars PFN: /root/reference/PAPC/models/detect/pointpillars/models/bones/pillars.py
+# --------------------------------------------------------------------------------------------
+def get_paddings_indicator(actual_num, max_num):
+    """libs/tools/__init__.py:26-35 (axis=0): mask[p,t] = actual_num[p] > t."""
+    return np.asarray(actual_num).astype(np.int64)[:, None] > np.arange(max_num, dtype=np.int64)[None, :]
+
+
+def pillar_decorate(features, num_voxels, coors, vx, vy, x_offset, y_offset):
+    """pillars.py:79-102 -> masked 9-channel rows [P,T,9] (fp32, op order as written)."""
+    features = _f32(features)
+    nv = np.asarray(num_voxels).astype(np.float32).reshape(-1, 1, 1)
+    points_mean = features[:, :, :3].sum(axis=1, keepdims=True, dtype=np.float32) / nv      # :82
+    f_cluster = features[:, :, :3] - points_mean                                             # :83
+    f_center = np.zeros_like(features[:, :, :2])                                             # :86
+    cx = np.asarray(coors)[:, 3].astype(np.float32)[:, None]
+    cy = np.asarray(coors)[:, 2].astype(np.float32)[:, None]
+    f_center[:, :, 0] = features[:, :, 0] - (cx * np.float32(vx) + np.float32(x_offset))     # :87
+    f_center[:, :, 1] = features[:, :, 1] - (cy * np.float32(vy) + np.float32(y_offset))     # :88
+    feats = np.concatenate([features, f_cluster, f_center], axis=-1)                         # :91-95
+    mask = get_paddings_indicator(num_voxels, feats.shape[1])                                # :99-100
+    feats = feats * mask[..., None].astype(np.float32)                                       # :101-102
+    return feats
+
+
+def pfn_layer(inputs, w, gamma, beta, eps=1e-3, last_layer=True, f64=False):
+    """pillars.py:29-41.  ``w`` is [Cout,Cin] (paddle Linear stores [in,out]; pass the transpose)."""
+    P, T, Cin = inputs.shape
+    y = conv1x1_rows(inputs.reshape(P * T, Cin), w, None, f64)                               # :30
+    z, _, _ = batchnorm_train_rows(y, gamma, beta, eps, f64)                                 # :31
+    x = np.maximum(z, 0).reshape(P, T, -1)                                                   # :32
+    x_max = x.max(axis=1, keepdims=True)                                                     # :34
+    if last_layer:
+        return x_max                                                                         # :36-37
+    return np.concatenate([x, np.tile(x_max, (1, T, 1))], axis=2)                            # :39-41
+
+
+def pillar_feature_net(features, num_voxels, coors, layer_weights, voxel_size=(0.2, 0.2, 4),
+                       pc_range=(0, -40, -3, 70.4, 40, 1), f64=False):
+    """pillars.py:43-108.  ``layer_weights`` = [(w, gamma, beta), ...] one per PFNLayer."""
+    vx, vy = voxel_size[0], voxel_size[1]
+    x_offset = vx / 2 + pc_range[0]                                                          # :76
+    y_offset = vy / 2 + pc_range[1]                                                          # :77
+    feats = pillar_decorate(features, num_voxels, coors, vx, vy, x_offset, y_offset)
+    n = len(layer_weights)
+    for i, (w, g, b) in enumerate(layer_weights):
+        feats = pfn_layer(feats, w, g, b, last_layer=(i == n - 1), f64=f64)                  # :105-106
+    return np.squeeze(feats)                                                                 # :108

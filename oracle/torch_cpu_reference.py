@@ -1,0 +1,158 @@
+"""torch-CPU transliteration of the reference's PointNet++ SSG classifier, in the reference's own op
+decomposition -- TEST INFRASTRUCTURE / CPU BASELINE ONLY (see reference_np.py for the rules).
+
+This is what ``bench.py``'s ``cpu_baseline`` leg times ("kind": "port"): PaddlePaddle cannot be installed on
+either box, so the reference itself cannot run; this file keeps its *shape* -- the Python FPS loop with
+host round-trips per iteration (pointnet2_basic_layers.py:79-93), the dense [B,S,N] distance matrix + int64
+tile + full sort of query_ball_point (:110-124), numpy fancy-index gathers that cut autograd (:57-60), and
+unfused Conv2d(1x1) / BatchNorm2d / relu / max (:215-219) -- with torch-CPU (MKL) standing in for paddle-CPU.
+It doubles as a second opinion for the oracle: tests check its indices equal the C restatement bit for bit.
+PARITY UNPINNED (no reference tests or fixtures exist; see reference_np.py).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as TF
+
+
+def square_distance(src, dst):                                                   # :26-40
+    B, N, _ = src.shape
+    M = dst.shape[1]
+    dist = -2 * torch.matmul(src, dst.transpose(1, 2))
+    dist += torch.sum(src ** 2, -1).reshape(B, N, 1)
+    dist += torch.sum(dst ** 2, -1).reshape(B, 1, M)
+    return dist
+
+
+def index_points(points, idx):                                                   # :43-62 (numpy round trip)
+    B = points.shape[0]
+    shape = list(idx.shape)
+    view = [B] + [1] * (len(shape) - 1)
+    rep = [1] + shape[1:]
+    bidx = np.tile(np.arange(B).reshape(view), rep)
+    return torch.from_numpy(points.detach().numpy()[bidx, idx.numpy().astype('int64'), :])
+
+
+def farthest_point_sample(xyz, npoint, start_idx):                               # :65-95
+    B, N, _ = xyz.shape
+    centroids = torch.zeros(B, npoint)
+    distance = torch.ones(B, N)
+    farthest = torch.as_tensor(start_idx, dtype=torch.int64).clone()
+    brange = np.arange(B)
+    for i in range(npoint):
+        centroids[:, i] = farthest
+        centroid = torch.from_numpy(xyz.numpy()[brange, farthest.numpy(), :]).unsqueeze(1)
+        dist = torch.sum((xyz - centroid) ** 2, -1)
+        mask = (dist < distance).numpy()
+        d_np, n_np = distance.numpy().copy(), dist.numpy()
+        d_np[mask] = n_np[mask]
+        distance = torch.from_numpy(d_np)
+        farthest = torch.argmax(distance, -1)
+    return centroids
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):                             # :98-126
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    group_idx = torch.arange(N, dtype=torch.int64).reshape(1, 1, N).repeat(B, S, 1)
+    sqrdists = square_distance(new_xyz, xyz)
+    g = group_idx.numpy()
+    g[(sqrdists > radius ** 2).numpy()] = N
+    group_idx = torch.from_numpy(g).sort(dim=-1)[0][:, :, :nsample]
+    first = group_idx[:, :, 0].reshape(B, S, 1).repeat(1, 1, nsample)
+    g = group_idx.numpy().copy()
+    m = g == N
+    g[m] = first.numpy()[m]
+    return torch.from_numpy(g)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, start_idx):           # :129-157
+    B, N, C = xyz.shape
+    fps_idx = farthest_point_sample(xyz, npoint, start_idx)
+    new_xyz = index_points(xyz, fps_idx)
+    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped = index_points(xyz, idx) - new_xyz.reshape(B, npoint, 1, C)
+    if points is not None:
+        grouped = torch.cat([grouped, index_points(points, idx)], dim=-1)
+    return new_xyz, grouped, fps_idx, idx
+
+
+class SetAbstraction(nn.Module):                                                 # :179-221
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.convs, self.bns = nn.ModuleList(), nn.ModuleList()
+        last = in_channel
+        for out in mlp:
+            self.convs.append(nn.Conv2d(last, out, 1))
+            self.bns.append(nn.BatchNorm2d(out))
+            last = out
+
+    def forward(self, xyz, points, start_idx=None):
+        xyz = xyz.permute(0, 2, 1)
+        if points is not None:
+            points = points.permute(0, 2, 1)
+        if self.group_all:
+            B, N, C = xyz.shape
+            new_xyz = torch.zeros(B, 1, C)
+            new_points = xyz.reshape(B, 1, N, C)
+            if points is not None:
+                new_points = torch.cat([new_points, points.reshape(B, 1, N, -1)], dim=-1)
+        else:
+            new_xyz, new_points, _, _ = sample_and_group(self.npoint, self.radius, self.nsample, xyz.contiguous(),
+                                                         None if points is None else points.contiguous(), start_idx)
+        new_points = new_points.permute(0, 3, 2, 1)
+        for conv, bn in zip(self.convs, self.bns):
+            new_points = TF.relu(bn(conv(new_points)))
+        new_points = torch.max(new_points, 2)[0]
+        return new_xyz.permute(0, 2, 1), new_points
+
+
+class SSGClas(nn.Module):                       # classify/pointnet2/pointnet2.py:6-41
+    def __init__(self, num_classes=16):
+        super().__init__()
+        self.sa1 = SetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False)
+        self.sa2 = SetAbstraction(128, 0.4, 64, 128 + 3, [128, 128, 256], False)
+        self.sa3 = SetAbstraction(None, None, None, 256 + 3, [256, 512, 1024], True)
+        self.fc1, self.bn1, self.drop1 = nn.Linear(1024, 512), nn.BatchNorm1d(512), nn.Dropout(0.4)
+        self.fc2, self.bn2, self.drop2 = nn.Linear(512, 256), nn.BatchNorm1d(256), nn.Dropout(0.4)
+        self.fc3 = nn.Linear(256, num_classes)
+
+    def forward(self, xyz, start_idx=(None, None)):
+        B = xyz.shape[0]
+        l1_xyz, l1_points = self.sa1(xyz, None, start_idx[0])
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, start_idx[1])
+        _, l3_points = self.sa3(l2_xyz, l2_points)
+        x = l3_points.reshape(B, 1024)
+        x = self.drop1(TF.relu(self.bn1(self.fc1(x))))
+        x = self.drop2(TF.relu(self.bn2(self.fc2(x))))
+        return self.fc3(x)
+
+
+def time_train_step(B, N, threads, seed=1234, repeats=1):
+    """One fwd + CrossEntropy + bwd + Adam step (PAPC/train.py:106-116) on a seeded synthetic batch.
+    Returns (seconds per step, clouds per second)."""
+    import time
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from papc_amd.synthetic import make_clouds, make_labels, make_start_idx
+    torch.set_num_threads(threads)
+    torch.manual_seed(seed)
+    model = SSGClas()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-3)
+    x = torch.from_numpy(make_clouds(B, N, seed))
+    y = torch.from_numpy(make_labels(B, 16, seed)).reshape(-1)
+    s1 = make_start_idx(B, N, seed)
+    s2 = make_start_idx(B, 512, seed + 1)
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        loss = TF.cross_entropy(model(x, (s1, s2)), y)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return best, B / best

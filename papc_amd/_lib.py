@@ -1,0 +1,105 @@
+"""ctypes binding of ``libpapc_hip.so`` (the C ABI declared in ``include/papc_hip.h``).
+
+There is NO fallback: if the shared library is missing or a call fails, this module raises.  Build it with
+``python -m papc_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpapc_hip.so")
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_f = ctypes.c_float
+
+
+class PapcError(RuntimeError):
+    pass
+
+
+class GroupSrc(ctypes.Structure):
+    """papc_group_src"""
+    _fields_ = [("xyz", c_p), ("sb", c_l), ("sn", c_l), ("sc", c_l), ("new_xyz", c_p), ("feats", c_p),
+                ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("xyz_first", c_i)]
+
+
+class BwdDy(ctypes.Structure):
+    """papc_bwd_dy"""
+    _fields_ = [("dz_mode", c_i), ("dz", c_p), ("gout", c_p), ("argmax", c_p), ("K", c_i), ("y", c_p),
+                ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("c1", c_p), ("c2", c_p)]
+
+
+class ScatterDst(ctypes.Structure):
+    """papc_scatter_dst"""
+    _fields_ = [("grad_feats", c_p), ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("col0", c_i)]
+
+
+# every exported symbol of include/papc_hip.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "papc_version": (c_i, []),
+    "papc_last_error_string": (ctypes.c_char_p, []),
+    "papc_fps_f32": (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p]),
+    "papc_ball_query_f32": (c_i, [c_p, c_l, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "papc_square_distance_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "papc_index_points_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "papc_index_points_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "papc_group_points_f32": (c_i, [c_p, c_l, c_l, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "papc_mlp_gemm_parts": (c_i, [c_l]),
+    "papc_mlp_gemm_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
+    "papc_bn_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_bn_relu_max_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
+    "papc_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_p]),
+    "papc_bn_bwd_reduce_f32": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p]),
+    "papc_bn_bwd_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "papc_mlp_bwd_dx_f32": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
+    "papc_mlp_bwd_dw_f32": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "papc_reduce_partials_f32": (c_i, [c_p, c_i, c_l, c_p, c_p]),
+    "papc_pfn_decorate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "papc_pfn_stats_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p]),
+    "papc_pfn_apply_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "papc_pfn_num_blocks": (c_i, [c_i]),
+    "papc_pfn_bwd_reduce_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_pfn_bwd_dw_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_adam_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "papc_prof_enable": (c_i, [ctypes.c_uint]),
+    "papc_prof_reset": (c_i, []),
+    "papc_prof_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_l)]),
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library with typed signatures; raises PapcError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PapcError("libpapc_hip.so not found at %s -- build it with `python -m papc_amd.build` "
+                            "(there is no CPU fallback)" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        missing = [n for n in SIGNATURES if not hasattr(lib, n)]
+        if missing:  # the header and the library drifted apart: refuse to run on half a library
+            raise PapcError("libpapc_hip.so lacks symbols declared in include/papc_hip.h: %s" % ", ".join(missing))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().papc_last_error_string().decode("utf-8", "replace")
+        raise PapcError("%s failed (%d): %s" % (what, status, msg))
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

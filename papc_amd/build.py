@@ -1,0 +1,78 @@
+"""Builds libpapc_hip.so in-tree with hipcc for gfx950 (no cmake, no JIT cache).
+
+    python -m papc_amd.build [--force]
+
+Each ``csrc/*.hip`` is compiled to an object (in parallel, skipped when newer than its sources and
+headers) and linked into ``papc_amd/libpapc_hip.so``.  The index-exact kernels are compiled with
+``-ffp-contract=off`` so the only FMAs are the ones the source spells out.
+"""
+import concurrent.futures
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "obj")
+LIB = os.path.join(HERE, "libpapc_hip.so")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off",
+          "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
+# per-file extra flags
+EXTRA = {}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + [__file__]
+    hdr_time = _newest(hdrs)
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            cmd = [_hipcc(), "-c", s, "-o", o] + COMMON + EXTRA.get(os.path.basename(s), [])
+            jobs.append((s, cmd))
+
+    def run(job):
+        s, cmd = job
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return s, r.returncode, r.stdout
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for s, rc, out in ex.map(run, jobs):
+                if verbose and out.strip():
+                    print(out)
+                if rc != 0:
+                    raise RuntimeError("hipcc failed on %s\n%s" % (s, out))
+                if verbose:
+                    print("[papc_amd.build] compiled", os.path.basename(s))
+    if force or jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed\n" + r.stdout)
+        if verbose:
+            print("[papc_amd.build] linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,335 @@
+// bn_ops.hip -- the HBM-bound passes around the MFMA kernels (gfx950): train-mode BatchNorm statistics
+// finalisation, BN+ReLU+max over nsample, the reductions of the BN/ReLU/max backward, fixed-order partial
+// sums, and the harness's Adam step.
+// Reference ops: nn.BatchNorm2D (train) + F.relu + paddle.max(axis=2),
+// /root/reference/PAPC/models/layers/pointnet2_basic_layers.py:190,217,219.
+#include "common.h"
+
+namespace papc {
+
+template <int V> struct Vec;
+template <> struct Vec<4> {
+    float4 v;
+    __device__ static Vec load(const float *p) { Vec r; r.v = *reinterpret_cast<const float4 *>(p); return r; }
+    __device__ void store(float *p) const { *reinterpret_cast<float4 *>(p) = v; }
+    __device__ float &operator[](int i) { return (&v.x)[i]; }
+    __device__ float operator[](int i) const { return (&v.x)[i]; }
+};
+template <> struct Vec<1> {
+    float v;
+    __device__ static Vec load(const float *p) { Vec r; r.v = *p; return r; }
+    __device__ void store(float *p) const { *p = v; }
+    __device__ float &operator[](int) { return v; }
+    __device__ float operator[](int) const { return v; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// stats partials [n_tiles][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float eps, float momentum, float *mean, float *invstd, float *scale,
+                                                          float *shift, float *rmean, float *rvar)
+{
+    __shared__ double r1[8][32], r2[8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = tl; t < n_tiles; t += 8) {
+            s1 += (double)part[((int64_t)t * 2 + 0) * C + c];
+            s2 += (double)part[((int64_t)t * 2 + 1) * C + c];
+        }
+    r1[tl][cl] = s1; r2[tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        for (int g = 1; g < 8; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
+        const double mu = s1 / (double)M;
+        double var = s2 / (double)M - mu * mu;  // biased variance (paddle BatchNorm training)
+        if (var < 0.0) var = 0.0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const double sc = (gamma ? (double)gamma[c] : 1.0) * is;
+        mean[c] = (float)mu;
+        invstd[c] = (float)is;
+        scale[c] = (float)sc;
+        shift[c] = (float)((beta ? (double)beta[c] : 0.0) - mu * sc);
+        if (rmean) rmean[c] = momentum * rmean[c] + (1.f - momentum) * (float)mu;   // paddle: momentum weighs the running value
+        if (rvar) rvar[c] = momentum * rvar[c] + (1.f - momentum) * (float)var;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// out[g,c] = max_k relu(scale*y[g*K+k,c]+shift), argmax = first k attaining it
+// ---------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restrict__ y, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int64_t G, int K, int C,
+                                                          float *__restrict__ out, int32_t *__restrict__ argmax)
+{
+    const int CV = C / V;
+    const int64_t total = G * CV;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = e / CV;
+        const int c = (int)(e - g * CV) * V;
+        const Vec<V> sc = Vec<V>::load(scale + c), sh = Vec<V>::load(shift + c);
+        Vec<V> best;
+        int bi[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) { best[i] = -1.0f; bi[i] = 0; }
+        const float *yp = y + (g * K) * (int64_t)C + c;
+        for (int k = 0; k < K; ++k) {
+            const Vec<V> v = Vec<V>::load(yp + (int64_t)k * C);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float z = fmaxf(fmaf(sc[i], v[i], sh[i]), 0.f);
+                if (z > best[i]) { best[i] = z; bi[i] = k; }
+            }
+        }
+        best.store(out + g * C + c);
+        if (argmax) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) argmax[g * C + c + i] = bi[i];
+        }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_relu_kernel(const float *__restrict__ y, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, int64_t M, int C, float *__restrict__ z)
+{
+    const int CV = C / V;
+    const int64_t total = M * CV;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % CV) * V;
+        const Vec<V> sc = Vec<V>::load(scale + c), sh = Vec<V>::load(shift + c);
+        Vec<V> v = Vec<V>::load(y + e * V);
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = fmaxf(fmaf(sc[i], v[i], sh[i]), 0.f);
+        v.store(z + e * V);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward reductions: p = dz*[scale*y+shift > 0]; partial[blk] = (sum p, sum p*xhat) per channel
+// threads: (cg = channel group, rl = row lane); block covers a contiguous range of rows / groups
+// ---------------------------------------------------------------------------------------------------
+template <int V, bool MAXMODE>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restrict__ dz, const float *__restrict__ gout,
+                                                            const int32_t *__restrict__ argmax, int K,
+                                                            const float *__restrict__ y, const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, int64_t M, int C,
+                                                            float *__restrict__ part)
+{
+    __shared__ float red[2][256 * 4];
+    const int CV = C / V;                       // channel groups
+    const int CG = CV < 256 ? CV : 256;         // channel groups per pass
+    const int RL = 256 / CG;                    // row lanes
+    const int cgi = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const int64_t units = MAXMODE ? M / K : M;  // groups or rows
+    const int64_t per = (units + gridDim.x - 1) / gridDim.x;
+    const int64_t u0 = (int64_t)blockIdx.x * per, u1 = min(units, u0 + per);
+
+    for (int cb = 0; cb < CV; cb += CG) {
+        const int cg = cb + cgi;
+        Vec<V> a1, a2;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { a1[i] = 0.f; a2[i] = 0.f; }
+        if (cg < CV && rl < RL) {
+            const int c = cg * V;
+            const Vec<V> sc = Vec<V>::load(scale + c), sh = Vec<V>::load(shift + c);
+            const Vec<V> mu = Vec<V>::load(mean + c), is = Vec<V>::load(invstd + c);
+            for (int64_t u = u0 + rl; u < u1; u += RL) {
+                if (MAXMODE) {
+                    const Vec<V> g = Vec<V>::load(gout + u * C + c);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const int am = argmax[u * C + c + i];
+                        const float yv = y[(u * K + am) * (int64_t)C + c + i];
+                        const float z = fmaf(sc[i], yv, sh[i]);
+                        const float p = z > 0.f ? g[i] : 0.f;
+                        a1[i] += p;
+                        a2[i] = fmaf(p, (yv - mu[i]) * is[i], a2[i]);
+                    }
+                } else {
+                    const Vec<V> d = Vec<V>::load(dz + u * C + c);
+                    const Vec<V> yv = Vec<V>::load(y + u * C + c);
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const float z = fmaf(sc[i], yv[i], sh[i]);
+                        const float p = z > 0.f ? d[i] : 0.f;
+                        a1[i] += p;
+                        a2[i] = fmaf(p, (yv[i] - mu[i]) * is[i], a2[i]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; ++i) { red[0][threadIdx.x * V + i] = a1[i]; red[1][threadIdx.x * V + i] = a2[i]; }
+        __syncthreads();
+        // thread t < CG*V sums over row lanes for channel (cb*V + t)
+        for (int t = threadIdx.x; t < CG * V; t += 256) {
+            const int c = cb * V + t;
+            if (c < C) {
+                const int g = t / V, i = t - g * V;
+                float s1 = 0.f, s2 = 0.f;
+                for (int r = 0; r < RL; ++r) { s1 += red[0][(r * CG + g) * V + i]; s2 += red[1][(r * CG + g) * V + i]; }
+                part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s1;
+                part[((int64_t)blockIdx.x * 2 + 1) * C + c] = s2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
+                                                              float *dgamma, float *dbeta, float *c1, float *c2)
+{
+    __shared__ double r1[8][32], r2[8][32];
+    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = tl; t < n_tiles; t += 8) {
+            s1 += (double)part[((int64_t)t * 2 + 0) * C + c];
+            s2 += (double)part[((int64_t)t * 2 + 1) * C + c];
+        }
+    r1[tl][cl] = s1; r2[tl][cl] = s2;
+    __syncthreads();
+    if (tl == 0 && c < C) {
+        for (int g = 1; g < 8; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        c1[c] = (float)(s1 / (double)M);
+        c2[c] = (float)(s2 / (double)M);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int n_chunks, int64_t n,
+                                                              float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int t = 0; t < n_chunks; ++t) s += part[(int64_t)t * n + i];
+        out[i] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float bc1, float bc2, float gscale)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale + wd * p[i];  // L2 regularisation folded into the gradient (paddle weight_decay=float)
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    }
+}
+
+static inline unsigned ew_grid(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 256 * 16)); }
+
+}  // namespace papc
+
+using namespace papc;
+
+extern "C" {
+
+int papc_bn_finalize_f32(const float *stats_partial, int n_tiles, int64_t M, int C, const float *gamma,
+                         const float *beta, float eps, float momentum, float *mean, float *invstd,
+                         float *scale, float *shift, float *running_mean, float *running_var,
+                         papc_stream_t stream)
+{
+    PAPC_REQUIRE(stats_partial && mean && invstd && scale && shift, PAPC_E_INVALID, "papc_bn_finalize_f32: null pointer");
+    PAPC_REQUIRE(n_tiles >= 1 && M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_finalize_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, stats_partial, n_tiles, M, C, gamma,
+                       beta, eps, momentum, mean, invstd, scale, shift, running_mean, running_var);
+    return check_launch("papc_bn_finalize_f32");
+}
+
+int papc_bn_relu_max_f32(const float *y, const float *scale, const float *shift, int64_t G, int K, int C,
+                         float *out, int32_t *argmax, papc_stream_t stream)
+{
+    PAPC_REQUIRE(y && scale && shift && out, PAPC_E_INVALID, "papc_bn_relu_max_f32: null pointer");
+    PAPC_REQUIRE(G >= 1 && K >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_relu_max_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BN_RELU_MAX, st);
+    const bool v4 = (C % 4 == 0) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(out);
+    if (v4) hipLaunchKernelGGL(bn_relu_max_kernel<4>, dim3(ew_grid(G * (C / 4))), dim3(256), 0, st, y, scale, shift, G, K, C, out, argmax);
+    else hipLaunchKernelGGL(bn_relu_max_kernel<1>, dim3(ew_grid(G * C)), dim3(256), 0, st, y, scale, shift, G, K, C, out, argmax);
+    return check_launch("papc_bn_relu_max_f32");
+}
+
+int papc_bn_relu_f32(const float *y, const float *scale, const float *shift, int64_t M, int C, float *z, papc_stream_t stream)
+{
+    PAPC_REQUIRE(y && scale && shift && z, PAPC_E_INVALID, "papc_bn_relu_f32: null pointer");
+    PAPC_REQUIRE(M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_relu_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    const bool v4 = (C % 4 == 0) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(z);
+    if (v4) hipLaunchKernelGGL(bn_relu_kernel<4>, dim3(ew_grid(M * (C / 4))), dim3(256), 0, st, y, scale, shift, M, C, z);
+    else hipLaunchKernelGGL(bn_relu_kernel<1>, dim3(ew_grid(M * C)), dim3(256), 0, st, y, scale, shift, M, C, z);
+    return check_launch("papc_bn_relu_f32");
+}
+
+int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, const int32_t *argmax, int K,
+                           const float *y, const float *mean, const float *invstd, const float *scale,
+                           const float *shift, int64_t M, int C, int n_parts, float *red_partial, papc_stream_t stream)
+{
+    PAPC_REQUIRE(y && mean && invstd && scale && shift && red_partial, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: null pointer");
+    PAPC_REQUIRE(M >= 1 && C >= 1 && n_parts >= 1, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_REDUCE, st);
+    if (dz_mode == PAPC_DZ_DENSE) {
+        PAPC_REQUIRE(dz, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: DENSE needs dz");
+        const bool v4 = (C % 4 == 0) && aligned16(dz) && aligned16(y) && aligned16(mean) && aligned16(invstd) && aligned16(scale) && aligned16(shift);
+        if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, false>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
+    } else {
+        PAPC_REQUIRE(gout && argmax && K >= 1 && M % K == 0, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: MAX needs gout/argmax and K | M");
+        const bool v4 = (C % 4 == 0) && aligned16(gout) && aligned16(mean) && aligned16(invstd) && aligned16(scale) && aligned16(shift);
+        if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, true>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
+    }
+    return check_launch("papc_bn_bwd_reduce_f32");
+}
+
+int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, int C, float *dgamma,
+                             float *dbeta, float *c1, float *c2, papc_stream_t stream)
+{
+    PAPC_REQUIRE(red_partial && c1 && c2, PAPC_E_INVALID, "papc_bn_bwd_finalize_f32: null pointer");
+    PAPC_REQUIRE(n_tiles >= 1 && M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_bwd_finalize_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, red_partial, n_tiles, M, C, dgamma, dbeta, c1, c2);
+    return check_launch("papc_bn_bwd_finalize_f32");
+}
+
+int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, papc_stream_t stream)
+{
+    PAPC_REQUIRE(partial && out, PAPC_E_INVALID, "papc_reduce_partials_f32: null pointer");
+    PAPC_REQUIRE(n_chunks >= 1 && n >= 1, PAPC_E_INVALID, "papc_reduce_partials_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ew_grid(n)), dim3(256), 0, st, partial, n_chunks, n, out);
+    return check_launch("papc_reduce_partials_f32");
+}
+
+int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       float grad_scale, papc_stream_t stream)
+{
+    PAPC_REQUIRE(param && grad && exp_avg && exp_avg_sq, PAPC_E_INVALID, "papc_adam_step_f32: null pointer");
+    PAPC_REQUIRE(n >= 1 && step >= 1, PAPC_E_INVALID, "papc_adam_step_f32: bad n/step");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2, grad_scale);
+    return check_launch("papc_adam_step_f32");
+}
+
+}  // extern "C"

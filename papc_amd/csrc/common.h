@@ -1,0 +1,96 @@
+// common.h -- shared host/device helpers for libpapc_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+
+#include "papc_hip.h"
+
+namespace papc {
+
+// ---- error plumbing (thread-local message, negative status codes) ---------------------------------
+void set_error(const char *fmt, ...);
+int check_launch(const char *what);
+
+#define PAPC_REQUIRE(cond, code, ...)      \
+    do {                                   \
+        if (!(cond)) {                     \
+            papc::set_error(__VA_ARGS__);  \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+// ---- optional event profiler ----------------------------------------------------------------------
+struct ProfScope {
+    int kernel;
+    hipStream_t stream;
+    bool on;
+    hipEvent_t e0;
+    ProfScope(int kernel, hipStream_t stream);
+    ~ProfScope();
+};
+
+static inline hipStream_t as_stream(papc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- device: wave64 DPP reductions ------------------------------------------------------------------
+// DPP controls (gfx9 family): quad_perm [1,0,3,2]=0xB1, [2,3,0,1]=0x4E, row_ror:n = 0x120+n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143.  After the sequence lane 63 holds the wave result.
+#define PAPC_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false)
+
+template <int CTRL, int RMASK>
+__device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long v)
+{
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    unsigned lo2 = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, RMASK, 0xF, false);
+    unsigned hi2 = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, RMASK, 0xF, false);
+    return ((unsigned long long)hi2 << 32) | lo2;
+}
+
+// max over the 64 lanes of a u64 key; result valid in lane 63 (use readlane63_u64 to broadcast)
+__device__ __forceinline__ unsigned long long wave_max_u64_to_lane63(unsigned long long v)
+{
+    unsigned long long t;
+    t = dpp_move_u64<0xB1, 0xF>(v);  v = t > v ? t : v;
+    t = dpp_move_u64<0x4E, 0xF>(v);  v = t > v ? t : v;
+    t = dpp_move_u64<0x124, 0xF>(v); v = t > v ? t : v;
+    t = dpp_move_u64<0x128, 0xF>(v); v = t > v ? t : v;
+    t = dpp_move_u64<0x142, 0xA>(v); v = t > v ? t : v;
+    t = dpp_move_u64<0x143, 0xC>(v); v = t > v ? t : v;
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long readlane63_u64(unsigned long long v)
+{
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// sum over the 64 lanes of a float; every lane of the last row (48..63) holds the total, lane 63 canonical
+__device__ __forceinline__ float wave_sum_f32_to_lane63(float v)
+{
+    float t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0xB1, 0xF));  v += t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0x4E, 0xF));  v += t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0x124, 0xF)); v += t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0x128, 0xF)); v += t;
+    // row_bcast adds lane 15 of the previous row into rows 1 and 3, then lane 31 into rows 2,3
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false)); v += t;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false)); v += t;
+    return v;
+}
+
+__device__ __forceinline__ float readlane63_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+}  // namespace papc

@@ -1,0 +1,307 @@
+// mlp_gemm.hip -- fp32-MFMA row GEMM with fused operand producers and epilogues (gfx950).
+//
+//   forward  : y[M,Cout]  = A(x)[M,Cin] . w[Cout,Cin]^T + bias      (+ per-channel sum / sum-of-squares partials)
+//   backward : dX[M,Cin]  = dY[M,Cout] . w[Cout,Cin]                 (dY recomputed in the load; optional scatter-add)
+//
+// Replaces nn.Conv2D(cin,cout,1) on the [B,C,K,S] tensors of
+// /root/reference/PAPC/models/layers/pointnet2_basic_layers.py:189,215-217 (rows = (b,s,k), channel-contiguous).
+//
+// Shape of the problem: M is huge (up to 1M rows), K and N are small (3..1024).  Tiling for CDNA4:
+//   * 256 threads = 4 waves per workgroup, 128-row M tile, BN in {128,64,32}; each wave owns WMxWN 32x32
+//     accumulator tiles of v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
+//   * both operands sit in LDS K-contiguous with a 36-float row stride (9 x 16 B: odd number of 16-B slots ->
+//     conflict-free ds_read_b128 for the 16-lane groups of the instruction); one ds_read_b128 per operand tile
+//     feeds FOUR MFMAs: lanes 0-31 carry k = kk..kk+3, lanes 32-63 carry k = kk+4..kk+7.
+//   * workgroups are persistent over row tiles (grid.x <= 1024), so the BN-statistics partials are one
+//     deterministic row per workgroup, no atomics.
+#include "mlp_loaders.h"
+
+namespace papc {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_STORE = 0, EPI_SCATTER = 1 };
+
+struct ScatterDst {
+    float *gf; const int32_t *idx; int N, S, K, D;
+};
+
+struct GemmArgs {
+    ASrc a;
+    const float *w; int64_t ldw;  // weights [Nout][Kin]
+    int wmap;                      // map internal k -> weight column with gk() (GROUP forward)
+    int nmap;                      // map internal n -> weight row with gk() (GROUP dX)
+    const float *bias;
+    int64_t M; int Kin; int Nout;
+    float *y; int64_t ldy;
+    float *stats;                  // [gridDim.x][2][Nout] or null
+    ScatterDst sc;
+    int wvec;
+};
+
+constexpr int LDT = 36;  // LDS row stride (floats)
+constexpr int BK = 32;
+constexpr int GEMM_MAX_PARTS = 1024;
+
+template <int AMODE, int EPI, int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p)
+{
+    constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(BM == 128, "row tile is 128");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT + 2 * WGM * BN];
+    float *As = smem;
+    float *Ws = smem + BM * LDT;
+    float *red = smem + (BM + BN) * LDT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wgm = wave / WGN, wgn = wave % WGN;
+    const int n0 = blockIdx.y * BN;
+    const int64_t n_mtiles = (p.M + BM - 1) / BM;
+    const int Kpad = (p.Kin + 7) & ~7;
+    const int kq = (tid & 7) * 4;
+    const int r0 = tid >> 3;  // 0..31
+
+    float s1[WN], s2[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) { s1[wn] = 0.f; s2[wn] = 0.f; }
+
+    for (int64_t tile = blockIdx.x; tile < n_mtiles; tile += gridDim.x) {
+        const int64_t m0 = tile * BM;
+        floatx16 acc[WM][WN];
+#pragma unroll
+        for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+
+        RowCtx rows[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rows[i] = make_row<AMODE>(p.a, m0 + r0 + 32 * i, p.M);
+
+        for (int k0 = 0; k0 < Kpad; k0 += BK) {
+            const int k = k0 + kq;
+            const KConst kc = make_kconst<AMODE>(p.a, k, p.Kin);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 v = load_a4<AMODE>(p.a, rows[i], k, p.Kin, kc);
+                *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.Nout && k < p.Kin) {
+                    const int nrow = p.nmap ? gk(p.a.g, n) : n;
+                    const float *wr = p.w + (int64_t)nrow * p.ldw;
+                    if (p.wmap) {
+                        v.x = wr[gk(p.a.g, k)];
+                        v.y = k + 1 < p.Kin ? wr[gk(p.a.g, k + 1)] : 0.f;
+                        v.z = k + 2 < p.Kin ? wr[gk(p.a.g, k + 2)] : 0.f;
+                        v.w = k + 3 < p.Kin ? wr[gk(p.a.g, k + 3)] : 0.f;
+                    } else {
+                        v = p.wvec ? ld4_or_zero(wr, k, p.Kin) : ld4s_or_zero(wr, k, p.Kin);
+                    }
+                }
+                *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = v;
+            }
+            __syncthreads();
+            const int kend = min(BK, Kpad - k0);
+            for (int kk = 0; kk < kend; kk += 8) {
+                float4 af[WM], bf[WN];
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm)
+                    af[wm] = *reinterpret_cast<const float4 *>(&As[((wgm * WM + wm) * 32 + l31) * LDT + kk + 4 * hi]);
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+                    bf[wn] = *reinterpret_cast<const float4 *>(&Ws[((wgn * WN + wn) * 32 + l31) * LDT + kk + 4 * hi]);
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn) {
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].x, bf[wn].x, acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].y, bf[wn].y, acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].z, bf[wn].z, acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].w, bf[wn].w, acc[wm][wn], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) {
+            const int col = n0 + (wgn * WN + wn) * 32 + l31;
+            const bool cok = col < p.Nout;
+            const float bias = (EPI == EPI_STORE && p.bias && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + (wgm * WM + wm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < p.M && cok) {
+                        const float v = acc[wm][wn][r] + bias;
+                        if (EPI == EPI_STORE) {
+                            p.y[row * p.ldy + col] = v;
+                            s1[wn] += v;
+                            s2[wn] = fmaf(v, v, s2[wn]);
+                        } else {
+                            // gradient of index_points: grad_feats[b, idx[m], col] += dX[m, col] (feature columns only)
+                            if (col < p.sc.D) {
+                                const int64_t b = row / ((int64_t)p.sc.S * p.sc.K);
+                                const int j = p.sc.idx ? p.sc.idx[row] : (int)(row - b * (int64_t)p.sc.S * p.sc.K);
+                                if (j >= 0 && j < p.sc.N) unsafeAtomicAdd(&p.sc.gf[(b * p.sc.N + j) * (int64_t)p.sc.D + col], v);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (EPI == EPI_STORE && p.stats) {
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) {
+            s1[wn] += __shfl_xor(s1[wn], 32);
+            s2[wn] += __shfl_xor(s2[wn], 32);
+            if (hi == 0) {
+                red[(0 * WGM + wgm) * BN + (wgn * WN + wn) * 32 + l31] = s1[wn];
+                red[(1 * WGM + wgm) * BN + (wgn * WN + wn) * 32 + l31] = s2[wn];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i - which * BN;
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < WGM; ++g) t += red[(which * WGM + g) * BN + c];
+            if (n0 + c < p.Nout) p.stats[((int64_t)blockIdx.x * 2 + which) * p.Nout + n0 + c] = t;
+        }
+    }
+}
+
+static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128, GEMM_MAX_PARTS); }
+
+template <int AMODE, int EPI>
+static int launch_gemm(const GemmArgs &p, hipStream_t st)
+{
+    const unsigned gx = (unsigned)gemm_parts(p.M);
+    if (p.Nout > 64) {
+        dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+    } else if (p.Nout > 32) {
+        dim3 grid(gx, 1);
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
+    } else {
+        dim3 grid(gx, 1);
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+    }
+    return check_launch("mlp gemm");
+}
+
+static void fill_group(GroupSrc &g, const papc_group_src *s)
+{
+    g.xyz = s->xyz; g.sb = s->sb; g.sn = s->sn; g.sc = s->sc; g.new_xyz = s->new_xyz; g.feats = s->feats;
+    g.idx = s->idx; g.N = s->N; g.S = s->S; g.K = s->K; g.D = s->D; g.xyz_first = s->xyz_first;
+}
+
+void fill_dy(DySrc &d, const papc_bwd_dy *s)
+{
+    d.dz = s->dz; d.gout = s->gout; d.argmax = s->argmax; d.K = s->K; d.y = s->y; d.mean = s->mean;
+    d.invstd = s->invstd; d.scale = s->scale; d.shift = s->shift; d.c1 = s->c1; d.c2 = s->c2;
+}
+
+int fill_asrc(ASrc &a, int a_mode, const float *x, int64_t ldx, const papc_group_src *grp, const float *sc,
+              const float *sh, int Cin, const char *who)
+{
+    memset(&a, 0, sizeof(a));
+    if (a_mode == A_PLAIN || a_mode == A_BNRELU) {
+        PAPC_REQUIRE(x && ldx >= Cin, PAPC_E_INVALID, "%s: x null or ldx < Cin", who);
+        PAPC_REQUIRE(a_mode == A_PLAIN || (sc && sh), PAPC_E_INVALID, "%s: BNRELU needs bn_scale/bn_shift", who);
+        a.x = x; a.ldx = ldx; a.sc = sc; a.sh = sh;
+        a.vec = aligned16(x) && (ldx % 4 == 0);
+    } else if (a_mode == A_GROUP) {
+        PAPC_REQUIRE(grp && grp->xyz && grp->new_xyz, PAPC_E_INVALID, "%s: GROUP needs grp->xyz/new_xyz", who);
+        PAPC_REQUIRE(grp->D == 0 || grp->feats, PAPC_E_INVALID, "%s: GROUP D=%d but feats null", who, grp->D);
+        PAPC_REQUIRE(Cin == grp->D + 3, PAPC_E_INVALID, "%s: GROUP Cin=%d != D+3=%d", who, Cin, grp->D + 3);
+        PAPC_REQUIRE(grp->N >= 1 && grp->S >= 1 && grp->K >= 1, PAPC_E_INVALID, "%s: GROUP bad N/S/K", who);
+        fill_group(a.g, grp);
+        a.vec = grp->D > 0 && aligned16(grp->feats) && (grp->D % 4 == 0);
+    } else {
+        set_error("%s: bad a_mode %d", who, a_mode);
+        return PAPC_E_INVALID;
+    }
+    return PAPC_OK;
+}
+
+}  // namespace papc
+
+using namespace papc;
+
+extern "C" {
+
+int papc_mlp_gemm_parts(int64_t M) { return gemm_parts(M); }
+
+int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
+                      const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
+                      int64_t M, int Cin, int Cout, float *y, float *stats_partial, papc_stream_t stream)
+{
+    PAPC_REQUIRE(w && y, PAPC_E_INVALID, "papc_mlp_gemm_f32: null w/y");
+    PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_gemm_f32: M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
+    GemmArgs p;
+    memset(&p, 0, sizeof(p));
+    int rc = fill_asrc(p.a, a_mode, x, ldx, grp, bn_scale, bn_shift, Cin, "papc_mlp_gemm_f32");
+    if (rc) return rc;
+    p.w = w; p.ldw = Cin; p.bias = bias; p.M = M; p.Kin = Cin; p.Nout = Cout; p.y = y; p.ldy = Cout; p.stats = stats_partial;
+    p.wmap = (a_mode == A_GROUP && grp->xyz_first) ? 1 : 0;
+    p.wvec = aligned16(w) && (Cin % 4 == 0);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MLP_GEMM, st);
+    switch (a_mode) {
+    case A_PLAIN: return launch_gemm<A_PLAIN, EPI_STORE>(p, st);
+    case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE>(p, st);
+    default: return launch_gemm<A_GROUP, EPI_STORE>(p, st);
+    }
+}
+
+int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, float *dx,
+                        const papc_scatter_dst *scatter, papc_stream_t stream)
+{
+    PAPC_REQUIRE(dy && wt && dy->y && dy->mean && dy->invstd && dy->scale && dy->shift && dy->c1 && dy->c2,
+                 PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: null pointer");
+    PAPC_REQUIRE(dx || scatter, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: need dx or scatter");
+    PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: bad sizes");
+    GemmArgs p;
+    memset(&p, 0, sizeof(p));
+    fill_dy(p.a.d, dy);
+    if (dy->dz_mode == PAPC_DZ_DENSE) {
+        PAPC_REQUIRE(dy->dz, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: DENSE needs dz");
+        p.a.vec = aligned16(dy->dz) && aligned16(dy->y) && (Cout % 4 == 0);
+    } else {
+        PAPC_REQUIRE(dy->gout && dy->argmax && dy->K >= 1 && M % dy->K == 0, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: MAX needs gout/argmax/K | M");
+        p.a.vec = aligned16(dy->gout) && aligned16(dy->y) && (Cout % 4 == 0);
+    }
+    // GEMM view: rows M, reduction over Cout, outputs Cin; weights = wt [Cin][Cout]
+    p.w = wt; p.ldw = Cout; p.M = M; p.Kin = Cout; p.Nout = Cin; p.y = dx; p.ldy = Cin;
+    p.wvec = aligned16(wt) && (Cout % 4 == 0);
+    if (scatter) {
+        PAPC_REQUIRE(scatter->grad_feats && scatter->D >= 1 && scatter->D + 3 == Cin, PAPC_E_INVALID,
+                     "papc_mlp_bwd_dx_f32: scatter needs grad_feats and D+3 == Cin");
+        p.sc.gf = scatter->grad_feats; p.sc.idx = scatter->idx; p.sc.N = scatter->N; p.sc.S = scatter->S;
+        p.sc.K = scatter->K; p.sc.D = scatter->D;
+        // output column n is internal order [feats, xyz]; weight row = caller's channel order
+        p.nmap = scatter->col0 ? 1 : 0;
+        p.a.g.D = scatter->D; p.a.g.xyz_first = scatter->col0 ? 1 : 0;
+        p.Nout = scatter->D;  // xyz columns carry no gradient: skip them entirely
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_DX, st);
+    if (scatter) {
+        return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_SCATTER>(p, st) : launch_gemm<A_DY_MAX, EPI_SCATTER>(p, st);
+    }
+    return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_STORE>(p, st) : launch_gemm<A_DY_MAX, EPI_STORE>(p, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+"""The reference's free functions, same names / argument order / layouts, on PyTorch-ROCm tensors.
+
+Mirrors /root/reference/PAPC/models/layers/pointnet2_basic_layers.py (``square_distance`` :26,
+``index_points`` :43, ``farthest_point_sample`` :65, ``query_ball_point`` :98, ``sample_and_group`` :129,
+``sample_and_group_all`` :160).  Every function launches hand-written gfx950 kernels through the C ABI in
+``include/papc_hip.h``; there is no eager/CPU fallback -- CPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.PapcError("papc_amd ops need CUDA(ROCm) tensors; got a %s tensor (no CPU fallback)" % t.device)
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+def radius_threshold(radius):
+    """``radius ** 2`` as the reference's comparison sees it: a python double rounded to fp32 (:112)."""
+    return ctypes.c_float(float(radius) * float(radius)).value
+
+
+def square_distance(src, dst):
+    """:26-40.  src [B,N,3], dst [B,M,3] -> [B,N,M] (API parity; the hot path never builds this matrix)."""
+    _need_cuda(src, dst)
+    src, dst = _f32c(src), _f32c(dst)
+    B, N, C = src.shape
+    M = dst.shape[1]
+    if C != 3 or dst.shape[2] != 3:
+        raise _lib.PapcError("square_distance: only C=3 is built (got %d)" % C)
+    out = torch.empty(B, N, M, device=src.device, dtype=torch.float32)
+    check(_lib.load().papc_square_distance_f32(ptr(src), ptr(dst), B, N, M, ptr(out), stream_ptr()), "papc_square_distance_f32")
+    return out
+
+
+def index_points(points, idx):
+    """:43-62.  points [B,N,C], idx [B,S] or [B,S,K] (any integer or float dtype, like the source) ->
+    [B,S,C] / [B,S,K,C].  Differentiable w.r.t. ``points`` (the reference cuts autograd here, :57-60)."""
+    return _IndexPoints.apply(points, idx)
+
+
+class _IndexPoints(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        _need_cuda(points, idx)
+        points = _f32c(points)
+        if idx.dtype not in (torch.int32, torch.int64):
+            idx = idx.to(torch.int64)  # idx_np.astype('int64')  (:59)
+        idx = idx.contiguous()
+        B, N, C = points.shape
+        S = idx[0].numel()
+        out = torch.empty(tuple(idx.shape) + (C,), device=points.device, dtype=torch.float32)
+        check(_lib.load().papc_index_points_f32(ptr(points), ptr(idx), int(idx.dtype == torch.int64), B, N, C, S,
+                                                ptr(out), stream_ptr()), "papc_index_points_f32")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, N, C, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, C, S = ctx.shape
+        g = _f32c(g)
+        gp = torch.zeros(B, N, C, device=g.device, dtype=torch.float32)
+        check(_lib.load().papc_index_points_bwd_f32(ptr(g), ptr(idx), int(idx.dtype == torch.int64), B, N, C, S,
+                                                    ptr(gp), stream_ptr()), "papc_index_points_bwd_f32")
+        return gp, None
+
+
+def _fps_raw(xyz, npoint, start_idx, init_dist=1.0, want_new_xyz=True):
+    """xyz [B,N,3] (any strides, e.g. a transposed [B,3,N]) -> (idx int32 [B,npoint], new_xyz [B,npoint,3])."""
+    _need_cuda(xyz)
+    if xyz.dtype != torch.float32:
+        xyz = xyz.float()
+    B, N, C = xyz.shape
+    assert C == 3
+    if start_idx is None:
+        start_idx = torch.randint(0, N, (B,), device=xyz.device, dtype=torch.int64)  # paddle.randint (:76)
+    start_idx = start_idx.to(device=xyz.device, dtype=torch.int64).contiguous()
+    idx = torch.empty(B, npoint, device=xyz.device, dtype=torch.int32)
+    new_xyz = torch.empty(B, npoint, 3, device=xyz.device, dtype=torch.float32) if want_new_xyz else None
+    check(_lib.load().papc_fps_f32(ptr(xyz), xyz.stride(0), xyz.stride(1), xyz.stride(2), B, N, npoint,
+                                   ptr(start_idx), float(init_dist), ptr(idx), ptr(new_xyz), stream_ptr()), "papc_fps_f32")
+    return idx, new_xyz
+
+
+def farthest_point_sample(xyz, npoint, start_idx=None, init_dist=1.0, as_float=False):
+    """:65-95.  xyz [B,N,3] -> sampled indices [B,npoint].
+
+    ``start_idx`` [B] pins the first centroid (the source draws it with paddle.randint, :76; ``None`` draws
+    it with torch.randint).  ``init_dist`` is the source's running-distance init (1.0, :75).  The source
+    returns float32 (``paddle.zeros`` :74): ``as_float=True`` reproduces that dtype; the default is int64.
+    """
+    idx, _ = _fps_raw(xyz, npoint, start_idx, init_dist, want_new_xyz=False)
+    return idx.float() if as_float else idx.long()
+
+
+def _ball_query_raw(radii, nsamples, xyz, new_xyz, idx64=False):
+    """All radii in one scan.  xyz [B,N,3] strided, new_xyz [B,S,3] -> list of [B,S,K_r] (int32 / int64)."""
+    _need_cuda(xyz, new_xyz)
+    if xyz.dtype != torch.float32:
+        xyz = xyz.float()
+    new_xyz = _f32c(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    n = len(radii)
+    dt = torch.int64 if idx64 else torch.int32
+    outs = [torch.empty(B, S, int(k), device=xyz.device, dtype=dt) for k in nsamples]
+    thr = (ctypes.c_float * n)(*[radius_threshold(r) for r in radii])
+    ns = (ctypes.c_int * n)(*[int(k) for k in nsamples])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    check(_lib.load().papc_ball_query_f32(ptr(xyz), xyz.stride(0), xyz.stride(1), xyz.stride(2), ptr(new_xyz), B, N, S,
+                                          n, ctypes.cast(thr, ctypes.c_void_p), ctypes.cast(ns, ctypes.c_void_p),
+                                          ctypes.cast(op, ctypes.c_void_p), int(idx64), stream_ptr()), "papc_ball_query_f32")
+    return outs
+
+
+def query_ball_point(radius, nsample, xyz, new_xyz):
+    """:98-126.  -> group_idx [B,S,nsample] int64 (the source's dtype)."""
+    return _ball_query_raw([radius], [nsample], xyz, new_xyz, idx64=True)[0]
+
+
+def _group_raw(xyz, new_xyz, feats, idx, xyz_first=True):
+    """[B,S,K,3+D] = concat(xyz[idx]-new_xyz, feats[idx]) (or feats first).  idx int32 [B,S,K]."""
+    B, N, _ = xyz.shape
+    S, K = idx.shape[1], idx.shape[2]
+    D = 0 if feats is None else feats.shape[2]
+    if feats is not None:
+        feats = _f32c(feats)
+    out = torch.empty(B, S, K, 3 + D, device=xyz.device, dtype=torch.float32)
+    check(_lib.load().papc_group_points_f32(ptr(xyz), xyz.stride(0), xyz.stride(1), xyz.stride(2), ptr(new_xyz), ptr(feats),
+                                            ptr(idx), B, N, S, K, D, int(xyz_first), ptr(out), stream_ptr()), "papc_group_points_f32")
+    return out
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, start_idx=None, init_dist=1.0):
+    """:129-157.  xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D]
+    (xyz-normalised coordinates first, :151)."""
+    _need_cuda(xyz, points)
+    if xyz.dtype != torch.float32:
+        xyz = xyz.float()
+    fps_idx, new_xyz = _fps_raw(xyz, npoint, start_idx, init_dist)                 # :143-144
+    idx = _ball_query_raw([radius], [nsample], xyz, new_xyz)[0]                    # :145
+    new_points = _group_raw(xyz, new_xyz, points, idx, xyz_first=True)             # :146-153
+    if returnfps:
+        grouped_xyz = index_points(xyz.contiguous(), idx)
+        return new_xyz, new_points, grouped_xyz, fps_idx.long()
+    return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """:160-176 (pure reshape/concat; raw xyz, not centred)."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device, dtype=xyz.dtype)
+    grouped_xyz = xyz.reshape(B, 1, N, C)
+    if points is not None:
+        new_points = torch.cat([grouped_xyz, points.reshape(B, 1, N, -1)], dim=-1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points

@@ -1,0 +1,118 @@
+"""PointNet++ set-abstraction layers with the reference's constructor and forward signatures.
+
+Mirrors /root/reference/PAPC/models/layers/pointnet2_basic_layers.py: ``PointNetSetAbstraction`` :179-221 and
+``PointNetSetAbstractionMsg`` :224-281.  forward(xyz [B,3,N], points [B,D,N] | None) -> (new_xyz [B,3,S],
+new_points [B,D',S]).  The returned tensors are transposed *views* of point-major buffers ([B,S,3], [B,S,D']),
+so chaining layers costs no transposes: the next layer's ``.transpose(1,2)`` (:203-205) is contiguous again.
+
+Deliberate, flagged deviations from the source:
+  * the conv/BN parameters are registered (``nn.ModuleList``) and trained; the source keeps them in plain Python
+    lists (:185-191, :230-241) so its optimiser never sees them;
+  * gradients flow through the gathers; the source cuts autograd at every ``index_points`` (:57-60).
+  ``reference_quirks=True`` restores both behaviours (SA parameters frozen, gather gradients cut).
+  * as in the source, the SA BatchNorms always normalise with batch statistics (``.eval()`` never reaches them).
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from .mlp import StackSpec, shared_mlp_max
+
+
+def _stack_params(convs, bns):
+    ps = []
+    for conv, bn in zip(convs, bns):
+        ps += [conv.weight, conv.bias, bn.weight, bn.bias]
+    return ps
+
+
+def _bn_buffers(bns):
+    return [(bn.running_mean, bn.running_var) for bn in bns]
+
+
+class PointNetSetAbstraction(nn.Module):
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, reference_quirks=False, init_dist=1.0):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1))      # :189
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel, eps=1e-5))          # :190 (paddle default epsilon)
+            last_channel = out_channel
+        self.group_all = group_all
+        self.reference_quirks = reference_quirks
+        self.init_dist = init_dist   # the source initialises the FPS running distance with ones (:75)
+        if reference_quirks:
+            for p in self.parameters():
+                p.requires_grad_(False)
+
+    def forward(self, xyz, points, start_idx=None):
+        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]."""
+        xyz = xyz.transpose(1, 2)                                               # :203  [B,N,3] view
+        if xyz.dtype != torch.float32:
+            xyz = xyz.float()
+        feats = None
+        if points is not None:
+            feats = points.transpose(1, 2).contiguous().float()                 # :205  [B,N,D]
+        B, N, _ = xyz.shape
+        D = 0 if feats is None else feats.shape[2]
+        if self.group_all:                                                      # sample_and_group_all :160-176
+            S, K = 1, N
+            new_xyz = torch.zeros(B, 1, 3, device=xyz.device, dtype=torch.float32)
+            idx = None
+        else:                                                                   # sample_and_group :129-157
+            S, K = self.npoint, self.nsample
+            _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)
+            idx = F_._ball_query_raw([self.radius], [K], xyz, new_xyz)[0]
+        spec = StackSpec(B, N, S, K, D, xyz_first=True, eps=self.mlp_bns[0].eps, momentum=0.9,
+                         cut_gather_grad=self.reference_quirks)
+        out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx,
+                             _stack_params(self.mlp_convs, self.mlp_bns))       # :214-219
+        new_points = out.view(B, S, -1).transpose(1, 2)                         # [B,D',S]
+        return new_xyz.transpose(1, 2), new_points                              # :220-221
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list, reference_quirks=False, init_dist=1.0):
+        super().__init__()
+        self.npoint, self.radius_list, self.nsample_list = npoint, radius_list, nsample_list
+        self.conv_blocks = nn.ModuleList()
+        self.bn_blocks = nn.ModuleList()
+        for i in range(len(mlp_list)):
+            convs, bns = nn.ModuleList(), nn.ModuleList()
+            last_channel = in_channel + 3                                       # :235
+            for out_channel in mlp_list[i]:
+                convs.append(nn.Conv2d(last_channel, out_channel, 1))
+                bns.append(nn.BatchNorm2d(out_channel, eps=1e-5))
+                last_channel = out_channel
+            self.conv_blocks.append(convs)
+            self.bn_blocks.append(bns)
+        self.reference_quirks = reference_quirks
+        self.init_dist = init_dist
+        if reference_quirks:
+            for p in self.parameters():
+                p.requires_grad_(False)
+
+    def forward(self, xyz, points, start_idx=None):
+        xyz = xyz.transpose(1, 2)                                               # :252
+        if xyz.dtype != torch.float32:
+            xyz = xyz.float()
+        feats = None
+        if points is not None:
+            feats = points.transpose(1, 2).contiguous().float()
+        B, N, _ = xyz.shape
+        D = 0 if feats is None else feats.shape[2]
+        S = self.npoint
+        _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)             # :258 (one FPS for all radii)
+        idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz)   # :260-262, one scan
+        outs = []
+        for i, K in enumerate(self.nsample_list):
+            spec = StackSpec(B, N, S, K, D, xyz_first=False, eps=self.bn_blocks[i][0].eps, momentum=0.9,
+                             cut_gather_grad=self.reference_quirks)             # feats first, then xyz (:267)
+            o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats, idxs[i],
+                               _stack_params(self.conv_blocks[i], self.bn_blocks[i]))   # :271-276
+            outs.append(o.view(B, S, -1))
+        new_points_concat = torch.cat(outs, dim=2).transpose(1, 2)              # :280  [B,D',S]
+        return new_xyz.transpose(1, 2), new_points_concat

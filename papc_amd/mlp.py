@@ -1,0 +1,205 @@
+"""Shared pointwise MLP stack -- relu(bn(conv1x1(x))) x L, then max over the K rows of each group -- as ONE
+autograd node driving the HIP kernels (include/papc_hip.h: papc_mlp_gemm_f32, papc_bn_finalize_f32,
+papc_bn_relu_max_f32 and the papc_*bwd* family).
+
+Reference: /root/reference/PAPC/models/layers/pointnet2_basic_layers.py:214-219 (SSG), :271-276 (MSG),
+/root/reference/PAPC/models/classify/pointnet_base/pointnet_base.py:7-25,44 (PointNet-Basic Conv1D stack).
+
+What is stored between forward and backward: only the pre-BN conv outputs y_l [M,C_l], the per-channel BN
+constants and the argmax of the final max.  Grouped input rows, BN+ReLU activations and dY are recomputed
+inside the operand loads of the MFMA kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import BwdDy, GroupSrc, ScatterDst, check, ptr, stream_ptr
+
+A_PLAIN, A_BNRELU, A_GROUP = 0, 1, 2
+DZ_DENSE, DZ_MAX = 0, 1
+
+
+class StackSpec:
+    """Static description of one stack invocation (not a tensor; passed through autograd untouched)."""
+
+    def __init__(self, B, N, S, K, D, xyz_first, eps=1e-5, momentum=0.9, cut_gather_grad=False):
+        self.B, self.N, self.S, self.K, self.D = B, N, S, K, D
+        self.xyz_first = bool(xyz_first)
+        self.eps, self.momentum = float(eps), float(momentum)
+        self.cut_gather_grad = cut_gather_grad
+        self.M = B * S * K
+
+
+def _group_src(spec, xyz, new_xyz, feats, idx):
+    g = GroupSrc()
+    g.xyz = xyz.data_ptr()
+    g.sb, g.sn, g.sc = xyz.stride(0), xyz.stride(1), xyz.stride(2)
+    g.new_xyz = new_xyz.data_ptr()
+    g.feats = ptr(feats)
+    g.idx = ptr(idx)
+    g.N, g.S, g.K, g.D = spec.N, spec.S, spec.K, spec.D
+    g.xyz_first = int(spec.xyz_first)
+    return g
+
+
+def _dw_rows_per_chunk(M, cout, cin):
+    """Row-chunk size for the dW kernel: aim for >= ~512 workgroups in total, chunks of >= 256 rows."""
+    tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
+    want = max(1, 768 // tiles)
+    rpc = (M + want - 1) // want
+    rpc = max(256, ((rpc + 31) // 32) * 32)
+    return rpc
+
+
+class SharedMLPMax(torch.autograd.Function):
+    """out[g, :] = max_{k<K} relu(bn_L(conv_L(... relu(bn_1(conv_1(rows)))...)))   with rows gathered on the fly.
+
+    apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, w1, b1, gamma1, beta1, w2, ...)
+      x_rows   None, or plain input rows [M, Cin] (then xyz/new_xyz/feats/idx are ignored: PFNLayer)
+      xyz      [B,N,3] any strides        new_xyz [B,S,3] contiguous
+      feats    [B,N,D] contiguous or None idx     [B,S,K] int32 or None (identity: S=1, K=N)
+      w_l      [C_l, C_{l-1}] (conv weight, trailing 1x1 dims dropped); b_l, gamma_l, beta_l [C_l]
+      bn_buffers: list of (running_mean, running_var) per layer (updated in place) or None
+    returns [B*S, C_L]
+    """
+
+    @staticmethod
+    def forward(ctx, spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params):
+        lib = _lib.load()
+        st = stream_ptr()
+        dev = params[0].device
+        L = len(params) // 4
+        M = spec.M
+        parts = lib.papc_mlp_gemm_parts(M)
+        plain = x_rows is not None
+        grp = None if plain else _group_src(spec, xyz, new_xyz, feats, idx)
+        ys, consts = [], []
+        prev_y, prev_sc, prev_sh = None, None, None
+        cin = x_rows.shape[1] if plain else spec.D + 3
+        cin0 = cin
+        for l in range(L):
+            w, b, gamma, beta = params[4 * l: 4 * l + 4]
+            cout = w.shape[0]
+            w2 = w.reshape(cout, cin)
+            assert w2.is_contiguous()
+            y = torch.empty(M, cout, device=dev, dtype=torch.float32)
+            stats = torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
+            if l == 0 and plain:
+                check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(x_rows), cin, None, None, None, ptr(w2), ptr(b), M, cin, cout,
+                                            ptr(y), ptr(stats), st), "papc_mlp_gemm_f32")
+            elif l == 0:
+                check(lib.papc_mlp_gemm_f32(A_GROUP, None, 0, ctypes.byref(grp), None, None, ptr(w2), ptr(b), M, cin, cout,
+                                            ptr(y), ptr(stats), st), "papc_mlp_gemm_f32")
+            else:
+                check(lib.papc_mlp_gemm_f32(A_BNRELU, ptr(prev_y), cin, None, ptr(prev_sc), ptr(prev_sh), ptr(w2), ptr(b), M, cin,
+                                            cout, ptr(y), ptr(stats), st), "papc_mlp_gemm_f32")
+            cst = torch.empty(4, cout, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
+            rm, rv = (bn_buffers[l] if bn_buffers is not None else (None, None))
+            check(lib.papc_bn_finalize_f32(ptr(stats), parts, M, cout, ptr(gamma), ptr(beta), spec.eps, spec.momentum,
+                                           cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(),
+                                           ptr(rm), ptr(rv), st), "papc_bn_finalize_f32")
+            ys.append(y)
+            consts.append(cst)
+            prev_y, prev_sc, prev_sh = y, cst[2], cst[3]
+            cin = cout
+        G = spec.B * spec.S
+        out = torch.empty(G, cin, device=dev, dtype=torch.float32)
+        argmax = torch.empty(G, cin, device=dev, dtype=torch.int32)
+        check(lib.papc_bn_relu_max_f32(ptr(prev_y), ptr(prev_sc), ptr(prev_sh), G, spec.K, cin, ptr(out), ptr(argmax), st),
+              "papc_bn_relu_max_f32")
+        ctx.spec = spec
+        ctx.L = L
+        ctx.feats_needs_grad = feats is not None and feats.requires_grad and not spec.cut_gather_grad
+        ctx.x_needs_grad = plain and x_rows.requires_grad
+        ctx.cin0 = cin0
+        ctx.save_for_backward(xyz, new_xyz, feats, idx, x_rows, argmax, *params, *ys, *consts)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        st = stream_ptr()
+        spec, L = ctx.spec, ctx.L
+        saved = ctx.saved_tensors
+        xyz, new_xyz, feats, idx, x_rows, argmax = saved[:6]
+        params = saved[6:6 + 4 * L]
+        ys = saved[6 + 4 * L: 6 + 5 * L]
+        consts = saved[6 + 5 * L: 6 + 6 * L]
+        plain = x_rows is not None
+        dev = gout.device
+        M = spec.M
+        gout = gout.contiguous().float()
+        grp = None if plain else _group_src(spec, xyz, new_xyz, feats, idx)
+        n_parts = min(1024, (M + 127) // 128)
+        grads = [None] * (4 * L)
+        grad_feats = None
+        grad_x = None
+        dz = None
+        for l in range(L - 1, -1, -1):
+            w = params[4 * l]
+            cout = w.shape[0]
+            cin = ctx.cin0 if l == 0 else params[4 * (l - 1)].shape[0]
+            w2 = w.reshape(cout, cin)
+            cst = consts[l]
+            c12 = torch.empty(2, cout, device=dev, dtype=torch.float32)
+            dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)  # dgamma, dbeta
+            red = torch.empty(n_parts, 2, cout, device=dev, dtype=torch.float32)
+            dy = BwdDy()
+            if l == L - 1:
+                dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_MAX, None, gout.data_ptr(), argmax.data_ptr(), spec.K
+            else:
+                dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_DENSE, dz.data_ptr(), None, None, 1
+            dy.y = ys[l].data_ptr()
+            dy.mean, dy.invstd, dy.scale, dy.shift = (cst[i].data_ptr() for i in range(4))
+            dy.c1, dy.c2 = c12[0].data_ptr(), c12[1].data_ptr()
+            check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
+                                             dy.shift, M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
+            check(lib.papc_bn_bwd_finalize_f32(ptr(red), n_parts, M, cout, dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                               c12[0].data_ptr(), c12[1].data_ptr(), st), "papc_bn_bwd_finalize_f32")
+            # ---- dW, db
+            rpc = _dw_rows_per_chunk(M, cout, cin)
+            n_chunks = (M + rpc - 1) // rpc
+            dwp = torch.empty(n_chunks, cout, cin, device=dev, dtype=torch.float32)
+            dbp = torch.empty(n_chunks, cout, device=dev, dtype=torch.float32)
+            if l == 0 and plain:
+                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_PLAIN, ptr(x_rows), cin, None, None, None, M, cin, cout, rpc,
+                                              ptr(dwp), ptr(dbp), st), "papc_mlp_bwd_dw_f32")
+            elif l == 0:
+                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_GROUP, None, 0, ctypes.byref(grp), None, None, M, cin, cout, rpc,
+                                              ptr(dwp), ptr(dbp), st), "papc_mlp_bwd_dw_f32")
+            else:
+                pc = consts[l - 1]
+                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_BNRELU, ys[l - 1].data_ptr(), cin, None, pc[2].data_ptr(),
+                                              pc[3].data_ptr(), M, cin, cout, rpc, ptr(dwp), ptr(dbp), st), "papc_mlp_bwd_dw_f32")
+            dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
+            db = torch.empty(cout, device=dev, dtype=torch.float32)
+            check(lib.papc_reduce_partials_f32(ptr(dwp), n_chunks, cout * cin, ptr(dw), st), "papc_reduce_partials_f32")
+            check(lib.papc_reduce_partials_f32(ptr(dbp), n_chunks, cout, ptr(db), st), "papc_reduce_partials_f32")
+            grads[4 * l + 0] = dw.reshape(w.shape)
+            grads[4 * l + 1] = db
+            grads[4 * l + 2] = dgb[0]
+            grads[4 * l + 3] = dgb[1]
+            # ---- dX
+            if l > 0:
+                wt = w2.t().contiguous()
+                dz_prev = torch.empty(M, cin, device=dev, dtype=torch.float32)
+                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dz_prev), None, st), "papc_mlp_bwd_dx_f32")
+                dz = dz_prev
+            elif plain and ctx.x_needs_grad:
+                wt = w2.t().contiguous()
+                grad_x = torch.empty(M, cin, device=dev, dtype=torch.float32)
+                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(grad_x), None, st), "papc_mlp_bwd_dx_f32")
+            elif (not plain) and ctx.feats_needs_grad:
+                wt = w2.t().contiguous()
+                grad_feats = torch.zeros(spec.B, spec.N, spec.D, device=dev, dtype=torch.float32)
+                sc = ScatterDst()
+                sc.grad_feats, sc.idx = grad_feats.data_ptr(), ptr(idx)
+                sc.N, sc.S, sc.K, sc.D = spec.N, spec.S, spec.K, spec.D
+                sc.col0 = 3 if spec.xyz_first else 0
+                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, None, ctypes.byref(sc), st), "papc_mlp_bwd_dx_f32")
+        return (None, None, None, None, grad_feats, None, grad_x) + tuple(grads)
+
+
+def shared_mlp_max(spec, bn_buffers, xyz, new_xyz, feats, idx, params, x_rows=None):
+    return SharedMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)

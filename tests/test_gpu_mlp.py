@@ -1,0 +1,159 @@
+"""GPU parity of the MFMA MLP stack (forward vs the oracle, backward vs a torch float64 autograd reference)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+from papc_amd import functional as F
+from papc_amd.layers import PointNetSetAbstraction, PointNetSetAbstractionMsg
+from papc_amd.mlp import StackSpec, shared_mlp_max
+from papc_amd.synthetic import make_clouds, make_start_idx
+from tests import torch_ref
+from tests.util import assert_close, seeded_weights
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5   # north-star tolerance for MLP activations
+
+
+def _load_stack(convs, bns, ws, dev):
+    with torch.no_grad():
+        for conv, bn, (w, b, g, bt) in zip(convs, bns, ws):
+            conv.weight.copy_(torch.from_numpy(w).reshape(conv.weight.shape))
+            conv.bias.copy_(torch.from_numpy(b))
+            bn.weight.copy_(torch.from_numpy(g))
+            bn.bias.copy_(torch.from_numpy(bt))
+
+
+@pytest.mark.parametrize("B,N,npoint,radius,nsample,D,mlp", [
+    (2, 1024, 128, 0.2, 32, 0, [64, 64, 128]),        # SA1-shaped (no features)
+    (2, 512, 64, 0.4, 64, 128, [128, 128, 256]),       # SA2-shaped (131 input channels)
+    (3, 300, 20, 0.3, 16, 5, [32, 48, 20]),            # ragged everything: odd N, D%4!=0, Cout%32!=0
+    (1, 256, 16, 0.25, 8, 3, [16]),                    # single layer stack
+])
+def test_sa_forward_vs_oracle(dev, B, N, npoint, radius, nsample, D, mlp):
+    x = make_clouds(B, N, 77 + N)
+    st = make_start_idx(B, N, 3)
+    rng = np.random.default_rng(9)
+    pts = rng.normal(size=(B, D, N)).astype(np.float32) if D else None
+    ws = seeded_weights([D + 3] + mlp, 5)
+    ora = R.PointNetSetAbstraction(npoint, radius, nsample, D + 3, mlp, False, ws)
+    ref_xyz, ref32, acts = ora.forward(x, pts, st, f64=False, return_all=True)
+    _, ref64 = ora.forward(x, pts, st, f64=True)
+    layer = PointNetSetAbstraction(npoint, radius, nsample, D + 3, mlp, False).to(dev)
+    _load_stack(layer.mlp_convs, layer.mlp_bns, ws, dev)
+    got_xyz, got = layer(torch.from_numpy(x).to(dev), None if pts is None else torch.from_numpy(pts).to(dev),
+                         torch.from_numpy(st).to(dev))
+    assert tuple(got_xyz.shape) == (B, 3, npoint) and tuple(got.shape) == (B, mlp[-1], npoint)
+    assert np.array_equal(got_xyz.cpu().numpy(), ref_xyz)
+    e64 = assert_close(got.detach().cpu().numpy(), ref64, REL, "vs f64 oracle")
+    e32 = assert_close(got.detach().cpu().numpy(), ref32, REL, "vs f32 oracle")
+    print("rel err vs f64 %.2e, vs f32 %.2e" % (e64, e32))
+
+
+def test_sa_group_all_vs_oracle(dev):
+    B, N, D = 2, 128, 256
+    x = make_clouds(B, N, 5)
+    rng = np.random.default_rng(1)
+    pts = rng.normal(size=(B, D, N)).astype(np.float32)
+    mlp = [256, 512, 1024]
+    ws = seeded_weights([D + 3] + mlp, 6)
+    ora = R.PointNetSetAbstraction(None, None, None, D + 3, mlp, True, ws)
+    ref_xyz, ref64 = ora.forward(x, pts, f64=True)
+    layer = PointNetSetAbstraction(None, None, None, D + 3, mlp, True).to(dev)
+    _load_stack(layer.mlp_convs, layer.mlp_bns, ws, dev)
+    got_xyz, got = layer(torch.from_numpy(x).to(dev), torch.from_numpy(pts).to(dev))
+    assert np.array_equal(got_xyz.cpu().numpy(), ref_xyz)
+    assert_close(got.detach().cpu().numpy(), ref64, REL, "group_all vs f64 oracle")
+
+
+def test_sa_msg_vs_oracle(dev):
+    B, N, S = 2, 1024, 128
+    x = make_clouds(B, N, 15)
+    st = make_start_idx(B, N, 4)
+    rng = np.random.default_rng(2)
+    pts = rng.normal(size=(B, 3, N)).astype(np.float32)
+    radii, ks, mlps = [0.1, 0.2, 0.4], [16, 32, 64], [[32, 32, 64], [64, 64, 128], [64, 96, 128]]
+    ws = [seeded_weights([6] + m, 20 + i) for i, m in enumerate(mlps)]
+    ora = R.PointNetSetAbstractionMsg(S, radii, ks, 3, mlps, ws)
+    ref_xyz, ref64 = ora.forward(x, pts, st, f64=True)
+    layer = PointNetSetAbstractionMsg(S, radii, ks, 3, mlps).to(dev)
+    for i in range(3):
+        _load_stack(layer.conv_blocks[i], layer.bn_blocks[i], ws[i], dev)
+    got_xyz, got = layer(torch.from_numpy(x).to(dev), torch.from_numpy(pts).to(dev), torch.from_numpy(st).to(dev))
+    assert tuple(got.shape) == (B, 320, S)
+    assert np.array_equal(got_xyz.cpu().numpy(), ref_xyz)
+    assert_close(got.detach().cpu().numpy(), ref64, REL, "MSG vs f64 oracle")
+
+
+@pytest.mark.parametrize("B,N,S,K,D,mlp,xyz_first,use_idx", [
+    (2, 512, 64, 32, 0, [64, 64, 128], True, True),
+    (2, 256, 32, 16, 128, [128, 64], True, True),
+    (2, 256, 32, 16, 12, [32, 40, 24], False, True),     # MSG channel order, ragged widths
+    (2, 128, 1, 128, 64, [64, 128], True, False),          # group_all: identity rows
+    (1, 200, 10, 8, 6, [16], True, True),                  # single-layer stack (MAX-mode dY with GROUP input)
+])
+def test_stack_backward_vs_torch(dev, B, N, S, K, D, mlp, xyz_first, use_idx):
+    x = make_clouds(B, N, 31 + N)
+    xyz = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 1)).to(dev)
+    rng = np.random.default_rng(8)
+    feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev) if D else None
+    if use_idx:
+        _, new_xyz = F._fps_raw(xyz, S, st)
+        idx = F._ball_query_raw([0.3], [K], xyz, new_xyz)[0]
+    else:
+        new_xyz = torch.zeros(B, 1, 3, device=dev)
+        idx = None
+    ws = seeded_weights([D + 3] + mlp, 40)
+    params = []
+    for (w, b, g, bt) in ws:
+        params += [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b, g, bt)]
+    if feats is not None:
+        feats.requires_grad_(True)
+    spec = StackSpec(B, N, S, K, D, xyz_first)
+    out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+    gout = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+    out.backward(gout)
+
+    # float64 torch reference on the same indices
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    f64 = feats.detach().double().requires_grad_(True) if feats is not None else None
+    ridx = idx if idx is not None else torch.arange(N, device=dev).view(1, 1, N).expand(B, 1, N)
+    rows = torch_ref.group(xyz.double(), new_xyz.double(), f64, ridx, xyz_first).reshape(B * S * K, D + 3)
+    ref = torch_ref.stack_max(rows, [tuple(p64[4 * l:4 * l + 4]) for l in range(len(mlp))], K, 1e-5)
+    assert_close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), REL, "stack forward")
+    ref.backward(gout.double())
+    names = ["w", "b", "gamma", "beta"]
+    for l in range(len(mlp)):
+        for j in range(4):
+            got, want = params[4 * l + j].grad, p64[4 * l + j].grad
+            if j == 1:
+                # conv bias feeds a train-mode BN: its true gradient is exactly zero; both sides hold rounding noise
+                scale = float(p64[4 * l].grad.abs().max())
+                assert float(got.abs().max()) <= 1e-4 * scale, "db layer %d not ~0" % l
+                continue
+            assert_close(got.cpu().numpy(), want.cpu().numpy(), 2e-4, "d%s layer %d" % (names[j], l))
+    if feats is not None:
+        assert_close(feats.grad.cpu().numpy(), f64.grad.cpu().numpy(), 2e-4, "dfeats")
+
+
+def test_full_size_sa1_properties(dev):
+    """BASELINE config 2, SA1 at full size (B=32, N=4096): BN'd output is a max over K -> invariant to permuting
+    the nsample slots, and equal for duplicated (padded) neighbour lists; checked through shuffled idx."""
+    B, N, S, K = 32, 4096, 512, 32
+    x = torch.from_numpy(make_clouds(B, N, 1234)).to(dev)
+    xyz = x.transpose(1, 2)
+    st = torch.from_numpy(make_start_idx(B, N, 1234)).to(dev)
+    _, new_xyz = F._fps_raw(xyz, S, st)
+    idx = F._ball_query_raw([0.2], [K], xyz, new_xyz)[0]
+    ws = seeded_weights([3, 64, 64, 128], 1)
+    params = [torch.from_numpy(a).to(dev) for tup in ws for a in tup]
+    spec = StackSpec(B, N, S, K, 0, True)
+    out1 = shared_mlp_max(spec, None, xyz, new_xyz, None, idx, params)
+    perm = torch.randperm(K, device=dev)
+    out2 = shared_mlp_max(spec, None, xyz, new_xyz, None, idx[:, :, perm].contiguous(), params)
+    assert torch.isfinite(out1).all()
+    assert_close(out2.cpu().numpy(), out1.cpu().numpy(), 1e-5, "slot-permutation invariance")
+    out3 = shared_mlp_max(spec, None, xyz, new_xyz, None, idx, params)
+    assert torch.equal(out1, out3)                     # deterministic: no atomics in the forward

