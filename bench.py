@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- the reference's headline metric on MI355X:
+point-clouds/sec (fwd+bwd) of PointNet++ SSG classify, B=32 per GPU, N=4096 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one synthetic batch: forward (FPS, ball query, fused gather + MFMA MLP
+stacks, FC head), cross-entropy, backward through every layer, one flat-bucket gradient all-reduce (N>1), one Adam
+step (the reference's loop, /root/reference/PAPC/train.py:102-116).  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events (library-side event pairs on the
+launch stream) around the dominant kernel family over the timed region; `cpu_baseline` times the torch-CPU port of
+the reference's op decomposition (oracle/torch_cpu_reference.py) on the host cores of this box.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (6.3 TB/s measured achievable)
+
+K_NAMES = ["fps", "ball_query", "group", "mlp_gemm_fwd", "bn_relu_max", "bwd_bn_reduce", "bwd_dx_gemm", "bwd_dw_gemm", "pfn", "misc"]
+K_MLP_GEMM, K_BN_RELU_MAX, K_BWD_REDUCE, K_BWD_DX, K_BWD_DW, K_FPS, K_BQ = 3, 4, 5, 6, 7, 0, 1
+
+
+def ssg_layers(B, N):
+    """(M rows, [channel widths]) of the three SA stacks of PointNet2_SSG_Clas for one per-GPU batch."""
+    return [(B * 512 * 32, [3, 64, 64, 128], 0), (B * 128 * 64, [131, 128, 128, 256], 128), (B * 1 * 128, [259, 256, 512, 1024], 256)]
+
+
+def algorithmic_work(B, N):
+    """ALGORITHMIC work per step per family (DESIGN.md 'Measurement'): FLOP for the MFMA families, bytes for the
+    HBM-bound ones.  {family: (amount, 'flop'|'byte')}"""
+    w = {}
+    fwd = dx = 0.0
+    for M, ch, D in ssg_layers(B, N):
+        for l in range(3):
+            fwd += 2.0 * M * ch[l] * ch[l + 1]
+            if l > 0:
+                dx += 2.0 * M * ch[l] * ch[l + 1]
+            elif D:
+                dx += 2.0 * M * D * ch[1]             # only the feature columns carry gradient
+    w[K_MLP_GEMM] = (fwd, "flop")
+    w[K_BWD_DW] = (fwd, "flop")
+    w[K_BWD_DX] = (dx, "flop")
+    w[K_FPS] = ((B * 512 * N + B * 128 * 512) * 20.0, "byte")
+    w[K_BQ] = ((B * 512 * N + B * 128 * 512) * 12.0, "byte")
+    w[K_BN_RELU_MAX] = (sum(M * ch[3] * 4.0 for M, ch, _ in ssg_layers(B, N)), "byte")
+    w[K_BWD_REDUCE] = (sum(2.0 * M * (ch[1] + ch[2]) * 4.0 for M, ch, _ in ssg_layers(B, N)), "byte")
+    return w
+
+
+def prof_read(lib):
+    out = {}
+    for k in range(len(K_NAMES)):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        lib.papc_prof_read(k, ctypes.byref(ms), ctypes.byref(n))
+        out[k] = (ms.value, n.value)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config: 32)")
+    ap.add_argument("--npoints", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
+    args = ap.parse_args()
+
+    from papc_amd import _lib
+    from papc_amd.distributed import FlatAdam, FlatParams, init_from_env
+    from papc_amd.models import PointNet2_SSG_Clas
+    from papc_amd.synthetic import make_clouds, make_labels, make_start_idx
+
+    rank, world, local = init_from_env()
+    assert world == max(1, args.gpus) or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    lib = _lib.load()
+
+    B, N = args.batch, args.npoints
+    torch.manual_seed(1234)                       # same initial weights on every rank (then broadcast anyway)
+    model = PointNet2_SSG_Clas(num_classes=16).to(dev)
+    model.train()
+    flat = FlatParams(model)
+    flat.broadcast(0)
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=1e-3)
+
+    seed = 1234 + rank                            # each rank owns its own shard of clouds
+    x = torch.from_numpy(make_clouds(B, N, seed)).to(dev)
+    y = torch.from_numpy(make_labels(B, 16, seed)).reshape(-1).to(dev)
+    s1 = torch.from_numpy(make_start_idx(B, N, seed)).to(dev)
+    s2 = torch.from_numpy(make_start_idx(B, 512, seed + 1)).to(dev)
+
+    def step():
+        flat.zero_grad()
+        logits = model(x, (s1, s2))
+        loss = F.cross_entropy(logits, y)
+        loss.backward()
+        scale = flat.allreduce_grads()
+        opt.step(scale)
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # ---- warmup, then an untimed 3-step pass with the event profiler on every family to find the dominant one
+    loss = None
+    for _ in range(max(1, args.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    lib.papc_prof_enable(0x3FF)
+    lib.papc_prof_reset()
+    NPROF = 3
+    for _ in range(NPROF):
+        loss = step()
+    torch.cuda.synchronize()
+    fam = prof_read(lib)
+    dominant = max((k for k in fam if k != 9), key=lambda k: fam[k][0])
+    if args.profile_all and rank == 0:
+        tot = sum(v[0] for v in fam.values())
+        for k, (ms, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+            print("  %-14s %8.3f ms/step  %4d launches/step  %5.1f%%" % (K_NAMES[k], ms / NPROF, n // NPROF,
+                                                                         100.0 * ms / max(tot, 1e-9)), file=sys.stderr)
+    lib.papc_prof_enable(1 << dominant)           # timed region: event pairs only around the dominant family
+    lib.papc_prof_reset()
+
+    # ---- timed region
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    dom_ms, dom_n = prof_read(lib)[dominant]
+    lib.papc_prof_enable(0)
+    final_loss = float(loss.item())
+    assert final_loss == final_loss, "loss is NaN"
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        work, kind = algorithmic_work(B, N)[dominant] if dominant in algorithmic_work(B, N) else (0.0, "byte")
+        per_step_s = (dom_ms / 1e3) / args.steps if dom_ms > 0 else float("nan")
+        if kind == "flop":
+            achieved = work / per_step_s / 1e12
+            roof = {"bound": "mfma", "kernel": K_NAMES[dominant], "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None}
+        else:
+            achieved = work / per_step_s / 1e9
+            roof = {"bound": "hbm", "kernel": K_NAMES[dominant], "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+        roof["launches_per_step"] = dom_n // args.steps
+        roof["avg_launch_ms"] = round(dom_ms / max(1, dom_n), 4)
+        roof["ms_per_step"] = round(dom_ms / args.steps, 3)
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(N)
+        out = {
+            "metric": "point-clouds/sec (fwd+bwd) PointNet++SSG B=32 N=4096",
+            "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(N):
+    """torch-CPU port of the reference's op decomposition, one full train step, on this box's host cores.
+    Bounded: a 2-cloud probe decides whether the full B=32 step fits the ~10-30 s budget."""
+    from oracle import torch_cpu_reference as T
+    cores = len(os.sched_getaffinity(0))
+    threads = min(cores, 64)
+    t_probe, _ = T.time_train_step(2, N, threads)
+    Bs = 32 if t_probe * 16 < 45 else (8 if t_probe * 4 < 45 else 2)
+    if Bs == 2:
+        t, cps = t_probe, 2 / t_probe
+    else:
+        t, cps = T.time_train_step(Bs, N, threads)
+    return {"value": round(cps, 3), "unit": "point-clouds/s", "cores": threads, "kind": "port",
+            "sample": "1 fwd+bwd+Adam step of the torch-CPU transliteration (oracle/torch_cpu_reference.py), B=%d N=%d, %.1f s"
+                      % (Bs, N, t)}
+
+
+if __name__ == "__main__":
+    main()

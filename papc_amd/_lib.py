@@ -75,6 +75,9 @@ def load():
     """Return the loaded library with typed signatures; raises PapcError when it is not built."""
     global _lib
     if _lib is None:
+        # torch must own the process's HIP runtime: it bundles its own libamdhip64, and loading ours first would pull
+        # in /opt/rocm's copy as a second, device-less runtime ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise PapcError("libpapc_hip.so not found at %s -- build it with `python -m papc_amd.build` "
                             "(there is no CPU fallback)" % LIB_PATH)

@@ -26,24 +26,24 @@ template <> struct Vec<1> {
 // ---------------------------------------------------------------------------------------------------
 // stats partials [n_tiles][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           float eps, float momentum, float *mean, float *invstd, float *scale,
                                                           float *shift, float *rmean, float *rvar)
 {
-    __shared__ double r1[8][32], r2[8][32];
-    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double r1[64][16], r2[64][16];
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 channels x 64 part-lanes
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int t = tl; t < n_tiles; t += 8) {
+        for (int t = tl; t < n_tiles; t += 64) {
             s1 += (double)part[((int64_t)t * 2 + 0) * C + c];
             s2 += (double)part[((int64_t)t * 2 + 1) * C + c];
         }
     r1[tl][cl] = s1; r2[tl][cl] = s2;
     __syncthreads();
     if (tl == 0 && c < C) {
-        for (int g = 1; g < 8; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
+        for (int g = 1; g < 64; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
         const double mu = s1 / (double)M;
         double var = s2 / (double)M - mu * mu;  // biased variance (paddle BatchNorm training)
         if (var < 0.0) var = 0.0;
@@ -182,22 +182,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
                                                               float *dgamma, float *dbeta, float *c1, float *c2)
 {
-    __shared__ double r1[8][32], r2[8][32];
-    const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double r1[64][16], r2[64][16];
+    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 channels x 64 part-lanes
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int t = tl; t < n_tiles; t += 8) {
+        for (int t = tl; t < n_tiles; t += 64) {
             s1 += (double)part[((int64_t)t * 2 + 0) * C + c];
             s2 += (double)part[((int64_t)t * 2 + 1) * C + c];
         }
     r1[tl][cl] = s1; r2[tl][cl] = s2;
     __syncthreads();
     if (tl == 0 && c < C) {
-        for (int g = 1; g < 8; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
+        for (int g = 1; g < 64; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
         if (dbeta) dbeta[c] = (float)s1;
         if (dgamma) dgamma[c] = (float)s2;
         c1[c] = (float)(s1 / (double)M);
@@ -205,12 +205,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
     }
 }
 
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int n_chunks, int64_t n,
-                                                              float *__restrict__ out)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ part, int n_chunks, int64_t n,
+                                                               float *__restrict__ out)
 {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int t = 0; t < n_chunks; ++t) s += part[(int64_t)t * n + i];
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
+    const int64_t i = (int64_t)blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (i < n)
+        for (int t = cl; t < n_chunks; t += 16) s += part[(int64_t)t * n + i];
+    red[cl][el] = s;
+    __syncthreads();
+    if (cl == 0 && i < n) {
+#pragma unroll
+        for (int g = 1; g < 16; ++g) s += red[g][el];
         out[i] = s;
     }
 }
@@ -245,7 +253,7 @@ int papc_bn_finalize_f32(const float *stats_partial, int n_tiles, int64_t M, int
     PAPC_REQUIRE(n_tiles >= 1 && M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_finalize_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, stats_partial, n_tiles, M, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, stats_partial, n_tiles, M, C, gamma,
                        beta, eps, momentum, mean, invstd, scale, shift, running_mean, running_var);
     return check_launch("papc_bn_finalize_f32");
 }
@@ -304,7 +312,7 @@ int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, i
     PAPC_REQUIRE(n_tiles >= 1 && M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_bwd_finalize_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 32)), dim3(256), 0, st, red_partial, n_tiles, M, C, dgamma, dbeta, c1, c2);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, red_partial, n_tiles, M, C, dgamma, dbeta, c1, c2);
     return check_launch("papc_bn_bwd_finalize_f32");
 }
 
@@ -314,7 +322,7 @@ int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, floa
     PAPC_REQUIRE(n_chunks >= 1 && n >= 1, PAPC_E_INVALID, "papc_reduce_partials_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ew_grid(n)), dim3(256), 0, st, partial, n_chunks, n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, out);
     return check_launch("papc_reduce_partials_f32");
 }
 

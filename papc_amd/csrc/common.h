@@ -91,6 +91,47 @@ __device__ __forceinline__ float readlane63_f32(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+
+// ---- 32-bit wave / row reductions (full-rate VALU; v_max_f32 / v_min_u32 fuse with the DPP operand)
+#define PAPC_DPPF(v, ctrl, rmask) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), (ctrl), (rmask), 0xF, false))
+#define PAPC_DPPU(v, ctrl, rmask) ((unsigned)__builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false))
+
+__device__ __forceinline__ float row_max_f32(float v)  // every lane of a 16-lane row ends with the row max
+{
+    v = fmaxf(v, PAPC_DPPF(v, 0xB1, 0xF));
+    v = fmaxf(v, PAPC_DPPF(v, 0x4E, 0xF));
+    v = fmaxf(v, PAPC_DPPF(v, 0x124, 0xF));
+    v = fmaxf(v, PAPC_DPPF(v, 0x128, 0xF));
+    return v;
+}
+__device__ __forceinline__ unsigned row_min_u32(unsigned v)
+{
+    unsigned t;
+    t = PAPC_DPPU(v, 0xB1, 0xF);  v = t < v ? t : v;
+    t = PAPC_DPPU(v, 0x4E, 0xF);  v = t < v ? t : v;
+    t = PAPC_DPPU(v, 0x124, 0xF); v = t < v ? t : v;
+    t = PAPC_DPPU(v, 0x128, 0xF); v = t < v ? t : v;
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32_to_lane63(float v)
+{
+    v = row_max_f32(v);
+    v = fmaxf(v, PAPC_DPPF(v, 0x142, 0xA));
+    v = fmaxf(v, PAPC_DPPF(v, 0x143, 0xC));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32_to_lane63(unsigned v)
+{
+    unsigned t;
+    v = row_min_u32(v);
+    t = PAPC_DPPU(v, 0x142, 0xA); v = t < v ? t : v;
+    t = PAPC_DPPU(v, 0x143, 0xC); v = t < v ? t : v;
+    return v;
+}
+__device__ __forceinline__ unsigned readlane63_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ float readlane0_f32(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
+__device__ __forceinline__ unsigned readlane0_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 0); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace papc

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
                                                 float *__restrict__ out_new_xyz)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64 *keys = reinterpret_cast<u64 *>(smem);  // [2][16]
+    uint2 *keys2 = reinterpret_cast<uint2 *>(smem);  // [2][16] {max distance bits, index} per wave
     float *sx = reinterpret_cast<float *>(smem + 256);
     float *sy = sx + N;
     float *sz = sy + N;
@@ -78,19 +78,22 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
             d[j] = __builtin_fminf(dd, d[j]);               // where(dist < distance, dist, distance) (:87-92)
             if (d[j] > bestd) { bestd = d[j]; bestj = j; }  // strict >: lowest j (= lowest index) on ties
         }
-        u64 key = ((u64)__float_as_uint(bestd) << 32) | (u64)(u32)(~(u32)(bestj * T + tid));
-        key = wave_max_u64_to_lane63(key);
+        // wave argmax in two 32-bit DPP passes (64-bit compares are quarter rate): max distance, then the
+        // LOWEST index among the lanes holding it -- argmax(distance, -1) returns the first maximum (:93)
+        const float mw = readlane63_f32(wave_max_f32_to_lane63(bestd));
+        const u32 iw = readlane63_u32(wave_min_u32_to_lane63(bestd == mw ? (u32)(bestj * T + tid) : 0xFFFFFFFFu));
         if (NW == 1) {
-            key = readlane63_u64(key);
+            far = (int)iw;
         } else {
-            if (lane == 63) keys[(it & 1) * 16 + wave] = key;
+            if (lane == 0) keys2[(it & 1) * 16 + wave] = make_uint2(__float_as_uint(mw), iw);
             __syncthreads();
-            const u64 *k = keys + (it & 1) * 16;
-            key = k[0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) { const u64 t = k[w]; key = t > key ? t : key; }
+            // every wave combines the <=16 per-wave results with a 16-lane row reduce (same two passes)
+            uint2 kv = make_uint2(0xBF800000u /* -1.0f */, 0xFFFFFFFFu);
+            if (lane < NW) kv = keys2[(it & 1) * 16 + lane];
+            const float km = __uint_as_float(kv.x);
+            const float bm = readlane0_f32(row_max_f32(km));
+            far = (int)readlane0_u32(row_min_u32(km == bm ? kv.y : 0xFFFFFFFFu));
         }
-        far = (int)(~(u32)key);  // argmax(distance, -1)  (:93)
     }
 }
 

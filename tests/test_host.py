@@ -1,0 +1,58 @@
+"""CPU tests of the host-side logic (no GPU compute)."""
+import numpy as np
+import torch
+
+from papc_amd import functional as F
+from papc_amd.layers import PointNetSetAbstraction, PointNetSetAbstractionMsg
+from papc_amd.mlp import StackSpec, _dw_rows_per_chunk
+from papc_amd.models import PointNet2_MSG_Clas, PointNet2_SSG_Clas, PointNet_Basic_Clas
+from papc_amd.pillars import PillarFeatureNet
+from papc_amd.synthetic import make_clouds, make_labels, make_pillars, make_start_idx
+
+
+def test_radius_threshold_matches_python_double_square():
+    assert F.radius_threshold(0.2) == float(np.float32(0.2 * 0.2))
+    assert F.radius_threshold(0.2) != float(np.float32(0.2) * np.float32(0.2))
+
+
+def test_synthetic_generators_are_deterministic_and_normalised():
+    a, b = make_clouds(4, 256, 9), make_clouds(4, 256, 9)
+    assert a.dtype == np.float32 and a.shape == (4, 3, 256) and np.array_equal(a, b)
+    n = np.sqrt((a ** 2).sum(1)).max(1)
+    assert np.allclose(n, 1.0, atol=1e-5)                       # pc_normalize: max norm 1
+    assert make_labels(5).shape == (5, 1) and make_labels(5).dtype == np.int64
+    assert make_start_idx(6, 100).max() < 100
+    v, n_, c = make_pillars(P=32, T=20)
+    assert v.shape == (32, 20, 4) and c.shape == (32, 4) and n_.min() >= 1
+    assert not v[np.arange(20)[None, :] >= n_[:, None]].any()   # padded rows are zero
+
+
+def test_dw_chunking():
+    for M, co, ci in [(524288, 128, 64), (4096, 1024, 512), (300, 16, 9), (262144, 256, 128)]:
+        r = _dw_rows_per_chunk(M, co, ci)
+        assert r % 32 == 0 and r >= 256
+    assert StackSpec(2, 10, 3, 4, 5, True).M == 24
+
+
+def test_parameter_inventory_matches_reference_shapes():
+    m = PointNet2_SSG_Clas()
+    head = sum(p.numel() for n, p in m.named_parameters() if n.split(".")[0] in ("fc1", "bn1", "fc2", "bn2", "fc3"))
+    assert head == 661776                                        # the params the reference registers
+    total = sum(p.numel() for p in m.parameters())
+    assert total == 1469520                                      # all params (SA stacks registered here)
+    q = PointNet2_SSG_Clas(reference_quirks=True)
+    assert sum(p.numel() for p in q.parameters() if p.requires_grad) == 661776
+    assert PointNet2_MSG_Clas().sa1.conv_blocks[2][1].weight.shape == (96, 64, 1, 1)
+    assert PointNet_Basic_Clas().convs[4].weight.shape == (1024, 128, 1)
+    pfn = PillarFeatureNet(num_filters=(64,), voxel_size=(1, 2, 3), pc_range=(0, -40, -3, 70.4, 40, 1))
+    assert (pfn.vx, pfn.vy, pfn.x_offset, pfn.y_offset) == (1, 2, 0.5, -39.0)   # the reference's own wiring
+    assert pfn.pfn_layers[0].linear.weight.shape == (64, 9)
+    two = PillarFeatureNet()                                      # default (64,128): first layer halves (:18-19)
+    assert two.pfn_layers[0].units == 32 and two.pfn_layers[1].linear.weight.shape == (128, 64)
+
+
+def test_layer_constructors_mirror_reference_signatures():
+    sa = PointNetSetAbstraction(npoint=512, radius=0.2, nsample=32, in_channel=3, mlp=[64, 64, 128], group_all=False)
+    assert len(sa.mlp_convs) == 3 and sa.mlp_convs[0].weight.shape == (64, 3, 1, 1)
+    msg = PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
+    assert msg.conv_blocks[0][0].weight.shape == (32, 3, 1, 1)
