@@ -6,8 +6,15 @@
 // tile for its chunk and writes a partial that papc_reduce_partials_f32 sums in fixed order (deterministic).
 //
 // MFMA mapping (v_mfma_f32_32x32x2_f32): A operand = dY^T (i = cout, k = row), B operand = X (k = row, j = cin).
-// Tiles sit in LDS row-major [32 rows][128 ch]; lane l reads element [2*ks + (l>>5)][tile*32 + (l&31)] with
-// ds_read_b32: the 32 lanes of each half read 32 consecutive banks -> conflict-free without padding.
+// Row stages sit in LDS row-major [RS rows][TOp | TIp channels]; lane l reads element [2*ks + (l>>5)][tile*32 + (l&31)]
+// with ds_read_b32: the 32 lanes of each half read 32 consecutive banks -> conflict-free without padding.
+// Every wave owns NT (1, 2 or 4) 32x32 output tiles; absent tiles (narrow layers) are computed on clamped
+// coordinates and simply not stored, so the MFMA loop has no branches.
+//
+// Software pipeline (same scheme as mlp_gemm.hip): the raw global loads of row stage s+1 are issued before the
+// MFMAs of stage s and transformed + written to the other LDS buffer after them; one barrier per stage; two
+// workgroups per CU.  For gathered rows the neighbour indices of stage s+2 are prefetched as well, so the
+// idx -> address -> data dependency never sits in front of the matrix pipe.
 #include "mlp_loaders.h"
 
 namespace papc {
@@ -15,6 +22,7 @@ namespace papc {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 void fill_dy(DySrc &d, const papc_bwd_dy *s);
+int check_dy(const papc_bwd_dy *dy, int64_t M, int C, bool *vec, const char *who);
 int fill_asrc(ASrc &a, int a_mode, const float *x, int64_t ldx, const papc_group_src *grp, const float *sc,
               const float *sh, int Cin, const char *who);
 
@@ -24,113 +32,185 @@ struct DwArgs {
     int64_t M; int Cin; int Cout; int rows_per_chunk;
     float *dw_partial;  // [n_chunks][Cout][Cin]
     float *db_partial;  // [n_chunks][Cout] or null
-    int xmap;           // map internal cin -> caller's column (GROUP with xyz_first)
+    int xmap;           // map internal cin -> caller's column (GROUP)
+    int TOp, TIp;       // padded tile widths (32 / 64 / 128)
+    int RS;             // rows per stage (32 or 64)
 };
 
-constexpr int DW_RS = 32;    // rows per LDS stage
-constexpr int DW_T = 128;    // output tile edge (channels)
+constexpr int DW_T = 128;              // output tile edge (channels)
+constexpr int DW_STAGE_FLOATS = 8192;  // RS * (TOp + TIp) <= 8192 floats = 32 KiB per buffer
 
-template <int XMODE, int DYMODE>
-__global__ __launch_bounds__(256) void dw_kernel(DwArgs p)
+template <int XMODE, int DYMODE, bool VEC, int NT>
+__global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
 {
-    __shared__ __attribute__((aligned(16))) float smem[2 * DW_RS * DW_T + 8 * DW_T];
-    float *Ys = smem;                    // dY tile  [32][128]
-    float *Xs = smem + DW_RS * DW_T;     // X tile   [32][128]
-    float *dbred = smem + 2 * DW_RS * DW_T;
+    __shared__ __attribute__((aligned(16))) float smem[2 * DW_STAGE_FLOATS + DW_T];
+    float *dbred = smem + 2 * DW_STAGE_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
     const int o0 = blockIdx.y * DW_T, i0 = blockIdx.z * DW_T;
-    const int nto = min(4, (p.Cout - o0 + 31) / 32);  // 32-wide tiles in this block's output tile
-    const int nti = min(4, (p.Cin - i0 + 31) / 32);
+    const int TOp = p.TOp, TIp = p.TIp, RS = p.RS;
+    const int nto = min(TOp / 32, (p.Cout - o0 + 31) / 32);  // 32-wide tiles actually present
+    const int nti = min(TIp / 32, (p.Cin - i0 + 31) / 32);
     const int ntiles = nto * nti;
-    const int kq = (tid & 31) * 4;   // channel group within the 128-wide tile
-    const int rr = tid >> 5;         // 0..7
+    // loader mapping: a stage of the dY tile is RS x TOp floats = RS*TOp/4 float4 slots; thread t owns slots
+    // t, t+256, ... -> channel group fixed per thread (TOp/4 divides 256), rows advance by 256/(TOp/4)
+    const int cgy = TOp / 4, cgx = TIp / 4;
+    const int kqy = (tid % cgy) * 4, ry0 = tid / cgy, rsy = 256 / cgy, nsy = RS / rsy;  // nsy <= 4
+    const int kqx = (tid % cgx) * 4, rx0 = tid / cgx, rsx = 256 / cgx, nsx = RS / rsx;
+    const bool use_jpre = (XMODE == A_GROUP) && p.x.g.idx != nullptr;
 
-    floatx16 acc[4];
+    floatx16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // tile ids handled by this wave: wave, wave+4, wave+8, wave+12  -> (to = id / nti, ti = id % nti)
-    int to_[4], ti_[4];
+    // tile ids of this wave: wave, wave+4, ... ; absent ids are clamped onto tile 0 (computed, never stored)
+    int toff[NT], tiff[NT];
+    bool tok[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { const int id = wave + 4 * t; to_[t] = id / nti; ti_[t] = id - to_[t] * nti; }
+    for (int t = 0; t < NT; ++t) {
+        const int id = wave + 4 * t;
+        tok[t] = id < ntiles;
+        const int idc = tok[t] ? id : 0;
+        const int to = idc / nti, ti = idc - to * nti;
+        toff[t] = to * 32; tiff[t] = ti * 32;
+    }
 
-    const KConst kcy = make_kconst<DYMODE>(p.dy, o0 + kq, p.Cout);
-    const KConst kcx = make_kconst<XMODE>(p.x, i0 + kq, p.Cin);
+    const KConst kcy = make_kconst<DYMODE, VEC>(p.dy, o0 + kqy, p.Cout);
+    const KConst kcx = make_kconst<XMODE, VEC>(p.x, i0 + kqx, p.Cin);
     float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
-    for (int64_t m0 = mbeg; m0 < mend; m0 += DW_RS) {
+
+    RowCtx rowy[4], rowx[4];
+    Raw3 rawy[4], rawx[4];
+    int jpre[4] = {-2, -2, -2, -2};  // gathered rows: neighbour indices of the NEXT fetch, loaded one stage early
+
+    auto prefetch_j = [&](int64_t m0) {
+        if (use_jpre) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = rr + 8 * i;
-            const int64_t m = m0 + row;
-            const int64_t mlim = mend;  // rows past the chunk end contribute zero
-            RowCtx ry = make_row<DYMODE>(p.dy, m, mlim);
-            float4 vy = load_a4<DYMODE>(p.dy, ry, o0 + kq, p.Cout, kcy);
-            dbs.x += vy.x; dbs.y += vy.y; dbs.z += vy.z; dbs.w += vy.w;
-            *reinterpret_cast<float4 *>(&Ys[row * DW_T + kq]) = vy;
-            RowCtx rx = make_row<XMODE>(p.x, m, mlim);
-            float4 vx = load_a4<XMODE>(p.x, rx, i0 + kq, p.Cin, kcx);
-            *reinterpret_cast<float4 *>(&Xs[row * DW_T + kq]) = vx;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int ks = 0; ks < DW_RS / 2; ++ks) {
-            const float *yr = Ys + (2 * ks + hi) * DW_T + l31;
-            const float *xr = Xs + (2 * ks + hi) * DW_T + l31;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (wave + 4 * t < ntiles) {
-                    const float a = yr[to_[t] * 32];
-                    const float b = xr[ti_[t] * 32];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = m0 + rx0 + rsx * i;
+                jpre[i] = p.x.g.idx[m < p.M ? m : 0];
             }
         }
+    };
+    auto fetch = [&](int64_t m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nsy) {
+                rowy[i] = make_row<DYMODE>(p.dy, m0 + ry0 + rsy * i, mend);
+                rawy[i] = fetch_a4<DYMODE, VEC>(p.dy, rowy[i], o0 + kqy, p.Cout);
+            }
+            if (i < nsx) {
+                rowx[i] = make_row<XMODE>(p.x, m0 + rx0 + rsx * i, mend, use_jpre ? jpre[i] : -2);
+                rawx[i] = fetch_a4<XMODE, VEC>(p.x, rowx[i], i0 + kqx, p.Cin);
+            }
+        }
+    };
+    auto finish = [&](float *Ys, float *Xs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < nsy) {
+                const float4 vy = finish_a4<DYMODE, VEC>(p.dy, rowy[i], o0 + kqy, p.Cout, kcy, rawy[i]);
+                dbs.x += vy.x; dbs.y += vy.y; dbs.z += vy.z; dbs.w += vy.w;
+                *reinterpret_cast<float4 *>(&Ys[(ry0 + rsy * i) * TOp + kqy]) = vy;
+            }
+            if (i < nsx) {
+                const float4 vx = finish_a4<XMODE, VEC>(p.x, rowx[i], i0 + kqx, p.Cin, kcx, rawx[i]);
+                *reinterpret_cast<float4 *>(&Xs[(rx0 + rsx * i) * TIp + kqx]) = vx;
+            }
+        }
+    };
+
+    // ---- prologue
+    bool have = mbeg < mend;
+    if (have) {
+        prefetch_j(mbeg);
+        fetch(mbeg);
+        prefetch_j(mbeg + RS);
+        finish(smem, smem + RS * TOp);
+    }
+    __syncthreads();
+    int buf = 0;
+    int64_t m0 = mbeg;
+    while (have) {
+        const int64_t mn = m0 + RS;
+        const bool have_next = mn < mend;
+        if (have_next) {
+            fetch(mn);                // uses jpre loaded during the previous stage
+            prefetch_j(mn + RS);      // indices for the stage after next
+        }
+        {
+            const float *Ys = smem + buf * DW_STAGE_FLOATS + hi * TOp + l31;
+            const float *Xs = smem + buf * DW_STAGE_FLOATS + RS * TOp + hi * TIp + l31;
+            const int nks = RS / 2;
+#pragma unroll 4
+            for (int ks = 0; ks < nks; ++ks) {
+                const float *yr = Ys + 2 * ks * TOp;
+                const float *xr = Xs + 2 * ks * TIp;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(yr[toff[t]], xr[tiff[t]], acc[t], 0, 0, 0);
+            }
+        }
+        if (have_next) {
+            float *Ys = smem + (buf ^ 1) * DW_STAGE_FLOATS;
+            finish(Ys, Ys + RS * TOp);
+        }
         __syncthreads();
+        buf ^= 1;
+        m0 = mn;
+        have = have_next;
     }
 
     // ---- store the partial tile: row (cout) = (r&3)+8*(r>>2)+4*hi, col (cin) = l31
     float *out = p.dw_partial + (int64_t)blockIdx.x * p.Cout * p.Cin;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (wave + 4 * t < ntiles) {
-            const int ci = i0 + ti_[t] * 32 + l31;
-            if (ci < p.Cin) {
-                const int cig = p.xmap ? gk(p.x.g, ci) : ci;
+    for (int t = 0; t < NT; ++t) {
+        const int ci = i0 + tiff[t] + l31;
+        if (tok[t] && ci < p.Cin) {
+            const int cig = p.xmap ? gk(p.x.g, ci) : ci;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = o0 + to_[t] * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (co < p.Cout) out[(int64_t)co * p.Cin + cig] = acc[t][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int co = o0 + toff[t] + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (co < p.Cout) out[(int64_t)co * p.Cin + cig] = acc[t][r];
             }
         }
     }
 
-    // ---- bias gradient partial: column sums of dY over this chunk (only the first cin tile writes it)
+    // ---- bias gradient partial: column sums of dY over this chunk (only the first cin tile writes it).
+    // Threads with the same channel group differ in ry0 (0 .. rsy-1): add them in that fixed order (deterministic).
     if (p.db_partial && blockIdx.z == 0) {
-        *reinterpret_cast<float4 *>(&dbred[rr * DW_T + kq]) = dbs;
+        if (tid < DW_T) dbred[tid] = 0.f;
         __syncthreads();
-        if (tid < DW_T) {
-            float s = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) s += dbred[g * DW_T + tid];
-            if (o0 + tid < p.Cout) p.db_partial[(int64_t)blockIdx.x * p.Cout + o0 + tid] = s;
+        for (int g = 0; g < rsy; ++g) {
+            if (ry0 == g) { dbred[kqy + 0] += dbs.x; dbred[kqy + 1] += dbs.y; dbred[kqy + 2] += dbs.z; dbred[kqy + 3] += dbs.w; }
+            __syncthreads();
         }
+        if (tid < TOp && o0 + tid < p.Cout) p.db_partial[(int64_t)blockIdx.x * p.Cout + o0 + tid] = dbred[tid];
     }
 }
 
-template <int XMODE, int DYMODE>
-static int launch_dw(const DwArgs &p, hipStream_t st)
+template <int XMODE, int DYMODE, bool VEC>
+static int launch_dw_v(const DwArgs &p, hipStream_t st)
 {
     dim3 grid((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)cdiv(p.Cout, DW_T), (unsigned)cdiv(p.Cin, DW_T));
-    hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE>), grid, dim3(256), 0, st, p);
+    const int tiles = (p.TOp / 32) * (p.TIp / 32);  // upper bound of 32x32 tiles per workgroup
+    if (tiles <= 4) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 1>), grid, dim3(256), 0, st, p);
+    else if (tiles <= 8) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 4>), grid, dim3(256), 0, st, p);
     return check_launch("papc_mlp_bwd_dw_f32");
 }
+
+template <int XMODE, int DYMODE>
+static int launch_dw(const DwArgs &p, bool vec, hipStream_t st)
+{
+    return vec ? launch_dw_v<XMODE, DYMODE, true>(p, st) : launch_dw_v<XMODE, DYMODE, false>(p, st);
+}
+
+static int pad_tile(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : 128); }
 
 }  // namespace papc
 
@@ -141,31 +221,30 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
                                    int Cin, int Cout, int rows_per_chunk, float *dw_partial, float *db_partial,
                                    papc_stream_t stream)
 {
-    PAPC_REQUIRE(dy && dw_partial && dy->y && dy->mean && dy->invstd && dy->scale && dy->shift && dy->c1 && dy->c2,
-                 PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: null pointer");
+    PAPC_REQUIRE(dw_partial, PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: null dw_partial");
     PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: bad sizes");
-    PAPC_REQUIRE(rows_per_chunk >= DW_RS && rows_per_chunk % DW_RS == 0, PAPC_E_INVALID,
-                 "papc_mlp_bwd_dw_f32: rows_per_chunk=%d must be a positive multiple of %d", rows_per_chunk, DW_RS);
+    PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_mlp_bwd_dw_f32: M=%lld >= 2^31 rows", (long long)M);
+    PAPC_REQUIRE(rows_per_chunk >= 64 && rows_per_chunk % 64 == 0, PAPC_E_INVALID,
+                 "papc_mlp_bwd_dw_f32: rows_per_chunk=%d must be a positive multiple of 64", rows_per_chunk);
+    bool vdy = false;
+    int rc = check_dy(dy, M, Cout, &vdy, "papc_mlp_bwd_dw_f32");
+    if (rc) return rc;
     DwArgs p;
     memset(&p, 0, sizeof(p));
-    int rc = fill_asrc(p.x, a_mode, x, ldx, grp, bn_scale, bn_shift, Cin, "papc_mlp_bwd_dw_f32");
+    rc = fill_asrc(p.x, a_mode, x, ldx, grp, bn_scale, bn_shift, Cin, "papc_mlp_bwd_dw_f32");
     if (rc) return rc;
     fill_dy(p.dy.d, dy);
-    if (dy->dz_mode == PAPC_DZ_DENSE) {
-        PAPC_REQUIRE(dy->dz, PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: DENSE needs dz");
-        p.dy.vec = aligned16(dy->dz) && aligned16(dy->y) && (Cout % 4 == 0);
-    } else {
-        PAPC_REQUIRE(dy->gout && dy->argmax && dy->K >= 1 && M % dy->K == 0, PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: MAX needs gout/argmax/K | M");
-        p.dy.vec = aligned16(dy->gout) && aligned16(dy->y) && (Cout % 4 == 0);
-    }
+    const bool vec = vdy && p.x.vec;
     p.M = M; p.Cin = Cin; p.Cout = Cout; p.rows_per_chunk = rows_per_chunk; p.dw_partial = dw_partial; p.db_partial = db_partial;
-    p.xmap = (a_mode == A_GROUP && grp->xyz_first) ? 1 : 0;
+    p.xmap = (a_mode == A_GROUP) ? 1 : 0;
+    p.TOp = pad_tile(Cout); p.TIp = pad_tile(Cin);
+    p.RS = (p.TOp + p.TIp <= 128) ? 64 : 32;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);
     const bool dense = dy->dz_mode == PAPC_DZ_DENSE;
     switch (a_mode) {
-    case A_PLAIN: return dense ? launch_dw<A_PLAIN, A_DY_DENSE>(p, st) : launch_dw<A_PLAIN, A_DY_MAX>(p, st);
-    case A_BNRELU: return dense ? launch_dw<A_BNRELU, A_DY_DENSE>(p, st) : launch_dw<A_BNRELU, A_DY_MAX>(p, st);
-    default: return dense ? launch_dw<A_GROUP, A_DY_DENSE>(p, st) : launch_dw<A_GROUP, A_DY_MAX>(p, st);
+    case A_PLAIN: return dense ? launch_dw<A_PLAIN, A_DY_DENSE>(p, vec, st) : launch_dw<A_PLAIN, A_DY_MAX>(p, vec, st);
+    case A_BNRELU: return dense ? launch_dw<A_BNRELU, A_DY_DENSE>(p, vec, st) : launch_dw<A_BNRELU, A_DY_MAX>(p, vec, st);
+    default: return dense ? launch_dw<A_GROUP, A_DY_DENSE>(p, vec, st) : launch_dw<A_GROUP, A_DY_MAX>(p, vec, st);
     }
 }

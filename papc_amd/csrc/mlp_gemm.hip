@@ -14,6 +14,11 @@
 //     feeds FOUR MFMAs: lanes 0-31 carry k = kk..kk+3, lanes 32-63 carry k = kk+4..kk+7.
 //   * workgroups are persistent over row tiles (grid.x <= 1024), so the BN-statistics partials are one
 //     deterministic row per workgroup, no atomics.
+//   * software pipeline: the (row tile, k-chunk) pairs of a workgroup form one flat sequence of stages; stage
+//     s+1's global loads are issued (raw, into registers) BEFORE the MFMAs of stage s and are transformed + written
+//     to the other LDS buffer after them, so HBM/L2 latency hides under the matrix pipe and one barrier per stage
+//     suffices (writes of stage s go to the buffer last read in stage s-1, which every wave left before the
+//     previous barrier).  Two workgroups per CU: one computes while the other writes / stores.
 #include "mlp_loaders.h"
 
 namespace papc {
@@ -24,6 +29,7 @@ enum { EPI_STORE = 0, EPI_SCATTER = 1 };
 
 struct ScatterDst {
     float *gf; const int32_t *idx; int N, S, K, D;
+    FastDiv divSK;
 };
 
 struct GemmArgs {
@@ -36,23 +42,49 @@ struct GemmArgs {
     float *y; int64_t ldy;
     float *stats;                  // [gridDim.x][2][Nout] or null
     ScatterDst sc;
-    int wvec;
 };
 
 constexpr int LDT = 36;  // LDS row stride (floats)
 constexpr int BK = 32;
 constexpr int GEMM_MAX_PARTS = 1024;
 
-template <int AMODE, int EPI, int WGM, int WGN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p)
+// the thread's float4 of the weight tile: row n (output channel), internal channels k..k+3.  Loads are
+// unconditional (clamped indices); out-of-range elements are zeroed afterwards.  wmap / nmap are grid-uniform.
+template <bool VEC>
+__device__ __forceinline__ float4 fetch_w4(const GemmArgs &p, int n, int k)
+{
+    const int nn = n < p.Nout ? n : 0;
+    const int nrow = p.nmap ? gk(p.a.g, nn) : nn;
+    const float *wr = p.w + (int64_t)nrow * p.ldw;
+    float4 v;
+    if (p.wmap) {
+        v.x = wr[k < p.Kin ? gk(p.a.g, k) : 0];
+        v.y = wr[k + 1 < p.Kin ? gk(p.a.g, k + 1) : 0];
+        v.z = wr[k + 2 < p.Kin ? gk(p.a.g, k + 2) : 0];
+        v.w = wr[k + 3 < p.Kin ? gk(p.a.g, k + 3) : 0];
+    } else if (VEC) {
+        v = ld4(wr + (k < p.Kin ? k : 0));
+    } else {
+        v = ld4s_or_zero(wr, k, p.Kin);
+    }
+    const bool nok = n < p.Nout;
+    if (!(nok && k < p.Kin)) v.x = 0.f;
+    if (!(nok && k + 1 < p.Kin)) v.y = 0.f;
+    if (!(nok && k + 2 < p.Kin)) v.z = 0.f;
+    if (!(nok && k + 3 < p.Kin)) v.w = 0.f;
+    return v;
+}
+
+template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
+    constexpr int NWL = BN / 32;  // weight float4 loads per thread per stage
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(BM == 128, "row tile is 128");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDT + 2 * WGM * BN];
-    float *As = smem;
-    float *Ws = smem + BM * LDT;
-    float *red = smem + (BM + BN) * LDT;
+    constexpr int STAGE = (BM + BN) * LDT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * WGM * BN];
+    float *red = smem + 2 * STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -60,55 +92,88 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p)
     const int n0 = blockIdx.y * BN;
     const int64_t n_mtiles = (p.M + BM - 1) / BM;
     const int Kpad = (p.Kin + 7) & ~7;
+    const int n_kc = (Kpad + BK - 1) / BK;
     const int kq = (tid & 7) * 4;
     const int r0 = tid >> 3;  // 0..31
+    const bool use_jpre = (AMODE == A_GROUP) && p.a.g.idx != nullptr;
 
     float s1[WN], s2[WN];
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) { s1[wn] = 0.f; s2[wn] = 0.f; }
 
-    for (int64_t tile = blockIdx.x; tile < n_mtiles; tile += gridDim.x) {
-        const int64_t m0 = tile * BM;
-        floatx16 acc[WM][WN];
+    floatx16 acc[WM][WN];
 #pragma unroll
-        for (int wm = 0; wm < WM; ++wm)
+    for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-            for (int wn = 0; wn < WN; ++wn)
+        for (int wn = 0; wn < WN; ++wn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
-        RowCtx rows[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rows[i] = make_row<AMODE>(p.a, m0 + r0 + 32 * i, p.M);
+    int64_t tile_f = blockIdx.x;  // tile of the stage being fetched
+    int kc_f = 0;                 // k-chunk of the stage being fetched
+    RowCtx rows[4];
+    Raw3 ra[4];
+    float4 rw[NWL];
+    KConst kc;
+    int jpre[4] = {-2, -2, -2, -2};  // GROUP: neighbour indices of the NEXT tile, loaded one tile early
 
-        for (int k0 = 0; k0 < Kpad; k0 += BK) {
-            const int k = k0 + kq;
-            const KConst kc = make_kconst<AMODE>(p.a, k, p.Kin);
+    auto load_j = [&](int64_t tile) {  // issue the idx loads of `tile`'s rows (clamped: always in range)
+        if (use_jpre) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 v = load_a4<AMODE>(p.a, rows[i], k, p.Kin, kc);
-                *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = v;
+                const int64_t m = tile * BM + r0 + 32 * i;
+                jpre[i] = p.a.g.idx[m < p.M ? m : 0];
             }
+        }
+    };
+
+    // ---- prologue: stage 0 of this workgroup's first tile
+    bool have = tile_f < n_mtiles;
+    if (have) {
+        load_j(tile_f);
 #pragma unroll
-            for (int i = 0; i < BN / 32; ++i) {
-                const int n = n0 + r0 + 32 * i;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < p.Nout && k < p.Kin) {
-                    const int nrow = p.nmap ? gk(p.a.g, n) : n;
-                    const float *wr = p.w + (int64_t)nrow * p.ldw;
-                    if (p.wmap) {
-                        v.x = wr[gk(p.a.g, k)];
-                        v.y = k + 1 < p.Kin ? wr[gk(p.a.g, k + 1)] : 0.f;
-                        v.z = k + 2 < p.Kin ? wr[gk(p.a.g, k + 2)] : 0.f;
-                        v.w = k + 3 < p.Kin ? wr[gk(p.a.g, k + 3)] : 0.f;
-                    } else {
-                        v = p.wvec ? ld4_or_zero(wr, k, p.Kin) : ld4s_or_zero(wr, k, p.Kin);
-                    }
-                }
-                *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = v;
+        for (int i = 0; i < 4; ++i) rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + 32 * i, p.M, use_jpre ? jpre[i] : -2);
+        load_j(tile_f + gridDim.x);
+        kc = make_kconst<AMODE, VEC>(p.a, kq, p.Kin);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = fetch_a4<AMODE, VEC>(p.a, rows[i], kq, p.Kin);
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC>(p, n0 + r0 + 32 * i, kq);
+        float *As = smem, *Ws = smem + BM * LDT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, rows[i], kq, p.Kin, kc, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = rw[i];
+    }
+    __syncthreads();
+
+    int buf = 0;
+    int64_t tile_c = tile_f;  // tile / chunk of the stage being computed
+    int kc_c = 0;
+    while (have) {
+        // ---- advance the fetch cursor to stage s+1 and issue its loads
+        kc_f += 1;
+        if (kc_f == n_kc) { kc_f = 0; tile_f += gridDim.x; }
+        const bool have_next = tile_f < n_mtiles;
+        const int kf = kc_f * BK + kq;
+        if (have_next) {
+            if (kc_f == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + 32 * i, p.M, use_jpre ? jpre[i] : -2);
+                load_j(tile_f + gridDim.x);
             }
-            __syncthreads();
-            const int kend = min(BK, Kpad - k0);
+            kc = make_kconst<AMODE, VEC>(p.a, kf, p.Kin);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = fetch_a4<AMODE, VEC>(p.a, rows[i], kf, p.Kin);
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC>(p, n0 + r0 + 32 * i, kf);
+        }
+
+        // ---- MFMAs of stage s from LDS buffer `buf`
+        {
+            const float *As = smem + buf * STAGE, *Ws = As + BM * LDT;
+            const int kend = min(BK, Kpad - kc_c * BK);
             for (int kk = 0; kk < kend; kk += 8) {
                 float4 af[WM], bf[WN];
 #pragma unroll
@@ -127,38 +192,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p)
                         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].w, bf[wn].w, acc[wm][wn], 0, 0, 0);
                     }
             }
-            __syncthreads();
         }
 
-        // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // ---- last k-chunk of the tile: epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (kc_c == n_kc - 1) {
+            const int64_t m0 = tile_c * BM;
 #pragma unroll
-        for (int wn = 0; wn < WN; ++wn) {
-            const int col = n0 + (wgn * WN + wn) * 32 + l31;
-            const bool cok = col < p.Nout;
-            const float bias = (EPI == EPI_STORE && p.bias && cok) ? p.bias[col] : 0.f;
+            for (int wn = 0; wn < WN; ++wn) {
+                const int col = n0 + (wgn * WN + wn) * 32 + l31;
+                const bool cok = col < p.Nout;
+                const float bias = (EPI == EPI_STORE && p.bias && cok) ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int wm = 0; wm < WM; ++wm) {
+                for (int wm = 0; wm < WM; ++wm) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + (wgm * WM + wm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < p.M && cok) {
-                        const float v = acc[wm][wn][r] + bias;
-                        if (EPI == EPI_STORE) {
-                            p.y[row * p.ldy + col] = v;
-                            s1[wn] += v;
-                            s2[wn] = fmaf(v, v, s2[wn]);
-                        } else {
-                            // gradient of index_points: grad_feats[b, idx[m], col] += dX[m, col] (feature columns only)
-                            if (col < p.sc.D) {
-                                const int64_t b = row / ((int64_t)p.sc.S * p.sc.K);
-                                const int j = p.sc.idx ? p.sc.idx[row] : (int)(row - b * (int64_t)p.sc.S * p.sc.K);
-                                if (j >= 0 && j < p.sc.N) unsafeAtomicAdd(&p.sc.gf[(b * p.sc.N + j) * (int64_t)p.sc.D + col], v);
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = m0 + (wgm * WM + wm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (row < p.M && cok) {
+                            const float v = acc[wm][wn][r] + bias;
+                            if (EPI == EPI_STORE) {
+                                p.y[row * p.ldy + col] = v;
+                                s1[wn] += v;
+                                s2[wn] = fmaf(v, v, s2[wn]);
+                            } else {
+                                // gradient of index_points: grad_feats[b, idx[m], col] += dX[m, col] (feature columns only)
+                                const int b = (int)fdiv((uint32_t)row, p.sc.divSK);
+                                const int j = p.sc.idx ? p.sc.idx[row] : (int)row - b * p.sc.S * p.sc.K;
+                                if (j >= 0 && j < p.sc.N) unsafeAtomicAdd(&p.sc.gf[((int64_t)b * p.sc.N + j) * p.sc.D + col], v);
                             }
                         }
+                        acc[wm][wn][r] = 0.f;
                     }
                 }
             }
         }
+
+        // ---- finish stage s+1: transform the landed registers, write the other LDS buffer
+        if (have_next) {
+            float *As = smem + (buf ^ 1) * STAGE, *Ws = As + BM * LDT;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, rows[i], kf, p.Kin, kc, ra[i]);
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = rw[i];
+        }
+        __syncthreads();
+        buf ^= 1;
+        tile_c = tile_f;
+        kc_c = kc_f;
+        have = have_next;
     }
 
     if (EPI == EPI_STORE && p.stats) {
@@ -184,33 +265,62 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p)
 
 static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128, GEMM_MAX_PARTS); }
 
-template <int AMODE, int EPI>
-static int launch_gemm(const GemmArgs &p, hipStream_t st)
+template <int AMODE, int EPI, bool VEC>
+static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
 {
     const unsigned gx = (unsigned)gemm_parts(p.M);
     if (p.Nout > 64) {
         dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
     } else if (p.Nout > 32) {
         dim3 grid(gx, 1);
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
     } else {
         dim3 grid(gx, 1);
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
     }
     return check_launch("mlp gemm");
+}
+
+template <int AMODE, int EPI>
+static int launch_gemm(const GemmArgs &p, bool vec, hipStream_t st)
+{
+    return vec ? launch_gemm_v<AMODE, EPI, true>(p, st) : launch_gemm_v<AMODE, EPI, false>(p, st);
 }
 
 static void fill_group(GroupSrc &g, const papc_group_src *s)
 {
     g.xyz = s->xyz; g.sb = s->sb; g.sn = s->sn; g.sc = s->sc; g.new_xyz = s->new_xyz; g.feats = s->feats;
     g.idx = s->idx; g.N = s->N; g.S = s->S; g.K = s->K; g.D = s->D; g.xyz_first = s->xyz_first;
+    g.divK = make_fastdiv((uint32_t)s->K);
+    g.divS = make_fastdiv((uint32_t)s->S);
 }
 
 void fill_dy(DySrc &d, const papc_bwd_dy *s)
 {
-    d.dz = s->dz; d.gout = s->gout; d.argmax = s->argmax; d.K = s->K; d.y = s->y; d.mean = s->mean;
+    d.dz = s->dz; d.gout = s->gout; d.argmax = s->argmax; d.K = s->K > 0 ? s->K : 1; d.y = s->y; d.mean = s->mean;
     d.invstd = s->invstd; d.scale = s->scale; d.shift = s->shift; d.c1 = s->c1; d.c2 = s->c2;
+    d.divK = make_fastdiv((uint32_t)d.K);
+}
+
+// validates a dY descriptor and says whether its VEC flavour is legal
+int check_dy(const papc_bwd_dy *dy, int64_t M, int C, bool *vec, const char *who)
+{
+    PAPC_REQUIRE(dy && dy->y && dy->mean && dy->invstd && dy->scale && dy->shift && dy->c1 && dy->c2, PAPC_E_INVALID,
+                 "%s: null pointer in dy", who);
+    const bool cst = aligned16(dy->mean) && aligned16(dy->invstd) && aligned16(dy->scale) && aligned16(dy->shift) &&
+                     aligned16(dy->c1) && aligned16(dy->c2);
+    if (dy->dz_mode == PAPC_DZ_DENSE) {
+        PAPC_REQUIRE(dy->dz, PAPC_E_INVALID, "%s: DENSE needs dz", who);
+        *vec = cst && aligned16(dy->dz) && aligned16(dy->y) && (C % 4 == 0);
+    } else if (dy->dz_mode == PAPC_DZ_MAX) {
+        PAPC_REQUIRE(dy->gout && dy->argmax && dy->K >= 1 && M % dy->K == 0, PAPC_E_INVALID, "%s: MAX needs gout/argmax and K | M", who);
+        *vec = cst && aligned16(dy->gout) && aligned16(dy->argmax) && aligned16(dy->y) && (C % 4 == 0);
+    } else {
+        set_error("%s: bad dz_mode %d", who, dy->dz_mode);
+        return PAPC_E_INVALID;
+    }
+    return PAPC_OK;
 }
 
 int fill_asrc(ASrc &a, int a_mode, const float *x, int64_t ldx, const papc_group_src *grp, const float *sc,
@@ -221,14 +331,14 @@ int fill_asrc(ASrc &a, int a_mode, const float *x, int64_t ldx, const papc_group
         PAPC_REQUIRE(x && ldx >= Cin, PAPC_E_INVALID, "%s: x null or ldx < Cin", who);
         PAPC_REQUIRE(a_mode == A_PLAIN || (sc && sh), PAPC_E_INVALID, "%s: BNRELU needs bn_scale/bn_shift", who);
         a.x = x; a.ldx = ldx; a.sc = sc; a.sh = sh;
-        a.vec = aligned16(x) && (ldx % 4 == 0);
+        a.vec = aligned16(x) && (ldx % 4 == 0) && (Cin % 4 == 0) && (a_mode == A_PLAIN || (aligned16(sc) && aligned16(sh)));
     } else if (a_mode == A_GROUP) {
         PAPC_REQUIRE(grp && grp->xyz && grp->new_xyz, PAPC_E_INVALID, "%s: GROUP needs grp->xyz/new_xyz", who);
         PAPC_REQUIRE(grp->D == 0 || grp->feats, PAPC_E_INVALID, "%s: GROUP D=%d but feats null", who, grp->D);
         PAPC_REQUIRE(Cin == grp->D + 3, PAPC_E_INVALID, "%s: GROUP Cin=%d != D+3=%d", who, Cin, grp->D + 3);
         PAPC_REQUIRE(grp->N >= 1 && grp->S >= 1 && grp->K >= 1, PAPC_E_INVALID, "%s: GROUP bad N/S/K", who);
         fill_group(a.g, grp);
-        a.vec = grp->D > 0 && aligned16(grp->feats) && (grp->D % 4 == 0);
+        a.vec = (grp->D == 0) || (aligned16(grp->feats) && (grp->D % 4 == 0));
     } else {
         set_error("%s: bad a_mode %d", who, a_mode);
         return PAPC_E_INVALID;
@@ -250,47 +360,46 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
 {
     PAPC_REQUIRE(w && y, PAPC_E_INVALID, "papc_mlp_gemm_f32: null w/y");
     PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_gemm_f32: M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
+    PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_mlp_gemm_f32: M=%lld >= 2^31 rows", (long long)M);
     GemmArgs p;
     memset(&p, 0, sizeof(p));
     int rc = fill_asrc(p.a, a_mode, x, ldx, grp, bn_scale, bn_shift, Cin, "papc_mlp_gemm_f32");
     if (rc) return rc;
     p.w = w; p.ldw = Cin; p.bias = bias; p.M = M; p.Kin = Cin; p.Nout = Cout; p.y = y; p.ldy = Cout; p.stats = stats_partial;
-    p.wmap = (a_mode == A_GROUP && grp->xyz_first) ? 1 : 0;
-    p.wvec = aligned16(w) && (Cin % 4 == 0);
+    p.wmap = (a_mode == A_GROUP) ? 1 : 0;  // GROUP: internal order [feats, xyz] -> caller's columns through gk()
+    const bool vec = p.a.vec && (p.wmap || (aligned16(w) && Cin % 4 == 0));
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MLP_GEMM, st);
     switch (a_mode) {
-    case A_PLAIN: return launch_gemm<A_PLAIN, EPI_STORE>(p, st);
-    case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE>(p, st);
-    default: return launch_gemm<A_GROUP, EPI_STORE>(p, st);
+    case A_PLAIN: return launch_gemm<A_PLAIN, EPI_STORE>(p, vec, st);
+    case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE>(p, vec, st);
+    default: return launch_gemm<A_GROUP, EPI_STORE>(p, vec, st);
     }
 }
 
 int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, float *dx,
                         const papc_scatter_dst *scatter, papc_stream_t stream)
 {
-    PAPC_REQUIRE(dy && wt && dy->y && dy->mean && dy->invstd && dy->scale && dy->shift && dy->c1 && dy->c2,
-                 PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: null pointer");
+    PAPC_REQUIRE(wt, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: null wt");
     PAPC_REQUIRE(dx || scatter, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: need dx or scatter");
     PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: bad sizes");
+    PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_mlp_bwd_dx_f32: M=%lld >= 2^31 rows", (long long)M);
+    bool vec = false;
+    int rc = check_dy(dy, M, Cout, &vec, "papc_mlp_bwd_dx_f32");
+    if (rc) return rc;
     GemmArgs p;
     memset(&p, 0, sizeof(p));
     fill_dy(p.a.d, dy);
-    if (dy->dz_mode == PAPC_DZ_DENSE) {
-        PAPC_REQUIRE(dy->dz, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: DENSE needs dz");
-        p.a.vec = aligned16(dy->dz) && aligned16(dy->y) && (Cout % 4 == 0);
-    } else {
-        PAPC_REQUIRE(dy->gout && dy->argmax && dy->K >= 1 && M % dy->K == 0, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: MAX needs gout/argmax/K | M");
-        p.a.vec = aligned16(dy->gout) && aligned16(dy->y) && (Cout % 4 == 0);
-    }
     // GEMM view: rows M, reduction over Cout, outputs Cin; weights = wt [Cin][Cout]
     p.w = wt; p.ldw = Cout; p.M = M; p.Kin = Cout; p.Nout = Cin; p.y = dx; p.ldy = Cin;
-    p.wvec = aligned16(wt) && (Cout % 4 == 0);
+    vec = vec && aligned16(wt);
     if (scatter) {
         PAPC_REQUIRE(scatter->grad_feats && scatter->D >= 1 && scatter->D + 3 == Cin, PAPC_E_INVALID,
                      "papc_mlp_bwd_dx_f32: scatter needs grad_feats and D+3 == Cin");
+        PAPC_REQUIRE(scatter->N >= 1 && scatter->S >= 1 && scatter->K >= 1, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: scatter bad N/S/K");
         p.sc.gf = scatter->grad_feats; p.sc.idx = scatter->idx; p.sc.N = scatter->N; p.sc.S = scatter->S;
         p.sc.K = scatter->K; p.sc.D = scatter->D;
+        p.sc.divSK = make_fastdiv((uint32_t)scatter->S * (uint32_t)scatter->K);
         // output column n is internal order [feats, xyz]; weight row = caller's channel order
         p.nmap = scatter->col0 ? 1 : 0;
         p.a.g.D = scatter->D; p.a.g.xyz_first = scatter->col0 ? 1 : 0;
@@ -299,9 +408,9 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DX, st);
     if (scatter) {
-        return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_SCATTER>(p, st) : launch_gemm<A_DY_MAX, EPI_SCATTER>(p, st);
+        return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_SCATTER>(p, vec, st) : launch_gemm<A_DY_MAX, EPI_SCATTER>(p, vec, st);
     }
-    return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_STORE>(p, st) : launch_gemm<A_DY_MAX, EPI_STORE>(p, st);
+    return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_STORE>(p, vec, st) : launch_gemm<A_DY_MAX, EPI_STORE>(p, vec, st);
 }
 
 }  // extern "C"

@@ -6,6 +6,14 @@
 //
 // Internal channel order of a GROUP layer is always [feats(D), xyz(3)] so the feature part is float4
 // aligned; `xyz_first` (SSG order, :151) only changes the weight-column mapping gk().
+//
+// Two flavours per producer, chosen at compile time:
+//   VEC = true : every access is an UNCONDITIONAL float4 (or int4) load from a clamped in-range address and
+//                out-of-range lanes are zeroed by a select afterwards -- no branch sits around a load, so the
+//                compiler batches the loads of a stage and keeps them in flight across the MFMA phase.
+//                Needs 16-byte aligned bases and channel counts that are multiples of 4 (D % 4 == 0 for GROUP).
+//   VEC = false: element-wise predicated loads for ragged shapes (correct for anything, slow).
+// fetch_a4 only issues loads (raw registers); finish_a4 does the arithmetic once they have landed.
 #pragma once
 #include "common.h"
 
@@ -13,15 +21,37 @@ namespace papc {
 
 enum { A_PLAIN = PAPC_A_PLAIN, A_BNRELU = PAPC_A_BNRELU, A_GROUP = PAPC_A_GROUP, A_DY_DENSE = 3, A_DY_MAX = 4 };
 
+// unsigned 32-bit division by an invariant (Granlund-Montgomery round-up form)
+struct FastDiv {
+    uint32_t mul, sh1, sh2;
+};
+static inline FastDiv make_fastdiv(uint32_t d)
+{
+    FastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l - f.sh1;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f)
+{
+    const uint32_t t = __umulhi(n, f.mul);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 struct GroupSrc {
     const float *xyz; int64_t sb, sn, sc;
     const float *new_xyz; const float *feats; const int32_t *idx;
     int N, S, K, D, xyz_first;
+    FastDiv divK, divS;
 };
 
 struct DySrc {
     const float *dz; const float *gout; const int32_t *argmax; int K;
     const float *y; const float *mean, *invstd, *scale, *shift, *c1, *c2;
+    FastDiv divK;
 };
 
 struct ASrc {
@@ -29,73 +59,76 @@ struct ASrc {
     const float *sc, *sh;                 // BNRELU
     GroupSrc g;                           // GROUP
     DySrc d;                              // DY_*
-    int vec;                              // float4 loads allowed (alignment + Kin % 4 == 0)
+    int vec;                              // host-side: the VEC = true flavour is legal for this operand
 };
 
 // internal input-channel index -> column in the caller's weight matrix
 __device__ __forceinline__ int gk(const GroupSrc &g, int k) { return g.xyz_first ? (k < g.D ? k + 3 : k - g.D) : k; }
 
-// per-row context, computed once per (thread, row tile)
+// per-row context (32-bit: M < 2^31 is enforced by the host entry points)
 struct RowCtx {
-    int64_t m;     // global row
+    int m;       // global row (clamped to 0 when invalid)
+    int j;       // GROUP: source point index
+    int b;       // GROUP: cloud
+    int grp;     // GROUP / DY_MAX: m / K
+    int kin;     // DY_MAX: m % K
     bool valid;
-    int j;         // GROUP: source point index
-    int64_t b;     // GROUP: cloud
-    int64_t grp;   // GROUP / DY_MAX: m / K
-    int kin;       // DY_MAX: m % K
 };
 
+// jpre >= -1: neighbour index already loaded by the caller (prefetched); jpre == -2: load it here
 template <int AMODE>
-__device__ __forceinline__ RowCtx make_row(const ASrc &a, int64_t m, int64_t M)
+__device__ __forceinline__ RowCtx make_row(const ASrc &a, int64_t m64, int64_t M, int jpre = -2)
 {
     RowCtx r;
-    r.m = m; r.valid = m < M; r.j = 0; r.b = 0; r.grp = 0; r.kin = 0;
-    if (!r.valid) return r;
+    r.valid = m64 < M;
+    r.m = r.valid ? (int)m64 : 0;
+    r.j = 0; r.b = 0; r.grp = 0; r.kin = 0;
     if (AMODE == A_GROUP) {
-        r.grp = m / a.g.K;
-        r.b = r.grp / a.g.S;
-        r.j = a.g.idx ? a.g.idx[m] : (int)(m - r.b * (int64_t)a.g.S * a.g.K);
-        if (r.j < 0 || r.j >= a.g.N) r.valid = false;  // no-hit sentinel N (reference raises) -> zero row
+        r.grp = (int)fdiv((uint32_t)r.m, a.g.divK);
+        r.b = (int)fdiv((uint32_t)r.grp, a.g.divS);
+        int j;
+        if (a.g.idx) j = (jpre == -2) ? a.g.idx[r.m] : jpre;
+        else j = r.m - r.b * a.g.S * a.g.K;
+        if (j < 0 || j >= a.g.N) { r.valid = false; j = 0; }  // no-hit sentinel N (the reference raises) -> zero row
+        r.j = j;
     } else if (AMODE == A_DY_MAX) {
-        r.grp = m / a.d.K;
-        r.kin = (int)(m - r.grp * a.d.K);
+        r.grp = (int)fdiv((uint32_t)r.m, a.d.divK);
+        r.kin = r.m - r.grp * a.d.K;
     }
     return r;
 }
 
-// per-(thread, k-chunk) constants: the thread's 4 consecutive channels k..k+3
+// per-(thread, channel group) constants: the thread's 4 consecutive channels k..k+3
 struct KConst {
     float4 c0, c1, c2, c3, c4, c5;
 };
 
-__device__ __forceinline__ float4 ld4_or_zero(const float *p, int k, int K)
-{
-    float4 v;
-    if (k + 3 < K) { v = *reinterpret_cast<const float4 *>(p + k); }
-    else {
-        v.x = k < K ? p[k] : 0.f; v.y = k + 1 < K ? p[k + 1] : 0.f; v.z = k + 2 < K ? p[k + 2] : 0.f; v.w = 0.f;
-    }
-    return v;
-}
-__device__ __forceinline__ float4 ld4s_or_zero(const float *p, int k, int K)  // scalar loads (unaligned base)
+__device__ __forceinline__ float4 ld4s_or_zero(const float *p, int k, int K)  // element-wise predicated (slow path)
 {
     float4 v;
     v.x = k < K ? p[k] : 0.f; v.y = k + 1 < K ? p[k + 1] : 0.f; v.z = k + 2 < K ? p[k + 2] : 0.f; v.w = k + 3 < K ? p[k + 3] : 0.f;
     return v;
 }
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-template <int AMODE>
+template <int AMODE, bool VEC>
 __device__ __forceinline__ KConst make_kconst(const ASrc &a, int k, int Kin)
 {
     KConst c;
     c.c0 = c.c1 = c.c2 = c.c3 = c.c4 = c.c5 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k >= Kin) return c;
     if (AMODE == A_BNRELU) {
-        c.c0 = ld4s_or_zero(a.sc, k, Kin); c.c1 = ld4s_or_zero(a.sh, k, Kin);
+        if (VEC) { const int kk = k < Kin ? k : 0; c.c0 = ld4(a.sc + kk); c.c1 = ld4(a.sh + kk); }
+        else { c.c0 = ld4s_or_zero(a.sc, k, Kin); c.c1 = ld4s_or_zero(a.sh, k, Kin); }
     } else if (AMODE == A_DY_DENSE || AMODE == A_DY_MAX) {
-        c.c0 = ld4s_or_zero(a.d.scale, k, Kin); c.c1 = ld4s_or_zero(a.d.shift, k, Kin);
-        c.c2 = ld4s_or_zero(a.d.mean, k, Kin);  c.c3 = ld4s_or_zero(a.d.invstd, k, Kin);
-        c.c4 = ld4s_or_zero(a.d.c1, k, Kin);    c.c5 = ld4s_or_zero(a.d.c2, k, Kin);
+        if (VEC) {
+            const int kk = k < Kin ? k : 0;
+            c.c0 = ld4(a.d.scale + kk); c.c1 = ld4(a.d.shift + kk); c.c2 = ld4(a.d.mean + kk);
+            c.c3 = ld4(a.d.invstd + kk); c.c4 = ld4(a.d.c1 + kk);   c.c5 = ld4(a.d.c2 + kk);
+        } else {
+            c.c0 = ld4s_or_zero(a.d.scale, k, Kin); c.c1 = ld4s_or_zero(a.d.shift, k, Kin);
+            c.c2 = ld4s_or_zero(a.d.mean, k, Kin);  c.c3 = ld4s_or_zero(a.d.invstd, k, Kin);
+            c.c4 = ld4s_or_zero(a.d.c1, k, Kin);    c.c5 = ld4s_or_zero(a.d.c2, k, Kin);
+        }
     }
     return c;
 }
@@ -109,59 +142,112 @@ __device__ __forceinline__ float dy_elem(float dz, float y, float sc, float sh, 
     return sc * ((p - c1) - xhat * c2);
 }
 
-// the thread's 4 consecutive A elements (row r, internal channels k..k+3); zero outside [0,M)x[0,Kin)
-template <int AMODE>
-__device__ __forceinline__ float4 load_a4(const ASrc &a, const RowCtx &r, int k, int Kin, const KConst &kc)
+struct Raw3 {
+    float4 p;  // x / feats|xyz / y
+    float4 q;  // new_xyz (GROUP xyz columns) / dz / gout
+    int4 r;    // argmax (DY_MAX)
+};
+
+template <int AMODE, bool VEC>
+__device__ __forceinline__ Raw3 fetch_a4(const ASrc &a, const RowCtx &r, int k, int Kin)
 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!r.valid || k >= Kin) return v;
-    if (AMODE == A_PLAIN || AMODE == A_BNRELU) {
-        const float *row = a.x + r.m * a.ldx;
-        v = a.vec ? ld4_or_zero(row, k, Kin) : ld4s_or_zero(row, k, Kin);
-        if (AMODE == A_BNRELU) {  // relu(bn(.)) of the previous layer, folded (:217)
-            v.x = fmaxf(fmaf(kc.c0.x, v.x, kc.c1.x), 0.f); v.y = fmaxf(fmaf(kc.c0.y, v.y, kc.c1.y), 0.f);
-            v.z = fmaxf(fmaf(kc.c0.z, v.z, kc.c1.z), 0.f); v.w = fmaxf(fmaf(kc.c0.w, v.w, kc.c1.w), 0.f);
-            if (k + 1 >= Kin) v.y = 0.f;
-            if (k + 2 >= Kin) v.z = 0.f;
-            if (k + 3 >= Kin) v.w = 0.f;
+    Raw3 w;
+    w.p = make_float4(0.f, 0.f, 0.f, 0.f);
+    w.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    w.r = make_int4(-1, -1, -1, -1);
+    if (VEC) {
+        // unconditional loads from clamped addresses (r.m / r.j / r.grp are already clamped to 0 when invalid)
+        const int kk = k < Kin ? k : 0;
+        if (AMODE == A_PLAIN || AMODE == A_BNRELU) {
+            w.p = ld4(a.x + (int64_t)r.m * a.ldx + kk);
+        } else if (AMODE == A_GROUP) {
+            const GroupSrc &g = a.g;
+            if (kk < g.D) {
+                w.p = ld4(g.feats + ((int64_t)r.b * g.N + r.j) * g.D + kk);
+            } else {  // the xyz slot (k == D): three coordinates and the centroid they are centred on
+                const float *pp = g.xyz + (int64_t)r.b * g.sb + (int64_t)r.j * g.sn;
+                const float *qq = g.new_xyz + (int64_t)r.grp * 3;
+                w.p = make_float4(pp[0], pp[g.sc], pp[2 * g.sc], 0.f);
+                w.q = make_float4(qq[0], qq[1], qq[2], 0.f);
+            }
+        } else {
+            const DySrc &d = a.d;
+            w.p = ld4(d.y + (int64_t)r.m * Kin + kk);
+            if (AMODE == A_DY_DENSE) {
+                w.q = ld4(d.dz + (int64_t)r.m * Kin + kk);
+            } else {
+                w.q = ld4(d.gout + (int64_t)r.grp * Kin + kk);
+                w.r = *reinterpret_cast<const int4 *>(d.argmax + (int64_t)r.grp * Kin + kk);
+            }
         }
+        return w;
+    }
+    // ---- slow path: element-wise predicated
+    if (!r.valid || k >= Kin) return w;
+    if (AMODE == A_PLAIN || AMODE == A_BNRELU) {
+        w.p = ld4s_or_zero(a.x + (int64_t)r.m * a.ldx, k, Kin);
     } else if (AMODE == A_GROUP) {
         const GroupSrc &g = a.g;
-        if (k + 3 < g.D && a.vec) {
-            v = *reinterpret_cast<const float4 *>(g.feats + (r.b * g.N + r.j) * (int64_t)g.D + k);
-        } else {
-            float e[4];
+        float e[4], f[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int kk = k + i;
-                if (kk < g.D) e[i] = g.feats[(r.b * g.N + r.j) * (int64_t)g.D + kk];
-                else if (kk < g.D + 3) {
-                    const int c = kk - g.D;  // grouped_xyz - new_xyz (:147); group_all passes new_xyz = 0 (:170)
-                    e[i] = g.xyz[r.b * g.sb + (int64_t)r.j * g.sn + c * g.sc] - g.new_xyz[r.grp * 3 + c];
-                } else e[i] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int kk = k + i;
+            e[i] = 0.f; f[i] = 0.f;
+            if (kk < g.D) e[i] = g.feats[((int64_t)r.b * g.N + r.j) * g.D + kk];
+            else if (kk < g.D + 3) {
+                const int c = kk - g.D;
+                e[i] = g.xyz[(int64_t)r.b * g.sb + (int64_t)r.j * g.sn + c * g.sc];
+                f[i] = g.new_xyz[(int64_t)r.grp * 3 + c];
             }
-            v = make_float4(e[0], e[1], e[2], e[3]);
         }
-    } else {  // A_DY_DENSE / A_DY_MAX
+        w.p = make_float4(e[0], e[1], e[2], e[3]);
+        w.q = make_float4(f[0], f[1], f[2], f[3]);
+    } else {
         const DySrc &d = a.d;
-        const float4 y = a.vec ? ld4_or_zero(d.y + r.m * (int64_t)Kin, k, Kin) : ld4s_or_zero(d.y + r.m * (int64_t)Kin, k, Kin);
-        float4 dz;
+        w.p = ld4s_or_zero(d.y + (int64_t)r.m * Kin, k, Kin);
         if (AMODE == A_DY_DENSE) {
-            dz = a.vec ? ld4_or_zero(d.dz + r.m * (int64_t)Kin, k, Kin) : ld4s_or_zero(d.dz + r.m * (int64_t)Kin, k, Kin);
+            w.q = ld4s_or_zero(d.dz + (int64_t)r.m * Kin, k, Kin);
         } else {
-            const float *gp = d.gout + r.grp * (int64_t)Kin;
-            const int32_t *ap = d.argmax + r.grp * (int64_t)Kin;
-            const float4 g = a.vec ? ld4_or_zero(gp, k, Kin) : ld4s_or_zero(gp, k, Kin);
-            dz.x = (ap[k] == r.kin) ? g.x : 0.f;
-            dz.y = (k + 1 < Kin && ap[k + 1] == r.kin) ? g.y : 0.f;
-            dz.z = (k + 2 < Kin && ap[k + 2] == r.kin) ? g.z : 0.f;
-            dz.w = (k + 3 < Kin && ap[k + 3] == r.kin) ? g.w : 0.f;
+            const int32_t *ap = d.argmax + (int64_t)r.grp * Kin;
+            w.q = ld4s_or_zero(d.gout + (int64_t)r.grp * Kin, k, Kin);
+            w.r.x = ap[k];
+            w.r.y = k + 1 < Kin ? ap[k + 1] : -1;
+            w.r.z = k + 2 < Kin ? ap[k + 2] : -1;
+            w.r.w = k + 3 < Kin ? ap[k + 3] : -1;
         }
-        v.x = dy_elem(dz.x, y.x, kc.c0.x, kc.c1.x, kc.c2.x, kc.c3.x, kc.c4.x, kc.c5.x);
-        v.y = k + 1 < Kin ? dy_elem(dz.y, y.y, kc.c0.y, kc.c1.y, kc.c2.y, kc.c3.y, kc.c4.y, kc.c5.y) : 0.f;
-        v.z = k + 2 < Kin ? dy_elem(dz.z, y.z, kc.c0.z, kc.c1.z, kc.c2.z, kc.c3.z, kc.c4.z, kc.c5.z) : 0.f;
-        v.w = k + 3 < Kin ? dy_elem(dz.w, y.w, kc.c0.w, kc.c1.w, kc.c2.w, kc.c3.w, kc.c4.w, kc.c5.w) : 0.f;
     }
+    return w;
+}
+
+template <int AMODE, bool VEC>
+__device__ __forceinline__ float4 finish_a4(const ASrc &a, const RowCtx &r, int k, int Kin, const KConst &kc, const Raw3 &w)
+{
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool ok = r.valid && k < Kin;
+    // element masks inside the float4 (only the slow path can straddle Kin; VEC shapes have Kin % 4 == 0,
+    // except the GROUP xyz slot whose 4th element is a structural zero)
+    const bool ky = VEC || k + 1 < Kin, kz = VEC || k + 2 < Kin, kw = VEC || k + 3 < Kin;
+    if (AMODE == A_PLAIN) {
+        v = w.p;
+    } else if (AMODE == A_BNRELU) {  // relu(bn(.)) of the previous layer, folded (:217)
+        v.x = fmaxf(fmaf(kc.c0.x, w.p.x, kc.c1.x), 0.f);
+        v.y = ky ? fmaxf(fmaf(kc.c0.y, w.p.y, kc.c1.y), 0.f) : 0.f;
+        v.z = kz ? fmaxf(fmaf(kc.c0.z, w.p.z, kc.c1.z), 0.f) : 0.f;
+        v.w = kw ? fmaxf(fmaf(kc.c0.w, w.p.w, kc.c1.w), 0.f) : 0.f;
+    } else if (AMODE == A_GROUP) {   // feats pass through (q = 0: p - 0 is exact); xyz columns: grouped_xyz - new_xyz (:147)
+        v.x = w.p.x - w.q.x; v.y = w.p.y - w.q.y; v.z = w.p.z - w.q.z; v.w = w.p.w - w.q.w;
+    } else {
+        float4 dz = w.q;
+        if (AMODE == A_DY_MAX) {
+            dz.x = (w.r.x == r.kin) ? w.q.x : 0.f; dz.y = (w.r.y == r.kin) ? w.q.y : 0.f;
+            dz.z = (w.r.z == r.kin) ? w.q.z : 0.f; dz.w = (w.r.w == r.kin) ? w.q.w : 0.f;
+        }
+        v.x = dy_elem(dz.x, w.p.x, kc.c0.x, kc.c1.x, kc.c2.x, kc.c3.x, kc.c4.x, kc.c5.x);
+        v.y = ky ? dy_elem(dz.y, w.p.y, kc.c0.y, kc.c1.y, kc.c2.y, kc.c3.y, kc.c4.y, kc.c5.y) : 0.f;
+        v.z = kz ? dy_elem(dz.z, w.p.z, kc.c0.z, kc.c1.z, kc.c2.z, kc.c3.z, kc.c4.z, kc.c5.z) : 0.f;
+        v.w = kw ? dy_elem(dz.w, w.p.w, kc.c0.w, kc.c1.w, kc.c2.w, kc.c3.w, kc.c4.w, kc.c5.w) : 0.f;
+    }
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
 }
 

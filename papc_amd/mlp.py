@@ -48,7 +48,7 @@ def _dw_rows_per_chunk(M, cout, cin):
     tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
     want = max(1, 768 // tiles)
     rpc = (M + want - 1) // want
-    rpc = max(256, ((rpc + 31) // 32) * 32)
+    rpc = max(256, ((rpc + 63) // 64) * 64)
     return rpc
 
 

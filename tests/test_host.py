@@ -30,7 +30,7 @@ def test_synthetic_generators_are_deterministic_and_normalised():
 def test_dw_chunking():
     for M, co, ci in [(524288, 128, 64), (4096, 1024, 512), (300, 16, 9), (262144, 256, 128)]:
         r = _dw_rows_per_chunk(M, co, ci)
-        assert r % 32 == 0 and r >= 256
+        assert r % 64 == 0 and r >= 256
     assert StackSpec(2, 10, 3, 4, 5, True).M == 24
 
 
