@@ -148,9 +148,9 @@ int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, cons
                            papc_stream_t stream);
 
 /* Reduce red_partial -> dgamma[c] = sum p*xhat, dbeta[c] = sum p, and the two per-channel constants of
- * dy = scale*(p - c1 - xhat*c2): c1 = dbeta/M, c2 = dgamma/M. */
+ * dy = scale*(p - c1 - xhat*c2): c1 = dbeta/M, c2 = dgamma/M.  accumulate != 0 adds into dgamma/dbeta. */
 int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, int C, float *dgamma,
-                             float *dbeta, float *c1, float *c2, papc_stream_t stream);
+                             float *dbeta, float *c1, float *c2, int accumulate, papc_stream_t stream);
 
 typedef struct papc_bwd_dy {
     int dz_mode;           /* PAPC_DZ_* */
@@ -184,8 +184,10 @@ int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const float *x, int64
                         int Cin, int Cout, int rows_per_chunk, float *dw_partial, float *db_partial,
                         papc_stream_t stream);
 
-/* out[i] = sum_t partial[t, i]  (fixed order -> deterministic); n = elements per chunk */
-int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, papc_stream_t stream);
+/* out[i] (+)= sum_t partial[t, i]  (fixed order -> deterministic); n = elements per chunk; accumulate != 0 adds
+ * into out (gradient accumulation straight into a parameter's .grad) */
+int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, int accumulate,
+                             papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PointPillars PillarFeatureNet (PAPC/models/detect/pointpillars/models/bones/pillars.py)

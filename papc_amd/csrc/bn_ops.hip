@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
 }
 
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
-                                                              float *dgamma, float *dbeta, float *c1, float *c2)
+                                                              float *dgamma, float *dbeta, float *c1, float *c2, int accumulate)
 {
     __shared__ double r1[64][16], r2[64][16];
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 channels x 64 part-lanes
@@ -198,15 +198,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
     __syncthreads();
     if (tl == 0 && c < C) {
         for (int g = 1; g < 64; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
-        if (dbeta) dbeta[c] = (float)s1;
-        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
         c1[c] = (float)(s1 / (double)M);
         c2[c] = (float)(s2 / (double)M);
     }
 }
 
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ part, int n_chunks, int64_t n,
-                                                               float *__restrict__ out)
+                                                               float *__restrict__ out, int accumulate)
 {
     __shared__ float red[16][64];
     const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
     if (cl == 0 && i < n) {
 #pragma unroll
         for (int g = 1; g < 16; ++g) s += red[g][el];
-        out[i] = s;
+        out[i] = accumulate ? out[i] + s : s;
     }
 }
 
@@ -306,23 +306,23 @@ int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, cons
 }
 
 int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, int C, float *dgamma,
-                             float *dbeta, float *c1, float *c2, papc_stream_t stream)
+                             float *dbeta, float *c1, float *c2, int accumulate, papc_stream_t stream)
 {
     PAPC_REQUIRE(red_partial && c1 && c2, PAPC_E_INVALID, "papc_bn_bwd_finalize_f32: null pointer");
     PAPC_REQUIRE(n_tiles >= 1 && M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_bwd_finalize_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, red_partial, n_tiles, M, C, dgamma, dbeta, c1, c2);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, red_partial, n_tiles, M, C, dgamma, dbeta, c1, c2, accumulate);
     return check_launch("papc_bn_bwd_finalize_f32");
 }
 
-int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, papc_stream_t stream)
+int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, int accumulate, papc_stream_t stream)
 {
     PAPC_REQUIRE(partial && out, PAPC_E_INVALID, "papc_reduce_partials_f32: null pointer");
     PAPC_REQUIRE(n_chunks >= 1 && n >= 1, PAPC_E_INVALID, "papc_reduce_partials_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, out);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, out, accumulate);
     return check_launch("papc_reduce_partials_f32");
 }
 

@@ -38,9 +38,10 @@ struct DwArgs {
 };
 
 constexpr int DW_T = 128;              // output tile edge (channels)
-constexpr int DW_STAGE_FLOATS = 8192;  // RS * (TOp + TIp) <= 8192 floats = 32 KiB per buffer
+constexpr int DW_TI_WIDE = 160;           // gather layers (Cin = D+3 in (128,160]) keep all of cin in ONE tile
+constexpr int DW_STAGE_FLOATS = 9216;  // RS * (TOp + TIp) <= 32*(128+160) floats = 36 KiB per buffer
 
-template <int XMODE, int DYMODE, bool VEC, int NT>
+template <int XMODE, int DYMODE, bool VEC, int NT, int NSX>
 __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
 {
     __shared__ __attribute__((aligned(16))) float smem[2 * DW_STAGE_FLOATS + DW_T];
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int o0 = blockIdx.y * DW_T, i0 = blockIdx.z * DW_T;
+    const int o0 = blockIdx.y * DW_T, i0 = blockIdx.z * (NSX > 4 ? DW_TI_WIDE : DW_T);
     const int TOp = p.TOp, TIp = p.TIp, RS = p.RS;
     const int nto = min(TOp / 32, (p.Cout - o0 + 31) / 32);  // 32-wide tiles actually present
     const int nti = min(TIp / 32, (p.Cin - i0 + 31) / 32);
@@ -57,7 +58,19 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
     // t, t+256, ... -> channel group fixed per thread (TOp/4 divides 256), rows advance by 256/(TOp/4)
     const int cgy = TOp / 4, cgx = TIp / 4;
     const int kqy = (tid % cgy) * 4, ry0 = tid / cgy, rsy = 256 / cgy, nsy = RS / rsy;  // nsy <= 4
-    const int kqx = (tid % cgx) * 4, rx0 = tid / cgx, rsx = 256 / cgx, nsx = RS / rsx;
+    // X slots are mapped generically (slot = tid + 256*i -> row = slot / cgx, channel group = slot % cgx) so the
+    // 160-wide gather tile (cgx = 40, which does not divide 256) works too; when cgx | 256 every slot of a thread
+    // has the same channel group, which the per-thread BN constants of the BNRELU producer rely on.
+    const int nsx = (RS * cgx + 255) / 256;
+    int xr[NSX], xk[NSX];
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) {
+        const int s = tid + 256 * i;
+        xr[i] = s / cgx;
+        xk[i] = (s - xr[i] * cgx) * 4;
+        if (xr[i] >= RS) { xr[i] = RS - 1; }  // clamped duplicate slot (same value written twice: harmless)
+    }
+    const int kqx = xk[0];
     const bool use_jpre = (XMODE == A_GROUP) && p.x.g.idx != nullptr;
 
     floatx16 acc[NT];
@@ -84,15 +97,17 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
     const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
 
-    RowCtx rowy[4], rowx[4];
-    Raw3 rawy[4], rawx[4];
-    int jpre[4] = {-2, -2, -2, -2};  // gathered rows: neighbour indices of the NEXT fetch, loaded one stage early
+    RowCtx rowy[4], rowx[NSX];
+    Raw3 rawy[4], rawx[NSX];
+    int jpre[NSX];
+#pragma unroll
+    for (int i = 0; i < NSX; ++i) jpre[i] = -2;  // gathered rows: neighbour indices of the NEXT fetch, loaded one stage early
 
     auto prefetch_j = [&](int64_t m0) {
         if (use_jpre) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t m = m0 + rx0 + rsx * i;
+            for (int i = 0; i < NSX; ++i) {
+                const int64_t m = m0 + xr[i];
                 jpre[i] = p.x.g.idx[m < p.M ? m : 0];
             }
         }
@@ -104,9 +119,12 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
                 rowy[i] = make_row<DYMODE>(p.dy, m0 + ry0 + rsy * i, mend);
                 rawy[i] = fetch_a4<DYMODE, VEC>(p.dy, rowy[i], o0 + kqy, p.Cout);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NSX; ++i) {
             if (i < nsx) {
-                rowx[i] = make_row<XMODE>(p.x, m0 + rx0 + rsx * i, mend, use_jpre ? jpre[i] : -2);
-                rawx[i] = fetch_a4<XMODE, VEC>(p.x, rowx[i], i0 + kqx, p.Cin);
+                rowx[i] = make_row<XMODE>(p.x, m0 + xr[i], mend, use_jpre ? jpre[i] : -2);
+                rawx[i] = fetch_a4<XMODE, VEC>(p.x, rowx[i], i0 + xk[i], p.Cin);
             }
         }
     };
@@ -118,9 +136,12 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
                 dbs.x += vy.x; dbs.y += vy.y; dbs.z += vy.z; dbs.w += vy.w;
                 *reinterpret_cast<float4 *>(&Ys[(ry0 + rsy * i) * TOp + kqy]) = vy;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NSX; ++i) {
             if (i < nsx) {
-                const float4 vx = finish_a4<XMODE, VEC>(p.x, rowx[i], i0 + kqx, p.Cin, kcx, rawx[i]);
-                *reinterpret_cast<float4 *>(&Xs[(rx0 + rsx * i) * TIp + kqx]) = vx;
+                const float4 vx = finish_a4<XMODE, VEC>(p.x, rowx[i], i0 + xk[i], p.Cin, kcx, rawx[i]);
+                *reinterpret_cast<float4 *>(&Xs[xr[i] * TIp + xk[i]]) = vx;
             }
         }
     };
@@ -196,11 +217,14 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
 template <int XMODE, int DYMODE, bool VEC>
 static int launch_dw_v(const DwArgs &p, hipStream_t st)
 {
-    dim3 grid((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)cdiv(p.Cout, DW_T), (unsigned)cdiv(p.Cin, DW_T));
+    const bool wide = p.TIp == DW_TI_WIDE;
+    dim3 grid((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)cdiv(p.Cout, DW_T), (unsigned)cdiv(p.Cin, wide ? DW_TI_WIDE : DW_T));
     const int tiles = (p.TOp / 32) * (p.TIp / 32);  // upper bound of 32x32 tiles per workgroup
-    if (tiles <= 4) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 1>), grid, dim3(256), 0, st, p);
-    else if (tiles <= 8) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 4>), grid, dim3(256), 0, st, p);
+    if (wide) {
+        if (XMODE == A_GROUP) hipLaunchKernelGGL((dw_kernel<A_GROUP, DYMODE, VEC, 5, 5>), grid, dim3(256), 0, st, p);
+    } else if (tiles <= 4) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 1, 4>), grid, dim3(256), 0, st, p);
+    else if (tiles <= 8) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 4, 4>), grid, dim3(256), 0, st, p);
     return check_launch("papc_mlp_bwd_dw_f32");
 }
 
@@ -238,6 +262,7 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     p.M = M; p.Cin = Cin; p.Cout = Cout; p.rows_per_chunk = rows_per_chunk; p.dw_partial = dw_partial; p.db_partial = db_partial;
     p.xmap = (a_mode == A_GROUP) ? 1 : 0;
     p.TOp = pad_tile(Cout); p.TIp = pad_tile(Cin);
+    if (a_mode == A_GROUP && Cin > DW_T && Cin <= DW_TI_WIDE && p.TOp == 128) p.TIp = DW_TI_WIDE;  // D+3 with D = 128
     p.RS = (p.TOp + p.TIp <= 128) ? 64 : 32;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);

@@ -338,10 +338,10 @@ int papc_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, in
     PAPC_REQUIRE(N <= 16384, PAPC_E_UNSUPPORTED, "papc_fps_f32: N=%d > 16384 not supported", N);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_FPS, st);
-    // geometry: aim for 4 points per lane (several waves per SIMD hide the DPP/LDS latency of the argmax),
-    // growing the per-lane tile only once the workgroup is at 1024 threads.
+    // geometry (measured on MI355X, N=4096: 512 threads x 8 points beats 256x16 and 1024x4): 8 points per lane
+    // up to 512 threads (two waves per SIMD hide each other's DPP/LDS latency; more waves only add barrier cost)
     int T = 64;
-    while (T < 1024 && T * 4 < N) T *= 2;
+    while (T < 512 && T * 8 < N) T *= 2;
     const char *env = getenv("PAPC_FPS_THREADS");
     if (env) { int t = atoi(env); if (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) T = t; }
     int ppt = 1;

@@ -29,6 +29,9 @@ class StackSpec:
         self.eps, self.momentum = float(eps), float(momentum)
         self.cut_gather_grad = cut_gather_grad
         self.M = B * S * K
+        # optional: per-parameter gradient buffers (contiguous, same shape as the parameter) that the backward
+        # accumulates into directly instead of returning gradients to autograd (see grad_targets_of)
+        self.grad_targets = None
 
 
 def _group_src(spec, xyz, new_xyz, feats, idx):
@@ -143,7 +146,13 @@ class SharedMLPMax(torch.autograd.Function):
             w2 = w.reshape(cout, cin)
             cst = consts[l]
             c12 = torch.empty(2, cout, device=dev, dtype=torch.float32)
-            dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)  # dgamma, dbeta
+            tgt = spec.grad_targets[4 * l: 4 * l + 4] if spec.grad_targets is not None else None
+            inplace = tgt is not None and all(t is not None for t in tgt)
+            if inplace:   # accumulate straight into the parameters' .grad (flat-bucket views): no autograd add kernels
+                dgamma_p, dbeta_p = tgt[2].data_ptr(), tgt[3].data_ptr()
+            else:
+                dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)  # dgamma, dbeta
+                dgamma_p, dbeta_p = dgb[0].data_ptr(), dgb[1].data_ptr()
             red = torch.empty(n_parts, 2, cout, device=dev, dtype=torch.float32)
             dy = BwdDy()
             if l == L - 1:
@@ -155,8 +164,8 @@ class SharedMLPMax(torch.autograd.Function):
             dy.c1, dy.c2 = c12[0].data_ptr(), c12[1].data_ptr()
             check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
                                              dy.shift, M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
-            check(lib.papc_bn_bwd_finalize_f32(ptr(red), n_parts, M, cout, dgb[0].data_ptr(), dgb[1].data_ptr(),
-                                               c12[0].data_ptr(), c12[1].data_ptr(), st), "papc_bn_bwd_finalize_f32")
+            check(lib.papc_bn_bwd_finalize_f32(ptr(red), n_parts, M, cout, dgamma_p, dbeta_p,
+                                               c12[0].data_ptr(), c12[1].data_ptr(), int(inplace), st), "papc_bn_bwd_finalize_f32")
             # ---- dW, db
             rpc = _dw_rows_per_chunk(M, cout, cin)
             n_chunks = (M + rpc - 1) // rpc
@@ -172,14 +181,18 @@ class SharedMLPMax(torch.autograd.Function):
                 pc = consts[l - 1]
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_BNRELU, ys[l - 1].data_ptr(), cin, None, pc[2].data_ptr(),
                                               pc[3].data_ptr(), M, cin, cout, rpc, ptr(dwp), ptr(dbp), st), "papc_mlp_bwd_dw_f32")
-            dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
-            db = torch.empty(cout, device=dev, dtype=torch.float32)
-            check(lib.papc_reduce_partials_f32(ptr(dwp), n_chunks, cout * cin, ptr(dw), st), "papc_reduce_partials_f32")
-            check(lib.papc_reduce_partials_f32(ptr(dbp), n_chunks, cout, ptr(db), st), "papc_reduce_partials_f32")
-            grads[4 * l + 0] = dw.reshape(w.shape)
-            grads[4 * l + 1] = db
-            grads[4 * l + 2] = dgb[0]
-            grads[4 * l + 3] = dgb[1]
+            if inplace:
+                check(lib.papc_reduce_partials_f32(ptr(dwp), n_chunks, cout * cin, tgt[0].data_ptr(), 1, st), "papc_reduce_partials_f32")
+                check(lib.papc_reduce_partials_f32(ptr(dbp), n_chunks, cout, tgt[1].data_ptr(), 1, st), "papc_reduce_partials_f32")
+            else:
+                dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
+                db = torch.empty(cout, device=dev, dtype=torch.float32)
+                check(lib.papc_reduce_partials_f32(ptr(dwp), n_chunks, cout * cin, ptr(dw), 0, st), "papc_reduce_partials_f32")
+                check(lib.papc_reduce_partials_f32(ptr(dbp), n_chunks, cout, ptr(db), 0, st), "papc_reduce_partials_f32")
+                grads[4 * l + 0] = dw.reshape(w.shape)
+                grads[4 * l + 1] = db
+                grads[4 * l + 2] = dgb[0]
+                grads[4 * l + 3] = dgb[1]
             # ---- dX
             if l > 0:
                 wt = w2.t().contiguous()
@@ -201,5 +214,21 @@ class SharedMLPMax(torch.autograd.Function):
         return (None, None, None, None, grad_feats, None, grad_x) + tuple(grads)
 
 
+def grad_targets_of(params):
+    """The parameters' existing contiguous fp32 .grad tensors (e.g. views of distributed.FlatParams.grad), or None
+    if any is missing.  With targets the backward adds each gradient in place (one fused accumulate in the reduce
+    kernels) and hands autograd ``None``: no per-parameter AccumulateGrad add kernels."""
+    tg = []
+    for p in params:
+        g = getattr(p, "grad", None)
+        if not (isinstance(p, torch.nn.Parameter) and p.requires_grad and g is not None and g.is_contiguous()
+                and g.dtype == torch.float32 and g.shape == p.shape):
+            return None
+        tg.append(g)
+    return tg
+
+
 def shared_mlp_max(spec, bn_buffers, xyz, new_xyz, feats, idx, params, x_rows=None):
+    if spec.grad_targets is None and torch.is_grad_enabled():
+        spec.grad_targets = grad_targets_of(params)
     return SharedMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)

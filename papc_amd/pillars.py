@@ -62,12 +62,12 @@ class _PFNFused(torch.autograd.Function):
         dgb = torch.empty(2, C, device=dev, dtype=torch.float32)
         c12 = torch.empty(2, C, device=dev, dtype=torch.float32)
         check(lib.papc_bn_bwd_finalize_f32(ptr(red), nb, P * T, C, dgb[0].data_ptr(), dgb[1].data_ptr(), c12[0].data_ptr(),
-                                           c12[1].data_ptr(), st), "papc_bn_bwd_finalize_f32")
+                                           c12[1].data_ptr(), 0, st), "papc_bn_bwd_finalize_f32")
         dwp = torch.empty(nb, C, 9, device=dev, dtype=torch.float32)
         check(lib.papc_pfn_bwd_dw_f32(*geo, ptr(gout), ptr(argmax), *bn, c12[0].data_ptr(), c12[1].data_ptr(), ptr(dwp), st),
               "papc_pfn_bwd_dw_f32")
         dw = torch.empty(C, 9, device=dev, dtype=torch.float32)
-        check(lib.papc_reduce_partials_f32(ptr(dwp), nb, C * 9, ptr(dw), st), "papc_reduce_partials_f32")
+        check(lib.papc_reduce_partials_f32(ptr(dwp), nb, C * 9, ptr(dw), 0, st), "papc_reduce_partials_f32")
         return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None
 
 

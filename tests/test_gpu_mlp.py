@@ -157,3 +157,27 @@ def test_full_size_sa1_properties(dev):
     assert_close(out2.cpu().numpy(), out1.cpu().numpy(), 1e-5, "slot-permutation invariance")
     out3 = shared_mlp_max(spec, None, xyz, new_xyz, None, idx, params)
     assert torch.equal(out1, out3)                     # deterministic: no atomics in the forward
+
+
+def test_inplace_grad_accumulation_matches_autograd_path(dev):
+    """With pre-allocated contiguous .grad tensors (FlatParams) the backward adds gradients in place and returns None
+    to autograd; the result must equal the ordinary autograd-accumulated gradients (and really accumulate)."""
+    B, N = 2, 512
+    x = torch.from_numpy(make_clouds(B, N, 9)).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 9)).to(dev)
+    torch.manual_seed(1)
+    a = PointNetSetAbstraction(64, 0.3, 16, 3, [32, 64], False).to(dev)
+    b = PointNetSetAbstraction(64, 0.3, 16, 3, [32, 64], False).to(dev)
+    b.load_state_dict(a.state_dict())
+    for p in b.parameters():
+        p.grad = torch.ones_like(p)                      # pre-existing gradient -> in-place path, must ADD to it
+    _, oa = a(x, None, st)
+    _, ob = b(x, None, st)
+    g = torch.randn_like(oa)
+    oa.backward(g)
+    ob.backward(g)
+    for (name, pa), pb in zip(a.named_parameters(), b.parameters()):
+        if name.startswith("mlp_convs") and name.endswith("bias"):
+            continue                                     # conv bias under train-mode BN: true gradient 0, only rounding noise
+        # (1 + g) - 1 costs one ulp of 1.0 per element
+        assert torch.allclose(pb.grad - 1.0, pa.grad, rtol=1e-4, atol=3e-7), name
