@@ -132,6 +132,15 @@ __device__ __forceinline__ unsigned readlane63_u32(unsigned v) { return (unsigne
 __device__ __forceinline__ float readlane0_f32(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
 __device__ __forceinline__ unsigned readlane0_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 0); }
 
+// Workgroup barrier that orders LDS traffic only: waits for this wave's outstanding LDS ops (lgkmcnt) and joins the
+// barrier, but -- unlike __syncthreads(), whose fence makes hipcc drain vmcnt(0) -- leaves global loads AND stores in
+// flight.  On CDNA vmcnt counts stores too, so a plain __syncthreads() after an epilogue exposes the full store latency.
+// Only valid where no global-memory hand-off between waves depends on the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace papc

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
             float *Ys = smem + (buf ^ 1) * DW_STAGE_FLOATS;
             finish(Ys, Ys + RS * TOp);
         }
-        __syncthreads();
+        lds_barrier();  // LDS-only barrier: the idx prefetch of stage s+2 stays in flight
         buf ^= 1;
         m0 = mn;
         have = have_next;

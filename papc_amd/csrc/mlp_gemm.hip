@@ -48,16 +48,18 @@ constexpr int LDT = 36;  // LDS row stride (floats)
 constexpr int BK = 32;
 constexpr int GEMM_MAX_PARTS = 1024;
 
-// the thread's float4 of the weight tile: row n (output channel), internal channels k..k+3.  Loads are
-// unconditional (clamped indices); out-of-range elements are zeroed afterwards.  wmap / nmap are grid-uniform.
-template <bool VEC>
+// The thread's float4 of the weight tile: row n (output channel), internal channels k..k+3.  fetch_w4 ONLY issues
+// loads (unconditional, clamped indices) so they stay in flight across the MFMA phase; mask_w4 zeroes the
+// out-of-range elements when the registers are written to LDS.  WMAP / NMAP are compile-time (GROUP forward /
+// scatter dX): internal channel order [feats, xyz] -> the caller's weight columns / rows through gk().
+template <bool VEC, bool WMAP, bool NMAP>
 __device__ __forceinline__ float4 fetch_w4(const GemmArgs &p, int n, int k)
 {
     const int nn = n < p.Nout ? n : 0;
-    const int nrow = p.nmap ? gk(p.a.g, nn) : nn;
+    const int nrow = NMAP ? gk(p.a.g, nn) : nn;
     const float *wr = p.w + (int64_t)nrow * p.ldw;
     float4 v;
-    if (p.wmap) {
+    if (WMAP) {
         v.x = wr[k < p.Kin ? gk(p.a.g, k) : 0];
         v.y = wr[k + 1 < p.Kin ? gk(p.a.g, k + 1) : 0];
         v.z = wr[k + 2 < p.Kin ? gk(p.a.g, k + 2) : 0];
@@ -65,8 +67,15 @@ __device__ __forceinline__ float4 fetch_w4(const GemmArgs &p, int n, int k)
     } else if (VEC) {
         v = ld4(wr + (k < p.Kin ? k : 0));
     } else {
-        v = ld4s_or_zero(wr, k, p.Kin);
+        v.x = wr[k < p.Kin ? k : 0];
+        v.y = wr[k + 1 < p.Kin ? k + 1 : 0];
+        v.z = wr[k + 2 < p.Kin ? k + 2 : 0];
+        v.w = wr[k + 3 < p.Kin ? k + 3 : 0];
     }
+    return v;
+}
+__device__ __forceinline__ float4 mask_w4(const GemmArgs &p, int n, int k, float4 v)
+{
     const bool nok = n < p.Nout;
     if (!(nok && k < p.Kin)) v.x = 0.f;
     if (!(nok && k + 1 < p.Kin)) v.y = 0.f;
@@ -75,11 +84,18 @@ __device__ __forceinline__ float4 fetch_w4(const GemmArgs &p, int n, int k)
     return v;
 }
 
+// Per iteration (stage s):   issue raw loads of stage s+1  ->  MFMAs of stage s (LDS buffer s&1)  ->  consume the loads
+// (transform, write LDS buffer (s+1)&1)  ->  epilogue stores if s closed a row tile  ->  LDS-only barrier.
+// The consume step sits BEFORE the stores on purpose: gfx9-family vmcnt counts loads and stores together and, with both
+// kinds pending, a wait for a load degenerates to vmcnt(0); ordered this way the stores are the youngest VMEM ops of
+// the iteration and drain under the next stage's MFMAs (the barrier does not wait for them: lds_barrier()).
 template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     constexpr int NWL = BN / 32;  // weight float4 loads per thread per stage
+    constexpr bool WMAP = (AMODE == A_GROUP);
+    constexpr bool NMAP = (EPI == EPI_SCATTER);
     static_assert(WGM * WGN == 4, "4 waves");
     static_assert(BM == 128, "row tile is 128");
     constexpr int STAGE = (BM + BN) * LDT;
@@ -97,9 +113,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
     const int r0 = tid >> 3;  // 0..31
     const bool use_jpre = (AMODE == A_GROUP) && p.a.g.idx != nullptr;
 
-    float s1[WN], s2[WN];
+    float s1[WN], s2[WN], biasv[WN];
+    bool cok[WN];
 #pragma unroll
-    for (int wn = 0; wn < WN; ++wn) { s1[wn] = 0.f; s2[wn] = 0.f; }
+    for (int wn = 0; wn < WN; ++wn) {
+        s1[wn] = 0.f; s2[wn] = 0.f;
+        const int col = n0 + (wgn * WN + wn) * 32 + l31;
+        cok[wn] = col < p.Nout;
+        biasv[wn] = (EPI == EPI_STORE && p.bias) ? p.bias[cok[wn] ? col : 0] : 0.f;
+    }
 
     floatx16 acc[WM][WN];
 #pragma unroll
@@ -126,6 +148,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
             }
         }
     };
+    auto write_stage = [&](float *As, int kf) {  // consume the landed registers: transform + write one LDS buffer
+        float *Ws = As + BM * LDT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, rows[i], kf, p.Kin, kc, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NWL; ++i)
+            *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = mask_w4(p, n0 + r0 + 32 * i, kf, rw[i]);
+    };
 
     // ---- prologue: stage 0 of this workgroup's first tile
     bool have = tile_f < n_mtiles;
@@ -138,13 +169,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = fetch_a4<AMODE, VEC>(p.a, rows[i], kq, p.Kin);
 #pragma unroll
-        for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC>(p, n0 + r0 + 32 * i, kq);
-        float *As = smem, *Ws = smem + BM * LDT;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, rows[i], kq, p.Kin, kc, ra[i]);
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = rw[i];
+        for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + 32 * i, kq);
+        write_stage(smem, kq);
     }
     __syncthreads();
 
@@ -152,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
     int64_t tile_c = tile_f;  // tile / chunk of the stage being computed
     int kc_c = 0;
     while (have) {
-        // ---- advance the fetch cursor to stage s+1 and issue its loads
+        // ---- advance the fetch cursor to stage s+1 and issue its loads (loads only: nothing here touches the values)
         kc_f += 1;
         if (kc_f == n_kc) { kc_f = 0; tile_f += gridDim.x; }
         const bool have_next = tile_f < n_mtiles;
@@ -167,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = fetch_a4<AMODE, VEC>(p.a, rows[i], kf, p.Kin);
 #pragma unroll
-            for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC>(p, n0 + r0 + 32 * i, kf);
+            for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + 32 * i, kf);
         }
 
         // ---- MFMAs of stage s from LDS buffer `buf`
@@ -194,48 +220,65 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
             }
         }
 
-        // ---- last k-chunk of the tile: epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // ---- consume stage s+1's loads: transform, write the other LDS buffer
+        if (have_next) write_stage(smem + (buf ^ 1) * STAGE, kf);
+
+        // ---- last k-chunk of the tile: epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+        // Straight-line stores (no per-element branch) for full tiles; the ragged last tile takes the predicated path.
         if (kc_c == n_kc - 1) {
             const int64_t m0 = tile_c * BM;
+            const bool full = m0 + BM <= p.M;
 #pragma unroll
             for (int wn = 0; wn < WN; ++wn) {
                 const int col = n0 + (wgn * WN + wn) * 32 + l31;
-                const bool cok = col < p.Nout;
-                const float bias = (EPI == EPI_STORE && p.bias && cok) ? p.bias[col] : 0.f;
+                if (cok[wn]) {
 #pragma unroll
-                for (int wm = 0; wm < WM; ++wm) {
+                    for (int wm = 0; wm < WM; ++wm) {
+                        const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
+                        if (EPI == EPI_STORE) {
+                            float *yp = p.y + rb * p.ldy + col;
+                            if (full) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int64_t row = m0 + (wgm * WM + wm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (row < p.M && cok) {
-                            const float v = acc[wm][wn][r] + bias;
-                            if (EPI == EPI_STORE) {
-                                p.y[row * p.ldy + col] = v;
-                                s1[wn] += v;
-                                s2[wn] = fmaf(v, v, s2[wn]);
+                                for (int r = 0; r < 16; ++r) {
+                                    const float v = acc[wm][wn][r] + biasv[wn];
+                                    yp[(int64_t)((r & 3) + 8 * (r >> 2)) * p.ldy] = v;
+                                    s1[wn] += v;
+                                    s2[wn] = fmaf(v, v, s2[wn]);
+                                }
                             } else {
-                                // gradient of index_points: grad_feats[b, idx[m], col] += dX[m, col] (feature columns only)
-                                const int b = (int)fdiv((uint32_t)row, p.sc.divSK);
-                                const int j = p.sc.idx ? p.sc.idx[row] : (int)row - b * p.sc.S * p.sc.K;
-                                if (j >= 0 && j < p.sc.N) unsafeAtomicAdd(&p.sc.gf[((int64_t)b * p.sc.N + j) * p.sc.D + col], v);
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int ro = (r & 3) + 8 * (r >> 2);
+                                    if (rb + ro < p.M) {
+                                        const float v = acc[wm][wn][r] + biasv[wn];
+                                        yp[(int64_t)ro * p.ldy] = v;
+                                        s1[wn] += v;
+                                        s2[wn] = fmaf(v, v, s2[wn]);
+                                    }
+                                }
+                            }
+                        } else {
+                            // gradient of index_points: grad_feats[b, idx[m], col] += dX[m, col] (feature columns only)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int64_t row = rb + (r & 3) + 8 * (r >> 2);
+                                if (row < p.M) {
+                                    const int b = (int)fdiv((uint32_t)row, p.sc.divSK);
+                                    const int j = p.sc.idx ? p.sc.idx[row] : (int)row - b * p.sc.S * p.sc.K;
+                                    if (j >= 0 && j < p.sc.N) unsafeAtomicAdd(&p.sc.gf[((int64_t)b * p.sc.N + j) * p.sc.D + col], acc[wm][wn][r]);
+                                }
                             }
                         }
-                        acc[wm][wn][r] = 0.f;
                     }
                 }
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
             }
         }
 
-        // ---- finish stage s+1: transform the landed registers, write the other LDS buffer
-        if (have_next) {
-            float *As = smem + (buf ^ 1) * STAGE, *Ws = As + BM * LDT;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, rows[i], kf, p.Kin, kc, ra[i]);
-#pragma unroll
-            for (int i = 0; i < NWL; ++i) *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = rw[i];
-        }
-        __syncthreads();
+        lds_barrier();  // LDS-only: the epilogue's global stores and the idx prefetch stay in flight across it
         buf ^= 1;
         tile_c = tile_f;
         kc_c = kc_f;
