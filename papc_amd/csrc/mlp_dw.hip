@@ -8,8 +8,6 @@
 // MFMA mapping (v_mfma_f32_32x32x2_f32): A operand = dY^T (i = cout, k = row), B operand = X (k = row, j = cin).
 // Row stages sit in LDS row-major [RS rows][TOp | TIp channels]; lane l reads element [2*ks + (l>>5)][tile*32 + (l&31)]
 // with ds_read_b32: the 32 lanes of each half read 32 consecutive banks -> conflict-free without padding.
-// Every wave owns NT (1, 2 or 4) 32x32 output tiles; absent tiles (narrow layers) are computed on clamped
-// coordinates and simply not stored, so the MFMA loop has no branches.
 //
 // Software pipeline (same scheme as mlp_gemm.hip): the raw global loads of row stage s+1 are issued before the
 // MFMAs of stage s and transformed + written to the other LDS buffer after them; one barrier per stage; two
@@ -41,54 +39,54 @@ constexpr int DW_T = 128;              // output tile edge (channels)
 constexpr int DW_TI_WIDE = 160;           // gather layers (Cin = D+3 in (128,160]) keep all of cin in ONE tile
 constexpr int DW_STAGE_FLOATS = 9216;  // RS * (TOp + TIp) <= 32*(128+160) floats = 36 KiB per buffer
 
-template <int XMODE, int DYMODE, bool VEC, int NT, int NSX>
+// Waves are arranged WO x WI over the output tile; each owns NTO x NTI 32x32 tiles, so one k-step needs NTO + NTI
+// LDS operand reads for NTO*NTI MFMAs.  Absent tiles (narrow layers) are computed on clamped coordinates and not stored.
+template <int XMODE, int DYMODE, bool VEC, int WO, int WI, int NTO, int NTI, int NSX>
 __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
 {
+    static_assert(WO * WI == 4, "4 waves");
     __shared__ __attribute__((aligned(16))) float smem[2 * DW_STAGE_FLOATS + DW_T];
     float *dbred = smem + 2 * DW_STAGE_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
+    const int wo = wave / WI, wi = wave % WI;
     const int o0 = blockIdx.y * DW_T, i0 = blockIdx.z * (NSX > 4 ? DW_TI_WIDE : DW_T);
     const int TOp = p.TOp, TIp = p.TIp, RS = p.RS;
     const int nto = min(TOp / 32, (p.Cout - o0 + 31) / 32);  // 32-wide tiles actually present
     const int nti = min(TIp / 32, (p.Cin - i0 + 31) / 32);
-    const int ntiles = nto * nti;
-    // loader mapping: a stage of the dY tile is RS x TOp floats = RS*TOp/4 float4 slots; thread t owns slots
-    // t, t+256, ... -> channel group fixed per thread (TOp/4 divides 256), rows advance by 256/(TOp/4)
+    // loader mapping: slot = tid + 256*i -> row = slot / cg, channel group = slot % cg.  cg | 256 for every tile width
+    // except the 160-wide gather tile, so (outside that case) all slots of a thread share one channel group -- which the
+    // per-thread BN constants rely on.  Slots past the stage (narrow tiles) are clamped duplicates: they re-load and
+    // re-write the thread's last real slot, which keeps the fetch free of branches.
     const int cgy = TOp / 4, cgx = TIp / 4;
-    const int kqy = (tid % cgy) * 4, ry0 = tid / cgy, rsy = 256 / cgy, nsy = RS / rsy;  // nsy <= 4
-    // X slots are mapped generically (slot = tid + 256*i -> row = slot / cgx, channel group = slot % cgx) so the
-    // 160-wide gather tile (cgx = 40, which does not divide 256) works too; when cgx | 256 every slot of a thread
-    // has the same channel group, which the per-thread BN constants of the BNRELU producer rely on.
-    const int nsx = (RS * cgx + 255) / 256;
-    int xr[NSX], xk[NSX];
+    const int nsy = (RS * cgy + 255) / 256, nsx = (RS * cgx + 255) / 256;
+    int yr[4], xr[NSX], xk[NSX];
+    const int kqy = (tid % cgy) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) yr[i] = (tid + 256 * (i < nsy ? i : nsy - 1)) / cgy;
 #pragma unroll
     for (int i = 0; i < NSX; ++i) {
-        const int s = tid + 256 * i;
+        const int s = tid + 256 * (i < nsx ? i : nsx - 1);
         xr[i] = s / cgx;
         xk[i] = (s - xr[i] * cgx) * 4;
-        if (xr[i] >= RS) { xr[i] = RS - 1; }  // clamped duplicate slot (same value written twice: harmless)
     }
     const int kqx = xk[0];
     const bool use_jpre = (XMODE == A_GROUP) && p.x.g.idx != nullptr;
 
-    floatx16 acc[NT];
+    floatx16 acc[NTO][NTI];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int a = 0; a < NTO; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // tile ids of this wave: wave, wave+4, ... ; absent ids are clamped onto tile 0 (computed, never stored)
-    int toff[NT], tiff[NT];
-    bool tok[NT];
+        for (int b = 0; b < NTI; ++b)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int id = wave + 4 * t;
-        tok[t] = id < ntiles;
-        const int idc = tok[t] ? id : 0;
-        const int to = idc / nti, ti = idc - to * nti;
-        toff[t] = to * 32; tiff[t] = ti * 32;
-    }
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    int toff[NTO], tiff[NTI];
+    bool tok_o[NTO], tok_i[NTI];
+#pragma unroll
+    for (int a = 0; a < NTO; ++a) { const int to = wo * NTO + a; tok_o[a] = to < nto; toff[a] = (tok_o[a] ? to : 0) * 32; }
+#pragma unroll
+    for (int b = 0; b < NTI; ++b) { const int ti = wi * NTI + b; tok_i[b] = ti < nti; tiff[b] = (tok_i[b] ? ti : 0) * 32; }
 
     const KConst kcy = make_kconst<DYMODE, VEC>(p.dy, o0 + kqy, p.Cout);
     const KConst kcx = make_kconst<XMODE, VEC>(p.x, i0 + kqx, p.Cin);
@@ -112,37 +110,29 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
             }
         }
     };
-    auto fetch = [&](int64_t m0) {
+    auto fetch = [&](int64_t m0) {  // loads only
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i < nsy) {
-                rowy[i] = make_row<DYMODE>(p.dy, m0 + ry0 + rsy * i, mend);
-                rawy[i] = fetch_a4<DYMODE, VEC>(p.dy, rowy[i], o0 + kqy, p.Cout);
-            }
+            rowy[i] = make_row<DYMODE>(p.dy, m0 + yr[i], mend);
+            rawy[i] = fetch_a4<DYMODE, VEC>(p.dy, rowy[i], o0 + kqy, p.Cout);
         }
 #pragma unroll
         for (int i = 0; i < NSX; ++i) {
-            if (i < nsx) {
-                rowx[i] = make_row<XMODE>(p.x, m0 + xr[i], mend, use_jpre ? jpre[i] : -2);
-                rawx[i] = fetch_a4<XMODE, VEC>(p.x, rowx[i], i0 + xk[i], p.Cin);
-            }
+            rowx[i] = make_row<XMODE>(p.x, m0 + xr[i], mend, use_jpre ? jpre[i] : -2);
+            rawx[i] = fetch_a4<XMODE, VEC>(p.x, rowx[i], i0 + xk[i], p.Cin);
         }
     };
     auto finish = [&](float *Ys, float *Xs) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i < nsy) {
-                const float4 vy = finish_a4<DYMODE, VEC>(p.dy, rowy[i], o0 + kqy, p.Cout, kcy, rawy[i]);
-                dbs.x += vy.x; dbs.y += vy.y; dbs.z += vy.z; dbs.w += vy.w;
-                *reinterpret_cast<float4 *>(&Ys[(ry0 + rsy * i) * TOp + kqy]) = vy;
-            }
+            const float4 vy = finish_a4<DYMODE, VEC>(p.dy, rowy[i], o0 + kqy, p.Cout, kcy, rawy[i]);
+            if (i < nsy) { dbs.x += vy.x; dbs.y += vy.y; dbs.z += vy.z; dbs.w += vy.w; }
+            *reinterpret_cast<float4 *>(&Ys[yr[i] * TOp + kqy]) = vy;
         }
 #pragma unroll
         for (int i = 0; i < NSX; ++i) {
-            if (i < nsx) {
-                const float4 vx = finish_a4<XMODE, VEC>(p.x, rowx[i], i0 + xk[i], p.Cin, kcx, rawx[i]);
-                *reinterpret_cast<float4 *>(&Xs[xr[i] * TIp + xk[i]]) = vx;
-            }
+            const float4 vx = finish_a4<XMODE, VEC>(p.x, rowx[i], i0 + xk[i], p.Cin, kcx, rawx[i]);
+            *reinterpret_cast<float4 *>(&Xs[xr[i] * TIp + xk[i]]) = vx;
         }
     };
 
@@ -165,15 +155,36 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
             prefetch_j(mn + RS);      // indices for the stage after next
         }
         {
+            // MFMA phase with register double-buffered LDS operands: the reads of k-step ks+1 are issued before the
+            // MFMAs of k-step ks, so the matrix pipe never waits on LDS latency
             const float *Ys = smem + buf * DW_STAGE_FLOATS + hi * TOp + l31;
             const float *Xs = smem + buf * DW_STAGE_FLOATS + RS * TOp + hi * TIp + l31;
-            const int nks = RS / 2;
-#pragma unroll 4
-            for (int ks = 0; ks < nks; ++ks) {
-                const float *yr = Ys + 2 * ks * TOp;
-                const float *xr = Xs + 2 * ks * TIp;
+            const int nks = RS / 2;  // even
+            float a0[NTO], b0[NTI], a1[NTO], b1[NTI];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(yr[toff[t]], xr[tiff[t]], acc[t], 0, 0, 0);
+            for (int a = 0; a < NTO; ++a) a0[a] = Ys[toff[a]];
+#pragma unroll
+            for (int b = 0; b < NTI; ++b) b0[b] = Xs[tiff[b]];
+            for (int ks = 0; ks < nks; ks += 2) {
+                const float *y1 = Ys + (2 * ks + 2) * TOp, *x1 = Xs + (2 * ks + 2) * TIp;
+#pragma unroll
+                for (int a = 0; a < NTO; ++a) a1[a] = y1[toff[a]];
+#pragma unroll
+                for (int b = 0; b < NTI; ++b) b1[b] = x1[tiff[b]];
+#pragma unroll
+                for (int a = 0; a < NTO; ++a)
+#pragma unroll
+                    for (int b = 0; b < NTI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[a], b0[b], acc[a][b], 0, 0, 0);
+                const int k2 = (ks + 2 < nks) ? ks + 2 : ks;  // last pair: harmless re-read of valid rows
+                const float *y2 = Ys + (2 * k2) * TOp, *x2 = Xs + (2 * k2) * TIp;
+#pragma unroll
+                for (int a = 0; a < NTO; ++a) a0[a] = y2[toff[a]];
+#pragma unroll
+                for (int b = 0; b < NTI; ++b) b0[b] = x2[tiff[b]];
+#pragma unroll
+                for (int a = 0; a < NTO; ++a)
+#pragma unroll
+                    for (int b = 0; b < NTI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[a], b1[b], acc[a][b], 0, 0, 0);
             }
         }
         if (have_next) {
@@ -189,21 +200,27 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
     // ---- store the partial tile: row (cout) = (r&3)+8*(r>>2)+4*hi, col (cin) = l31
     float *out = p.dw_partial + (int64_t)blockIdx.x * p.Cout * p.Cin;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int ci = i0 + tiff[t] + l31;
-        if (tok[t] && ci < p.Cin) {
+    for (int b = 0; b < NTI; ++b) {
+        const int ci = i0 + tiff[b] + l31;
+        if (tok_i[b] && ci < p.Cin) {
             const int cig = p.xmap ? gk(p.x.g, ci) : ci;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = o0 + toff[t] + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (co < p.Cout) out[(int64_t)co * p.Cin + cig] = acc[t][r];
+            for (int a = 0; a < NTO; ++a) {
+                if (tok_o[a]) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = o0 + toff[a] + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (co < p.Cout) out[(int64_t)co * p.Cin + cig] = acc[a][b][r];
+                    }
+                }
             }
         }
     }
 
     // ---- bias gradient partial: column sums of dY over this chunk (only the first cin tile writes it).
-    // Threads with the same channel group differ in ry0 (0 .. rsy-1): add them in that fixed order (deterministic).
+    // Threads with the same channel group differ in their row lane (tid / cgy): add them in that fixed order.
     if (p.db_partial && blockIdx.z == 0) {
+        const int rsy = 256 / cgy, ry0 = tid / cgy;
         if (tid < DW_T) dbred[tid] = 0.f;
         __syncthreads();
         for (int g = 0; g < rsy; ++g) {
@@ -219,12 +236,15 @@ static int launch_dw_v(const DwArgs &p, hipStream_t st)
 {
     const bool wide = p.TIp == DW_TI_WIDE;
     dim3 grid((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)cdiv(p.Cout, DW_T), (unsigned)cdiv(p.Cin, wide ? DW_TI_WIDE : DW_T));
-    const int tiles = (p.TOp / 32) * (p.TIp / 32);  // upper bound of 32x32 tiles per workgroup
+    const int to = p.TOp / 32, ti = p.TIp / 32;  // 32-wide tiles per workgroup (upper bound)
     if (wide) {
-        if (XMODE == A_GROUP) hipLaunchKernelGGL((dw_kernel<A_GROUP, DYMODE, VEC, 5, 5>), grid, dim3(256), 0, st, p);
-    } else if (tiles <= 4) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 1, 4>), grid, dim3(256), 0, st, p);
-    else if (tiles <= 8) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2, 4>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 4, 4>), grid, dim3(256), 0, st, p);
+        if (XMODE == A_GROUP) hipLaunchKernelGGL((dw_kernel<A_GROUP, DYMODE, VEC, 4, 1, 1, 5, 5>), grid, dim3(256), 0, st, p);
+    } else if (!VEC) {
+        hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, false, 2, 2, 2, 2, 4>), grid, dim3(256), 0, st, p);  // ragged shapes: one generic variant
+    } else if (to > 2 && ti > 2) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2, 2, 2, 2, 4>), grid, dim3(256), 0, st, p);
+    else if (to > 2) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2, 2, 2, 1, 4>), grid, dim3(256), 0, st, p);
+    else if (ti > 2) hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2, 2, 1, 2, 4>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((dw_kernel<XMODE, DYMODE, VEC, 2, 2, 1, 1, 4>), grid, dim3(256), 0, st, p);
     return check_launch("papc_mlp_bwd_dw_f32");
 }
 

@@ -12,7 +12,7 @@
 //   * both operands sit in LDS K-contiguous with a 36-float row stride (9 x 16 B: odd number of 16-B slots ->
 //     conflict-free ds_read_b128 for the 16-lane groups of the instruction); one ds_read_b128 per operand tile
 //     feeds FOUR MFMAs: lanes 0-31 carry k = kk..kk+3, lanes 32-63 carry k = kk+4..kk+7.
-//   * workgroups are persistent over row tiles (grid.x <= 1024), so the BN-statistics partials are one
+//   * workgroups are persistent over row tiles (grid.x <= 512 = one residency wave), so the BN-statistics partials are one
 //     deterministic row per workgroup, no atomics.
 //   * software pipeline: the (row tile, k-chunk) pairs of a workgroup form one flat sequence of stages; stage
 //     s+1's global loads are issued (raw, into registers) BEFORE the MFMAs of stage s and are transformed + written
@@ -46,7 +46,7 @@ struct GemmArgs {
 
 constexpr int LDT = 36;  // LDS row stride (floats)
 constexpr int BK = 32;
-constexpr int GEMM_MAX_PARTS = 1024;
+constexpr int GEMM_MAX_PARTS = 512;  // one residency wave: 256 CUs x 2 workgroups
 
 // The thread's float4 of the weight tile: row n (output channel), internal channels k..k+3.  fetch_w4 ONLY issues
 // loads (unconditional, clamped indices) so they stay in flight across the MFMA phase; mask_w4 zeroes the

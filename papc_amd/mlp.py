@@ -47,9 +47,11 @@ def _group_src(spec, xyz, new_xyz, feats, idx):
 
 
 def _dw_rows_per_chunk(M, cout, cin):
-    """Row-chunk size for the dW kernel: aim for >= ~512 workgroups in total, chunks of >= 256 rows."""
-    tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
-    want = max(1, 768 // tiles)
+    """Row-chunk size for the dW kernel: ONE residency wave of workgroups (256 CUs x 2 per CU = 512) in total, so
+    no tail round; chunks of >= 256 rows."""
+    wide = 128 < cin <= 160
+    tiles = ((cout + 127) // 128) * (1 if wide else (cin + 127) // 128)
+    want = max(1, 512 // tiles)
     rpc = (M + want - 1) // want
     rpc = max(256, ((rpc + 63) // 64) * 64)
     return rpc
@@ -134,7 +136,7 @@ class SharedMLPMax(torch.autograd.Function):
         M = spec.M
         gout = gout.contiguous().float()
         grp = None if plain else _group_src(spec, xyz, new_xyz, feats, idx)
-        n_parts = min(1024, (M + 127) // 128)
+        n_parts = min(512, (M + 127) // 128)
         grads = [None] * (4 * L)
         grad_feats = None
         grad_x = None
