@@ -312,7 +312,18 @@ template <int AMODE, int EPI, bool VEC>
 static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
 {
     const unsigned gx = (unsigned)gemm_parts(p.M);
-    if (p.Nout > 64) {
+    // few row tiles (group_all layers: M = B*N ~ 4096): 128-wide column tiles would leave most CUs idle, so use
+    // 64- (or 32-) wide ones to get >= ~256 workgroups; the A tile is then re-read from L2 by more workgroups
+    const int64_t wg128 = (int64_t)gx * cdiv(p.Nout, 128);
+    if (p.Nout > 64 && wg128 < 192 && (int64_t)gx * cdiv(p.Nout, 64) < 1024) {
+        if ((int64_t)gx * cdiv(p.Nout, 64) >= 192 || p.Nout <= 64) {
+            dim3 grid(gx, (unsigned)cdiv(p.Nout, 64));
+            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
+        } else {
+            dim3 grid(gx, (unsigned)cdiv(p.Nout, 32));
+            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+        }
+    } else if (p.Nout > 64) {
         dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
         hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
     } else if (p.Nout > 32) {

@@ -48,8 +48,22 @@ class PointNetSetAbstraction(nn.Module):
             for p in self.parameters():
                 p.requires_grad_(False)
 
-    def forward(self, xyz, points, start_idx=None):
-        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S]."""
+    def sample(self, xyz, start_idx=None):
+        """The weight-independent half of the layer (FPS + ball query, :143-145) on its own: xyz [B,3,N] ->
+        (new_xyz [B,S,3], idx [B,S,K] int32).  Lets a training loop run batch i+1's sampling on a side stream while
+        batch i's MLP kernels own the other CUs (FPS is a serial chain that occupies only B of the 256 CUs)."""
+        if self.group_all:
+            return None
+        xyz = xyz.transpose(1, 2)
+        if xyz.dtype != torch.float32:
+            xyz = xyz.float()
+        _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist)
+        idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz)[0]
+        return new_xyz, idx
+
+    def forward(self, xyz, points, start_idx=None, sampled=None):
+        """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S].
+        ``sampled`` = optional (new_xyz, idx) from :meth:`sample` (skips FPS / ball query here)."""
         xyz = xyz.transpose(1, 2)                                               # :203  [B,N,3] view
         if xyz.dtype != torch.float32:
             xyz = xyz.float()
@@ -64,8 +78,11 @@ class PointNetSetAbstraction(nn.Module):
             idx = None
         else:                                                                   # sample_and_group :129-157
             S, K = self.npoint, self.nsample
-            _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)
-            idx = F_._ball_query_raw([self.radius], [K], xyz, new_xyz)[0]
+            if sampled is not None:
+                new_xyz, idx = sampled
+            else:
+                _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)
+                idx = F_._ball_query_raw([self.radius], [K], xyz, new_xyz)[0]
         spec = StackSpec(B, N, S, K, D, xyz_first=True, eps=self.mlp_bns[0].eps, momentum=0.9,
                          cut_gather_grad=self.reference_quirks)
         out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx,

@@ -41,8 +41,22 @@ class PointNet2_SSG_Clas(nn.Module):
         self.drop2 = nn.Dropout(0.4)
         self.fc3 = nn.Linear(256, num_classes)
 
-    def forward(self, inputs, start_idx=None):
-        """inputs [B,3,N]; ``start_idx`` = optional (s1 [B], s2 [B]) FPS start indices (the source draws them at random)."""
+    def plan_sampling(self, inputs, start_idx=None):
+        """The whole weight-independent sampling pyramid of one batch (FPS1, ball query 1, FPS2, ball query 2): returns
+        ((new_xyz1, idx1), (new_xyz2, idx2)).  Pass it to forward(plan=...); a training loop can compute it for batch
+        i+1 on a side stream while batch i trains (see bench.py)."""
+        xyz = torch.as_tensor(inputs)
+        if self.normal_channel:
+            xyz = xyz[:, :3, :]
+        s = _starts(start_idx, 2)
+        with torch.no_grad():
+            p1 = self.sa1.sample(xyz, s[0])
+            p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1])
+        return p1, p2
+
+    def forward(self, inputs, start_idx=None, plan=None):
+        """inputs [B,3,N]; ``start_idx`` = optional (s1 [B], s2 [B]) FPS start indices (the source draws them at random);
+        ``plan`` = optional result of :meth:`plan_sampling` for these inputs."""
         xyz = torch.as_tensor(inputs)
         B = xyz.shape[0]
         if self.normal_channel:
@@ -50,8 +64,9 @@ class PointNet2_SSG_Clas(nn.Module):
         else:
             norm = None
         s = _starts(start_idx, 2)
-        l1_xyz, l1_points = self.sa1(xyz, norm, s[0])
-        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1])
+        pl = plan if plan is not None else (None, None)
+        l1_xyz, l1_points = self.sa1(xyz, norm, s[0], sampled=pl[0])
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1], sampled=pl[1])
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
         x = self.drop1(F.relu(self.bn1(self.fc1(x))))

@@ -131,3 +131,23 @@ def test_train_step_decreases_loss_and_quirks_mode(dev):
     q = PointNet2_SSG_Clas(reference_quirks=True).to(dev)        # the source's behaviour: SA params frozen, gathers cut
     TF.cross_entropy(q(x, st), y).backward()
     assert q.sa1.mlp_convs[0].weight.grad is None and q.fc1.weight.grad is not None
+
+
+def test_sampling_plan_equals_inline(dev):
+    """forward(plan=plan_sampling(x)) must equal forward(x) bit for bit (same kernels, only scheduled earlier)."""
+    B, N = 2, 1024
+    x = torch.from_numpy(make_clouds(B, N, 8)).to(dev)
+    st = (torch.from_numpy(make_start_idx(B, N, 8)).to(dev), torch.from_numpy(make_start_idx(B, 512, 9)).to(dev))
+    torch.manual_seed(0)
+    m = PointNet2_SSG_Clas().to(dev)
+    m.eval()
+    with torch.no_grad():
+        a = m(x, st)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            plan = m.plan_sampling(x, st)
+        torch.cuda.current_stream().wait_stream(side)
+        b = m(x, st, plan=plan)
+    assert torch.equal(a, b)
+    assert plan[0][1].dtype == torch.int32 and tuple(plan[0][0].shape) == (B, 512, 3) and tuple(plan[1][1].shape) == (B, 128, 64)
