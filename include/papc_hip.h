@@ -178,16 +178,22 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
 
 /* dW partials: dw_partial[t, Cout, Cin] = sum over the rows of chunk t of dY[m,:]^T A(x)[m,:], and
  * db_partial[t, Cout] = sum dY[m,:].  A(x) as in papc_mlp_gemm_f32 (recomputed, not stored).
- * rows_per_chunk is a multiple of 128; n_chunks = ceil(M/rows_per_chunk). */
+ * rows_per_chunk is a multiple of 64; n_chunks = ceil(M/rows_per_chunk).  Chunk rows are addressed with the row
+ * stride part_ld (>= Cout*Cin for dw_partial, the same stride for db_partial), so both partials may share one buffer:
+ * pass db_partial = dw_partial + Cout*Cin and part_ld = Cout*Cin + Cout, then reduce with papc_reduce_partials2_f32. */
 int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const float *x, int64_t ldx,
                         const papc_group_src *grp, const float *bn_scale, const float *bn_shift, int64_t M,
                         int Cin, int Cout, int rows_per_chunk, float *dw_partial, float *db_partial,
-                        papc_stream_t stream);
+                        int64_t part_ld, papc_stream_t stream);
 
 /* out[i] (+)= sum_t partial[t, i]  (fixed order -> deterministic); n = elements per chunk; accumulate != 0 adds
  * into out (gradient accumulation straight into a parameter's .grad) */
 int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, int accumulate,
                              papc_stream_t stream);
+/* two outputs from ONE partial buffer whose chunk rows are [n1 | n2] floats with row stride ld (the dW and db
+ * partials of papc_mlp_bwd_dw_f32 laid out back to back): out1[i] (+)= sum_t partial[t*ld + i], out2[j] likewise */
+int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, int64_t n1, float *out1, int64_t n2,
+                              float *out2, int accumulate, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PointPillars PillarFeatureNet (PAPC/models/detect/pointpillars/models/bones/pillars.py)

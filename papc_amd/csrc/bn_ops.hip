@@ -42,8 +42,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
         }
     r1[tl][cl] = s1; r2[tl][cl] = s2;
     __syncthreads();
+    for (int h = 32; h >= 1; h >>= 1) {  // fixed-shape tree over the 64 part-lanes (deterministic)
+        if (tl < h) { r1[tl][cl] += r1[tl + h][cl]; r2[tl][cl] += r2[tl + h][cl]; }
+        __syncthreads();
+    }
     if (tl == 0 && c < C) {
-        for (int g = 1; g < 64; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
+        s1 = r1[0][cl]; s2 = r2[0][cl];
         const double mu = s1 / (double)M;
         double var = s2 / (double)M - mu * mu;  // biased variance (paddle BatchNorm training)
         if (var < 0.0) var = 0.0;
@@ -196,8 +200,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
         }
     r1[tl][cl] = s1; r2[tl][cl] = s2;
     __syncthreads();
+    for (int h = 32; h >= 1; h >>= 1) {  // fixed-shape tree over the 64 part-lanes (deterministic)
+        if (tl < h) { r1[tl][cl] += r1[tl + h][cl]; r2[tl][cl] += r2[tl + h][cl]; }
+        __syncthreads();
+    }
     if (tl == 0 && c < C) {
-        for (int g = 1; g < 64; ++g) { s1 += r1[g][cl]; s2 += r2[g][cl]; }
+        s1 = r1[0][cl]; s2 = r2[0][cl];
         if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
         if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
         c1[c] = (float)(s1 / (double)M);
@@ -206,20 +214,22 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
 }
 
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ part, int n_chunks, int64_t n,
-                                                               float *__restrict__ out, int accumulate)
+                                                               int64_t ld, float *__restrict__ out, int64_t n1,
+                                                               float *__restrict__ out2, int accumulate)
 {
     __shared__ float red[16][64];
     const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
     const int64_t i = (int64_t)blockIdx.x * 64 + el;
     float s = 0.f;
     if (i < n)
-        for (int t = cl; t < n_chunks; t += 16) s += part[(int64_t)t * n + i];
+        for (int t = cl; t < n_chunks; t += 16) s += part[(int64_t)t * ld + i];
     red[cl][el] = s;
     __syncthreads();
     if (cl == 0 && i < n) {
 #pragma unroll
         for (int g = 1; g < 16; ++g) s += red[g][el];
-        out[i] = accumulate ? out[i] + s : s;
+        float *o = i < n1 ? out + i : out2 + (i - n1);  // elements [0,n1) -> out, [n1,n) -> out2
+        *o = accumulate ? *o + s : s;
     }
 }
 
@@ -316,13 +326,25 @@ int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, i
     return check_launch("papc_bn_bwd_finalize_f32");
 }
 
+int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, int64_t n1, float *out1, int64_t n2,
+                              float *out2, int accumulate, papc_stream_t stream)
+{
+    PAPC_REQUIRE(partial && out1 && (n2 == 0 || out2), PAPC_E_INVALID, "papc_reduce_partials2_f32: null pointer");
+    PAPC_REQUIRE(n_chunks >= 1 && n1 >= 1 && n2 >= 0 && ld >= n1 + n2, PAPC_E_INVALID, "papc_reduce_partials2_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    const int64_t n = n1 + n2;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, ld, out1, n1, out2, accumulate);
+    return check_launch("papc_reduce_partials2_f32");
+}
+
 int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, int accumulate, papc_stream_t stream)
 {
     PAPC_REQUIRE(partial && out, PAPC_E_INVALID, "papc_reduce_partials_f32: null pointer");
     PAPC_REQUIRE(n_chunks >= 1 && n >= 1, PAPC_E_INVALID, "papc_reduce_partials_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, out, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, n, out, n, (float *)nullptr, accumulate);
     return check_launch("papc_reduce_partials_f32");
 }
 

@@ -30,6 +30,7 @@ struct DwArgs {
     int64_t M; int Cin; int Cout; int rows_per_chunk;
     float *dw_partial;  // [n_chunks][Cout][Cin]
     float *db_partial;  // [n_chunks][Cout] or null
+    int64_t part_ld;    // row stride (floats) of both partial buffers
     int xmap;           // map internal cin -> caller's column (GROUP)
     int TOp, TIp;       // padded tile widths (32 / 64 / 128)
     int RS;             // rows per stage (32 or 64)
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
     }
 
     // ---- store the partial tile: row (cout) = (r&3)+8*(r>>2)+4*hi, col (cin) = l31
-    float *out = p.dw_partial + (int64_t)blockIdx.x * p.Cout * p.Cin;
+    float *out = p.dw_partial + (int64_t)blockIdx.x * p.part_ld;
 #pragma unroll
     for (int b = 0; b < NTI; ++b) {
         const int ci = i0 + tiff[b] + l31;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
             if (ry0 == g) { dbred[kqy + 0] += dbs.x; dbred[kqy + 1] += dbs.y; dbred[kqy + 2] += dbs.z; dbred[kqy + 3] += dbs.w; }
             __syncthreads();
         }
-        if (tid < TOp && o0 + tid < p.Cout) p.db_partial[(int64_t)blockIdx.x * p.Cout + o0 + tid] = dbred[tid];
+        if (tid < TOp && o0 + tid < p.Cout) p.db_partial[(int64_t)blockIdx.x * p.part_ld + o0 + tid] = dbred[tid];
     }
 }
 
@@ -263,11 +264,12 @@ using namespace papc;
 extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const float *x, int64_t ldx,
                                    const papc_group_src *grp, const float *bn_scale, const float *bn_shift, int64_t M,
                                    int Cin, int Cout, int rows_per_chunk, float *dw_partial, float *db_partial,
-                                   papc_stream_t stream)
+                                   int64_t part_ld, papc_stream_t stream)
 {
     PAPC_REQUIRE(dw_partial, PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: null dw_partial");
     PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: bad sizes");
     PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_mlp_bwd_dw_f32: M=%lld >= 2^31 rows", (long long)M);
+    PAPC_REQUIRE(part_ld >= (int64_t)Cout * Cin, PAPC_E_INVALID, "papc_mlp_bwd_dw_f32: part_ld=%lld < Cout*Cin", (long long)part_ld);
     PAPC_REQUIRE(rows_per_chunk >= 64 && rows_per_chunk % 64 == 0, PAPC_E_INVALID,
                  "papc_mlp_bwd_dw_f32: rows_per_chunk=%d must be a positive multiple of 64", rows_per_chunk);
     bool vdy = false;
@@ -279,7 +281,7 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     if (rc) return rc;
     fill_dy(p.dy.d, dy);
     const bool vec = vdy && p.x.vec;
-    p.M = M; p.Cin = Cin; p.Cout = Cout; p.rows_per_chunk = rows_per_chunk; p.dw_partial = dw_partial; p.db_partial = db_partial;
+    p.M = M; p.Cin = Cin; p.Cout = Cout; p.rows_per_chunk = rows_per_chunk; p.dw_partial = dw_partial; p.db_partial = db_partial; p.part_ld = part_ld;
     p.xmap = (a_mode == A_GROUP) ? 1 : 0;
     p.TOp = pad_tile(Cout); p.TIp = pad_tile(Cin);
     if (a_mode == A_GROUP && Cin > DW_T && Cin <= DW_TI_WIDE && p.TOp == 128) p.TIp = DW_TI_WIDE;  // D+3 with D = 128

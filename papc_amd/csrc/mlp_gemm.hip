@@ -29,7 +29,7 @@ enum { EPI_STORE = 0, EPI_SCATTER = 1 };
 
 struct ScatterDst {
     float *gf; const int32_t *idx; int N, S, K, D;
-    FastDiv divSK;
+    FastDiv divSK, divK;
 };
 
 struct GemmArgs {
@@ -232,6 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
             for (int wn = 0; wn < WN; ++wn) {
                 const int col = n0 + (wgn * WN + wn) * 32 + l31;
                 if (cok[wn]) {
+                    float dsum = 0.f;                    // scatter epilogue: pending sum of padding duplicates ...
+                    int dgrp = -1, djf = -1, dbat = 0;   // ... of group dgrp (first neighbour djf, cloud dbat)
 #pragma unroll
                     for (int wm = 0; wm < WM; ++wm) {
                         const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
@@ -258,18 +260,40 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
                                 }
                             }
                         } else {
-                            // gradient of index_points: grad_feats[b, idx[m], col] += dX[m, col] (feature columns only)
+                            // gradient of index_points: grad_feats[b, idx[m], col] += dX[m, col] (feature columns only).
+                            // Ball-query padding repeats each group's FIRST neighbour (pointnet2_basic_layers.py:118-124),
+                            // often for half the nsample slots: those rows would hammer one L2 line with dependent atomics,
+                            // so they are summed in a register per group and flushed with a single atomic.
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int64_t row = rb + (r & 3) + 8 * (r >> 2);
                                 if (row < p.M) {
+                                    const float v = acc[wm][wn][r];
                                     const int b = (int)fdiv((uint32_t)row, p.sc.divSK);
-                                    const int j = p.sc.idx ? p.sc.idx[row] : (int)row - b * p.sc.S * p.sc.K;
-                                    if (j >= 0 && j < p.sc.N) unsafeAtomicAdd(&p.sc.gf[((int64_t)b * p.sc.N + j) * p.sc.D + col], acc[wm][wn][r]);
+                                    if (p.sc.idx) {
+                                        const int g = (int)fdiv((uint32_t)row, p.sc.divK);
+                                        const int jf = p.sc.idx[(int64_t)g * p.sc.K];
+                                        const int j = p.sc.idx[row];
+                                        if (j == jf && (int)row != g * p.sc.K) {
+                                            if (g != dgrp) {
+                                                if (dgrp >= 0 && djf >= 0 && djf < p.sc.N)
+                                                    unsafeAtomicAdd(&p.sc.gf[((int64_t)dbat * p.sc.N + djf) * p.sc.D + col], dsum);
+                                                dsum = 0.f; dgrp = g; djf = jf; dbat = b;
+                                            }
+                                            dsum += v;
+                                        } else if (j >= 0 && j < p.sc.N) {
+                                            unsafeAtomicAdd(&p.sc.gf[((int64_t)b * p.sc.N + j) * p.sc.D + col], v);
+                                        }
+                                    } else {
+                                        const int j = (int)row - b * p.sc.S * p.sc.K;
+                                        unsafeAtomicAdd(&p.sc.gf[((int64_t)b * p.sc.N + j) * p.sc.D + col], v);
+                                    }
                                 }
                             }
                         }
                     }
+                    if (EPI == EPI_SCATTER && dgrp >= 0 && djf >= 0 && djf < p.sc.N)
+                        unsafeAtomicAdd(&p.sc.gf[((int64_t)dbat * p.sc.N + djf) * p.sc.D + col], dsum);
                 }
 #pragma unroll
                 for (int wm = 0; wm < WM; ++wm)
@@ -454,6 +478,7 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
         p.sc.gf = scatter->grad_feats; p.sc.idx = scatter->idx; p.sc.N = scatter->N; p.sc.S = scatter->S;
         p.sc.K = scatter->K; p.sc.D = scatter->D;
         p.sc.divSK = make_fastdiv((uint32_t)scatter->S * (uint32_t)scatter->K);
+        p.sc.divK = make_fastdiv((uint32_t)scatter->K);
         // output column n is internal order [feats, xyz]; weight row = caller's channel order
         p.nmap = scatter->col0 ? 1 : 0;
         p.a.g.D = scatter->D; p.a.g.xyz_first = scatter->col0 ? 1 : 0;

@@ -171,26 +171,27 @@ class SharedMLPMax(torch.autograd.Function):
             # ---- dW, db
             rpc = _dw_rows_per_chunk(M, cout, cin)
             n_chunks = (M + rpc - 1) // rpc
-            dwp = torch.empty(n_chunks, cout, cin, device=dev, dtype=torch.float32)
-            dbp = torch.empty(n_chunks, cout, device=dev, dtype=torch.float32)
+            pld = cout * cin + cout          # one partial buffer: chunk rows are [dW (cout*cin) | db (cout)]
+            part = torch.empty(n_chunks, pld, device=dev, dtype=torch.float32)
+            dwp_p, dbp_p = part.data_ptr(), part.data_ptr() + 4 * cout * cin
             if l == 0 and plain:
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_PLAIN, ptr(x_rows), cin, None, None, None, M, cin, cout, rpc,
-                                              ptr(dwp), ptr(dbp), st), "papc_mlp_bwd_dw_f32")
+                                              dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
             elif l == 0:
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_GROUP, None, 0, ctypes.byref(grp), None, None, M, cin, cout, rpc,
-                                              ptr(dwp), ptr(dbp), st), "papc_mlp_bwd_dw_f32")
+                                              dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
             else:
                 pc = consts[l - 1]
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_BNRELU, ys[l - 1].data_ptr(), cin, None, pc[2].data_ptr(),
-                                              pc[3].data_ptr(), M, cin, cout, rpc, ptr(dwp), ptr(dbp), st), "papc_mlp_bwd_dw_f32")
+                                              pc[3].data_ptr(), M, cin, cout, rpc, dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
             if inplace:
-                check(lib.papc_reduce_partials_f32(ptr(dwp), n_chunks, cout * cin, tgt[0].data_ptr(), 1, st), "papc_reduce_partials_f32")
-                check(lib.papc_reduce_partials_f32(ptr(dbp), n_chunks, cout, tgt[1].data_ptr(), 1, st), "papc_reduce_partials_f32")
+                check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, tgt[0].data_ptr(), cout,
+                                                    tgt[1].data_ptr(), 1, st), "papc_reduce_partials2_f32")
             else:
                 dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
                 db = torch.empty(cout, device=dev, dtype=torch.float32)
-                check(lib.papc_reduce_partials_f32(ptr(dwp), n_chunks, cout * cin, ptr(dw), 0, st), "papc_reduce_partials_f32")
-                check(lib.papc_reduce_partials_f32(ptr(dbp), n_chunks, cout, ptr(db), 0, st), "papc_reduce_partials_f32")
+                check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, ptr(dw), cout, ptr(db), 0, st),
+                      "papc_reduce_partials2_f32")
                 grads[4 * l + 0] = dw.reshape(w.shape)
                 grads[4 * l + 1] = db
                 grads[4 * l + 2] = dgb[0]
