@@ -18,14 +18,18 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("PAPC_FORCE_DIST") == "1"   # 1-rank group: exercises the collective path on a 1-GPU box
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)   # binds the communicator to this rank's GPU up front
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
@@ -58,13 +62,13 @@ class FlatParams:
 
     def broadcast(self, src=0):
         """Make every rank start from rank ``src``'s weights."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():
             dist.broadcast(self.data, src=src)
 
     def allreduce_grads(self):
         """Sum the flat gradient bucket over ranks (ONE collective).  Returns the scale that turns the sum into the
         mean (1/world) -- folded into the optimiser kernel instead of a separate pass."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_initialized():
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()
         return 1.0
