@@ -173,8 +173,18 @@ typedef struct papc_scatter_dst {
     int N, S, K, D;
     int col0;              /* first dX column that maps to feature 0 */
 } papc_scatter_dst;
+/* next_red (optional, dense dx only): fuse the previous layer's BN-backward reductions into this kernel's epilogue.
+ * dx is that layer's dz; with y/mean/invstd/scale/shift of the PREVIOUS layer (channel count Cin) the kernel also
+ * writes red_partial [papc_mlp_gemm_parts(M), 2, Cin] = (sum p, sum p*xhat), exactly what papc_bn_bwd_reduce_f32
+ * (DENSE) would produce in a separate pass over dx -- feed it to papc_bn_bwd_finalize_f32 with n_tiles =
+ * papc_mlp_gemm_parts(M). */
+typedef struct papc_bwd_red {
+    const float *y;                                  /* [M,Cin] pre-BN output of the previous layer */
+    const float *mean, *invstd, *scale, *shift;      /* [Cin] */
+    float *red_partial;                              /* [papc_mlp_gemm_parts(M), 2, Cin] */
+} papc_bwd_red;
 int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, float *dx,
-                        const papc_scatter_dst *scatter, papc_stream_t stream);
+                        const papc_scatter_dst *scatter, const papc_bwd_red *next_red, papc_stream_t stream);
 
 /* dW partials: dw_partial[t, Cout, Cin] = sum over the rows of chunk t of dY[m,:]^T A(x)[m,:], and
  * db_partial[t, Cout] = sum dY[m,:].  A(x) as in papc_mlp_gemm_f32 (recomputed, not stored).

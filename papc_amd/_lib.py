@@ -31,6 +31,11 @@ class BwdDy(ctypes.Structure):
                 ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("c1", c_p), ("c2", c_p)]
 
 
+class BwdRed(ctypes.Structure):
+    """papc_bwd_red"""
+    _fields_ = [("y", c_p), ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("red_partial", c_p)]
+
+
 class ScatterDst(ctypes.Structure):
     """papc_scatter_dst"""
     _fields_ = [("grad_feats", c_p), ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("col0", c_i)]
@@ -53,7 +58,7 @@ SIGNATURES = {
     "papc_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_p]),
     "papc_bn_bwd_reduce_f32": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p]),
     "papc_bn_bwd_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
-    "papc_mlp_bwd_dx_f32": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
+    "papc_mlp_bwd_dx_f32": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_mlp_bwd_dw_f32": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "papc_reduce_partials2_f32": (c_i, [c_p, c_i, c_l, c_l, c_p, c_l, c_p, c_i, c_p]),
     "papc_reduce_partials_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p]),

@@ -25,7 +25,14 @@ namespace papc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_SCATTER = 1 };
+enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2 };
+
+// EPI_STORE_RED (dX only): besides storing dz_prev = dX, accumulate the BN-backward reductions of the PREVIOUS layer
+// (p = dz_prev * [scale*y_prev + shift > 0]; sum p and sum p*xhat per channel) into the stats partials, so no separate
+// pass has to re-read dz_prev.
+struct RedSrc {
+    const float *y; const float *mean, *invstd, *scale, *shift;  // previous layer: pre-BN output [M,Nout] and BN constants
+};
 
 struct ScatterDst {
     float *gf; const int32_t *idx; int N, S, K, D;
@@ -42,6 +49,7 @@ struct GemmArgs {
     float *y; int64_t ldy;
     float *stats;                  // [gridDim.x][2][Nout] or null
     ScatterDst sc;
+    RedSrc rd;
 };
 
 constexpr int LDT = 36;  // LDS row stride (floats)
@@ -121,6 +129,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
         const int col = n0 + (wgn * WN + wn) * 32 + l31;
         cok[wn] = col < p.Nout;
         biasv[wn] = (EPI == EPI_STORE && p.bias) ? p.bias[cok[wn] ? col : 0] : 0.f;
+    }
+    float rsc[WN], rsh[WN], rmu[WN], ris[WN];  // EPI_STORE_RED: previous layer's BN constants of this lane's columns
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const int col = n0 + (wgn * WN + wn) * 32 + l31;
+        const int cc = cok[wn] ? col : 0;
+        rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
+        if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[cc]; rsh[wn] = p.rd.shift[cc]; rmu[wn] = p.rd.mean[cc]; ris[wn] = p.rd.invstd[cc]; }
     }
 
     floatx16 acc[WM][WN];
@@ -234,10 +250,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
                 if (cok[wn]) {
                     float dsum = 0.f;                    // scatter epilogue: pending sum of padding duplicates ...
                     int dgrp = -1, djf = -1, dbat = 0;   // ... of group dgrp (first neighbour djf, cloud dbat)
+                    if (EPI == EPI_STORE_RED) {
+                        // issue the previous layer's y for ALL of this lane's rows first (one exposed latency per column),
+                        // then store dz_prev and accumulate p = dz*[z>0], p*xhat
+                        float yv[WM][16];
+#pragma unroll
+                        for (int wm = 0; wm < WM; ++wm) {
+                            const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
+                            const float *qp = p.rd.y + rb * p.ldy + col;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ro = (r & 3) + 8 * (r >> 2);
+                                yv[wm][r] = qp[(int64_t)((full || rb + ro < p.M) ? ro : 0) * p.ldy];
+                            }
+                        }
+#pragma unroll
+                        for (int wm = 0; wm < WM; ++wm) {
+                            const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
+                            float *yp = p.y + rb * p.ldy + col;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ro = (r & 3) + 8 * (r >> 2);
+                                if (full || rb + ro < p.M) {
+                                    const float v = acc[wm][wn][r];
+                                    yp[(int64_t)ro * p.ldy] = v;
+                                    const float pp = fmaf(rsc[wn], yv[wm][r], rsh[wn]) > 0.f ? v : 0.f;
+                                    s1[wn] += pp;
+                                    s2[wn] = fmaf(pp, (yv[wm][r] - rmu[wn]) * ris[wn], s2[wn]);
+                                }
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int wm = 0; wm < WM; ++wm) {
                         const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
-                        if (EPI == EPI_STORE) {
+                        if (EPI == EPI_STORE_RED) {
+                            // handled below (all row tiles of this column at once)
+                        } else if (EPI == EPI_STORE) {
                             float *yp = p.y + rb * p.ldy + col;
                             if (full) {
 #pragma unroll
@@ -309,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
         have = have_next;
     }
 
-    if (EPI == EPI_STORE && p.stats) {
+    if ((EPI == EPI_STORE || EPI == EPI_STORE_RED) && p.stats) {
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             s1[wn] += __shfl_xor(s1[wn], 32);
@@ -456,7 +505,7 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
 }
 
 int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, float *dx,
-                        const papc_scatter_dst *scatter, papc_stream_t stream)
+                        const papc_scatter_dst *scatter, const papc_bwd_red *next_red, papc_stream_t stream)
 {
     PAPC_REQUIRE(wt, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: null wt");
     PAPC_REQUIRE(dx || scatter, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: need dx or scatter");
@@ -484,8 +533,18 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
         p.a.g.D = scatter->D; p.a.g.xyz_first = scatter->col0 ? 1 : 0;
         p.Nout = scatter->D;  // xyz columns carry no gradient: skip them entirely
     }
+    if (next_red) {
+        PAPC_REQUIRE(!scatter && dx, PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: next_red needs a dense dx");
+        PAPC_REQUIRE(next_red->y && next_red->mean && next_red->invstd && next_red->scale && next_red->shift && next_red->red_partial,
+                     PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: null pointer in next_red");
+        p.rd.y = next_red->y; p.rd.mean = next_red->mean; p.rd.invstd = next_red->invstd; p.rd.scale = next_red->scale;
+        p.rd.shift = next_red->shift; p.stats = next_red->red_partial;
+    }
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DX, st);
+    if (next_red) {
+        return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_STORE_RED>(p, vec, st) : launch_gemm<A_DY_MAX, EPI_STORE_RED>(p, vec, st);
+    }
     if (scatter) {
         return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_SCATTER>(p, vec, st) : launch_gemm<A_DY_MAX, EPI_SCATTER>(p, vec, st);
     }

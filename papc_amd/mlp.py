@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BwdDy, GroupSrc, ScatterDst, check, ptr, stream_ptr
+from ._lib import BwdDy, BwdRed, GroupSrc, ScatterDst, check, ptr, stream_ptr
 
 A_PLAIN, A_BNRELU, A_GROUP = 0, 1, 2
 DZ_DENSE, DZ_MAX = 0, 1
@@ -141,6 +141,8 @@ class SharedMLPMax(torch.autograd.Function):
         grad_feats = None
         grad_x = None
         dz = None
+        fused_red = None
+        gemm_parts = lib.papc_mlp_gemm_parts(M)
         for l in range(L - 1, -1, -1):
             w = params[4 * l]
             cout = w.shape[0]
@@ -155,7 +157,6 @@ class SharedMLPMax(torch.autograd.Function):
             else:
                 dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)  # dgamma, dbeta
                 dgamma_p, dbeta_p = dgb[0].data_ptr(), dgb[1].data_ptr()
-            red = torch.empty(n_parts, 2, cout, device=dev, dtype=torch.float32)
             dy = BwdDy()
             if l == L - 1:
                 dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_MAX, None, gout.data_ptr(), argmax.data_ptr(), spec.K
@@ -164,9 +165,13 @@ class SharedMLPMax(torch.autograd.Function):
             dy.y = ys[l].data_ptr()
             dy.mean, dy.invstd, dy.scale, dy.shift = (cst[i].data_ptr() for i in range(4))
             dy.c1, dy.c2 = c12[0].data_ptr(), c12[1].data_ptr()
-            check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
-                                             dy.shift, M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
-            check(lib.papc_bn_bwd_finalize_f32(ptr(red), n_parts, M, cout, dgamma_p, dbeta_p,
+            if fused_red is None:   # (sum p, sum p*xhat): separate pass, unless the dX kernel of layer l+1 already produced it
+                red, red_parts = torch.empty(n_parts, 2, cout, device=dev, dtype=torch.float32), n_parts
+                check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
+                                                 dy.shift, M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
+            else:
+                red, red_parts = fused_red, gemm_parts
+            check(lib.papc_bn_bwd_finalize_f32(ptr(red), red_parts, M, cout, dgamma_p, dbeta_p,
                                                c12[0].data_ptr(), c12[1].data_ptr(), int(inplace), st), "papc_bn_bwd_finalize_f32")
             # ---- dW, db
             rpc = _dw_rows_per_chunk(M, cout, cin)
@@ -197,15 +202,24 @@ class SharedMLPMax(torch.autograd.Function):
                 grads[4 * l + 2] = dgb[0]
                 grads[4 * l + 3] = dgb[1]
             # ---- dX
+            fused_red = None
             if l > 0:
                 wt = w2.t().contiguous()
                 dz_prev = torch.empty(M, cin, device=dev, dtype=torch.float32)
-                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dz_prev), None, st), "papc_mlp_bwd_dx_f32")
+                # the dX kernel also accumulates layer l-1's BN-backward reductions over the dz it produces
+                pc = consts[l - 1]
+                fused_red = torch.empty(gemm_parts, 2, cin, device=dev, dtype=torch.float32)
+                nr = BwdRed()
+                nr.y = ys[l - 1].data_ptr()
+                nr.mean, nr.invstd, nr.scale, nr.shift = (pc[i].data_ptr() for i in range(4))
+                nr.red_partial = fused_red.data_ptr()
+                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dz_prev), None, ctypes.byref(nr), st),
+                      "papc_mlp_bwd_dx_f32")
                 dz = dz_prev
             elif plain and ctx.x_needs_grad:
                 wt = w2.t().contiguous()
                 grad_x = torch.empty(M, cin, device=dev, dtype=torch.float32)
-                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(grad_x), None, st), "papc_mlp_bwd_dx_f32")
+                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(grad_x), None, None, st), "papc_mlp_bwd_dx_f32")
             elif (not plain) and ctx.feats_needs_grad:
                 wt = w2.t().contiguous()
                 grad_feats = torch.zeros(spec.B, spec.N, spec.D, device=dev, dtype=torch.float32)
@@ -213,7 +227,7 @@ class SharedMLPMax(torch.autograd.Function):
                 sc.grad_feats, sc.idx = grad_feats.data_ptr(), ptr(idx)
                 sc.N, sc.S, sc.K, sc.D = spec.N, spec.S, spec.K, spec.D
                 sc.col0 = 3 if spec.xyz_first else 0
-                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, None, ctypes.byref(sc), st), "papc_mlp_bwd_dx_f32")
+                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, None, ctypes.byref(sc), None, st), "papc_mlp_bwd_dx_f32")
         return (None, None, None, None, grad_feats, None, grad_x) + tuple(grads)
 
 
