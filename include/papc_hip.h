@@ -110,9 +110,24 @@ typedef struct papc_group_src {
  * squares of y (deterministic, no atomics) for this layer's batch statistics. */
 /* rows of stats_partial written by papc_mlp_gemm_f32 for M rows (= its persistent grid size) */
 int papc_mlp_gemm_parts(int64_t M);
+/* gmax (optional; last layer of a stack): fuse the neighbourhood max (paddle.max(new_points, 2), :219) into the
+ * epilogue.  Per group of K consecutive rows the kernel writes max and min of y and the first row offset attaining
+ * each ([M/K, Cout] arrays); papc_bn_select_max_f32 then applies BN+ReLU to the max (scale >= 0) or the min
+ * (scale < 0).  Only where papc_mlp_gemm_gmax_ok(M, Cout, K) != 0; otherwise use papc_bn_relu_max_f32. */
+typedef struct papc_group_max {
+    float *gmax, *gmin;      /* [M/K, Cout] */
+    int32_t *amax, *amin;    /* [M/K, Cout] */
+    int K;
+} papc_group_max;
+int papc_mlp_gemm_gmax_ok(int64_t M, int Cout, int K);
 int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
                       const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
-                      int64_t M, int Cin, int Cout, float *y, float *stats_partial, papc_stream_t stream);
+                      int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
+                      papc_stream_t stream);
+/* out[g,c] = relu(scale*(scale >= 0 ? gmax : gmin) + shift), argmax[g,c] = the matching row offset */
+int papc_bn_select_max_f32(const float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
+                           const float *scale, const float *shift, int64_t G, int C, float *out, int32_t *argmax,
+                           papc_stream_t stream);
 
 /* Reduce stats_partial [n_tiles,2,C] (n_tiles = papc_mlp_gemm_parts(M)) -> train-mode BatchNorm constants (BatchNorm2D :190; paddle default
  * eps 1e-5, biased variance): mean, invstd, and the folded affine scale = gamma*invstd,

@@ -31,6 +31,11 @@ class BwdDy(ctypes.Structure):
                 ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("c1", c_p), ("c2", c_p)]
 
 
+class GroupMax(ctypes.Structure):
+    """papc_group_max"""
+    _fields_ = [("gmax", c_p), ("gmin", c_p), ("amax", c_p), ("amin", c_p), ("K", c_i)]
+
+
 class BwdRed(ctypes.Structure):
     """papc_bwd_red"""
     _fields_ = [("y", c_p), ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("red_partial", c_p)]
@@ -52,7 +57,9 @@ SIGNATURES = {
     "papc_index_points_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "papc_group_points_f32": (c_i, [c_p, c_l, c_l, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "papc_mlp_gemm_parts": (c_i, [c_l]),
-    "papc_mlp_gemm_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
+    "papc_mlp_gemm_gmax_ok": (c_i, [c_l, c_i, c_i]),
+    "papc_mlp_gemm_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "papc_bn_select_max_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p]),
     "papc_bn_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "papc_bn_relu_max_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
     "papc_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_p]),

@@ -97,6 +97,20 @@ __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restric
     }
 }
 
+__global__ __launch_bounds__(256) void bn_select_max_kernel(const float *__restrict__ gmax, const float *__restrict__ gmin,
+                                                            const int32_t *__restrict__ amax, const int32_t *__restrict__ amin,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift,
+                                                            int64_t total, int C, float *__restrict__ out, int32_t *__restrict__ argmax)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const float sc = scale[c], sh = shift[c];
+        const bool up = sc >= 0.f;   // relu(sc*y+sh) is non-decreasing in y for sc >= 0, non-increasing otherwise
+        out[e] = fmaxf(fmaf(sc, up ? gmax[e] : gmin[e], sh), 0.f);
+        if (argmax) argmax[e] = up ? amax[e] : amin[e];
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void bn_relu_kernel(const float *__restrict__ y, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, int64_t M, int C, float *__restrict__ z)
@@ -279,6 +293,18 @@ int papc_bn_relu_max_f32(const float *y, const float *scale, const float *shift,
     if (v4) hipLaunchKernelGGL(bn_relu_max_kernel<4>, dim3(ew_grid(G * (C / 4))), dim3(256), 0, st, y, scale, shift, G, K, C, out, argmax);
     else hipLaunchKernelGGL(bn_relu_max_kernel<1>, dim3(ew_grid(G * C)), dim3(256), 0, st, y, scale, shift, G, K, C, out, argmax);
     return check_launch("papc_bn_relu_max_f32");
+}
+
+int papc_bn_select_max_f32(const float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
+                           const float *scale, const float *shift, int64_t G, int C, float *out, int32_t *argmax,
+                           papc_stream_t stream)
+{
+    PAPC_REQUIRE(gmax && gmin && amax && amin && scale && shift && out, PAPC_E_INVALID, "papc_bn_select_max_f32: null pointer");
+    PAPC_REQUIRE(G >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_select_max_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BN_RELU_MAX, st);
+    hipLaunchKernelGGL(bn_select_max_kernel, dim3(ew_grid(G * C)), dim3(256), 0, st, gmax, gmin, amax, amin, scale, shift, G * C, C, out, argmax);
+    return check_launch("papc_bn_select_max_f32");
 }
 
 int papc_bn_relu_f32(const float *y, const float *scale, const float *shift, int64_t M, int C, float *z, papc_stream_t stream)

@@ -25,7 +25,7 @@ namespace papc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2 };
+enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2, EPI_STORE_GMAX = 3 };
 
 // EPI_STORE_RED (dX only): besides storing dz_prev = dX, accumulate the BN-backward reductions of the PREVIOUS layer
 // (p = dz_prev * [scale*y_prev + shift > 0]; sum p and sum p*xhat per channel) into the stats partials, so no separate
@@ -39,6 +39,14 @@ struct ScatterDst {
     FastDiv divSK, divK;
 };
 
+// EPI_STORE_GMAX (last forward layer): besides y and the statistics partials, write per group of K consecutive rows the
+// max and min of y and the first row offset attaining each.  relu(scale*y+shift) is monotone in y (direction = sign of
+// scale), so max_k relu(bn(y)) = relu(scale * (scale >= 0 ? max y : min y) + shift): the neighbourhood max
+// (pointnet2_basic_layers.py:219) no longer needs a separate pass over y.  K in {32, 64, 128}, M % 128 == 0.
+struct GmaxDst {
+    float *gmax, *gmin; int32_t *amax, *amin; int K;
+};
+
 struct GemmArgs {
     ASrc a;
     const float *w; int64_t ldw;  // weights [Nout][Kin]
@@ -50,6 +58,7 @@ struct GemmArgs {
     float *stats;                  // [gridDim.x][2][Nout] or null
     ScatterDst sc;
     RedSrc rd;
+    GmaxDst gm;
 };
 
 constexpr int LDT = 36;  // LDS row stride (floats)
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
         s1[wn] = 0.f; s2[wn] = 0.f;
         const int col = n0 + (wgn * WN + wn) * 32 + l31;
         cok[wn] = col < p.Nout;
-        biasv[wn] = (EPI == EPI_STORE && p.bias) ? p.bias[cok[wn] ? col : 0] : 0.f;
+        biasv[wn] = ((EPI == EPI_STORE || EPI == EPI_STORE_GMAX) && p.bias) ? p.bias[cok[wn] ? col : 0] : 0.f;
     }
     float rsc[WN], rsh[WN], rmu[WN], ris[WN];  // EPI_STORE_RED: previous layer's BN constants of this lane's columns
 #pragma unroll
@@ -250,6 +259,77 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
                 if (cok[wn]) {
                     float dsum = 0.f;                    // scatter epilogue: pending sum of padding duplicates ...
                     int dgrp = -1, djf = -1, dbat = 0;   // ... of group dgrp (first neighbour djf, cloud dbat)
+                    if (EPI == EPI_STORE_GMAX) {
+                        // store y, accumulate the BN statistics, and reduce max / min (+ first offsets) over each group of K rows.
+                        // A lane holds 16 of a 32-row tile's rows, ascending in r; lane^32 holds the other 16.
+                        float tmx[WM], tmn[WM];
+                        int tix[WM], tin[WM];
+#pragma unroll
+                        for (int wm = 0; wm < WM; ++wm) {
+                            const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
+                            float *yp = p.y + rb * p.ldy + col;
+                            float vmx = -INFINITY, vmn = INFINITY;
+                            int imx = 0, imn = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ro = (r & 3) + 8 * (r >> 2);
+                                const float v = acc[wm][wn][r] + biasv[wn];
+                                yp[(int64_t)ro * p.ldy] = v;
+                                s1[wn] += v;
+                                s2[wn] = fmaf(v, v, s2[wn]);
+                                if (v > vmx) { vmx = v; imx = ro + 4 * hi; }
+                                if (v < vmn) { vmn = v; imn = ro + 4 * hi; }
+                            }
+                            const float omx = __shfl_xor(vmx, 32), omn = __shfl_xor(vmn, 32);
+                            const int oix = __shfl_xor(imx, 32), oin = __shfl_xor(imn, 32);
+                            if (omx > vmx || (omx == vmx && oix < imx)) { vmx = omx; imx = oix; }
+                            if (omn < vmn || (omn == vmn && oin < imn)) { vmn = omn; imn = oin; }
+                            tmx[wm] = vmx; tix[wm] = imx; tmn[wm] = vmn; tin[wm] = imn;   // per 32-row tile, both halves agree
+                        }
+                        const int K = p.gm.K;
+                        if (K == 32) {
+                            if (hi == 0) {
+#pragma unroll
+                                for (int wm = 0; wm < WM; ++wm) {
+                                    const int64_t g = (m0 >> 5) + (wgm * WM + wm);
+                                    p.gm.gmax[g * p.Nout + col] = tmx[wm]; p.gm.amax[g * p.Nout + col] = tix[wm];
+                                    p.gm.gmin[g * p.Nout + col] = tmn[wm]; p.gm.amin[g * p.Nout + col] = tin[wm];
+                                }
+                            }
+                        } else {
+                            // K = 64: this wave's WM = 2 tiles form one group; K = 128: plus the partner wave (other wgm) through LDS
+                            float gx = tmx[0], gn = tmn[0];
+                            int ix = tix[0], in_ = tin[0];
+#pragma unroll
+                            for (int wm = 1; wm < WM; ++wm) {
+                                if (tmx[wm] > gx) { gx = tmx[wm]; ix = tix[wm] + 32 * wm; }
+                                if (tmn[wm] < gn) { gn = tmn[wm]; in_ = tin[wm] + 32 * wm; }
+                            }
+                            if (K == 64) {
+                                if (hi == 0) {
+                                    const int64_t g = (m0 >> 6) + wgm;
+                                    p.gm.gmax[g * p.Nout + col] = gx; p.gm.amax[g * p.Nout + col] = ix;
+                                    p.gm.gmin[g * p.Nout + col] = gn; p.gm.amin[g * p.Nout + col] = in_;
+                                }
+                            } else {  // K == 128 (WGM == 2): rows of wgm = 1 come after those of wgm = 0
+                                const int cl = (wgn * WN + wn) * 32 + l31;
+                                float *xf = red;                                   // [4][BN]: max, min, (int) imax, imin of wgm = 1
+                                if (wgm == 1 && hi == 0) {
+                                    xf[0 * BN + cl] = gx; xf[1 * BN + cl] = gn;
+                                    xf[2 * BN + cl] = __int_as_float(ix + 64); xf[3 * BN + cl] = __int_as_float(in_ + 64);
+                                }
+                                lds_barrier();
+                                if (wgm == 0 && hi == 0) {
+                                    const float ox = xf[0 * BN + cl], on = xf[1 * BN + cl];
+                                    if (ox > gx) { gx = ox; ix = __float_as_int(xf[2 * BN + cl]); }
+                                    if (on < gn) { gn = on; in_ = __float_as_int(xf[3 * BN + cl]); }
+                                    const int64_t g = m0 >> 7;
+                                    p.gm.gmax[g * p.Nout + col] = gx; p.gm.amax[g * p.Nout + col] = ix;
+                                    p.gm.gmin[g * p.Nout + col] = gn; p.gm.amin[g * p.Nout + col] = in_;
+                                }
+                            }
+                        }
+                    }
                     if (EPI == EPI_STORE_RED) {
                         // issue the previous layer's y for ALL of this lane's rows first (one exposed latency per column),
                         // then store dz_prev and accumulate p = dz*[z>0], p*xhat
@@ -284,8 +364,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 #pragma unroll
                     for (int wm = 0; wm < WM; ++wm) {
                         const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
-                        if (EPI == EPI_STORE_RED) {
-                            // handled below (all row tiles of this column at once)
+                        if (EPI == EPI_STORE_RED || EPI == EPI_STORE_GMAX) {
+                            // handled above (all row tiles of this column at once)
                         } else if (EPI == EPI_STORE) {
                             float *yp = p.y + rb * p.ldy + col;
                             if (full) {
@@ -358,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
         have = have_next;
     }
 
-    if ((EPI == EPI_STORE || EPI == EPI_STORE_RED) && p.stats) {
+    if ((EPI == EPI_STORE || EPI == EPI_STORE_RED || EPI == EPI_STORE_GMAX) && p.stats) {
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             s1[wn] += __shfl_xor(s1[wn], 32);
@@ -379,7 +459,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
     }
 }
 
-static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128, GEMM_MAX_PARTS); }
+static int gemm_max_parts()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PAPC_PARTS"); v = e ? atoi(e) : GEMM_MAX_PARTS; if (v < 1 || v > 1024) v = GEMM_MAX_PARTS; }
+    return v;
+}
+static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128, gemm_max_parts()); }
 
 template <int AMODE, int EPI, bool VEC>
 static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
@@ -481,9 +567,20 @@ extern "C" {
 
 int papc_mlp_gemm_parts(int64_t M) { return gemm_parts(M); }
 
+int papc_mlp_gemm_gmax_ok(int64_t M, int Cout, int K)
+{
+    // the fused epilogue needs whole groups inside one 128-row tile, full tiles only, and a 2x2-wave tile configuration;
+    // with few row tiles the launcher switches to the 4x1 narrow configuration (see launch_gemm_v), which is excluded too
+    if (!(K == 32 || K == 64 || K == 128) || M % 128 != 0 || Cout <= 32) return 0;
+    const int64_t gx = gemm_parts(M);
+    if (Cout > 64 && gx * cdiv(Cout, 128) < 192 && gx * cdiv(Cout, 64) < 1024 && !(gx * cdiv(Cout, 64) >= 192)) return 0;
+    return 1;
+}
+
 int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
                       const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
-                      int64_t M, int Cin, int Cout, float *y, float *stats_partial, papc_stream_t stream)
+                      int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
+                      papc_stream_t stream)
 {
     PAPC_REQUIRE(w && y, PAPC_E_INVALID, "papc_mlp_gemm_f32: null w/y");
     PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_gemm_f32: M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
@@ -497,6 +594,18 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
     const bool vec = p.a.vec && (p.wmap || (aligned16(w) && Cin % 4 == 0));
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MLP_GEMM, st);
+    if (gmax) {
+        PAPC_REQUIRE(gmax->gmax && gmax->gmin && gmax->amax && gmax->amin, PAPC_E_INVALID, "papc_mlp_gemm_f32: null pointer in gmax");
+        PAPC_REQUIRE(papc_mlp_gemm_gmax_ok(M, Cout, gmax->K), PAPC_E_UNSUPPORTED,
+                     "papc_mlp_gemm_f32: fused group max needs K in {32,64,128}, M %% 128 == 0, Cout > 32 (got K=%d M=%lld Cout=%d)",
+                     gmax->K, (long long)M, Cout);
+        p.gm.gmax = gmax->gmax; p.gm.gmin = gmax->gmin; p.gm.amax = gmax->amax; p.gm.amin = gmax->amin; p.gm.K = gmax->K;
+        switch (a_mode) {
+        case A_PLAIN: return launch_gemm<A_PLAIN, EPI_STORE_GMAX>(p, vec, st);
+        case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE_GMAX>(p, vec, st);
+        default: return launch_gemm<A_GROUP, EPI_STORE_GMAX>(p, vec, st);
+        }
+    }
     switch (a_mode) {
     case A_PLAIN: return launch_gemm<A_PLAIN, EPI_STORE>(p, vec, st);
     case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE>(p, vec, st);

@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BwdDy, BwdRed, GroupSrc, ScatterDst, check, ptr, stream_ptr
+from ._lib import BwdDy, BwdRed, GroupMax, GroupSrc, ScatterDst, check, ptr, stream_ptr
 
 A_PLAIN, A_BNRELU, A_GROUP = 0, 1, 2
 DZ_DENSE, DZ_MAX = 0, 1
@@ -46,12 +46,17 @@ def _group_src(spec, xyz, new_xyz, feats, idx):
     return g
 
 
+import os
+_FUSE_GMAX = os.environ.get("PAPC_NO_GMAX") != "1"          # A/B switch for the fused neighbourhood-max epilogue
+_RESIDENT_WGS = int(os.environ.get("PAPC_PARTS", "512"))   # persistent-grid size (tuning knob shared with the C side)
+
+
 def _dw_rows_per_chunk(M, cout, cin):
     """Row-chunk size for the dW kernel: ONE residency wave of workgroups (256 CUs x 2 per CU = 512) in total, so
     no tail round; chunks of >= 256 rows."""
     wide = 128 < cin <= 160
     tiles = ((cout + 127) // 128) * (1 if wide else (cin + 127) // 128)
-    want = max(1, 512 // tiles)
+    want = max(1, _RESIDENT_WGS // tiles)
     rpc = (M + want - 1) // want
     rpc = max(256, ((rpc + 63) // 64) * 64)
     return rpc
@@ -90,15 +95,26 @@ class SharedMLPMax(torch.autograd.Function):
             assert w2.is_contiguous()
             y = torch.empty(M, cout, device=dev, dtype=torch.float32)
             stats = torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
+            gm_ref = None
+            if l == L - 1 and _FUSE_GMAX and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
+                # last layer: the neighbourhood max is reduced in the GEMM epilogue (per-group max/min of the raw output)
+                G_ = M // spec.K
+                gbuf_f = torch.empty(2, G_, cout, device=dev, dtype=torch.float32)
+                gbuf_i = torch.empty(2, G_, cout, device=dev, dtype=torch.int32)
+                gm = GroupMax()
+                gm.gmax, gm.gmin = gbuf_f[0].data_ptr(), gbuf_f[1].data_ptr()
+                gm.amax, gm.amin = gbuf_i[0].data_ptr(), gbuf_i[1].data_ptr()
+                gm.K = spec.K
+                gm_ref = ctypes.byref(gm)
             if l == 0 and plain:
                 check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(x_rows), cin, None, None, None, ptr(w2), ptr(b), M, cin, cout,
-                                            ptr(y), ptr(stats), st), "papc_mlp_gemm_f32")
+                                            ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
             elif l == 0:
                 check(lib.papc_mlp_gemm_f32(A_GROUP, None, 0, ctypes.byref(grp), None, None, ptr(w2), ptr(b), M, cin, cout,
-                                            ptr(y), ptr(stats), st), "papc_mlp_gemm_f32")
+                                            ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
             else:
                 check(lib.papc_mlp_gemm_f32(A_BNRELU, ptr(prev_y), cin, None, ptr(prev_sc), ptr(prev_sh), ptr(w2), ptr(b), M, cin,
-                                            cout, ptr(y), ptr(stats), st), "papc_mlp_gemm_f32")
+                                            cout, ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
             cst = torch.empty(4, cout, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
             rm, rv = (bn_buffers[l] if bn_buffers is not None else (None, None))
             check(lib.papc_bn_finalize_f32(ptr(stats), parts, M, cout, ptr(gamma), ptr(beta), spec.eps, spec.momentum,
@@ -111,8 +127,12 @@ class SharedMLPMax(torch.autograd.Function):
         G = spec.B * spec.S
         out = torch.empty(G, cin, device=dev, dtype=torch.float32)
         argmax = torch.empty(G, cin, device=dev, dtype=torch.int32)
-        check(lib.papc_bn_relu_max_f32(ptr(prev_y), ptr(prev_sc), ptr(prev_sh), G, spec.K, cin, ptr(out), ptr(argmax), st),
-              "papc_bn_relu_max_f32")
+        if gm_ref is not None:
+            check(lib.papc_bn_select_max_f32(gbuf_f[0].data_ptr(), gbuf_f[1].data_ptr(), gbuf_i[0].data_ptr(), gbuf_i[1].data_ptr(),
+                                             ptr(prev_sc), ptr(prev_sh), G, cin, ptr(out), ptr(argmax), st), "papc_bn_select_max_f32")
+        else:
+            check(lib.papc_bn_relu_max_f32(ptr(prev_y), ptr(prev_sc), ptr(prev_sh), G, spec.K, cin, ptr(out), ptr(argmax), st),
+                  "papc_bn_relu_max_f32")
         ctx.spec = spec
         ctx.L = L
         ctx.feats_needs_grad = feats is not None and feats.requires_grad and not spec.cut_gather_grad
@@ -136,7 +156,7 @@ class SharedMLPMax(torch.autograd.Function):
         M = spec.M
         gout = gout.contiguous().float()
         grp = None if plain else _group_src(spec, xyz, new_xyz, feats, idx)
-        n_parts = min(512, (M + 127) // 128)
+        n_parts = min(_RESIDENT_WGS, (M + 127) // 128)
         grads = [None] * (4 * L)
         grad_feats = None
         grad_x = None

@@ -107,7 +107,7 @@ class PFNLayer(nn.Module):
             y = torch.empty(M, C, device=dev, dtype=torch.float32)
             stats = torch.empty(parts, 2, C, device=dev, dtype=torch.float32)
             check(lib.papc_mlp_gemm_f32(0, ptr(rows), Cin, None, None, None, ptr(self.linear.weight), None, M, Cin, C, ptr(y),
-                                        ptr(stats), st), "papc_mlp_gemm_f32")
+                                        ptr(stats), None, st), "papc_mlp_gemm_f32")
             cst = torch.empty(4, C, device=dev, dtype=torch.float32)
             check(lib.papc_bn_finalize_f32(ptr(stats), parts, M, C, ptr(self.norm.weight), ptr(self.norm.bias), self.norm.eps,
                                            self.norm.momentum, cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
