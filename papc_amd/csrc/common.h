@@ -43,35 +43,6 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 // row_bcast:15 = 0x142, row_bcast:31 = 0x143.  After the sequence lane 63 holds the wave result.
 #define PAPC_DPP(v, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(v), (int)(v), (ctrl), (rmask), 0xF, false)
 
-template <int CTRL, int RMASK>
-__device__ __forceinline__ unsigned long long dpp_move_u64(unsigned long long v)
-{
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    unsigned lo2 = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, RMASK, 0xF, false);
-    unsigned hi2 = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, RMASK, 0xF, false);
-    return ((unsigned long long)hi2 << 32) | lo2;
-}
-
-// max over the 64 lanes of a u64 key; result valid in lane 63 (use readlane63_u64 to broadcast)
-__device__ __forceinline__ unsigned long long wave_max_u64_to_lane63(unsigned long long v)
-{
-    unsigned long long t;
-    t = dpp_move_u64<0xB1, 0xF>(v);  v = t > v ? t : v;
-    t = dpp_move_u64<0x4E, 0xF>(v);  v = t > v ? t : v;
-    t = dpp_move_u64<0x124, 0xF>(v); v = t > v ? t : v;
-    t = dpp_move_u64<0x128, 0xF>(v); v = t > v ? t : v;
-    t = dpp_move_u64<0x142, 0xA>(v); v = t > v ? t : v;
-    t = dpp_move_u64<0x143, 0xC>(v); v = t > v ? t : v;
-    return v;
-}
-
-__device__ __forceinline__ unsigned long long readlane63_u64(unsigned long long v)
-{
-    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // sum over the 64 lanes of a float; every lane of the last row (48..63) holds the total, lane 63 canonical
 __device__ __forceinline__ float wave_sum_f32_to_lane63(float v)
 {

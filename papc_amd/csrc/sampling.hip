@@ -15,12 +15,13 @@ typedef unsigned int u32;
 //
 // One workgroup per cloud (the npoint-long argmax chain is serial; a cloud never spans CUs).  Each lane
 // keeps PPT points (x,y,z,running distance) in VGPRs for the whole kernel; a copy of xyz sits in LDS so
-// the winner's coordinates are one broadcast ds_read away.  Per iteration: PPT distance updates, a
-// thread-local argmax, a 6-step DPP wave max on a packed 64-bit key {dist bits : ~index} (non-negative
-// floats order like their bit patterns; ~index makes the LOWEST index win ties, which the reference's
-// argmax requires -- ties at exactly 1.0 happen in the first iterations of every unit-sphere cloud because
-// the running distance starts at 1.0, :75), one LDS slot per wave, ONE barrier (slots double-buffered by
-// iteration parity), then every wave reduces the <=16 slots redundantly.
+// the winner's coordinates are one broadcast ds_read away.  Per iteration: PPT distance updates with a
+// thread-local argmax, then the wave argmax as TWO 32-bit DPP reductions (max distance, then the LOWEST
+// index among the lanes holding it -- 64-bit key compares are quarter rate on gfx950).  The lowest-index rule
+// is the reference's argmax (first maximum) and matters: ties at exactly 1.0 happen in the first iterations
+// of every unit-sphere cloud because the running distance starts at 1.0 (:75).  Each wave posts {max, index}
+// to an LDS slot, ONE barrier (slots double-buffered by iteration parity), then every wave combines the <=16
+// slots with the same two passes as a 16-lane DPP row reduce.
 // =====================================================================================================
 template <int T, int PPT, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
