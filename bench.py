@@ -80,9 +80,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config: 32)")
     ap.add_argument("--npoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="compute batch i+1's sampling pyramid on a side stream during "
-                    "batch i (off by default: the persistent MFMA grids are sized to one residency wave, and a co-running "
-                    "FPS kernel displaces workgroups into a serial second wave)")
+    ap.add_argument("--overlap", action="store_true", help="compute batch i+1's sampling pyramid on a side stream while "
+                    "batch i runs its small-grid kernels (SA3 + FC head, forward and backward)")
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     args = ap.parse_args()
 
@@ -138,9 +137,11 @@ def main():
                 launch_plan()
             plan, ev = state["plan"], state["ev"]
             main.wait_event(ev)
-            launch_plan()                          # next batch's pyramid, overlapped with everything below
         flat.zero_grad()
-        logits = model(x, (s1, s2), plan=plan)
+        # the next batch's pyramid is enqueued on the side stream when the main stream reaches SA3: the group_all layer,
+        # the FC head and their backward are small-grid kernels, so the 32 FPS workgroups run on idle CUs instead of
+        # displacing workgroups of the chip-filling persistent MFMA grids
+        logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap else None))
         loss = F.cross_entropy(logits, y)
         loss.backward()
         scale = flat.allreduce_grads()

@@ -47,6 +47,7 @@ def _group_src(spec, xyz, new_xyz, feats, idx):
 
 
 import os
+_FUSE_RED = os.environ.get("PAPC_NO_RED") != "1"            # A/B switch for the BN-backward reduce fused into the dX epilogue
 _FUSE_GMAX = os.environ.get("PAPC_NO_GMAX") != "1"          # A/B switch for the fused neighbourhood-max epilogue
 _RESIDENT_WGS = int(os.environ.get("PAPC_PARTS", "512"))   # persistent-grid size (tuning knob shared with the C side)
 
@@ -227,13 +228,16 @@ class SharedMLPMax(torch.autograd.Function):
                 wt = w2.t().contiguous()
                 dz_prev = torch.empty(M, cin, device=dev, dtype=torch.float32)
                 # the dX kernel also accumulates layer l-1's BN-backward reductions over the dz it produces
-                pc = consts[l - 1]
-                fused_red = torch.empty(gemm_parts, 2, cin, device=dev, dtype=torch.float32)
-                nr = BwdRed()
-                nr.y = ys[l - 1].data_ptr()
-                nr.mean, nr.invstd, nr.scale, nr.shift = (pc[i].data_ptr() for i in range(4))
-                nr.red_partial = fused_red.data_ptr()
-                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dz_prev), None, ctypes.byref(nr), st),
+                nr_ref = None
+                if _FUSE_RED:
+                    pc = consts[l - 1]
+                    fused_red = torch.empty(gemm_parts, 2, cin, device=dev, dtype=torch.float32)
+                    nr = BwdRed()
+                    nr.y = ys[l - 1].data_ptr()
+                    nr.mean, nr.invstd, nr.scale, nr.shift = (pc[i].data_ptr() for i in range(4))
+                    nr.red_partial = fused_red.data_ptr()
+                    nr_ref = ctypes.byref(nr)
+                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dz_prev), None, nr_ref, st),
                       "papc_mlp_bwd_dx_f32")
                 dz = dz_prev
             elif plain and ctx.x_needs_grad:
