@@ -106,7 +106,7 @@ __device__ __forceinline__ float4 mask_w4(const GemmArgs &p, int n, int k, float
 // The consume step sits BEFORE the stores on purpose: gfx9-family vmcnt counts loads and stores together and, with both
 // kinds pending, a wait for a load degenerates to vmcnt(0); ordered this way the stores are the youngest VMEM ops of
 // the iteration and drain under the next stage's MFMAs (the barrier does not wait for them: lds_barrier()).
-template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN>
+template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
@@ -156,13 +156,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
 
-    int64_t tile_f = blockIdx.x;  // tile of the stage being fetched
-    int kc_f = 0;                 // k-chunk of the stage being fetched
-    RowCtx rows[4];
-    Raw3 ra[4];
-    float4 rw[NWL];
-    KConst kc;
-    int jpre[4] = {-2, -2, -2, -2};  // GROUP: neighbour indices of the NEXT tile, loaded one tile early
+    // ---- pipeline state.  A `Stg` is the register image of one in-flight stage (raw loads + what is needed to finish them).
+    struct Stg {
+        RowCtx rows[4];
+        Raw3 ra[4];
+        float4 rw[NWL];
+        KConst kc;
+        int kf;          // this thread's first channel of the stage's k-chunk
+        int kci;         // k-chunk index
+        int64_t tile;    // row tile
+        bool ok;         // the stage exists
+    };
+    Stg sa, sb;
+    int64_t tile_f = blockIdx.x;  // fetch cursor: next stage to issue = (tile_f, kc_f)
+    int kc_f = 0;
+    int jcur[4] = {-2, -2, -2, -2};  // GROUP: neighbour indices of the fetch cursor's tile ...
+    int jpre[4] = {-2, -2, -2, -2};  // ... and of the tile after it (loaded one tile early)
 
     auto load_j = [&](int64_t tile) {  // issue the idx loads of `tile`'s rows (clamped: always in range)
         if (use_jpre) {
@@ -173,53 +182,61 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
             }
         }
     };
-    auto write_stage = [&](float *As, int kf) {  // consume the landed registers: transform + write one LDS buffer
+    // issue the loads of the stage under the fetch cursor into `s` (loads only: nothing here touches the values) and
+    // advance the cursor
+    auto issue = [&](Stg &s) {
+        s.ok = tile_f < n_mtiles;
+        s.tile = tile_f; s.kci = kc_f; s.kf = kc_f * BK + kq;
+        if (s.ok) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + 32 * i, p.M, use_jpre ? jcur[i] : -2);
+            s.kc = make_kconst<AMODE, VEC>(p.a, s.kf, p.Kin);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s.ra[i] = fetch_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin);
+#pragma unroll
+            for (int i = 0; i < NWL; ++i) s.rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + 32 * i, s.kf);
+        }
+        kc_f += 1;
+        if (kc_f == n_kc) {
+            kc_f = 0; tile_f += gridDim.x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jcur[i] = jpre[i];
+            load_j(tile_f + gridDim.x);
+        }
+    };
+    // consume the landed registers of `s`: transform + write one LDS buffer
+    auto consume = [&](const Stg &s, float *As) {
         float *Ws = As + BM * LDT;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, rows[i], kf, p.Kin, kc, ra[i]);
+            *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin, s.kc, s.ra[i]);
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
-            *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = mask_w4(p, n0 + r0 + 32 * i, kf, rw[i]);
+            *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = mask_w4(p, n0 + r0 + 32 * i, s.kf, s.rw[i]);
     };
 
-    // ---- prologue: stage 0 of this workgroup's first tile
-    bool have = tile_f < n_mtiles;
-    if (have) {
+    // ---- prologue: stage 0 goes through LDS synchronously; DEPTH - 1 further stages are put in flight
+    if (use_jpre) {
         load_j(tile_f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + 32 * i, p.M, use_jpre ? jpre[i] : -2);
+        for (int i = 0; i < 4; ++i) jcur[i] = jpre[i];
         load_j(tile_f + gridDim.x);
-        kc = make_kconst<AMODE, VEC>(p.a, kq, p.Kin);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = fetch_a4<AMODE, VEC>(p.a, rows[i], kq, p.Kin);
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + 32 * i, kq);
-        write_stage(smem, kq);
     }
+    issue(sa);
+    bool have = sa.ok;
+    int64_t tile_c = sa.tile;  // tile / chunk of the stage being computed
+    int kc_c = sa.kci;
+    if (have) consume(sa, smem);
+    if (DEPTH == 2) issue(sa);
     __syncthreads();
 
     int buf = 0;
-    int64_t tile_c = tile_f;  // tile / chunk of the stage being computed
-    int kc_c = 0;
-    while (have) {
-        // ---- advance the fetch cursor to stage s+1 and issue its loads (loads only: nothing here touches the values)
-        kc_f += 1;
-        if (kc_f == n_kc) { kc_f = 0; tile_f += gridDim.x; }
-        const bool have_next = tile_f < n_mtiles;
-        const int kf = kc_f * BK + kq;
-        if (have_next) {
-            if (kc_f == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + 32 * i, p.M, use_jpre ? jpre[i] : -2);
-                load_j(tile_f + gridDim.x);
-            }
-            kc = make_kconst<AMODE, VEC>(p.a, kf, p.Kin);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = fetch_a4<AMODE, VEC>(p.a, rows[i], kf, p.Kin);
-#pragma unroll
-            for (int i = 0; i < NWL; ++i) rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + 32 * i, kf);
-        }
+    // one pipeline step: issue a new stage into `si`, compute the current stage from LDS, then finish the OLDEST in-flight
+    // stage `sc` (the next one to compute) into the other LDS buffer.  DEPTH 1: si == sc; DEPTH 2: the two sets alternate, so
+    // every stage's loads get two MFMA phases to land.
+    auto step = [&](Stg &si, Stg &sc) -> bool {
+        if (!have) return false;
+        issue(si);
 
         // ---- MFMAs of stage s from LDS buffer `buf`
         {
@@ -245,8 +262,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
             }
         }
 
-        // ---- consume stage s+1's loads: transform, write the other LDS buffer
-        if (have_next) write_stage(smem + (buf ^ 1) * STAGE, kf);
+        // ---- consume the next stage's loads: transform, write the other LDS buffer
+        if (sc.ok) consume(sc, smem + (buf ^ 1) * STAGE);
 
         // ---- last k-chunk of the tile: epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
         // Straight-line stores (no per-element branch) for full tiles; the ragged last tile takes the predicated path.
@@ -433,10 +450,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 
         lds_barrier();  // LDS-only: the epilogue's global stores and the idx prefetch stay in flight across it
         buf ^= 1;
-        tile_c = tile_f;
-        kc_c = kc_f;
-        have = have_next;
-    }
+        tile_c = sc.tile;
+        kc_c = sc.kci;
+        have = sc.ok;
+        return true;
+    };
+    if (DEPTH == 2) { while (step(sb, sa) && step(sa, sb)) {} }
+    else { while (step(sa, sa)) {} }
 
     if ((EPI == EPI_STORE || EPI == EPI_STORE_RED || EPI == EPI_STORE_GMAX) && p.stats) {
 #pragma unroll
@@ -467,6 +487,11 @@ static int gemm_max_parts()
 }
 static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128, gemm_max_parts()); }
 
+// Prefetch depth: the kernel supports DEPTH = 2 (two stages of loads in flight, register sets alternating), but a
+// same-box A/B on MI355X showed no gain over DEPTH = 1 (loaded-memory latency is not what limits these kernels), so only
+// DEPTH = 1 is instantiated.
+#define GEMM_LAUNCH(a, b, c, d) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1>), grid, dim3(256), 0, st, p)
+
 template <int AMODE, int EPI, bool VEC>
 static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
 {
@@ -477,20 +502,20 @@ static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
     if (p.Nout > 64 && wg128 < 192 && (int64_t)gx * cdiv(p.Nout, 64) < 1024) {
         if ((int64_t)gx * cdiv(p.Nout, 64) >= 192 || p.Nout <= 64) {
             dim3 grid(gx, (unsigned)cdiv(p.Nout, 64));
-            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
+            GEMM_LAUNCH(2, 2, 2, 1);
         } else {
             dim3 grid(gx, (unsigned)cdiv(p.Nout, 32));
-            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+            GEMM_LAUNCH(4, 1, 1, 1);
         }
     } else if (p.Nout > 64) {
         dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2>), grid, dim3(256), 0, st, p);
+        GEMM_LAUNCH(2, 2, 2, 2);
     } else if (p.Nout > 32) {
         dim3 grid(gx, 1);
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 1>), grid, dim3(256), 0, st, p);
+        GEMM_LAUNCH(2, 2, 2, 1);
     } else {
         dim3 grid(gx, 1);
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 4, 1, 1, 1>), grid, dim3(256), 0, st, p);
+        GEMM_LAUNCH(4, 1, 1, 1);
     }
     return check_launch("mlp gemm");
 }

@@ -1,0 +1,75 @@
+"""Timings of the other BASELINE configs on one GPU (tuning harness): config 3 (MSG SA1+SA2, B=16 N=2048), config 5 (PFN
+12000x100), config 0 (PointNet-Basic B=8 N=1024).   python tools/bench_configs.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from papc_amd.layers import PointNetSetAbstractionMsg
+from papc_amd.models import PointNet_Basic_Clas, PointNet2_MSG_Clas
+from papc_amd.pillars import PillarFeatureNet
+from papc_amd.synthetic import make_clouds, make_pillars, make_start_idx
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+# ---- config 3: MSG segment SA1 + SA2 (segment/pointnet2/pointnet2.py:62-63)
+B, N = 16, 2048
+x = torch.from_numpy(make_clouds(B, N, 3)).to(dev)
+st1 = torch.from_numpy(make_start_idx(B, N, 3)).to(dev)
+st2 = torch.from_numpy(make_start_idx(B, 512, 4)).to(dev)
+sa1 = PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [32, 64, 128], 3 + 3, [[32, 32, 64], [64, 64, 128], [64, 96, 128]]).to(dev)
+sa2 = PointNetSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 128 + 128 + 64, [[128, 128, 256], [128, 196, 256]]).to(dev)
+pts = torch.cat([x, x], 1)   # 6 input channels (xyz + normals slot), as the seg model feeds it
+
+
+def msg_step():
+    for p in list(sa1.parameters()) + list(sa2.parameters()):
+        p.grad = None
+    l1_xyz, l1 = sa1(x, pts, st1)
+    l2_xyz, l2 = sa2(l1_xyz, l1, st2)
+    l2.square().mean().backward()
+
+
+print("config 3  MSG SA1+SA2 fwd+bwd, B=16 N=2048: %.3f ms  (%.0f clouds/s)" % (timeit(msg_step), B / timeit(msg_step) * 1e3))
+
+# ---- config 5: PillarFeatureNet 12000 x 100 (kitti yaml num_filters [64])
+v, n, c = make_pillars()
+tv, tn, tc = torch.from_numpy(v).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev)
+pfn = PillarFeatureNet(num_filters=(64,), voxel_size=(0.16, 0.16, 4), pc_range=(0, -39.68, -3, 69.12, 39.68, 1)).to(dev)
+with torch.no_grad():
+    t_f = timeit(lambda: pfn(tv, tn, tc), n=50)
+
+
+def pfn_step():
+    for p in pfn.parameters():
+        p.grad = None
+    pfn(tv, tn, tc).square().mean().backward()
+
+
+t_fb = timeit(pfn_step, n=50)
+print("config 5  PFN 12000x100: fwd %.3f ms (%.0f GB/s of the 41.5 MB algorithmic), fwd+bwd %.3f ms" % (t_f, 41.5e-3 / t_f * 1e3, t_fb))
+
+# ---- config 0: PointNet-Basic B=8 N=1024
+xb = torch.from_numpy(make_clouds(8, 1024, 6)).to(dev)
+pb = PointNet_Basic_Clas(num_classes=16).to(dev)
+
+
+def basic_step():
+    for p in pb.parameters():
+        p.grad = None
+    pb(xb).square().mean().backward()
+
+
+print("config 0  PointNet-Basic B=8 N=1024 fwd+bwd: %.3f ms" % timeit(basic_step))
