@@ -84,6 +84,27 @@ int papc_group_points_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, 
                           int xyz_first, float *out, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Feature propagation (PointNetFeaturePropagation, pointnet2_basic_layers.py:284-335) -- the interpolation half;
+ * its Conv1D/BN/ReLU stack runs on the MLP entry points below.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* For every query point of xyz1 [B,N,3] (strided like papc_fps_f32) the three smallest squared distances to the
+ * support points xyz2 [B,S,3] (strided), ascending, ties in ascending index order (:315-318 with
+ * square_distance's canonical arithmetic); weight3 = (1/(d+1e-8)) / sum (:320-322); idx3 = the TRUE neighbour
+ * indices.  (The reference sorts `dists` before calling argsort on it (:316-317), so ITS idx is always 0,1,2 --
+ * papc_amd.layers reproduces that by default and offers the true indices as an option.)  S >= 3. */
+int papc_three_nn_f32(const float *xyz1, int64_t sb1, int64_t sn1, int64_t sc1, const float *xyz2, int64_t sb2,
+                      int64_t sn2, int64_t sc2, int B, int N, int S, float *dist3, int32_t *idx3, float *weight3,
+                      papc_stream_t stream);
+/* out[b,n,:] = (points2[b,idx3[b,n,0],:]*w0 + points2[b,idx3[b,n,1],:]*w1) + points2[b,idx3[b,n,2],:]*w2   (:323).
+ * points2 [B,S,D], idx3/weight3 [B,N,3] -> out [B,N,D]. */
+int papc_three_interpolate_f32(const float *points2, const int32_t *idx3, const float *weight3, int B, int N, int S,
+                               int D, float *out, papc_stream_t stream);
+/* gradient w.r.t. points2: grad_points2[b, idx3[b,n,j], :] += w_j * grad_out[b,n,:]   (grad_points2 pre-zeroed) */
+int papc_three_interpolate_bwd_f32(const float *grad_out, const int32_t *idx3, const float *weight3, int B, int N,
+                                   int S, int D, float *grad_points2, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Shared pointwise MLP: relu(bn(conv1x1(x))) stacks + max  (pointnet2_basic_layers.py:215-219, :271-276;
  * PAPC/models/classify/pointnet_base/pointnet_base.py:7-25,44)
  * ---------------------------------------------------------------------------------------------- */

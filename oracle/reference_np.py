@@ -311,6 +311,74 @@ class PointNetSetAbstractionMsg:
 
 
 # --------------------------------------------------------------------------------------------
+# PointNetFeaturePropagation  :284-335
+# --------------------------------------------------------------------------------------------
+def three_nn_literal(xyz1, xyz2):
+    """:315-322 exactly as written: sort the distance matrix, THEN argsort the sorted matrix (so idx is the
+    argsort of an ascending row: 0,1,2 whenever the three smallest distances are distinct), keep 3, inverse-distance
+    weights.  Returns (dists [B,N,3], idx [B,N,3] int64, weight [B,N,3]).  ``kind='stable'`` pins tie order (paddle's
+    argsort leaves it unspecified)."""
+    dists = square_distance_c(xyz1, xyz2)                                           # :315
+    dists = np.sort(dists, axis=-1)                                                 # :316
+    idx = np.argsort(dists, axis=-1, kind="stable")                                 # :317 (of the SORTED matrix)
+    dists, idx = dists[:, :, :3], idx[:, :, :3]                                     # :318
+    dist_recip = (np.float32(1.0) / (dists + np.float32(1e-8))).astype(np.float32)  # :320
+    norm = (dist_recip[:, :, 0:1] + dist_recip[:, :, 1:2]) + dist_recip[:, :, 2:3]  # :321 sum over 3, left to right
+    weight = (dist_recip / norm).astype(np.float32)                                 # :322
+    return dists, idx.astype(np.int64), weight
+
+
+def three_nn_true(xyz1, xyz2):
+    """The neighbours the paper intends (what :316-317 would give with the two lines swapped): stable argsort of
+    the unsorted matrix.  Same distances / weights as the literal version, real indices."""
+    d = square_distance_c(xyz1, xyz2)
+    idx = np.argsort(d, axis=-1, kind="stable")[:, :, :3]
+    dists, _, weight = three_nn_literal(xyz1, xyz2)
+    return dists, idx.astype(np.int64), weight
+
+
+def three_interpolate(points2, idx, weight):
+    """:323  sum(index_points(points2, idx) * weight.reshape(B,N,3,1), axis=2) -- products rounded to fp32, then
+    added left to right."""
+    B, N, _ = idx.shape
+    g = index_points(_f32(points2), idx)                                            # [B,N,3,D]
+    prod = (g * _f32(weight).reshape(B, N, 3, 1)).astype(np.float32)
+    return ((prod[:, :, 0] + prod[:, :, 1]) + prod[:, :, 2]).astype(np.float32)
+
+
+class PointNetFeaturePropagation:
+    """:284-335.  ``weights`` = list of (conv_w [Cout,Cin], conv_b, bn_gamma, bn_beta) (Conv1D k=1 + BatchNorm1D)."""
+
+    def __init__(self, in_channel, mlp, weights, neighbours="reference"):
+        self.weights = weights
+        self.neighbours = neighbours
+        assert len(weights) == len(mlp)
+
+    def forward(self, xyz1, xyz2, points1, points2, f64=False, return_interp=False):
+        xyz1 = np.transpose(_f32(xyz1), (0, 2, 1))                                  # :305
+        xyz2 = np.transpose(_f32(xyz2), (0, 2, 1))                                  # :306
+        points2 = np.transpose(_f32(points2), (0, 2, 1))                            # :308
+        B, N, C = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interpolated = np.tile(points2, (1, N, 1))                              # :312
+        else:
+            fn = three_nn_literal if self.neighbours == "reference" else three_nn_true
+            _, idx, weight = fn(xyz1, xyz2)
+            interpolated = three_interpolate(points2, idx, weight)                  # :323
+        if points1 is not None:
+            points1 = np.transpose(_f32(points1), (0, 2, 1))                        # :326
+            new_points = np.concatenate([points1, interpolated], axis=-1)           # :327
+        else:
+            new_points = interpolated
+        # :331-333 Conv1D/BatchNorm1D/relu on [B,D,N] == the same ops on rows (b,n) x D
+        rows = new_points.reshape(B * N, -1)
+        z = mlp_stack_rows(rows, self.weights, f64)
+        out = np.transpose(z.reshape(B, N, -1), (0, 2, 1))
+        return (out, interpolated) if return_interp else out
+
+
+# --------------------------------------------------------------------------------------------
 # PointPillars PFN: /root/reference/PAPC/models/detect/pointpillars/models/bones/pillars.py
 # --------------------------------------------------------------------------------------------
 def get_paddings_indicator(actual_num, max_num):

@@ -108,6 +108,45 @@ class SetAbstraction(nn.Module):                                                
         return new_xyz.permute(0, 2, 1), new_points
 
 
+class FeaturePropagation(nn.Module):                                              # :284-335
+    """Second opinion for reference_np.PointNetFeaturePropagation in the reference's own op decomposition
+    (dense [B,N,S] distances, full sort, argsort OF THE SORTED matrix, fancy-index gather, Conv1d/BatchNorm1d)."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.convs, self.bns = nn.ModuleList(), nn.ModuleList()
+        last = in_channel
+        for c in mlp:
+            self.convs.append(nn.Conv1d(last, c, 1))
+            self.bns.append(nn.BatchNorm1d(c, eps=1e-5))
+            last = c
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        xyz1, xyz2 = xyz1.transpose(1, 2), xyz2.transpose(1, 2)
+        points2 = points2.transpose(1, 2)
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interpolated = points2.repeat(1, N, 1)
+        else:
+            dists = square_distance(xyz1, xyz2)
+            dists = torch.sort(dists, dim=-1).values                              # :316
+            idx = torch.argsort(dists, dim=-1, stable=True)                        # :317
+            dists, idx = dists[:, :, :3], idx[:, :, :3]
+            dist_recip = 1.0 / (dists + 1e-8)
+            norm = torch.sum(dist_recip, dim=2, keepdim=True)
+            weight = dist_recip / norm
+            interpolated = torch.sum(index_points(points2, idx) * weight.reshape(B, N, 3, 1), dim=2)
+        if points1 is not None:
+            new_points = torch.cat([points1.transpose(1, 2), interpolated], dim=-1)
+        else:
+            new_points = interpolated
+        new_points = new_points.transpose(1, 2)
+        for conv, bn in zip(self.convs, self.bns):
+            new_points = TF.relu(bn(conv(new_points)))
+        return new_points
+
+
 class SSGClas(nn.Module):                       # classify/pointnet2/pointnet2.py:6-41
     def __init__(self, num_classes=16):
         super().__init__()

@@ -166,3 +166,56 @@ def sample_and_group_all(xyz, points):
     else:
         new_points = grouped_xyz
     return new_xyz, new_points
+
+
+def three_nn(xyz1, xyz2):
+    """The neighbour search of PointNetFeaturePropagation.forward (:315-322) in one kernel: xyz1 [B,N,3], xyz2 [B,S,3]
+    (any strides, S >= 3) -> (dist3 [B,N,3] the three smallest ``square_distance`` values ascending, idx3 [B,N,3]
+    int32 the TRUE neighbour indices (stable order), weight3 [B,N,3] = (1/(d+1e-8)) / sum).  No [B,N,S] matrix and
+    no sort is materialised."""
+    _need_cuda(xyz1, xyz2)
+    xyz1 = xyz1 if xyz1.dtype == torch.float32 else xyz1.float()
+    xyz2 = xyz2 if xyz2.dtype == torch.float32 else xyz2.float()
+    B, N, C = xyz1.shape
+    S = xyz2.shape[1]
+    assert C == 3 and xyz2.shape[0] == B and xyz2.shape[2] == 3
+    dist3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+    idx3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int32)
+    w3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+    check(_lib.load().papc_three_nn_f32(ptr(xyz1), xyz1.stride(0), xyz1.stride(1), xyz1.stride(2), ptr(xyz2), xyz2.stride(0),
+                                        xyz2.stride(1), xyz2.stride(2), B, N, S, ptr(dist3), ptr(idx3), ptr(w3), stream_ptr()),
+          "papc_three_nn_f32")
+    return dist3, idx3, w3
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points2, idx3, weight3):
+        _need_cuda(points2, idx3, weight3)
+        points2 = _f32c(points2)
+        idx3 = idx3.to(torch.int32).contiguous()
+        weight3 = _f32c(weight3)
+        B, S, D = points2.shape
+        N = idx3.shape[1]
+        out = torch.empty(B, N, D, device=points2.device, dtype=torch.float32)
+        check(_lib.load().papc_three_interpolate_f32(ptr(points2), ptr(idx3), ptr(weight3), B, N, S, D, ptr(out), stream_ptr()),
+              "papc_three_interpolate_f32")
+        ctx.save_for_backward(idx3, weight3)
+        ctx.shape = (B, N, S, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx3, weight3 = ctx.saved_tensors
+        B, N, S, D = ctx.shape
+        g = _f32c(g)
+        gp = torch.zeros(B, S, D, device=g.device, dtype=torch.float32)
+        check(_lib.load().papc_three_interpolate_bwd_f32(ptr(g), ptr(idx3), ptr(weight3), B, N, S, D, ptr(gp), stream_ptr()),
+              "papc_three_interpolate_bwd_f32")
+        return gp, None, None
+
+
+def three_interpolate(points2, idx3, weight3):
+    """sum(index_points(points2, idx) * weight[..., None], axis=2)  (:323): points2 [B,S,D], idx3/weight3 [B,N,3] ->
+    [B,N,D].  Differentiable w.r.t. ``points2`` (the weights depend on coordinates only)."""
+    return _ThreeInterpolate.apply(points2, idx3, weight3)

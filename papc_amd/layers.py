@@ -1,7 +1,7 @@
 """PointNet++ set-abstraction layers with the reference's constructor and forward signatures.
 
 Mirrors /root/reference/PAPC/models/layers/pointnet2_basic_layers.py: ``PointNetSetAbstraction`` :179-221 and
-``PointNetSetAbstractionMsg`` :224-281.  forward(xyz [B,3,N], points [B,D,N] | None) -> (new_xyz [B,3,S],
+``PointNetSetAbstractionMsg`` :224-281, ``PointNetFeaturePropagation`` :284-335.  forward(xyz [B,3,N], points [B,D,N] | None) -> (new_xyz [B,3,S],
 new_points [B,D',S]).  The returned tensors are transposed *views* of point-major buffers ([B,S,3], [B,S,D']),
 so chaining layers costs no transposes: the next layer's ``.transpose(1,2)`` (:203-205) is contiguous again.
 
@@ -133,3 +133,64 @@ class PointNetSetAbstractionMsg(nn.Module):
             outs.append(o.view(B, S, -1))
         new_points_concat = torch.cat(outs, dim=2).transpose(1, 2)              # :280  [B,D',S]
         return new_xyz.transpose(1, 2), new_points_concat
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """:284-335.  forward(xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N] | None, points2 [B,D2,S]) -> [B,D',N].
+
+    ``neighbours``:
+      * ``"reference"`` (default) -- what the source computes: it sorts ``dists`` and THEN argsorts the sorted
+        matrix (:316-317), so its ``idx`` is 0,1,2 for every query: the three smallest distances weight the
+        support points 0, 1 and 2.  Kept bit-compatible so a PAPC checkpoint / loss curve carries over.
+      * ``"nearest"`` -- the PointNet++ paper's intent: the weights go to the three nearest support points.
+    Same flagged deviations as the SA layers: parameters are registered and trained, and the gradient flows into
+    ``points2`` through the interpolation (the source's ``index_points`` cuts it, :57-60);
+    ``reference_quirks=True`` restores both.  The returned tensor is a transposed view of a point-major buffer.
+    """
+
+    def __init__(self, in_channel, mlp, neighbours="reference", reference_quirks=False):
+        super().__init__()
+        assert neighbours in ("reference", "nearest")
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))      # :291
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel, eps=1e-5))          # :292
+            last_channel = out_channel
+        self.neighbours = neighbours
+        self.reference_quirks = reference_quirks
+        if reference_quirks:
+            for p in self.parameters():
+                p.requires_grad_(False)
+
+    def interpolate(self, xyz1, xyz2, points2):
+        """:311-323 on point-major tensors: xyz1 [B,N,3], xyz2 [B,S,3], points2 [B,S,D] -> [B,N,D]"""
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if self.reference_quirks:
+            points2 = points2.detach()
+        if S == 1:
+            return points2.expand(B, N, points2.shape[2])                        # paddle.tile (:312)
+        _, idx3, w3 = F_.three_nn(xyz1, xyz2)
+        if self.neighbours == "reference":
+            idx3 = torch.arange(3, device=idx3.device, dtype=torch.int32).expand(B, N, 3)   # argsort of a sorted row
+        return F_.three_interpolate(points2, idx3, w3)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        xyz1 = xyz1.transpose(1, 2)                                              # :305-306
+        xyz2 = xyz2.transpose(1, 2)
+        points2 = points2.transpose(1, 2)                                        # :308
+        B, N, _ = xyz1.shape
+        interpolated = self.interpolate(xyz1, xyz2, points2)
+        if points1 is not None:
+            new_points = torch.cat([points1.transpose(1, 2).float(), interpolated], dim=-1)   # :326-327
+        else:
+            new_points = interpolated
+        rows = new_points.reshape(B * N, new_points.shape[2])
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        spec = StackSpec(B, N, N, 1, rows.shape[1], True, eps=self.mlp_bns[0].eps, momentum=0.9, pool=False)
+        out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), None, None, None, None,
+                             _stack_params(self.mlp_convs, self.mlp_bns), x_rows=rows)   # :331-333
+        return out.view(B, N, -1).transpose(1, 2)

@@ -23,8 +23,11 @@ DZ_DENSE, DZ_MAX = 0, 1
 class StackSpec:
     """Static description of one stack invocation (not a tensor; passed through autograd untouched)."""
 
-    def __init__(self, B, N, S, K, D, xyz_first, eps=1e-5, momentum=0.9, cut_gather_grad=False):
+    def __init__(self, B, N, S, K, D, xyz_first, eps=1e-5, momentum=0.9, cut_gather_grad=False, pool=True):
         self.B, self.N, self.S, self.K, self.D = B, N, S, K, D
+        # pool=False: no max over K -- the stack returns relu(bn_L(.)) for every row (PointNetFeaturePropagation's
+        # Conv1D stack, pointnet2_basic_layers.py:330-333)
+        self.pool = bool(pool)
         self.xyz_first = bool(xyz_first)
         self.eps, self.momentum = float(eps), float(momentum)
         self.cut_gather_grad = cut_gather_grad
@@ -72,7 +75,7 @@ class SharedMLPMax(torch.autograd.Function):
       feats    [B,N,D] contiguous or None idx     [B,S,K] int32 or None (identity: S=1, K=N)
       w_l      [C_l, C_{l-1}] (conv weight, trailing 1x1 dims dropped); b_l, gamma_l, beta_l [C_l]
       bn_buffers: list of (running_mean, running_var) per layer (updated in place) or None
-    returns [B*S, C_L]
+    returns [B*S, C_L]   (spec.pool=False: [M, C_L], every row's activation)
     """
 
     @staticmethod
@@ -97,7 +100,7 @@ class SharedMLPMax(torch.autograd.Function):
             y = torch.empty(M, cout, device=dev, dtype=torch.float32)
             stats = torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
             gm_ref = None
-            if l == L - 1 and _FUSE_GMAX and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
+            if l == L - 1 and spec.pool and _FUSE_GMAX and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
                 # last layer: the neighbourhood max is reduced in the GEMM epilogue (per-group max/min of the raw output)
                 G_ = M // spec.K
                 gbuf_f = torch.empty(2, G_, cout, device=dev, dtype=torch.float32)
@@ -126,9 +129,16 @@ class SharedMLPMax(torch.autograd.Function):
             prev_y, prev_sc, prev_sh = y, cst[2], cst[3]
             cin = cout
         G = spec.B * spec.S
-        out = torch.empty(G, cin, device=dev, dtype=torch.float32)
-        argmax = torch.empty(G, cin, device=dev, dtype=torch.int32)
-        if gm_ref is not None:
+        argmax = None
+        if not spec.pool:
+            out = torch.empty(M, cin, device=dev, dtype=torch.float32)
+            check(lib.papc_bn_relu_f32(ptr(prev_y), ptr(prev_sc), ptr(prev_sh), M, cin, ptr(out), st), "papc_bn_relu_f32")
+        else:
+            out = torch.empty(G, cin, device=dev, dtype=torch.float32)
+            argmax = torch.empty(G, cin, device=dev, dtype=torch.int32)
+        if not spec.pool:
+            pass
+        elif gm_ref is not None:
             check(lib.papc_bn_select_max_f32(gbuf_f[0].data_ptr(), gbuf_f[1].data_ptr(), gbuf_i[0].data_ptr(), gbuf_i[1].data_ptr(),
                                              ptr(prev_sc), ptr(prev_sh), G, cin, ptr(out), ptr(argmax), st), "papc_bn_select_max_f32")
         else:
@@ -179,7 +189,9 @@ class SharedMLPMax(torch.autograd.Function):
                 dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)  # dgamma, dbeta
                 dgamma_p, dbeta_p = dgb[0].data_ptr(), dgb[1].data_ptr()
             dy = BwdDy()
-            if l == L - 1:
+            if l == L - 1 and not spec.pool:
+                dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_DENSE, gout.data_ptr(), None, None, 1
+            elif l == L - 1:
                 dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_MAX, None, gout.data_ptr(), argmax.data_ptr(), spec.K
             else:
                 dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_DENSE, dz.data_ptr(), None, None, 1

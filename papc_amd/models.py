@@ -2,6 +2,7 @@
 
   PointNet2_SSG_Clas / PointNet2_MSG_Clas  <- /root/reference/PAPC/models/classify/pointnet2/pointnet2.py:6-41, :43-75
   PointNet_Basic_Clas                      <- /root/reference/PAPC/models/classify/pointnet_base/pointnet_base.py:4-47
+  PointNet2_SSG_Seg / PointNet2_MSG_Seg    <- /root/reference/PAPC/models/segment/pointnet2/pointnet2.py:6-52, :54-100
 
 Inputs are ``[B,3,N]`` float32 (``[B,6,N]`` with normals).  The FC head (661 776 parameters, 0.04 GFLOP) uses
 plain library ops (nn.Linear / BatchNorm1d / Dropout); everything upstream runs in libpapc_hip.so.
@@ -10,7 +11,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import PointNetSetAbstraction, PointNetSetAbstractionMsg
+from .layers import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg, _bn_buffers,
+                     _stack_params)
 from .mlp import StackSpec, shared_mlp_max
 
 
@@ -137,3 +139,108 @@ class PointNet_Basic_Clas(nn.Module):
             ps += [conv.weight, conv.bias, bn.weight, bn.bias]
         feat = shared_mlp_max(spec, [(bn.running_mean, bn.running_var) for bn in self.bns], xyz, zero, None, None, ps)  # :42-44
         return self.fc(feat)                                      # :45
+
+
+def Categorical(y, num_class=16):
+    """pointnet2_basic_layers.py:7-14: class labels [B,1] (or [B]) -> one-hot float32 [B,num_class,1]."""
+    y = torch.as_tensor(y).long().reshape(-1)
+    return F.one_hot(y, num_class).to(torch.float32).unsqueeze(2)
+
+
+class _PartSegBase(nn.Module):
+    """Shared decoder half of the two part-segmentation nets (segment/pointnet2/pointnet2.py:36-51, :84-99): three
+    feature-propagation levels, then conv1/bn1/relu/dropout/conv2 per point.  forward(inputs) with
+    inputs = (points [B,C,N], cls_label [B,1]) -> logits [B,N,num_parts]."""
+
+    def _head_init(self, num_parts):
+        self.conv1 = nn.Conv1d(128, 128, 1)
+        self.bn1 = nn.BatchNorm1d(128, eps=1e-5)
+        self.drop1 = nn.Dropout(0.5)
+        self.conv2 = nn.Conv1d(128, num_parts, 1)
+
+    def _encode(self, l0_xyz, l0_points, start_idx):
+        raise NotImplementedError
+
+    def sa1_first_weight(self):
+        """first conv weight of the first set-abstraction level (SSG: mlp_convs, MSG: first radius branch)"""
+        sa1 = self.sa1
+        return (sa1.mlp_convs[0] if hasattr(sa1, "mlp_convs") else sa1.conv_blocks[0][0]).weight
+
+    def forward(self, inputs, start_idx=None):
+        xyz = torch.as_tensor(inputs[0])
+        dev = xyz.device
+        cls_label = Categorical(inputs[1], self.num_classes).to(dev)                               # :28
+        B, C, N = xyz.shape
+        l0_points = xyz                                                                            # :32-37
+        l0_xyz = xyz[:, :3, :] if self.normal_channel else xyz
+        (l1_xyz, l1_points), (l2_xyz, l2_points), (l3_xyz, l3_points) = self._encode(l0_xyz, l0_points, start_idx)
+        l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)                                 # :42
+        l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points)                                 # :43
+        cls_label_one_hot = cls_label.reshape(B, self.num_classes, 1).expand(B, self.num_classes, N)   # :44
+        l0_points = self.fp1(l0_xyz, l1_xyz, torch.cat([cls_label_one_hot, l0_xyz, l0_points], 1), l1_points)   # :45
+        rows = l0_points.transpose(1, 2).reshape(B * N, 128)            # point-major rows (a view of fp1's buffer)
+        if self.training:                                               # :47 relu(bn1(conv1(.))) on the fused stack
+            spec = StackSpec(B, N, N, 1, 128, True, eps=self.bn1.eps, momentum=0.9, pool=False)
+            feat = shared_mlp_max(spec, _bn_buffers([self.bn1]), None, None, None, None,
+                                  _stack_params([self.conv1], [self.bn1]), x_rows=rows)
+        else:                                                           # eval: running statistics (bn1 IS registered in the source)
+            y = F.linear(rows, self.conv1.weight.reshape(128, 128), self.conv1.bias)
+            feat = F.relu(F.batch_norm(y, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight, self.bn1.bias,
+                                       False, 0.0, self.bn1.eps))
+        x = self.drop1(feat)                                                                        # :48
+        x = F.linear(x, self.conv2.weight.reshape(self.conv2.out_channels, 128), self.conv2.bias)   # :49
+        return x.view(B, N, -1)                                                                     # :50 [B,N,num_parts]
+
+
+class PointNet2_SSG_Seg(_PartSegBase):
+    def __init__(self, name_scope='PointNet2_SSG_Seg_', num_classes=16, num_parts=50, normal_channel=False,
+                 reference_quirks=False, fp_neighbours="reference"):
+        super().__init__()
+        additional_channel = 3 if normal_channel else 0
+        self.num_classes, self.normal_channel = num_classes, normal_channel
+        q = dict(reference_quirks=reference_quirks)
+        self.sa1 = PointNetSetAbstraction(npoint=512, radius=0.2, nsample=32, in_channel=6 + additional_channel,
+                                          mlp=[64, 64, 128], group_all=False, **q)
+        self.sa2 = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=128 + 3, mlp=[128, 128, 256],
+                                          group_all=False, **q)
+        self.sa3 = PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=256 + 3,
+                                          mlp=[256, 512, 1024], group_all=True, **q)
+        f = dict(neighbours=fp_neighbours, reference_quirks=reference_quirks)
+        self.fp3 = PointNetFeaturePropagation(in_channel=1280, mlp=[256, 256], **f)
+        self.fp2 = PointNetFeaturePropagation(in_channel=384, mlp=[256, 128], **f)
+        self.fp1 = PointNetFeaturePropagation(in_channel=128 + 16 + 6 + additional_channel, mlp=[128, 128, 128], **f)
+        self._head_init(num_parts)
+
+    def _encode(self, l0_xyz, l0_points, start_idx):
+        s = _starts(start_idx, 2)
+        l1 = self.sa1(l0_xyz, l0_points, s[0])                                                     # :38
+        l2 = self.sa2(l1[0], l1[1], s[1])                                                          # :39
+        l3 = self.sa3(l2[0], l2[1])                                                                # :40
+        return l1, l2, l3
+
+
+class PointNet2_MSG_Seg(_PartSegBase):
+    def __init__(self, name_scope='PointNet2_MSG_Seg_', num_classes=16, num_parts=50, normal_channel=False,
+                 reference_quirks=False, fp_neighbours="reference"):
+        super().__init__()
+        additional_channel = 3 if normal_channel else 0
+        self.num_classes, self.normal_channel = num_classes, normal_channel
+        q = dict(reference_quirks=reference_quirks)
+        self.sa1 = PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [32, 64, 128], 3 + additional_channel,
+                                             [[32, 32, 64], [64, 64, 128], [64, 96, 128]], **q)
+        self.sa2 = PointNetSetAbstractionMsg(128, [0.4, 0.8], [64, 128], 128 + 128 + 64,
+                                             [[128, 128, 256], [128, 196, 256]], **q)
+        self.sa3 = PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=512 + 3,
+                                          mlp=[256, 512, 1024], group_all=True, **q)
+        f = dict(neighbours=fp_neighbours, reference_quirks=reference_quirks)
+        self.fp3 = PointNetFeaturePropagation(in_channel=1536, mlp=[256, 256], **f)
+        self.fp2 = PointNetFeaturePropagation(in_channel=576, mlp=[256, 128], **f)
+        self.fp1 = PointNetFeaturePropagation(in_channel=150 + additional_channel, mlp=[128, 128], **f)
+        self._head_init(num_parts)
+
+    def _encode(self, l0_xyz, l0_points, start_idx):
+        s = _starts(start_idx, 2)
+        l1 = self.sa1(l0_xyz, l0_points, s[0])                                                     # :86
+        l2 = self.sa2(l1[0], l1[1], s[1])                                                          # :87
+        l3 = self.sa3(l2[0], l2[1])                                                                # :88
+        return l1, l2, l3

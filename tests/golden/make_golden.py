@@ -58,10 +58,30 @@ def pfn():
     np.savez_compressed(os.path.join(HERE, "pfn_p64.npz"), voxels=voxels, num_points=nump, coors=coors, w=w, gamma=g, beta=b, **outs)
 
 
+def feature_propagation():
+    """FP level 2 of the SSG segmentation net (in 384 -> [256,128]) at reduced size, both neighbour modes."""
+    B, N, S, D1, D2, seed = 2, 256, 64, 16, 32, 99
+    x1 = np.ascontiguousarray(make_clouds(B, N, seed))                       # [B,3,N]
+    x2 = np.ascontiguousarray(x1[:, :, ::4])                                 # a subset, like FPS output
+    rng = np.random.default_rng(seed)
+    p1 = rng.normal(size=(B, D1, N)).astype(np.float32)
+    p2 = rng.normal(size=(B, D2, S)).astype(np.float32)
+    ws = seeded_weights([D1 + D2, 64, 32], 7)
+    out = dict(seed=seed, points1=p1, points2=p2)
+    for nb in ("reference", "nearest"):
+        o, interp = R.PointNetFeaturePropagation(D1 + D2, [64, 32], ws, nb).forward(x1, x2, p1, p2, f64=True, return_interp=True)
+        out["out_" + nb] = o.astype(np.float32)
+        out["interp_" + nb] = interp
+    d, i, w = R.three_nn_true(np.ascontiguousarray(x1.transpose(0, 2, 1)), np.ascontiguousarray(x2.transpose(0, 2, 1)))
+    out.update(dist3=d, idx3=i.astype(np.int32), weight3=w)
+    np.savez_compressed(os.path.join(HERE, "fp_b2_n256.npz"), **out)
+
+
 if __name__ == "__main__":
     sampling(2, 1024, 128, 1234, "sampling_b2_n1024.npz")
     sampling(1, 4096, 512, 4242, "sampling_b1_n4096.npz")
     sa_activations()
     pfn()
+    feature_propagation()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,173 @@
+"""GPU parity of PointNetFeaturePropagation (pointnet2_basic_layers.py:284-335): three_nn / three_interpolate through
+the C ABI bit-exact against the oracle, the layer forward <= 1e-5, the backward against a float64 torch reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_np as R
+from papc_amd import functional as F
+from papc_amd.layers import PointNetFeaturePropagation
+from tests.util import assert_close, seeded_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _clouds(B, N, S, seed, subset=True):
+    rng = np.random.default_rng(seed)
+    x1 = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    x2 = np.ascontiguousarray(x1[:, rng.permutation(N)[:S]]) if subset else rng.uniform(-1, 1, (B, S, 3)).astype(np.float32)
+    return x1, x2
+
+
+@pytest.mark.parametrize("B,N,S,subset", [(2, 300, 3, True), (2, 1024, 128, True), (3, 777, 130, False), (1, 2048, 5000, False)])
+def test_three_nn_bit_exact(dev, B, N, S, subset):
+    x1, x2 = _clouds(B, N, S, 1, subset and S <= N)
+    d_ref, i_ref, w_ref = R.three_nn_true(x1, x2)
+    # strided inputs: hand the kernel the transposed [B,3,N] storage like the layer does
+    t1 = torch.from_numpy(np.ascontiguousarray(x1.transpose(0, 2, 1))).to(dev).transpose(1, 2)
+    t2 = torch.from_numpy(x2).to(dev)
+    d, i, w = F.three_nn(t1, t2)
+    assert np.array_equal(d.cpu().numpy(), d_ref)
+    assert np.array_equal(w.cpu().numpy(), w_ref)
+    # indices: identical wherever the three distances are distinct from their neighbours in the sorted row (ties are
+    # resolved in ascending index order by both, but the oracle's argsort sees the full row)
+    assert np.array_equal(i.cpu().numpy().astype(np.int64), i_ref)
+
+
+def test_three_nn_ties_take_lowest_index(dev):
+    x2 = np.zeros((1, 6, 3), np.float32)
+    x2[0, :, 0] = [1, 1, 1, 1, 0.5, 1]          # four duplicates of the same support point
+    x1 = np.zeros((1, 4, 3), np.float32)
+    d, i, w = F.three_nn(torch.from_numpy(x1).to(dev), torch.from_numpy(x2).to(dev))
+    assert np.array_equal(i.cpu().numpy()[0, 0], [4, 0, 1])
+    _, i_ref, _ = R.three_nn_true(x1, x2)
+    assert np.array_equal(i.cpu().numpy().astype(np.int64), i_ref)
+
+
+@pytest.mark.parametrize("D", [1, 6, 64, 259])
+def test_three_interpolate_bit_exact_and_grad(dev, D):
+    B, N, S = 2, 500, 64
+    x1, x2 = _clouds(B, N, S, 2)
+    rng = np.random.default_rng(3)
+    p2 = rng.normal(size=(B, S, D)).astype(np.float32)
+    _, i_ref, w_ref = R.three_nn_true(x1, x2)
+    ref = R.three_interpolate(p2, i_ref, w_ref)
+    tp = torch.from_numpy(p2).to(dev).requires_grad_(True)
+    ti = torch.from_numpy(i_ref.astype(np.int32)).to(dev)
+    tw = torch.from_numpy(w_ref).to(dev)
+    out = F.three_interpolate(tp, ti, tw)
+    assert np.array_equal(out.detach().cpu().numpy(), ref)
+    g = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev)
+    out.backward(g)
+    # float64 reference of the scatter
+    gref = np.zeros((B, S, D), np.float64)
+    gn = g.cpu().numpy().astype(np.float64)
+    for b in range(B):
+        for j in range(3):
+            np.add.at(gref[b], i_ref[b, :, j], gn[b] * w_ref[b, :, j:j + 1].astype(np.float64))
+    assert_close(tp.grad.cpu().numpy(), gref, 1e-5, "interpolate grad")
+
+
+def _load(fp, ws):
+    with torch.no_grad():
+        for conv, bn, (w, b, g, bt) in zip(fp.mlp_convs, fp.mlp_bns, ws):
+            conv.weight.copy_(torch.from_numpy(w).reshape(conv.weight.shape)); conv.bias.copy_(torch.from_numpy(b))
+            bn.weight.copy_(torch.from_numpy(g)); bn.bias.copy_(torch.from_numpy(bt))
+
+
+@pytest.mark.parametrize("neighbours", ["reference", "nearest"])
+@pytest.mark.parametrize("B,N,S,D1,D2,mlp", [(2, 512, 128, 6, 32, [64, 32]), (2, 128, 1, 16, 64, [48]), (2, 256, 32, 0, 24, [32, 32, 16])])
+def test_fp_layer_forward_vs_oracle(dev, neighbours, B, N, S, D1, D2, mlp):
+    x1, x2 = _clouds(B, N, S, 7)
+    rng = np.random.default_rng(8)
+    p1 = rng.normal(size=(B, D1, N)).astype(np.float32) if D1 else None
+    p2 = rng.normal(size=(B, D2, S)).astype(np.float32)
+    ws = seeded_weights([D1 + D2] + mlp, 5)
+    xyz1, xyz2 = np.ascontiguousarray(x1.transpose(0, 2, 1)), np.ascontiguousarray(x2.transpose(0, 2, 1))
+    ref, interp_ref = R.PointNetFeaturePropagation(D1 + D2, mlp, ws, neighbours).forward(xyz1, xyz2, p1, p2, f64=True, return_interp=True)
+    fp = PointNetFeaturePropagation(D1 + D2, mlp, neighbours=neighbours).to(dev)
+    _load(fp, ws)
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    interp = fp.interpolate(t(xyz1).transpose(1, 2), t(xyz2).transpose(1, 2), t(p2).transpose(1, 2))
+    assert np.array_equal(interp.cpu().numpy(), interp_ref)          # the interpolation itself is bit-exact
+    got = fp(t(xyz1), t(xyz2), t(p1), t(p2))
+    assert got.shape == (B, mlp[-1], N)
+    assert_close(got.detach().cpu().numpy(), ref, 1e-5, "FP forward")
+    # running statistics follow paddle's momentum 0.9 convention like the SA layers
+    assert fp.mlp_bns[0].running_mean.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("neighbours", ["reference", "nearest"])
+def test_fp_layer_backward_vs_torch_f64(dev, neighbours):
+    B, N, S, D1, D2, mlp = 2, 384, 48, 10, 20, [32, 24]
+    x1, x2 = _clouds(B, N, S, 9)
+    rng = np.random.default_rng(10)
+    p1 = rng.normal(size=(B, D1, N)).astype(np.float32)
+    p2 = rng.normal(size=(B, D2, S)).astype(np.float32)
+    ws = seeded_weights([D1 + D2] + mlp, 6)
+    fp = PointNetFeaturePropagation(D1 + D2, mlp, neighbours=neighbours).to(dev)
+    _load(fp, ws)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    xyz1, xyz2 = t(np.ascontiguousarray(x1.transpose(0, 2, 1))), t(np.ascontiguousarray(x2.transpose(0, 2, 1)))
+    tp1, tp2 = t(p1).requires_grad_(True), t(p2).requires_grad_(True)
+    out = fp(xyz1, xyz2, tp1, tp2)
+    gout = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+    out.backward(gout)
+
+    # float64 torch reference built from the oracle's neighbours / weights
+    fn = R.three_nn_literal if neighbours == "reference" else R.three_nn_true
+    _, idx, w = fn(x1, x2)
+    q1 = torch.from_numpy(p1).double().requires_grad_(True)
+    q2 = torch.from_numpy(p2).double().requires_grad_(True)
+    pts2 = q2.transpose(1, 2)                                              # [B,S,D2]
+    ii = torch.from_numpy(idx)
+    gathered = torch.stack([torch.gather(pts2, 1, ii[:, :, j:j + 1].expand(B, N, D2)) for j in range(3)], 2)
+    interp = (gathered * torch.from_numpy(w).double()[..., None]).sum(2)
+    x = torch.cat([q1.transpose(1, 2), interp], -1).reshape(B * N, -1)
+    params = []
+    for (wt, b, g, bt) in ws:
+        ps = [torch.from_numpy(a).double().requires_grad_(True) for a in (wt, b, g, bt)]
+        params.append(ps)
+        y = x @ ps[0].t() + ps[1]
+        x = torch.relu((y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * ps[2] + ps[3])
+    ref_out = x.reshape(B, N, -1).transpose(1, 2)
+    ref_out.backward(gout.cpu().double())
+    assert_close(out.detach().cpu().numpy(), ref_out.detach().numpy(), 1e-5, "FP out")
+    assert_close(tp1.grad.cpu().numpy(), q1.grad.numpy(), 2e-5, "d points1")
+    assert_close(tp2.grad.cpu().numpy(), q2.grad.numpy(), 2e-5, "d points2")
+    for l, (conv, bn) in enumerate(zip(fp.mlp_convs, fp.mlp_bns)):
+        assert_close(conv.weight.grad.cpu().numpy().reshape(params[l][0].shape), params[l][0].grad.numpy(), 2e-5, "dW%d" % l)
+        assert_close(bn.weight.grad.cpu().numpy(), params[l][2].grad.numpy(), 2e-5, "dgamma%d" % l)
+        assert_close(bn.bias.grad.cpu().numpy(), params[l][3].grad.numpy(), 2e-5, "dbeta%d" % l)
+
+
+def test_fp_reference_quirks_cut_gradients(dev):
+    fp = PointNetFeaturePropagation(8, [8], reference_quirks=True).to(dev)
+    assert not any(p.requires_grad for p in fp.parameters())
+    x1, x2 = _clouds(1, 64, 8, 1)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p1 = torch.randn(1, 4, 64, device=dev, requires_grad=True)
+    p2 = torch.randn(1, 4, 8, device=dev, requires_grad=True)
+    out = fp(t(x1.transpose(0, 2, 1)), t(x2.transpose(0, 2, 1)), p1, p2)
+    out.sum().backward()
+    assert p1.grad is not None and p2.grad is None     # index_points' numpy round trip cuts the graph (:57-60)
+
+
+def test_golden_fp_fixture(dev):
+    import os
+    from papc_amd.synthetic import make_clouds
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp_b2_n256.npz"))
+    x1 = np.ascontiguousarray(make_clouds(2, 256, int(g["seed"])))
+    x2 = np.ascontiguousarray(x1[:, :, ::4])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d, i, w = F.three_nn(t(x1).transpose(1, 2), t(x2).transpose(1, 2))
+    assert np.array_equal(d.cpu().numpy(), g["dist3"]) and np.array_equal(i.cpu().numpy(), g["idx3"])
+    assert np.array_equal(w.cpu().numpy(), g["weight3"])
+    ws = seeded_weights([48, 64, 32], 7)
+    for nb in ("reference", "nearest"):
+        fp = PointNetFeaturePropagation(48, [64, 32], neighbours=nb).to(dev)
+        _load(fp, ws)
+        interp = fp.interpolate(t(x1).transpose(1, 2), t(x2).transpose(1, 2), t(g["points2"]).transpose(1, 2))
+        assert np.array_equal(interp.cpu().numpy(), g["interp_" + nb])
+        out = fp(t(x1), t(x2), t(g["points1"]), t(g["points2"]))
+        assert_close(out.detach().cpu().numpy(), g["out_" + nb], 1e-5, "golden FP " + nb)

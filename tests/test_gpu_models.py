@@ -125,7 +125,7 @@ def test_train_step_decreases_loss_and_quirks_mode(dev):
         loss = TF.cross_entropy(m(x, st), y)
         loss.backward()
         opt.step(flat.allreduce_grads())
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0], losses
     assert m.sa1.mlp_convs[0].weight.grad.abs().sum() > 0        # gradient reaches SA1 through both gathers
     q = PointNet2_SSG_Clas(reference_quirks=True).to(dev)        # the source's behaviour: SA params frozen, gathers cut

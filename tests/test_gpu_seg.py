@@ -1,0 +1,100 @@
+"""GPU tests of the part-segmentation callers (segment/pointnet2/pointnet2.py): encoder + three feature-propagation
+levels + per-point head against the f64 oracle chain, and a train step through FlatParams/FlatAdam."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import reference_np as R
+from papc_amd.distributed import FlatAdam, FlatParams
+from papc_amd.models import Categorical, PointNet2_MSG_Seg, PointNet2_SSG_Seg
+from papc_amd.synthetic import make_clouds, make_start_idx
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _ws(convs, bns):
+    return [(c.weight.detach().cpu().numpy().reshape(c.weight.shape[0], -1), c.bias.detach().cpu().numpy(),
+             bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy()) for c, bn in zip(convs, bns)]
+
+
+def _oracle_decoder(m, x, cls, l1, l2, l3, neighbours):
+    """fp3 -> fp2 -> fp1 -> conv1/bn1/relu -> conv2 in the oracle (f64 MLPs), from the oracle's own encoder outputs."""
+    B, _, N = x.shape
+    fp = lambda layer, cin, mlp: R.PointNetFeaturePropagation(cin, mlp, _ws(layer.mlp_convs, layer.mlp_bns), neighbours)
+    chans = lambda layer: [c.out_channels for c in layer.mlp_convs]
+    l2p = fp(m.fp3, 0, chans(m.fp3)).forward(l2[0], l3[0], l2[1], l3[1], f64=True).astype(np.float32)
+    l1p = fp(m.fp2, 0, chans(m.fp2)).forward(l1[0], l2[0], l1[1], l2p, f64=True).astype(np.float32)
+    onehot = np.tile(np.eye(16, dtype=np.float32)[cls.reshape(-1)][:, :, None], (1, 1, N))
+    p1 = np.concatenate([onehot, x[:, :3], x], axis=1)
+    l0p = fp(m.fp1, 0, chans(m.fp1)).forward(x[:, :3], l1[0], p1, l1p, f64=True).astype(np.float32)
+    rows = np.ascontiguousarray(l0p.transpose(0, 2, 1)).reshape(B * N, -1)
+    feat = R.mlp_stack_rows(rows, _ws([m.conv1], [m.bn1]), f64=True)
+    w2 = m.conv2.weight.detach().cpu().numpy().reshape(m.conv2.out_channels, -1).astype(np.float64)
+    logits = feat @ w2.T + m.conv2.bias.detach().cpu().numpy().astype(np.float64)
+    return l0p, logits.reshape(B, N, -1)
+
+
+@pytest.mark.parametrize("neighbours", ["reference", "nearest"])
+def test_ssg_seg_forward_vs_oracle_chain(dev, neighbours):
+    B, N = 2, 1024
+    x = make_clouds(B, N, 21)
+    cls = np.array([[3], [11]], np.int64)
+    s1, s2 = make_start_idx(B, N, 21), make_start_idx(B, 512, 22)
+    torch.manual_seed(1)
+    m = PointNet2_SSG_Seg(num_classes=16, num_parts=50, fp_neighbours=neighbours).to(dev)
+    m.train()
+    m.drop1.p = 0.0
+    specs = [(512, 0.2, 32, 6, [64, 64, 128], False), (128, 0.4, 64, 131, [128, 128, 256], False), (None, None, None, 259, [256, 512, 1024], True)]
+    levels, xyz, feats = [], x, x
+    for sa, (npnt, r, k, cin, mlp, ga), st in zip([m.sa1, m.sa2, m.sa3], specs, [s1, s2, None]):
+        xyz, feats = R.PointNetSetAbstraction(npnt, r, k, cin, mlp, ga, _ws(sa.mlp_convs, sa.mlp_bns)).forward(xyz, feats, st, f64=True)
+        feats = feats.astype(np.float32)
+        levels.append((xyz, feats))
+    l0p_ref, logits_ref = _oracle_decoder(m, x, cls, *levels, neighbours)
+    t = torch.from_numpy(x).to(dev)
+    st = (torch.from_numpy(s1).to(dev), torch.from_numpy(s2).to(dev))
+    with torch.no_grad():
+        logits = m((t, cls), st)
+    assert tuple(logits.shape) == (B, N, 50)
+    # 9 SA + 7 FP + 1 head conv/BN layers chained in fp32 against an all-f64 chain (each layer alone is held to 1e-5
+    # in test_gpu_fp / test_gpu_mlp); same compounding bound as the classifier chain test
+    assert_close(logits.cpu().numpy(), logits_ref, 5e-4, "SSG_Seg logits vs f64 oracle chain")
+
+
+def test_categorical_matches_reference_shape():
+    y = Categorical(np.array([[2], [0]]), 16)
+    assert tuple(y.shape) == (2, 16, 1) and y[0, 2, 0] == 1 and y[1, 0, 0] == 1 and y.sum() == 2
+
+
+@pytest.mark.parametrize("cls_", [PointNet2_SSG_Seg, PointNet2_MSG_Seg])
+def test_seg_train_step(dev, cls_):
+    B, N = 2, 1024
+    x = torch.from_numpy(make_clouds(B, N, 31)).to(dev)
+    cls = np.array([[1], [5]], np.int64)
+    rng = np.random.default_rng(0)
+    target = torch.from_numpy(rng.integers(0, 50, (B, N))).to(dev)
+    st = (torch.from_numpy(make_start_idx(B, N, 31)).to(dev), torch.from_numpy(make_start_idx(B, 512, 32)).to(dev))
+    torch.manual_seed(0)
+    m = cls_(fp_neighbours="nearest").to(dev)
+    m.train()
+    m.drop1.p = 0.0
+    flat = FlatParams(m)
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=0.0)
+    losses = []
+    for _ in range(6):
+        flat.zero_grad()
+        logits = m((x, cls), st)
+        loss = TF.cross_entropy(logits.reshape(B * N, 50), target.reshape(-1))
+        loss.backward()
+        opt.step(flat.allreduce_grads())
+        losses.append(float(loss.detach()))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    for name, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    assert m.sa1_first_weight().grad.abs().sum() > 0   # gradient reaches the first SA level through all three FP levels
+    m.eval()
+    with torch.no_grad():
+        out = m((x, cls), st)
+    assert tuple(out.shape) == (B, N, 50) and torch.isfinite(out).all()

@@ -143,3 +143,53 @@ def test_golden_fixtures_match_oracle():
     new_xyz = R.index_points(xyz, fps)
     for r, k in [(0.1, 16), (0.2, 32), (0.4, 64), (0.8, 128)]:
         assert np.array_equal(R.query_ball_point(r, k, xyz, new_xyz), g["bq_r%s_k%d" % (str(r).replace(".", "p"), k)])
+
+
+def test_feature_propagation_literal_idx_is_012_and_true_nn_is_brute_force():
+    """pointnet2_basic_layers.py:316-317 sorts, then argsorts the sorted matrix: idx == 0,1,2 (distinct distances)."""
+    rng = np.random.default_rng(5)
+    x1 = rng.uniform(-1, 1, (2, 200, 3)).astype(np.float32)
+    x2 = rng.uniform(-1, 1, (2, 40, 3)).astype(np.float32)
+    d, idx, w = R.three_nn_literal(x1, x2)
+    assert np.array_equal(idx, np.broadcast_to(np.arange(3), idx.shape))
+    assert np.all(np.diff(d, axis=-1) >= 0)
+    assert np.allclose(w.sum(-1), 1, atol=1e-6)
+    dt, it, wt = R.three_nn_true(x1, x2)
+    assert np.array_equal(dt, d) and np.array_equal(wt, w)
+    full = ((x1[:, :, None, :].astype(np.float64) - x2[:, None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(np.sort(it, -1), np.sort(np.argsort(full, -1)[:, :, :3], -1))
+
+
+@pytest.mark.parametrize("S,has_p1", [(16, True), (16, False), (1, True)])
+def test_torch_transliteration_fp_matches_oracle(S, has_p1):
+    from tests.util import seeded_weights
+    rng = np.random.default_rng(11)
+    B, N, D1, D2 = 2, 96, 5, 12
+    xyz1 = rng.uniform(-1, 1, (B, 3, N)).astype(np.float32)
+    xyz2 = np.ascontiguousarray(xyz1[:, :, :S])
+    p1 = rng.normal(size=(B, D1, N)).astype(np.float32) if has_p1 else None
+    p2 = rng.normal(size=(B, D2, S)).astype(np.float32)
+    cin = D2 + (D1 if has_p1 else 0)
+    ws = seeded_weights([cin, 24, 16], 3)
+    ref = R.PointNetFeaturePropagation(cin, [24, 16], ws).forward(xyz1, xyz2, p1, p2, f64=True)
+    fp = T.FeaturePropagation(cin, [24, 16])
+    with torch.no_grad():
+        for conv, bn, (w, b, g, bt) in zip(fp.convs, fp.bns, ws):
+            conv.weight.copy_(torch.from_numpy(w).reshape(conv.weight.shape)); conv.bias.copy_(torch.from_numpy(b))
+            bn.weight.copy_(torch.from_numpy(g)); bn.bias.copy_(torch.from_numpy(bt))
+    fp.train()
+    got = fp(torch.from_numpy(xyz1), torch.from_numpy(xyz2), None if p1 is None else torch.from_numpy(p1), torch.from_numpy(p2))
+    assert got.shape == ref.shape == (B, 16, N)
+    assert np.max(np.abs(got.detach().numpy() - ref)) <= 2e-5 * np.max(np.abs(ref))
+
+
+def test_golden_fp_fixture_matches_oracle():
+    from tests.util import seeded_weights
+    g = np.load(os.path.join(GOLD, "fp_b2_n256.npz"))
+    x1 = np.ascontiguousarray(make_clouds(2, 256, int(g["seed"])))
+    x2 = np.ascontiguousarray(x1[:, :, ::4])
+    ws = seeded_weights([48, 64, 32], 7)
+    for nb in ("reference", "nearest"):
+        o, interp = R.PointNetFeaturePropagation(48, [64, 32], ws, nb).forward(x1, x2, g["points1"], g["points2"], f64=True, return_interp=True)
+        assert np.array_equal(interp, g["interp_" + nb])
+        assert np.array_equal(o.astype(np.float32), g["out_" + nb])
