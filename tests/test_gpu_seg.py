@@ -98,3 +98,40 @@ def test_seg_train_step(dev, cls_):
     with torch.no_grad():
         out = m((x, cls), st)
     assert tuple(out.shape) == (B, N, 50) and torch.isfinite(out).all()
+
+
+def test_full_size_config3_msg_seg(dev):
+    """BASELINE config 3 at full size (PointNet2_MSG_Seg, B=16, N=2048): too large for the oracle in seconds, so
+    size-independent properties: finite outputs/gradients, bitwise-repeatable forward, the 3-NN kernel's invariants
+    (ascending distances, weights summing to 1, the reported neighbours really are at the reported distances and no
+    other support point is closer)."""
+    from papc_amd import functional as F
+    B, N = 16, 2048
+    x = torch.from_numpy(make_clouds(B, N, 41)).to(dev)
+    cls = (np.arange(B).reshape(B, 1) % 16).astype(np.int64)
+    st = (torch.from_numpy(make_start_idx(B, N, 41)).to(dev), torch.from_numpy(make_start_idx(B, 512, 42)).to(dev))
+    torch.manual_seed(0)
+    m = PointNet2_MSG_Seg(fp_neighbours="nearest").to(dev)
+    m.train()
+    m.drop1.p = 0.0
+    with torch.no_grad():
+        a = m((x, cls), st)
+        b = m((x, cls), st)
+    assert tuple(a.shape) == (B, N, 50) and torch.isfinite(a).all()
+    assert torch.equal(a, b)
+    tgt = torch.randint(0, 50, (B * N,), device=dev)
+    TF.cross_entropy(m((x, cls), st).reshape(B * N, 50), tgt).backward()
+    for name, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    # 3-NN invariants at the fp1 size (N=2048 queries against S=512 support points)
+    xyz1 = x.transpose(1, 2)
+    _, new_xyz = F._fps_raw(xyz1, 512, st[0])
+    d, i, w = F.three_nn(xyz1, new_xyz)
+    assert (d[..., 1] >= d[..., 0]).all() and (d[..., 2] >= d[..., 1]).all()
+    assert (i >= 0).all() and (i < 512).all()
+    full = torch.cdist(xyz1.double(), new_xyz.double()) ** 2                     # [B,N,S]
+    got = torch.gather(full, 2, i.long())
+    assert (got - d.double()).abs().max() < 1e-5
+    kth = full.topk(3, dim=2, largest=False).values
+    assert (kth - d.double()).abs().max() < 1e-5
+    assert (w.sum(-1) - 1).abs().max() < 1e-5

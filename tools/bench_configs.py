@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from papc_amd.layers import PointNetSetAbstractionMsg
-from papc_amd.models import PointNet_Basic_Clas, PointNet2_MSG_Clas
+from papc_amd.models import PointNet_Basic_Clas, PointNet2_MSG_Clas, PointNet2_MSG_Seg
 from papc_amd.pillars import PillarFeatureNet
 from papc_amd.synthetic import make_clouds, make_pillars, make_start_idx
 
@@ -43,6 +43,24 @@ def msg_step():
 
 
 print("config 3  MSG SA1+SA2 fwd+bwd, B=16 N=2048: %.3f ms  (%.0f clouds/s)" % (timeit(msg_step), B / timeit(msg_step) * 1e3))
+
+# ---- config 3, whole model: PointNet2_MSG_Seg (encoder + 3 feature-propagation levels + per-point head)
+import numpy as np
+seg = PointNet2_MSG_Seg(fp_neighbours=os.environ.get("PAPC_FP_NEIGHBOURS", "reference")).to(dev)
+seg.train()
+cls = np.arange(B).reshape(B, 1) % 16
+tgt = torch.randint(0, 50, (B * N,), device=dev)
+
+
+def seg_step():
+    for p in seg.parameters():
+        p.grad = None
+    logits = seg((x, cls), (st1, st2))
+    torch.nn.functional.cross_entropy(logits.reshape(B * N, 50), tgt).backward()
+
+
+t = timeit(seg_step)
+print("config 3  PointNet2_MSG_Seg whole model fwd+bwd, B=16 N=2048: %.3f ms  (%.0f clouds/s)" % (t, B / t * 1e3))
 
 # ---- config 5: PillarFeatureNet 12000 x 100 (kitti yaml num_filters [64])
 v, n, c = make_pillars()
