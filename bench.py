@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="compute batch i+1's sampling pyramid on a side stream while "
                     "batch i runs its small-grid kernels (SA3 + FC head, forward and backward)")
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
+                    "replaying the captured hipGraph of zero_grad + forward + loss + backward")
     args = ap.parse_args()
 
     from papc_amd import _lib
@@ -96,6 +98,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.load()
+    # everything runs on one non-default stream: autograd binds its AccumulateGrad nodes to the stream of the first
+    # backward, and nodes bound to the legacy default stream cannot take part in a stream capture
+    torch.cuda.set_stream(torch.cuda.Stream())
 
     B, N = args.batch, args.npoints
     torch.manual_seed(1234)                       # same initial weights on every rank (then broadcast anyway)
@@ -129,7 +134,7 @@ def main():
                 t.record_stream(main)              # consumed by main-stream kernels: keep the blocks alive for them
         state["plan"], state["ev"] = plan, ev
 
-    def step():
+    def step_eager():
         if not args.overlap:
             plan = None
         else:
@@ -147,6 +152,34 @@ def main():
         scale = flat.allreduce_grads()
         opt.step(scale)
         return loss
+
+    # hipGraph of the launch-bound part of the step: ~125 kernels of 3-400 us each are otherwise issued one by one from
+    # Python and the GPU idles ~12 % of the step between them.  zero_grad + forward + loss + backward are captured once
+    # (static buffers: the allocations made during capture live in the graph's private pool) and replayed; the gradient
+    # all-reduce and the Adam kernel (whose bias correction takes the step count as a host scalar) stay eager launches.
+    use_graph = not args.no_graph and not args.overlap
+    graph_state = {"g": None, "loss": None}
+
+    def fwd_bwd():
+        flat.zero_grad()
+        logits = model(x, (s1, s2))
+        loss = F.cross_entropy(logits, y)
+        loss.backward()
+        return loss
+
+    def capture():
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
+            graph_state["loss"] = fwd_bwd()
+        graph_state["g"] = g
+
+    def step():
+        if graph_state["g"] is None:
+            return step_eager()
+        graph_state["g"].replay()
+        opt.step(flat.allreduce_grads())
+        return graph_state["loss"]
 
     use_dist = dist.is_initialized()
 
@@ -168,14 +201,22 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     fam = prof_read(lib)
+    lib.papc_prof_enable(0)
     dominant = max((k for k in fam if k != 9), key=lambda k: fam[k][0])
     if args.profile_all and rank == 0:
         tot = sum(v[0] for v in fam.values())
         for k, (ms, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
             print("  %-14s %8.3f ms/step  %4d launches/step  %5.1f%%" % (K_NAMES[k], ms / NPROF, n // NPROF,
                                                                          100.0 * ms / max(tot, 1e-9)), file=sys.stderr)
-    lib.papc_prof_enable(1 << dominant)           # timed region: event pairs only around the dominant family
-    lib.papc_prof_reset()
+    if use_graph:
+        loss = None                               # drop the last eager autograd graph before capturing
+        capture()                                 # event profiler off: nothing but kernels, memsets and copies in the graph
+        for _ in range(2):
+            loss = step()
+        torch.cuda.synchronize()
+    else:
+        lib.papc_prof_enable(1 << dominant)       # eager timed region: event pairs only around the dominant family
+        lib.papc_prof_reset()
 
     # ---- timed region
     sync()
@@ -188,16 +229,26 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    final_loss = float(loss.item())
+    n_roof = args.steps
+    if use_graph:
+        # kernels inside a replayed graph cannot carry host-visible event pairs: the dominant family's launch durations are
+        # measured on the same kernels, same inputs, launched eagerly for min(K, 20) further steps right after the timed region
+        n_roof = min(args.steps, 20)
+        lib.papc_prof_enable(1 << dominant)
+        lib.papc_prof_reset()
+        for _ in range(n_roof):
+            step_eager()
+        torch.cuda.synchronize()
     dom_ms, dom_n = prof_read(lib)[dominant]
     lib.papc_prof_enable(0)
-    final_loss = float(loss.item())
     assert final_loss == final_loss, "loss is NaN"
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         work, kind = algorithmic_work(B, N)[dominant] if dominant in algorithmic_work(B, N) else (0.0, "byte")
-        per_step_s = (dom_ms / 1e3) / args.steps if dom_ms > 0 else float("nan")
+        per_step_s = (dom_ms / 1e3) / n_roof if dom_ms > 0 else float("nan")
         if kind == "flop":
             achieved = work / per_step_s / 1e12
             roof = {"bound": "mfma", "kernel": K_NAMES[dominant], "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
@@ -206,9 +257,11 @@ def main():
             achieved = work / per_step_s / 1e9
             roof = {"bound": "hbm", "kernel": K_NAMES[dominant], "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
-        roof["launches_per_step"] = dom_n // args.steps
+        roof["launches_per_step"] = dom_n // n_roof
         roof["avg_launch_ms"] = round(dom_ms / max(1, dom_n), 4)
-        roof["ms_per_step"] = round(dom_ms / args.steps, 3)
+        roof["ms_per_step"] = round(dom_ms / n_roof, 3)
+        roof["timing"] = ("HIP event pairs around every launch of the family, %d eager steps right after the graph-replayed "
+                          "timed region" % n_roof) if use_graph else "HIP event pairs around every launch of the family over the timed region"
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -220,7 +273,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
-                       "sampling": "batch i+1 pyramid on a side stream during batch i" if args.overlap else "in-line"},
+                       "sampling": "batch i+1 pyramid on a side stream during batch i" if args.overlap else "in-line",
+                       "mfma": "fwd/dX GEMMs: fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, "
+                               "fp32 accumulate (PAPC_GEMM_F32=1 selects v_mfma_f32_32x32x2_f32); dW: v_mfma_f32_32x32x2_f32",
+                       "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager all-reduce + Adam" if use_graph else "eager"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -280,6 +280,7 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     rc = fill_asrc(p.x, a_mode, x, ldx, grp, bn_scale, bn_shift, Cin, "papc_mlp_bwd_dw_f32");
     if (rc) return rc;
     fill_dy(p.dy.d, dy);
+    p.dy.d.C = Cout;
     const bool vec = vdy && p.x.vec;
     p.M = M; p.Cin = Cin; p.Cout = Cout; p.rows_per_chunk = rows_per_chunk; p.dw_partial = dw_partial; p.db_partial = db_partial; p.part_ld = part_ld;
     p.xmap = (a_mode == A_GROUP) ? 1 : 0;

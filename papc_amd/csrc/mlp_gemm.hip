@@ -106,16 +106,31 @@ __device__ __forceinline__ float4 mask_w4(const GemmArgs &p, int n, int k, float
 // The consume step sits BEFORE the stores on purpose: gfx9-family vmcnt counts loads and stores together and, with both
 // kinds pending, a wait for a load degenerates to vmcnt(0); ordered this way the stores are the youngest VMEM ops of
 // the iteration and drain under the next stage's MFMAs (the barrier does not wait for them: lds_barrier()).
-template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
+//
+// BF3 = true: the operands are split into three bf16 planes when they are written to LDS and the products run on
+// v_mfma_f32_32x32x16_bf16 (six per 32x32x16 block, see split3 in mlp_loaders.h) -- fp32 accuracy at 2.7x the fp32 matrix
+// rate.  A stage is then one 16-wide k block: LDS rows are [plane0 | plane1 | plane2] x 32 B + 16 B pad = 112 B (7 x 16 B,
+// odd -> the 16-lane groups of a ds_read_b128 hit 16 distinct 16-B slots); a lane's 16-B read at plane*32 + 16*(lane>>5) is
+// its 8 consecutive k of row lane&31, exactly the instruction's A/B operand.  BF3 = false is the exact fp32 path
+// (v_mfma_f32_32x32x2_f32), kept selectable (PAPC_GEMM_F32=1) as the A/B reference.
+template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH, bool BF3>
+__global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(GemmArgs p)
 {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
-    constexpr int NWL = BN / 32;  // weight float4 loads per thread per stage
+    constexpr int BKS = BF3 ? 16 : BK;        // k extent of one stage
+    constexpr int KQN = BKS / 4;              // threads along k (one float4 each)
+    constexpr int NT = WGM * WGN * 64;        // threads per workgroup (4 or 8 waves)
+    constexpr int RPI = NT / KQN;             // rows covered by one load iteration of the workgroup
+    constexpr int NAI = BM / RPI;             // A float4 loads per thread per stage
+    constexpr int NWL = (BN + RPI - 1) / RPI; // weight float4 loads per thread per stage
+    constexpr bool WPART = BN < RPI;          // only the first BN row-threads carry a weight row (wave-uniform)
+    constexpr int ROWB = 112;                 // BF3 LDS row stride in bytes
+    constexpr int ROWF = BF3 ? ROWB / 4 : LDT;
     constexpr bool WMAP = (AMODE == A_GROUP);
     constexpr bool NMAP = (EPI == EPI_SCATTER);
-    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
     static_assert(BM == 128, "row tile is 128");
-    constexpr int STAGE = (BM + BN) * LDT;
+    constexpr int STAGE = (BM + BN) * ROWF;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * WGM * BN];
     float *red = smem + 2 * STAGE;
 
@@ -124,10 +139,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
     const int wgm = wave / WGN, wgn = wave % WGN;
     const int n0 = blockIdx.y * BN;
     const int64_t n_mtiles = (p.M + BM - 1) / BM;
-    const int Kpad = (p.Kin + 7) & ~7;
-    const int n_kc = (Kpad + BK - 1) / BK;
-    const int kq = (tid & 7) * 4;
-    const int r0 = tid >> 3;  // 0..31
+    const int Kpad = BF3 ? ((p.Kin + 15) & ~15) : ((p.Kin + 7) & ~7);
+    const int n_kc = (Kpad + BKS - 1) / BKS;
+    const int kq = (tid % KQN) * 4;
+    const int r0 = tid / KQN;  // 0..RPI-1
+    const bool wrow = !WPART || r0 < BN;
     const bool use_jpre = (AMODE == A_GROUP) && p.a.g.idx != nullptr;
 
     float s1[WN], s2[WN], biasv[WN];
@@ -158,8 +174,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
 
     // ---- pipeline state.  A `Stg` is the register image of one in-flight stage (raw loads + what is needed to finish them).
     struct Stg {
-        RowCtx rows[4];
-        Raw3 ra[4];
+        RowCtx rows[NAI];
+        Raw3 ra[NAI];
         float4 rw[NWL];
         KConst kc;
         int kf;          // this thread's first channel of the stage's k-chunk
@@ -167,17 +183,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
         int64_t tile;    // row tile
         bool ok;         // the stage exists
     };
-    Stg sa, sb;
+    Stg sa = {}, sb = {};
     int64_t tile_f = blockIdx.x;  // fetch cursor: next stage to issue = (tile_f, kc_f)
     int kc_f = 0;
-    int jcur[4] = {-2, -2, -2, -2};  // GROUP: neighbour indices of the fetch cursor's tile ...
-    int jpre[4] = {-2, -2, -2, -2};  // ... and of the tile after it (loaded one tile early)
+    int jcur[NAI], jpre[NAI];  // GROUP: neighbour indices of the fetch cursor's tile and of the tile after it (loaded one tile early)
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) { jcur[i] = -2; jpre[i] = -2; }
 
     auto load_j = [&](int64_t tile) {  // issue the idx loads of `tile`'s rows (clamped: always in range)
         if (use_jpre) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t m = tile * BM + r0 + 32 * i;
+            for (int i = 0; i < NAI; ++i) {
+                const int64_t m = tile * BM + r0 + RPI * i;
                 jpre[i] = p.a.g.idx[m < p.M ? m : 0];
             }
         }
@@ -186,40 +203,64 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
     // advance the cursor
     auto issue = [&](Stg &s) {
         s.ok = tile_f < n_mtiles;
-        s.tile = tile_f; s.kci = kc_f; s.kf = kc_f * BK + kq;
+        s.tile = tile_f; s.kci = kc_f; s.kf = kc_f * BKS + kq;
         if (s.ok) {
+            if (DEPTH > 1 || kc_f == 0) {   // DEPTH 1: the one Stg keeps its row contexts for the tile's other k-chunks
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s.rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + 32 * i, p.M, use_jpre ? jcur[i] : -2);
+                for (int i = 0; i < NAI; ++i) s.rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + RPI * i, p.M, use_jpre ? jcur[i] : -2);
+            }
             s.kc = make_kconst<AMODE, VEC>(p.a, s.kf, p.Kin);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s.ra[i] = fetch_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin);
+            for (int i = 0; i < NAI; ++i) s.ra[i] = fetch_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin);
+            if (wrow) {
 #pragma unroll
-            for (int i = 0; i < NWL; ++i) s.rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + 32 * i, s.kf);
+                for (int i = 0; i < NWL; ++i) s.rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + RPI * i, s.kf);
+            }
         }
         kc_f += 1;
         if (kc_f == n_kc) {
             kc_f = 0; tile_f += gridDim.x;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) jcur[i] = jpre[i];
+            for (int i = 0; i < NAI; ++i) jcur[i] = jpre[i];
             load_j(tile_f + gridDim.x);
         }
     };
     // consume the landed registers of `s`: transform + write one LDS buffer
     auto consume = [&](const Stg &s, float *As) {
+        if (BF3) {
+            char *Ab = reinterpret_cast<char *>(As), *Wb = Ab + BM * ROWB;
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) {
+                uint2 q0, q1, q2;
+                split3(finish_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin, s.kc, s.ra[i]), q0, q1, q2);
+                char *d = Ab + (r0 + RPI * i) * ROWB + kq * 2;
+                *reinterpret_cast<uint2 *>(d) = q0; *reinterpret_cast<uint2 *>(d + 32) = q1; *reinterpret_cast<uint2 *>(d + 64) = q2;
+            }
+            if (wrow) {
+#pragma unroll
+                for (int i = 0; i < NWL; ++i) {
+                    uint2 q0, q1, q2;
+                    split3(mask_w4(p, n0 + r0 + RPI * i, s.kf, s.rw[i]), q0, q1, q2);
+                    char *d = Wb + (r0 + RPI * i) * ROWB + kq * 2;
+                    *reinterpret_cast<uint2 *>(d) = q0; *reinterpret_cast<uint2 *>(d + 32) = q1; *reinterpret_cast<uint2 *>(d + 64) = q2;
+                }
+            }
+            return;
+        }
         float *Ws = As + BM * LDT;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4 *>(&As[(r0 + 32 * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin, s.kc, s.ra[i]);
+        for (int i = 0; i < NAI; ++i)
+            *reinterpret_cast<float4 *>(&As[(r0 + RPI * i) * LDT + kq]) = finish_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin, s.kc, s.ra[i]);
 #pragma unroll
         for (int i = 0; i < NWL; ++i)
-            *reinterpret_cast<float4 *>(&Ws[(r0 + 32 * i) * LDT + kq]) = mask_w4(p, n0 + r0 + 32 * i, s.kf, s.rw[i]);
+            *reinterpret_cast<float4 *>(&Ws[(r0 + RPI * i) * LDT + kq]) = mask_w4(p, n0 + r0 + RPI * i, s.kf, s.rw[i]);
     };
 
     // ---- prologue: stage 0 goes through LDS synchronously; DEPTH - 1 further stages are put in flight
     if (use_jpre) {
         load_j(tile_f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) jcur[i] = jpre[i];
+        for (int i = 0; i < NAI; ++i) jcur[i] = jpre[i];
         load_j(tile_f + gridDim.x);
     }
     issue(sa);
@@ -239,7 +280,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
         issue(si);
 
         // ---- MFMAs of stage s from LDS buffer `buf`
-        {
+        if (BF3) {
+            const char *Ab = reinterpret_cast<const char *>(smem + buf * STAGE), *Wb = Ab + BM * ROWB;
+            bf16x8 af[WM][3], bq[WN][3];
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    af[wm][pl] = *reinterpret_cast<const bf16x8 *>(Ab + ((wgm * WM + wm) * 32 + l31) * ROWB + pl * 32 + hi * 16);
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bq[wn][pl] = *reinterpret_cast<const bf16x8 *>(Wb + ((wgn * WN + wn) * 32 + l31) * ROWB + pl * 32 + hi * 16);
+            // smallest terms first; consecutive MFMAs go to different accumulators
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn)
+                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[wm][PA[t]], bq[wn][PB[t]], acc[wm][wn], 0, 0, 0);
+        } else {
             const float *As = smem + buf * STAGE, *Ws = As + BM * LDT;
             const int kend = min(BK, Kpad - kc_c * BK);
             for (int kk = 0; kk < kend; kk += 8) {
@@ -348,32 +411,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
                         }
                     }
                     if (EPI == EPI_STORE_RED) {
-                        // issue the previous layer's y for ALL of this lane's rows first (one exposed latency per column),
-                        // then store dz_prev and accumulate p = dz*[z>0], p*xhat
-                        float yv[WM][16];
+                        // per 32-row tile: issue the previous layer's y for all 16 of this lane's rows first (one exposed
+                        // latency), then store dz_prev and accumulate p = dz*[z>0], p*xhat
 #pragma unroll
                         for (int wm = 0; wm < WM; ++wm) {
                             const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
                             const float *qp = p.rd.y + rb * p.ldy + col;
+                            float *yp = p.y + rb * p.ldy + col;
+                            float yv[16];
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int ro = (r & 3) + 8 * (r >> 2);
-                                yv[wm][r] = qp[(int64_t)((full || rb + ro < p.M) ? ro : 0) * p.ldy];
+                                yv[r] = qp[(int64_t)((full || rb + ro < p.M) ? ro : 0) * p.ldy];
                             }
-                        }
-#pragma unroll
-                        for (int wm = 0; wm < WM; ++wm) {
-                            const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
-                            float *yp = p.y + rb * p.ldy + col;
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int ro = (r & 3) + 8 * (r >> 2);
                                 if (full || rb + ro < p.M) {
                                     const float v = acc[wm][wn][r];
                                     yp[(int64_t)ro * p.ldy] = v;
-                                    const float pp = fmaf(rsc[wn], yv[wm][r], rsh[wn]) > 0.f ? v : 0.f;
+                                    const float pp = fmaf(rsc[wn], yv[r], rsh[wn]) > 0.f ? v : 0.f;
                                     s1[wn] += pp;
-                                    s2[wn] = fmaf(pp, (yv[wm][r] - rmu[wn]) * ris[wn], s2[wn]);
+                                    s2[wn] = fmaf(pp, (yv[r] - rmu[wn]) * ris[wn], s2[wn]);
                                 }
                             }
                         }
@@ -469,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs p)
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * BN; i += 256) {
+        for (int i = tid; i < 2 * BN; i += NT) {
             const int which = i / BN, c = i - which * BN;
             float t = 0.f;
 #pragma unroll
@@ -490,7 +549,23 @@ static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128
 // Prefetch depth: the kernel supports DEPTH = 2 (two stages of loads in flight, register sets alternating), but a
 // same-box A/B on MI355X showed no gain over DEPTH = 1 (loaded-memory latency is not what limits these kernels), so only
 // DEPTH = 1 is instantiated.
-#define GEMM_LAUNCH(a, b, c, d) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1>), grid, dim3(256), 0, st, p)
+static bool gemm_f32_exact()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PAPC_GEMM_F32"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+static bool gemm_8waves()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PAPC_GEMM_WAVES"); v = (e && e[0] == '4') ? 0 : 1; }
+    return v == 1;
+}
+#define GEMM_LAUNCH(a, b, c, d)                                                                                        \
+    do {                                                                                                               \
+        if (gemm_f32_exact()) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true>), grid, dim3(a * b * 64), 0, st, p); \
+    } while (0)
 
 template <int AMODE, int EPI, bool VEC>
 static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
@@ -509,7 +584,10 @@ static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
         }
     } else if (p.Nout > 64) {
         dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
-        GEMM_LAUNCH(2, 2, 2, 2);
+        if (!gemm_f32_exact() && gemm_8waves())   // same 128x128 tile on 8 waves (64x32 each): 4 waves per SIMD hide the staging latency
+            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true>), grid, dim3(512), 0, st, p);
+        else
+            GEMM_LAUNCH(2, 2, 2, 2);
     } else if (p.Nout > 32) {
         dim3 grid(gx, 1);
         GEMM_LAUNCH(2, 2, 2, 1);
@@ -539,6 +617,7 @@ void fill_dy(DySrc &d, const papc_bwd_dy *s)
     d.dz = s->dz; d.gout = s->gout; d.argmax = s->argmax; d.K = s->K > 0 ? s->K : 1; d.y = s->y; d.mean = s->mean;
     d.invstd = s->invstd; d.scale = s->scale; d.shift = s->shift; d.c1 = s->c1; d.c2 = s->c2;
     d.divK = make_fastdiv((uint32_t)d.K);
+    d.C = 0;  // set by the entry points (channels of the layer)
 }
 
 // validates a dY descriptor and says whether its VEC flavour is legal
@@ -596,7 +675,7 @@ int papc_mlp_gemm_gmax_ok(int64_t M, int Cout, int K)
 {
     // the fused epilogue needs whole groups inside one 128-row tile, full tiles only, and a 2x2-wave tile configuration;
     // with few row tiles the launcher switches to the 4x1 narrow configuration (see launch_gemm_v), which is excluded too
-    if (!(K == 32 || K == 64 || K == 128) || M % 128 != 0 || Cout <= 32) return 0;
+    if (!(K == 32 || K == 64 || K == 128) || M % 128 != 0 || Cout <= 32 || Cout % 32 != 0) return 0;  // (whole 32-column wave tiles: the K = 128 exchange has a barrier)
     const int64_t gx = gemm_parts(M);
     if (Cout > 64 && gx * cdiv(Cout, 128) < 192 && gx * cdiv(Cout, 64) < 1024 && !(gx * cdiv(Cout, 64) >= 192)) return 0;
     return 1;
@@ -651,6 +730,7 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
     GemmArgs p;
     memset(&p, 0, sizeof(p));
     fill_dy(p.a.d, dy);
+    p.a.d.C = Cout;
     // GEMM view: rows M, reduction over Cout, outputs Cin; weights = wt [Cin][Cout]
     p.w = wt; p.ldw = Cout; p.M = M; p.Kin = Cout; p.Nout = Cin; p.y = dx; p.ldy = Cin;
     vec = vec && aligned16(wt);

@@ -52,6 +52,7 @@ struct DySrc {
     const float *dz; const float *gout; const int32_t *argmax; int K;
     const float *y; const float *mean, *invstd, *scale, *shift, *c1, *c2;
     FastDiv divK;
+    int C;  // channels of the layer (row stride of y / dz / gout / argmax)
 };
 
 struct ASrc {
@@ -73,6 +74,10 @@ struct RowCtx {
     int grp;     // GROUP / DY_MAX: m / K
     int kin;     // DY_MAX: m % K
     bool valid;
+    // row base pointers for the VEC fetch (computed once per row; a k-chunk fetch only adds its channel offset):
+    //   PLAIN/BNRELU: x row;  GROUP: feats row, xyz point, centroid;  DY_*: y row, dz row | gout row, argmax row
+    const float *p0, *p1;
+    const void *p2;
 };
 
 // jpre >= -1: neighbour index already loaded by the caller (prefetched); jpre == -2: load it here
@@ -83,6 +88,13 @@ __device__ __forceinline__ RowCtx make_row(const ASrc &a, int64_t m64, int64_t M
     r.valid = m64 < M;
     r.m = r.valid ? (int)m64 : 0;
     r.j = 0; r.b = 0; r.grp = 0; r.kin = 0;
+    r.p0 = nullptr; r.p1 = nullptr; r.p2 = nullptr;
+    if (AMODE == A_PLAIN || AMODE == A_BNRELU) {
+        r.p0 = a.x + (int64_t)r.m * a.ldx;
+    } else if (AMODE == A_DY_DENSE) {
+        r.p0 = a.d.y + (int64_t)r.m * a.d.C;
+        r.p1 = a.d.dz + (int64_t)r.m * a.d.C;
+    }
     if (AMODE == A_GROUP) {
         r.grp = (int)fdiv((uint32_t)r.m, a.g.divK);
         r.b = (int)fdiv((uint32_t)r.grp, a.g.divS);
@@ -91,9 +103,15 @@ __device__ __forceinline__ RowCtx make_row(const ASrc &a, int64_t m64, int64_t M
         else j = r.m - r.b * a.g.S * a.g.K;
         if (j < 0 || j >= a.g.N) { r.valid = false; j = 0; }  // no-hit sentinel N (the reference raises) -> zero row
         r.j = j;
+        r.p0 = a.g.feats + ((int64_t)r.b * a.g.N + j) * a.g.D;
+        r.p1 = a.g.xyz + (int64_t)r.b * a.g.sb + (int64_t)j * a.g.sn;
+        r.p2 = a.g.new_xyz + (int64_t)r.grp * 3;
     } else if (AMODE == A_DY_MAX) {
         r.grp = (int)fdiv((uint32_t)r.m, a.d.divK);
         r.kin = r.m - r.grp * a.d.K;
+        r.p0 = a.d.y + (int64_t)r.m * a.d.C;
+        r.p1 = a.d.gout + (int64_t)r.grp * a.d.C;
+        r.p2 = a.d.argmax + (int64_t)r.grp * a.d.C;
     }
     return r;
 }
@@ -159,26 +177,21 @@ __device__ __forceinline__ Raw3 fetch_a4(const ASrc &a, const RowCtx &r, int k, 
         // unconditional loads from clamped addresses (r.m / r.j / r.grp are already clamped to 0 when invalid)
         const int kk = k < Kin ? k : 0;
         if (AMODE == A_PLAIN || AMODE == A_BNRELU) {
-            w.p = ld4(a.x + (int64_t)r.m * a.ldx + kk);
+            w.p = ld4(r.p0 + kk);
         } else if (AMODE == A_GROUP) {
             const GroupSrc &g = a.g;
             if (kk < g.D) {
-                w.p = ld4(g.feats + ((int64_t)r.b * g.N + r.j) * g.D + kk);
+                w.p = ld4(r.p0 + kk);
             } else {  // the xyz slot (k == D): three coordinates and the centroid they are centred on
-                const float *pp = g.xyz + (int64_t)r.b * g.sb + (int64_t)r.j * g.sn;
-                const float *qq = g.new_xyz + (int64_t)r.grp * 3;
+                const float *pp = r.p1;
+                const float *qq = reinterpret_cast<const float *>(r.p2);
                 w.p = make_float4(pp[0], pp[g.sc], pp[2 * g.sc], 0.f);
                 w.q = make_float4(qq[0], qq[1], qq[2], 0.f);
             }
         } else {
-            const DySrc &d = a.d;
-            w.p = ld4(d.y + (int64_t)r.m * Kin + kk);
-            if (AMODE == A_DY_DENSE) {
-                w.q = ld4(d.dz + (int64_t)r.m * Kin + kk);
-            } else {
-                w.q = ld4(d.gout + (int64_t)r.grp * Kin + kk);
-                w.r = *reinterpret_cast<const int4 *>(d.argmax + (int64_t)r.grp * Kin + kk);
-            }
+            w.p = ld4(r.p0 + kk);
+            w.q = ld4(r.p1 + kk);
+            if (AMODE == A_DY_MAX) w.r = *reinterpret_cast<const int4 *>(reinterpret_cast<const int32_t *>(r.p2) + kk);
         }
         return w;
     }
@@ -249,6 +262,36 @@ __device__ __forceinline__ float4 finish_a4(const ASrc &a, const RowCtx &r, int 
     }
     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
+}
+
+// ---- fp32 on the bf16 matrix pipe: exact 3-way split.
+// x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2) (round-to-nearest-even each; the
+// subtractions are exact in fp32).  Three 8-bit significands cover the 24-bit fp32 significand, so the split is exact
+// (up to underflow of the tails), and a product a*b is recovered as the six bf16 products
+//   a1*b1 + (a1*b2 + a2*b1) + (a1*b3 + a2*b2 + a3*b1)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the dropped terms (a2*b3, a3*b2, a3*b3) are below 2^-26 |a*b|,
+// i.e. under the rounding error of a single fp32 multiply-add.  6 MFMAs of 32 cycles per 32x32x16 block against
+// 8 x 64 cycles of v_mfma_f32_32x32x2_f32 for the same block: 2.7x the fp32 matrix rate at fp32 accuracy
+// (tools/probe/mfma_bf16_layout.hip measures 6.5e-8 max |err| / sum|a_k b_k| vs 1.5e-7 for the fp32 fma chain).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b)  // -> v_cvt_pk_bf16_f32 (a in the low half)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((floatx2_t){a, b}, bf16x2_t));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// planes p0 (leading), p1, p2 of four consecutive-k values, each as 4 packed bf16 (8 bytes)
+__device__ __forceinline__ void split3(float4 v, uint2 &p0, uint2 &p1, uint2 &p2)
+{
+    p0.x = pack_bf16x2(v.x, v.y); p0.y = pack_bf16x2(v.z, v.w);
+    v.x -= bf16_lo(p0.x); v.y -= bf16_hi(p0.x); v.z -= bf16_lo(p0.y); v.w -= bf16_hi(p0.y);
+    p1.x = pack_bf16x2(v.x, v.y); p1.y = pack_bf16x2(v.z, v.w);
+    v.x -= bf16_lo(p1.x); v.y -= bf16_hi(p1.x); v.z -= bf16_lo(p1.y); v.w -= bf16_hi(p1.y);
+    p2.x = pack_bf16x2(v.x, v.y); p2.y = pack_bf16x2(v.z, v.w);
 }
 
 }  // namespace papc

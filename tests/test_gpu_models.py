@@ -151,3 +151,43 @@ def test_sampling_plan_equals_inline(dev):
         b = m(x, st, plan=plan)
     assert torch.equal(a, b)
     assert plan[0][1].dtype == torch.int32 and tuple(plan[0][0].shape) == (B, 512, 3) and tuple(plan[1][1].shape) == (B, 128, 64)
+
+
+def test_hipgraph_replay_matches_eager(dev):
+    """zero_grad + forward + loss + backward captured into one hipGraph (what bench.py replays) gives the eager step's loss
+    and gradients (same weights, same batch; float atomics in the scatter-add make the two agree to rounding, not bitwise)."""
+    B, N = 4, 1024
+    x = torch.from_numpy(make_clouds(B, N, 5)).to(dev)
+    y = torch.from_numpy(make_labels(B, 16, 5)).reshape(-1).to(dev)
+    st = (torch.from_numpy(make_start_idx(B, N, 5)).to(dev), torch.from_numpy(make_start_idx(B, 512, 6)).to(dev))
+    torch.manual_seed(0)
+    m = PointNet2_SSG_Clas().to(dev)
+    m.train()
+    m.drop1.p = m.drop2.p = 0.0
+    flat = FlatParams(m)
+
+    def fwd_bwd():
+        flat.zero_grad()
+        loss = TF.cross_entropy(m(x, st), y)
+        loss.backward()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            loss_e = fwd_bwd()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    grad_e = flat.grad.clone()
+    bn_e = m.sa1.mlp_bns[0].running_mean.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        static_loss = fwd_bwd()
+    flat.grad.fill_(123.0)                                   # the replay must rewrite all of it
+    g.replay()
+    torch.cuda.synchronize()
+    assert abs(float(static_loss) - float(loss_e)) <= 1e-5 * abs(float(loss_e))
+    scale = float(grad_e.abs().max())
+    assert float((flat.grad - grad_e).abs().max()) <= 2e-4 * scale
+    assert not torch.equal(m.sa1.mlp_bns[0].running_mean, bn_e)   # the running statistics keep moving under replay
