@@ -59,6 +59,7 @@ struct GemmArgs {
     ScatterDst sc;
     RedSrc rd;
     GmaxDst gm;
+    unsigned long long *dbg;       // PAPC_GEMM_DBG=1: per-workgroup cycle counters (development aid)
 };
 
 constexpr int LDT = 36;  // LDS row stride (floats)
@@ -113,14 +114,25 @@ __device__ __forceinline__ float4 mask_w4(const GemmArgs &p, int n, int k, float
 // odd -> the 16-lane groups of a ds_read_b128 hit 16 distinct 16-B slots); a lane's 16-B read at plane*32 + 16*(lane>>5) is
 // its 8 consecutive k of row lane&31, exactly the instruction's A/B operand.  BF3 = false is the exact fp32 path
 // (v_mfma_f32_32x32x2_f32), kept selectable (PAPC_GEMM_F32=1) as the A/B reference.
-template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH, bool BF3>
-__global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(GemmArgs p)
+//
+// WS = G > 0 (wave-specialised, BF3 only): the workgroup has 4 CONSUMER waves that own the accumulators and do nothing but
+// ds_read + MFMA (+ the epilogue), and G groups of 4 PRODUCER waves that do nothing but global loads, the operand
+// transform, the bf16 split and the LDS writes.  A consumer and G producer waves share each SIMD, so the VALU work of the
+// transform runs in the shadow of another wave's MFMAs by construction (no reliance on the compiler interleaving one
+// wave's instruction stream).  Producer group g owns the stages s = g (mod G): it issues the loads of its next stage right
+// after finishing the previous one and only touches them G - 1 slots later, so the HBM latency is covered by plain
+// issue -> wait -> transform code per wave (register rings across a loop back-edge do not survive hipcc's waitcnt
+// insertion: it drains to vmcnt(0)).  Same two LDS buffers and the same single barrier per stage as the unspecialised loop.
+template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH, bool BF3, int WS>
+__global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WGN / 2) void gemm_kernel(GemmArgs p)
 {
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     constexpr int BKS = BF3 ? 16 : BK;        // k extent of one stage
     constexpr int KQN = BKS / 4;              // threads along k (one float4 each)
-    constexpr int NT = WGM * WGN * 64;        // threads per workgroup (4 or 8 waves)
-    constexpr int RPI = NT / KQN;             // rows covered by one load iteration of the workgroup
+    constexpr int NC = WGM * WGN * 64;        // threads that own accumulators (4 or 8 waves)
+    constexpr int NT = (1 + WS) * NC;         // threads per workgroup
+    constexpr int RPI = NC / KQN;             // rows covered by one load iteration of the loader threads
+    static_assert(!WS || (BF3 && WGM * WGN == 4 && DEPTH == 1 && WS <= 3), "wave specialisation: BF3, 4 + 4G waves");
     constexpr int NAI = BM / RPI;             // A float4 loads per thread per stage
     constexpr int NWL = (BN + RPI - 1) / RPI; // weight float4 loads per thread per stage
     constexpr bool WPART = BN < RPI;          // only the first BN row-threads carry a weight row (wave-uniform)
@@ -136,13 +148,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(Gem
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int wgm = wave / WGN, wgn = wave % WGN;
+    const bool producer = WS && wave >= WGM * WGN;          // wave-uniform role
+    const int pgrp = producer ? (wave - WGM * WGN) / (WGM * WGN) : 0;   // producer group
+    const int ltid = producer ? tid - NC * (1 + pgrp) : tid;            // loader thread index within its group
+    const int cwave = producer ? 0 : wave;
+    const int wgm = cwave / WGN, wgn = cwave % WGN;
     const int n0 = blockIdx.y * BN;
     const int64_t n_mtiles = (p.M + BM - 1) / BM;
     const int Kpad = BF3 ? ((p.Kin + 15) & ~15) : ((p.Kin + 7) & ~7);
     const int n_kc = (Kpad + BKS - 1) / BKS;
-    const int kq = (tid % KQN) * 4;
-    const int r0 = tid / KQN;  // 0..RPI-1
+    const int kq = (ltid % KQN) * 4;
+    const int r0 = ltid / KQN;  // 0..RPI-1
     const bool wrow = !WPART || r0 < BN;
     const bool use_jpre = (AMODE == A_GROUP) && p.a.g.idx != nullptr;
 
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(Gem
         bool ok;         // the stage exists
     };
     Stg sa = {}, sb = {};
+    RowCtx rows_f[NAI] = {};   // row contexts of the fetch cursor's tile
     int64_t tile_f = blockIdx.x;  // fetch cursor: next stage to issue = (tile_f, kc_f)
     int kc_f = 0;
     int jcur[NAI], jpre[NAI];  // GROUP: neighbour indices of the fetch cursor's tile and of the tile after it (loaded one tile early)
@@ -205,13 +222,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(Gem
         s.ok = tile_f < n_mtiles;
         s.tile = tile_f; s.kci = kc_f; s.kf = kc_f * BKS + kq;
         if (s.ok) {
-            if (DEPTH > 1 || kc_f == 0) {   // DEPTH 1: the one Stg keeps its row contexts for the tile's other k-chunks
+            if (kc_f == 0) {   // row contexts (base pointers, group / validity) are per tile: the other k-chunks reuse them
 #pragma unroll
-                for (int i = 0; i < NAI; ++i) s.rows[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + RPI * i, p.M, use_jpre ? jcur[i] : -2);
+                for (int i = 0; i < NAI; ++i) rows_f[i] = make_row<AMODE>(p.a, tile_f * BM + r0 + RPI * i, p.M, use_jpre ? jcur[i] : -2);
             }
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) s.rows[i] = rows_f[i];   // (only `valid` / `kin` stay live in the stage image)
             s.kc = make_kconst<AMODE, VEC>(p.a, s.kf, p.Kin);
 #pragma unroll
-            for (int i = 0; i < NAI; ++i) s.ra[i] = fetch_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin);
+            for (int i = 0; i < NAI; ++i) s.ra[i] = fetch_a4<AMODE, VEC>(p.a, rows_f[i], s.kf, p.Kin);
             if (wrow) {
 #pragma unroll
                 for (int i = 0; i < NWL; ++i) s.rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + RPI * i, s.kf);
@@ -257,29 +276,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(Gem
     };
 
     // ---- prologue: stage 0 goes through LDS synchronously; DEPTH - 1 further stages are put in flight
-    if (use_jpre) {
+    if (use_jpre && !WS) {
         load_j(tile_f);
 #pragma unroll
         for (int i = 0; i < NAI; ++i) jcur[i] = jpre[i];
         load_j(tile_f + gridDim.x);
     }
-    issue(sa);
+    if (!WS) issue(sa);
     bool have = sa.ok;
     int64_t tile_c = sa.tile;  // tile / chunk of the stage being computed
     int kc_c = sa.kci;
-    if (have) consume(sa, smem);
+    if (have && !WS) consume(sa, smem);
     if (DEPTH == 2) issue(sa);
-    __syncthreads();
+    if (!WS) __syncthreads();
 
-    int buf = 0;
-    // one pipeline step: issue a new stage into `si`, compute the current stage from LDS, then finish the OLDEST in-flight
-    // stage `sc` (the next one to compute) into the other LDS buffer.  DEPTH 1: si == sc; DEPTH 2: the two sets alternate, so
-    // every stage's loads get two MFMA phases to land.
-    auto step = [&](Stg &si, Stg &sc) -> bool {
-        if (!have) return false;
-        issue(si);
-
-        // ---- MFMAs of stage s from LDS buffer `buf`
+    // ---- MFMAs of one stage from LDS buffer `buf` (kc = its k-chunk index)
+    auto mfma_stage = [&](int buf, int kc_c) {
         if (BF3) {
             const char *Ab = reinterpret_cast<const char *>(smem + buf * STAGE), *Wb = Ab + BM * ROWB;
             bf16x8 af[WM][3], bq[WN][3];
@@ -325,12 +337,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(Gem
             }
         }
 
-        // ---- consume the next stage's loads: transform, write the other LDS buffer
-        if (sc.ok) consume(sc, smem + (buf ^ 1) * STAGE);
+    };
+    // ---- epilogue of row tile `tile_c` (its last k-chunk has been accumulated).  C/D layout: col = lane&31,
+    // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Straight-line stores (no per-element branch) for full tiles; the ragged last
+    // tile takes the predicated path.
+    auto epilogue = [&](int64_t tile_c) {
 
-        // ---- last k-chunk of the tile: epilogue.  C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-        // Straight-line stores (no per-element branch) for full tiles; the ragged last tile takes the predicated path.
-        if (kc_c == n_kc - 1) {
             const int64_t m0 = tile_c * BM;
             const bool full = m0 + BM <= p.M;
 #pragma unroll
@@ -505,8 +517,112 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(Gem
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
             }
-        }
+            };
 
+    if (WS) {
+        // every wave runs the same number of stage slots, hence the same number of barriers
+        const int64_t my_tiles = n_mtiles > (int64_t)blockIdx.x ? (n_mtiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        const int64_t n_stages = my_tiles * n_kc;
+        const bool xbar = (EPI == EPI_STORE_GMAX) && p.gm.K == 128;   // the K = 128 group-max exchange has its own barriers
+        if (producer) {
+            // this group's next stage: index ns, tile nt, k-chunk nk; `last` = tile whose row contexts are in rows_f
+            int64_t ns = pgrp, nt = blockIdx.x, last = -1;
+            int nk = pgrp;
+            while (nk >= n_kc) { nk -= n_kc; nt += gridDim.x; }
+            auto issue_ws = [&](Stg &st) {
+                st.ok = ns < n_stages;
+                st.tile = nt; st.kci = nk; st.kf = nk * BKS + kq;
+                if (st.ok) {
+                    if (nt != last) {   // row contexts (base pointers, group / validity) are per tile
+#pragma unroll
+                        for (int i = 0; i < NAI; ++i) rows_f[i] = make_row<AMODE>(p.a, nt * BM + r0 + RPI * i, p.M, -2);
+                        last = nt;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NAI; ++i) st.rows[i] = rows_f[i];
+                    st.kc = make_kconst<AMODE, VEC>(p.a, st.kf, p.Kin);
+#pragma unroll
+                    for (int i = 0; i < NAI; ++i) st.ra[i] = fetch_a4<AMODE, VEC>(p.a, rows_f[i], st.kf, p.Kin);
+                    if (wrow) {
+#pragma unroll
+                        for (int i = 0; i < NWL; ++i) st.rw[i] = fetch_w4<VEC, WMAP, NMAP>(p, n0 + r0 + RPI * i, st.kf);
+                    }
+                }
+            };
+            auto advance = [&]() {   // to this group's next stage
+                ns += WS; nk += WS;
+                while (nk >= n_kc) { nk -= n_kc; nt += gridDim.x; }
+            };
+            issue_ws(sa);
+            if (pgrp == 0) {         // stage 0 goes through LDS before the first slot
+                if (sa.ok) consume(sa, smem);
+                advance();
+                issue_ws(sa);
+            }
+            __syncthreads();
+            int kcs = 0;
+            unsigned long long tw = 0, tc = 0, ti = 0, tb = 0;
+            for (int64_t t = 0; t < n_stages; ++t) {
+                const unsigned long long c0 = p.dbg ? __builtin_readcyclecounter() : 0;
+                unsigned long long c1 = c0, c2 = c0, c3 = c0;
+                if (ns == t + 1) {   // this group's stage is the one the consumers need next: finish it into the other buffer
+                    if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = __builtin_readcyclecounter(); }
+                    if (sa.ok) consume(sa, smem + (int)((t + 1) & 1) * STAGE);
+                    if (p.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = __builtin_readcyclecounter(); }
+                    advance();
+                    issue_ws(sa);    // ... and put the group's next stage in flight for the coming WS - 1 slots
+                    if (p.dbg) c3 = __builtin_readcyclecounter();
+                    tw += c1 - c0; tc += c2 - c1; ti += c3 - c2;
+                }
+                if (kcs == n_kc - 1) {
+                    kcs = 0;
+                    if (xbar) {
+#pragma unroll
+                        for (int wn = 0; wn < WN; ++wn) lds_barrier();
+                    }
+                } else ++kcs;
+                const unsigned long long c4 = p.dbg ? __builtin_readcyclecounter() : 0;
+                lds_barrier();
+                if (p.dbg) tb += __builtin_readcyclecounter() - c4;
+            }
+            if (p.dbg && blockIdx.y == 0 && (tid & 63) == 0 && ((wave - 4) & 3) == 0) {
+                unsigned long long *d = p.dbg + ((int64_t)blockIdx.x * 4 + 1 + pgrp) * 8;
+                d[0] = tw; d[1] = tc; d[2] = ti; d[3] = tb; d[4] = (unsigned long long)n_stages;
+            }
+        } else {
+            __syncthreads();
+            int buf = 0, kcc = 0;
+            int64_t tile_c = blockIdx.x;
+            unsigned long long tm = 0, te = 0, tb = 0;
+            for (int64_t t = 0; t < n_stages; ++t) {
+                const unsigned long long c0 = p.dbg ? __builtin_readcyclecounter() : 0;
+                mfma_stage(buf, kcc);
+                unsigned long long c1 = c0;
+                if (p.dbg) { asm volatile("s_nop 0" ::: "memory"); c1 = __builtin_readcyclecounter(); }
+                if (kcc == n_kc - 1) { epilogue(tile_c); tile_c += gridDim.x; kcc = 0; } else ++kcc;
+                const unsigned long long c2 = p.dbg ? __builtin_readcyclecounter() : 0;
+                lds_barrier();
+                if (p.dbg) { const unsigned long long c3 = __builtin_readcyclecounter(); tm += c1 - c0; te += c2 - c1; tb += c3 - c2; }
+                buf ^= 1;
+            }
+            if (p.dbg && blockIdx.y == 0 && tid == 0) {
+                unsigned long long *d = p.dbg + ((int64_t)blockIdx.x * 4) * 8;
+                d[0] = tm; d[1] = te; d[2] = tb; d[4] = (unsigned long long)n_stages;
+            }
+        }
+    }
+
+    int buf = 0;
+    // one pipeline step: issue a new stage into `si`, compute the current stage from LDS, then finish the OLDEST in-flight
+    // stage `sc` (the next one to compute) into the other LDS buffer.  DEPTH 1: si == sc; DEPTH 2: the two sets alternate, so
+    // every stage's loads get two MFMA phases to land.
+    auto step = [&](Stg &si, Stg &sc) -> bool {
+        if (!have) return false;
+        issue(si);
+        mfma_stage(buf, kc_c);
+        // ---- consume the next stage's loads: transform, write the other LDS buffer
+        if (sc.ok) consume(sc, smem + (buf ^ 1) * STAGE);
+        if (kc_c == n_kc - 1) epilogue(tile_c);
         lds_barrier();  // LDS-only: the epilogue's global stores and the idx prefetch stay in flight across it
         buf ^= 1;
         tile_c = sc.tile;
@@ -514,15 +630,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, WGM * WGN / 2) void gemm_kernel(Gem
         have = sc.ok;
         return true;
     };
-    if (DEPTH == 2) { while (step(sb, sa) && step(sa, sb)) {} }
-    else { while (step(sa, sa)) {} }
+    if (!WS) {
+        if (DEPTH == 2) { while (step(sb, sa) && step(sa, sb)) {} }
+        else { while (step(sa, sa)) {} }
+    }
 
     if ((EPI == EPI_STORE || EPI == EPI_STORE_RED || EPI == EPI_STORE_GMAX) && p.stats) {
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             s1[wn] += __shfl_xor(s1[wn], 32);
             s2[wn] += __shfl_xor(s2[wn], 32);
-            if (hi == 0) {
+            if (hi == 0 && !producer) {
                 red[(0 * WGM + wgm) * BN + (wgn * WN + wn) * 32 + l31] = s1[wn];
                 red[(1 * WGM + wgm) * BN + (wgn * WN + wn) * 32 + l31] = s2[wn];
             }
@@ -555,21 +673,55 @@ static bool gemm_f32_exact()
     if (v < 0) { const char *e = getenv("PAPC_GEMM_F32"); v = (e && e[0] == '1') ? 1 : 0; }
     return v == 1;
 }
-static bool gemm_8waves()
+static bool gemm_waves8(int amode, int epi)   // 8-wave flavour of the 128x128 tile (PAPC_GEMM_WAVES=4|8 forces one; default per epilogue)
 {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("PAPC_GEMM_WAVES"); v = (e && e[0] == '4') ? 0 : 1; }
-    return v == 1;
+    if (v < 0) { const char *e = getenv("PAPC_GEMM_WAVES"); v = e ? atoi(e) : 0; }
+    if (v == 4) return false;
+    if (v == 8) return true;
+    return !(amode == A_DY_MAX && epi == EPI_STORE_RED);   // measured per kernel (MI355X): only that one is faster on 4 waves (189 vs 223 us)
+}
+static int gemm_ws()   // producer groups of the wave-specialised 128x128 kernel (0 = unspecialised)
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PAPC_GEMM_WS"); v = e ? atoi(e) : 0; if (v != 3) v = 0; }   // opt-in: see DESIGN.md 3.7
+    return v;
 }
 #define GEMM_LAUNCH(a, b, c, d)                                                                                        \
     do {                                                                                                               \
-        if (gemm_f32_exact()) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false>), grid, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true>), grid, dim3(a * b * 64), 0, st, p); \
+        if (gemm_f32_exact()) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false, 0>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0>), grid, dim3(a * b * 64), 0, st, p); \
     } while (0)
 
-template <int AMODE, int EPI, bool VEC>
-static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
+static unsigned long long *g_dbg = nullptr;
+static void dbg_report(const GemmArgs &p, int amode, int epi, unsigned gx)
 {
+    hipDeviceSynchronize();
+    static unsigned long long h[512 * 4 * 8];
+    hipMemcpy(h, g_dbg, sizeof(h), hipMemcpyDeviceToHost);
+    double c[3] = {0, 0, 0}, pr[3][4] = {{0}};
+    unsigned long long ns = 0;
+    for (unsigned b = 0; b < gx; ++b) {
+        for (int i = 0; i < 3; ++i) c[i] += (double)h[(b * 4) * 8 + i];
+        ns += h[(b * 4) * 8 + 4];
+        for (int g = 0; g < 3; ++g) for (int i = 0; i < 4; ++i) pr[g][i] += (double)h[(b * 4 + 1 + g) * 8 + i];
+    }
+    const double n = (double)ns;   // total slots over workgroups
+    fprintf(stderr, "[gemm dbg] amode %d epi %d M %lld K %d N %d: slots/wg %.0f | consumer cyc/slot: mfma-issue %.0f epilogue %.0f barrier %.0f | producer grp0 cyc/slot: wait %.0f transform %.0f issue %.0f barrier %.0f\n",
+            amode, epi, (long long)p.M, p.Kin, p.Nout, n / gx, c[0] / n, c[1] / n, c[2] / n, pr[0][0] / n, pr[0][1] / n, pr[0][2] / n, pr[0][3] / n);
+}
+
+template <int AMODE, int EPI, bool VEC>
+static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
+{
+    GemmArgs p = p_in;
+    static int dbg_on = -1;
+    if (dbg_on < 0) { const char *e = getenv("PAPC_GEMM_DBG"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+    if (dbg_on) {
+        if (!g_dbg) hipMalloc(&g_dbg, 512 * 4 * 8 * sizeof(unsigned long long));
+        hipMemsetAsync(g_dbg, 0, 512 * 4 * 8 * sizeof(unsigned long long), st);
+        p.dbg = g_dbg;
+    }
     const unsigned gx = (unsigned)gemm_parts(p.M);
     // few row tiles (group_all layers: M = B*N ~ 4096): 128-wide column tiles would leave most CUs idle, so use
     // 64- (or 32-) wide ones to get >= ~256 workgroups; the A tile is then re-read from L2 by more workgroups
@@ -584,8 +736,13 @@ static int launch_gemm_v(const GemmArgs &p, hipStream_t st)
         }
     } else if (p.Nout > 64) {
         dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
-        if (!gemm_f32_exact() && gemm_8waves())   // same 128x128 tile on 8 waves (64x32 each): 4 waves per SIMD hide the staging latency
-            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true>), grid, dim3(512), 0, st, p);
+        if (!gemm_f32_exact() && gemm_ws() == 3)        // 4 consumer + 12 producer waves on the same 128x128 tile
+        {
+            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2, 1, true, 3>), grid, dim3(1024), 0, st, p);
+            if (dbg_on) dbg_report(p, AMODE, EPI, gx);
+        }
+        else if (!gemm_f32_exact() && gemm_waves8(AMODE, EPI))   // same 128x128 tile on 8 waves of 64x32: 4 waves per SIMD
+            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0>), grid, dim3(512), 0, st, p);
         else
             GEMM_LAUNCH(2, 2, 2, 2);
     } else if (p.Nout > 32) {
@@ -676,6 +833,7 @@ int papc_mlp_gemm_gmax_ok(int64_t M, int Cout, int K)
     // the fused epilogue needs whole groups inside one 128-row tile, full tiles only, and a 2x2-wave tile configuration;
     // with few row tiles the launcher switches to the 4x1 narrow configuration (see launch_gemm_v), which is excluded too
     if (!(K == 32 || K == 64 || K == 128) || M % 128 != 0 || Cout <= 32 || Cout % 32 != 0) return 0;  // (whole 32-column wave tiles: the K = 128 exchange has a barrier)
+    if (K == 128 && !(Cout == 64 || Cout % 128 == 0)) return 0;   // every wave of a column block must take part in the exchange
     const int64_t gx = gemm_parts(M);
     if (Cout > 64 && gx * cdiv(Cout, 128) < 192 && gx * cdiv(Cout, 64) < 1024 && !(gx * cdiv(Cout, 64) >= 192)) return 0;
     return 1;
