@@ -34,6 +34,7 @@ struct DwArgs {
     int xmap;           // map internal cin -> caller's column (GROUP)
     int TOp, TIp;       // padded tile widths (32 / 64 / 128)
     int RS;             // rows per stage (32 or 64)
+    unsigned long long *dbg;  // PAPC_DW_DBG=1: cycle counters of workgroup 0 (development aid)
 };
 
 constexpr int DW_T = 128;              // output tile edge (channels)
@@ -232,12 +233,288 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
     }
 }
 
-template <int XMODE, int DYMODE, bool VEC>
-static int launch_dw_v(const DwArgs &p, hipStream_t st)
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised dW on the bf16 matrix pipe (fp32 operands as exact 3-way bf16 splits, see split3 in mlp_loaders.h).
+//
+// 16 waves per workgroup: 4 CONSUMER waves (2 x 2 over the <=128x128 output tile, NTO x NTI 32x32 accumulators each) that
+// only ds_read + MFMA, and 3 groups of 4 PRODUCER waves that only load, transform, split and write LDS.  A stage is 16
+// rows (one k block of v_mfma_f32_32x32x16_bf16); producer group g owns the stages s = g (mod 3): it issues the loads of
+// its next stage right after finishing one and touches them two slots later, so the HBM latency is covered by plain
+// issue -> wait -> transform code.  dW has no per-tile epilogue (one partial store per workgroup at the very end), so the
+// consumers run the matrix pipe back to back: this is where the specialised structure pays.
+//
+// LDS image per stage: channel-major, K(=row)-contiguous: [TOp + TIp channels][plane0 | plane1 | plane2] x 32 B + 16 B pad
+// (112 B, odd number of 16-B slots).  The MFMA reduces over ROWS, so the row-major global data is transposed on the way
+// in: a producer thread owns a 4-row x 4-channel block, builds per channel the 4 consecutive-row values, splits them and
+// writes 8 bytes per plane.  Lane l of a consumer reads its operand (channel tile*32 + (l&31), rows 8*(l>>5)..+7) with
+// one ds_read_b128 per plane.
+template <int XMODE, int DYMODE, int NTO, int NTI>
+__global__ __launch_bounds__(768, 3) void dw_ws_kernel(DwArgs p)
 {
+    constexpr int TO = NTO * 64, TI = NTI * 64;   // padded tile widths handled by this instantiation
+    // a stage is 32 rows = two k blocks; BOTH producer groups work in every slot (group g on rows 16g..16g+15 of the stage):
+    // a SIMD needs two active waves to keep its VALU busy, a lone producer wave issues only every ~8-10 cycles
+    constexpr int RS = 32, G = 2, ROWB = 3 * RS * 2 + 16;
+    constexpr int STAGE_B = (TO + TI) * ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const bool producer = wave >= 4;
+    const int pgrp = producer ? (wave - 4) >> 2 : 0;
+    const int lt = producer ? tid - 256 * (1 + pgrp) : tid;   // thread index within the producer group
+    const int o0 = blockIdx.y * DW_T, i0 = blockIdx.z * DW_T;
+    const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
+    const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
+    const int n_stages = mbeg < mend ? (int)((mend - mbeg + RS - 1) / RS) : 0;
+
+    if (producer) {
+        // block assignment: threads [0, TO) carry dY blocks, [TO, TO + TI) carry X blocks, the rest idle (wave-uniform split).
+        // A block = 4 consecutive rows x 4 consecutive channels; the channel quad is fixed for the whole kernel, so the BN
+        // constants are loaded (and pre-folded) once.
+        // (TO and TI are multiples of 64, so the role is the same for a whole wave: make that visible to the compiler)
+        const bool isy = __builtin_amdgcn_readfirstlane((int)(lt < TO)) != 0;
+        const bool isx = !isy && __builtin_amdgcn_readfirstlane((int)(lt < TO + TI)) != 0;
+        const int lb = isy ? lt : lt - TO;
+        // a wave covers 16 channel quads x all 4 row quads: its 8-byte LDS writes then spread over 32 of the 64 banks
+        // (the 112-byte channel stride maps channel quads to only 4 distinct bank offsets; the row quads supply the rest)
+        const int cq = (lb & 15) + 16 * (lb >> 6), rq = (lb >> 4) & 3;   // channel quad, row quad (0..3)
+        const int ch = (isy ? o0 : i0) + cq * 4;           // first global channel of the block
+        const int C = isy ? p.Cout : p.Cin;
+        const bool chok = ch < C;                          // VEC shapes: C % 4 == 0, so a quad is all in or all out
+        const int chc = chok ? ch : 0;
+        // constants: dY = sc*p - (A + Bp*(y - mean)) with p = [sc*y + sh > 0] * dz, A = sc*c1, Bp = sc*c2*invstd (the same
+        // value as dy_elem, 6 instead of 9 operations per element); X = relu(sc*x + sh).  Channels past C get all-zero
+        // constants, which makes their values exactly 0 without a per-element select.
+        float4 ksc = make_float4(0.f, 0.f, 0.f, 0.f), ksh = ksc, kmu = ksc, kA = ksc, kB = ksc;
+        if (isy) {
+            const DySrc &d = p.dy.d;
+            ksc = ld4(d.scale + chc); ksh = ld4(d.shift + chc); kmu = ld4(d.mean + chc);
+            const float4 is = ld4(d.invstd + chc), c1 = ld4(d.c1 + chc), c2 = ld4(d.c2 + chc);
+            kA = make_float4(ksc.x * c1.x, ksc.y * c1.y, ksc.z * c1.z, ksc.w * c1.w);
+            kB = make_float4(ksc.x * c2.x * is.x, ksc.y * c2.y * is.y, ksc.z * c2.z * is.z, ksc.w * c2.w * is.w);
+        } else if (XMODE == A_BNRELU) {
+            ksc = ld4(p.x.sc + chc); ksh = ld4(p.x.sh + chc);
+        }
+        if (!chok) { ksc = ksh = kmu = kA = kB = make_float4(0.f, 0.f, 0.f, 0.f); }
+        char *const wbase = smem + ((isy ? 0 : TO) + cq * 4) * ROWB + pgrp * 32 + rq * 8;   // plane-relative: row 16*pgrp + 4*rq
+
+        // addressing: workgroup-uniform chunk bases + 32-bit per-thread byte offsets (the host guarantees rows_per_chunk * ld * 4 < 2^31)
+        const int64_t ld = isy ? (int64_t)p.Cout : p.x.ldx;
+        const char *const b0 = reinterpret_cast<const char *>(isy ? p.dy.d.y + mbeg * p.Cout : p.x.x + mbeg * p.x.ldx);
+        const char *const b1 = reinterpret_cast<const char *>(p.dy.d.dz ? p.dy.d.dz + mbeg * p.Cout : p.dy.d.y);   // DENSE only
+        const uint32_t ldb = (uint32_t)ld * 4u;
+        uint32_t off = (uint32_t)(pgrp * 16 + rq * 4) * ldb + (uint32_t)chc * 4u;   // row 0 of this thread's block in its next stage
+        const uint32_t adv = (uint32_t)RS * ldb;
+
+        float4 ry[4], rz[4];   // raw rows: x | y, and dz (DENSE)
+        float4 rg = make_float4(0.f, 0.f, 0.f, 0.f);   // MAX: gout of the block's group
+        int4 ra = make_int4(-1, -1, -1, -1);           // MAX: argmax of the block's group
+        int kin0 = 0;                                   // MAX: position of the block's first row inside its group
+        int s_next = 0;      // next stage (every group takes part in every stage)
+        int nvalid = 4;      // rows of the block that exist (ragged last stage only)
+        auto issue = [&]() {
+            if (s_next < n_stages && (isy || isx)) {
+                const int64_t m0 = mbeg + (int64_t)s_next * RS + pgrp * 16 + rq * 4;
+                const int64_t left = mend - m0;
+                nvalid = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t o = off + (i < nvalid ? (uint32_t)i * ldb : 0u);   // rows past the end re-read a valid row
+                    ry[i] = *reinterpret_cast<const float4 *>(b0 + (nvalid ? o : (uint32_t)chc * 4u));
+                    if (isy && DYMODE == A_DY_DENSE) rz[i] = *reinterpret_cast<const float4 *>(b1 + (nvalid ? o : (uint32_t)chc * 4u));
+                }
+                if (isy && DYMODE == A_DY_MAX) {   // K % 4 == 0 (host-checked): the block's 4 rows share one group
+                    const uint32_t mc = (uint32_t)(nvalid ? m0 : mbeg);
+                    const int grp = (int)fdiv(mc, p.dy.d.divK);
+                    kin0 = (int)mc - grp * p.dy.d.K;
+                    rg = ld4(p.dy.d.gout + (int64_t)grp * p.Cout + chc);
+                    ra = *reinterpret_cast<const int4 *>(p.dy.d.argmax + (int64_t)grp * p.Cout + chc);
+                }
+                off += adv;
+            }
+        };
+        auto dyv = [&](float dz, float y, float sc, float sh, float mu, float A, float Bp) {
+            const float z = fmaf(sc, y, sh);
+            const float pp = z > 0.f ? dz : 0.f;
+            return fmaf(sc, pp, -fmaf(Bp, y - mu, A));
+        };
+        auto finish = [&](char *buf) {
+            if (!(isy || isx)) return;
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (isy) {
+                    float4 dz;
+                    if (DYMODE == A_DY_DENSE) dz = rz[i];
+                    else {
+                        const int kin = kin0 + i;
+                        dz.x = ra.x == kin ? rg.x : 0.f; dz.y = ra.y == kin ? rg.y : 0.f;
+                        dz.z = ra.z == kin ? rg.z : 0.f; dz.w = ra.w == kin ? rg.w : 0.f;
+                    }
+                    v[i].x = dyv(dz.x, ry[i].x, ksc.x, ksh.x, kmu.x, kA.x, kB.x);
+                    v[i].y = dyv(dz.y, ry[i].y, ksc.y, ksh.y, kmu.y, kA.y, kB.y);
+                    v[i].z = dyv(dz.z, ry[i].z, ksc.z, ksh.z, kmu.z, kA.z, kB.z);
+                    v[i].w = dyv(dz.w, ry[i].w, ksc.w, ksh.w, kmu.w, kA.w, kB.w);
+                } else if (XMODE == A_BNRELU) {
+                    v[i].x = fmaxf(fmaf(ksc.x, ry[i].x, ksh.x), 0.f); v[i].y = fmaxf(fmaf(ksc.y, ry[i].y, ksh.y), 0.f);
+                    v[i].z = fmaxf(fmaf(ksc.z, ry[i].z, ksh.z), 0.f); v[i].w = fmaxf(fmaf(ksc.w, ry[i].w, ksh.w), 0.f);
+                } else {
+                    v[i] = chok ? ry[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (nvalid < 4) {   // ragged last stage of the last chunk
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i >= nvalid) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // transpose in registers: per channel the 4 consecutive rows, split, 8 bytes per plane
+            char *d = buf + (wbase - smem);
+            uint2 q0, q1, q2;
+            split3(make_float4(v[0].x, v[1].x, v[2].x, v[3].x), q0, q1, q2);
+            constexpr int PL = RS * 2;   // bytes of one plane of a channel
+            *reinterpret_cast<uint2 *>(d) = q0; *reinterpret_cast<uint2 *>(d + PL) = q1; *reinterpret_cast<uint2 *>(d + 2 * PL) = q2;
+            split3(make_float4(v[0].y, v[1].y, v[2].y, v[3].y), q0, q1, q2);
+            *reinterpret_cast<uint2 *>(d + ROWB) = q0; *reinterpret_cast<uint2 *>(d + ROWB + PL) = q1; *reinterpret_cast<uint2 *>(d + ROWB + 2 * PL) = q2;
+            split3(make_float4(v[0].z, v[1].z, v[2].z, v[3].z), q0, q1, q2);
+            *reinterpret_cast<uint2 *>(d + 2 * ROWB) = q0; *reinterpret_cast<uint2 *>(d + 2 * ROWB + PL) = q1; *reinterpret_cast<uint2 *>(d + 2 * ROWB + 2 * PL) = q2;
+            split3(make_float4(v[0].w, v[1].w, v[2].w, v[3].w), q0, q1, q2);
+            *reinterpret_cast<uint2 *>(d + 3 * ROWB) = q0; *reinterpret_cast<uint2 *>(d + 3 * ROWB + PL) = q1; *reinterpret_cast<uint2 *>(d + 3 * ROWB + 2 * PL) = q2;
+        };
+
+        issue();                               // stage 0 goes through LDS before the first slot
+        if (n_stages > 0) finish(smem);
+        s_next = 1;
+        issue();
+        __syncthreads();
+        unsigned long long tw = 0, tf = 0, ti = 0, tb = 0;
+        for (int t = 0; t < n_stages; ++t) {
+            const unsigned long long c0 = p.dbg ? __builtin_readcyclecounter() : 0;
+            if (s_next < n_stages) {         // s_next == t + 1: finish it into the other buffer, put stage t + 2 in flight
+                unsigned long long c1 = c0, c2 = c0;
+                if (p.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = __builtin_readcyclecounter(); }
+                finish(smem + ((t + 1) & 1) * STAGE_B);
+                if (p.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = __builtin_readcyclecounter(); }
+                s_next += 1;
+                issue();
+                if (p.dbg) { const unsigned long long c3 = __builtin_readcyclecounter(); tw += c1 - c0; tf += c2 - c1; ti += c3 - c2; }
+            }
+            const unsigned long long c4 = p.dbg ? __builtin_readcyclecounter() : 0;
+            lds_barrier();
+            if (p.dbg) tb += __builtin_readcyclecounter() - c4;
+        }
+        if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && ((wave - 4) & 3) == 0) {
+            unsigned long long *d = p.dbg + (1 + pgrp) * 8;
+            d[0] = tw; d[1] = tf; d[2] = ti; d[3] = tb; d[4] = (unsigned long long)n_stages;
+        }
+    } else {
+        const int wo = wave >> 1, wi = wave & 1;
+        floatx16 acc[NTO][NTI];
+#pragma unroll
+        for (int a = 0; a < NTO; ++a)
+#pragma unroll
+            for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        __syncthreads();
+        unsigned long long tm = 0, tb = 0;
+        for (int t = 0; t < n_stages; ++t) {
+            const unsigned long long c0 = p.dbg ? __builtin_readcyclecounter() : 0;
+            const char *Yb = smem + (t & 1) * STAGE_B, *Xb = Yb + TO * ROWB;
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+            for (int kb = 0; kb < RS / 16; ++kb) {
+                bf16x8 ya[NTO][3], xb[NTI][3];
+#pragma unroll
+                for (int a = 0; a < NTO; ++a)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        ya[a][pl] = *reinterpret_cast<const bf16x8 *>(Yb + ((wo * NTO + a) * 32 + l31) * ROWB + pl * (RS * 2) + kb * 32 + hi * 16);
+#pragma unroll
+                for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        xb[b][pl] = *reinterpret_cast<const bf16x8 *>(Xb + ((wi * NTI + b) * 32 + l31) * ROWB + pl * (RS * 2) + kb * 32 + hi * 16);
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt)
+#pragma unroll
+                    for (int a = 0; a < NTO; ++a)
+#pragma unroll
+                        for (int b = 0; b < NTI; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya[a][PA[tt]], xb[b][PB[tt]], acc[a][b], 0, 0, 0);
+            }
+            const unsigned long long c1 = p.dbg ? __builtin_readcyclecounter() : 0;
+            lds_barrier();
+            if (p.dbg) { tm += c1 - c0; tb += __builtin_readcyclecounter() - c1; }
+        }
+        if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) { p.dbg[0] = tm; p.dbg[1] = tb; p.dbg[4] = (unsigned long long)n_stages; }
+        // ---- store the partial tile: row (cout) = (r&3)+8*(r>>2)+4*hi, col (cin) = l31
+        float *out = p.dw_partial + (int64_t)blockIdx.x * p.part_ld;
+#pragma unroll
+        for (int b = 0; b < NTI; ++b) {
+            const int ci = i0 + (wi * NTI + b) * 32 + l31;
+            if (ci < p.Cin) {
+#pragma unroll
+                for (int a = 0; a < NTO; ++a) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = o0 + (wo * NTO + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (co < p.Cout) out[(int64_t)co * p.Cin + ci] = acc[a][b][r];
+                    }
+                }
+            }
+        }
+    }
+    // Bias gradient: the bias feeds a train-mode BatchNorm, whose backward removes the per-channel mean of its input
+    // gradient -- sum_m dY[m, c] = sc * (sum p - M c1 - c2 sum xhat) = 0 identically.  The exact value is written instead
+    // of accumulating 1e-8-sized rounding noise.
+    if (p.db_partial && blockIdx.z == 0) {
+        if (tid < TO && o0 + tid < p.Cout) p.db_partial[(int64_t)blockIdx.x * p.part_ld + o0 + tid] = 0.f;
+    }
+}
+
+static bool dw_f32_exact()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PAPC_DW_F32"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+static unsigned long long *g_dw_dbg = nullptr;
+static void dw_dbg_report(const DwArgs &p, int xm, int dm)
+{
+    hipDeviceSynchronize();
+    unsigned long long h[32];
+    hipMemcpy(h, g_dw_dbg, sizeof(h), hipMemcpyDeviceToHost);
+    const double n = (double)h[4];
+    fprintf(stderr, "[dw dbg] x %d dy %d M %lld Cout %d Cin %d: slots %.0f | consumer cyc/slot: reads+mfma-issue %.0f barrier %.0f | producer grp0 per ACTIVE slot: wait %.0f finish %.0f issue %.0f ; barrier/slot %.0f\n",
+            xm, dm, (long long)p.M, p.Cout, p.Cin, n, h[0] / n, h[1] / n, h[8] / n, h[9] / n, h[10] / n, h[11] / n);
+}
+
+template <int XMODE, int DYMODE, bool VEC>
+static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
+{
+    DwArgs p = p_in;
+    static int dbg_on = -1;
+    if (dbg_on < 0) { const char *e = getenv("PAPC_DW_DBG"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+    if (dbg_on) {
+        if (!g_dw_dbg) hipMalloc(&g_dw_dbg, 32 * sizeof(unsigned long long));
+        hipMemsetAsync(g_dw_dbg, 0, 32 * sizeof(unsigned long long), st);
+        p.dbg = g_dw_dbg;
+    }
     const bool wide = p.TIp == DW_TI_WIDE;
     dim3 grid((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)cdiv(p.Cout, DW_T), (unsigned)cdiv(p.Cin, wide ? DW_TI_WIDE : DW_T));
     const int to = p.TOp / 32, ti = p.TIp / 32;  // 32-wide tiles per workgroup (upper bound)
+    const bool off32 = (int64_t)p.rows_per_chunk * std::max<int64_t>(p.Cout, XMODE == A_GROUP ? 1 : p.x.ldx) * 4 < (1ll << 31);
+    const bool k4 = DYMODE != A_DY_MAX || p.dy.d.K % 4 == 0;
+    if (VEC && XMODE != A_GROUP && !wide && to >= 2 && ti >= 2 && off32 && k4 && !dw_f32_exact()) {
+        // dense layers with >= 64-wide tiles: wave-specialised bf16x3 kernel
+        if (to > 2 && ti > 2) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 2, 2>), grid, dim3(768), 0, st, p);
+        else if (to > 2) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 2, 1>), grid, dim3(768), 0, st, p);
+        else if (ti > 2) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 1, 2>), grid, dim3(768), 0, st, p);
+        else hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 1, 1>), grid, dim3(768), 0, st, p);
+        if (dbg_on) dw_dbg_report(p, XMODE, DYMODE);
+        return check_launch("papc_mlp_bwd_dw_f32");
+    }
     if (wide) {
         if (XMODE == A_GROUP) hipLaunchKernelGGL((dw_kernel<A_GROUP, DYMODE, VEC, 4, 1, 1, 5, 5>), grid, dim3(256), 0, st, p);
     } else if (!VEC) {

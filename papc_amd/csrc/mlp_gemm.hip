@@ -425,26 +425,36 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                     if (EPI == EPI_STORE_RED) {
                         // per 32-row tile: issue the previous layer's y for all 16 of this lane's rows first (one exposed
                         // latency), then store dz_prev and accumulate p = dz*[z>0], p*xhat
+                        // RB 32-row tiles at a time (all of the lane's rows of the column on the 4-wave kernel, which has the registers)
+                        constexpr int RB = (WGM * WGN == 4 && WN == 2 && !WS) ? WM : 1;   // (measured: the 64-wide tile is faster unbatched)
 #pragma unroll
-                        for (int wm = 0; wm < WM; ++wm) {
-                            const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
-                            const float *qp = p.rd.y + rb * p.ldy + col;
-                            float *yp = p.y + rb * p.ldy + col;
-                            float yv[16];
+                        for (int w0 = 0; w0 < WM; w0 += RB) {
+                            float yv[RB][16];
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int ro = (r & 3) + 8 * (r >> 2);
-                                yv[r] = qp[(int64_t)((full || rb + ro < p.M) ? ro : 0) * p.ldy];
+                            for (int wi = 0; wi < RB; ++wi) {
+                                const int64_t rb = m0 + (wgm * WM + w0 + wi) * 32 + 4 * hi;
+                                const float *qp = p.rd.y + rb * p.ldy + col;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int ro = (r & 3) + 8 * (r >> 2);
+                                    yv[wi][r] = qp[(int64_t)((full || rb + ro < p.M) ? ro : 0) * p.ldy];
+                                }
                             }
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int ro = (r & 3) + 8 * (r >> 2);
-                                if (full || rb + ro < p.M) {
-                                    const float v = acc[wm][wn][r];
-                                    yp[(int64_t)ro * p.ldy] = v;
-                                    const float pp = fmaf(rsc[wn], yv[r], rsh[wn]) > 0.f ? v : 0.f;
-                                    s1[wn] += pp;
-                                    s2[wn] = fmaf(pp, (yv[r] - rmu[wn]) * ris[wn], s2[wn]);
+                            for (int wi = 0; wi < RB; ++wi) {
+                                const int wm = w0 + wi;
+                                const int64_t rb = m0 + (wgm * WM + wm) * 32 + 4 * hi;
+                                float *yp = p.y + rb * p.ldy + col;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int ro = (r & 3) + 8 * (r >> 2);
+                                    if (full || rb + ro < p.M) {
+                                        const float v = acc[wm][wn][r];
+                                        yp[(int64_t)ro * p.ldy] = v;
+                                        const float pp = fmaf(rsc[wn], yv[wi][r], rsh[wn]) > 0.f ? v : 0.f;
+                                        s1[wn] += pp;
+                                        s2[wn] = fmaf(pp, (yv[wi][r] - rmu[wn]) * ris[wn], s2[wn]);
+                                    }
                                 }
                             }
                         }
@@ -679,7 +689,7 @@ static bool gemm_waves8(int amode, int epi)   // 8-wave flavour of the 128x128 t
     if (v < 0) { const char *e = getenv("PAPC_GEMM_WAVES"); v = e ? atoi(e) : 0; }
     if (v == 4) return false;
     if (v == 8) return true;
-    return !(amode == A_DY_MAX && epi == EPI_STORE_RED);   // measured per kernel (MI355X): only that one is faster on 4 waves (189 vs 223 us)
+    return !(amode == A_DY_MAX && epi == EPI_STORE_RED);   // measured per kernel (MI355X): only that one is faster on 4 waves (178 vs 223 us)
 }
 static int gemm_ws()   // producer groups of the wave-specialised 128x128 kernel (0 = unspecialised)
 {
