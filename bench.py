@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_MFMA_BF16_TFLOPS = 2500.0  # dense bf16 (v_mfma_f32_32x32x16_bf16); an fp32 product costs SIX bf16 MFMA products here
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (6.3 TB/s measured achievable)
 
 K_NAMES = ["fps", "ball_query", "group", "mlp_gemm_fwd", "bn_relu_max", "bwd_bn_reduce", "bwd_dx_gemm", "bwd_dw_gemm", "pfn", "misc"]
@@ -41,24 +42,34 @@ def ssg_layers(B, N):
 
 
 def algorithmic_work(B, N):
-    """ALGORITHMIC work per step per family (DESIGN.md 'Measurement'): FLOP for the MFMA families, bytes for the
-    HBM-bound ones.  {family: (amount, 'flop'|'byte')}"""
+    """ALGORITHMIC work per step per family (DESIGN.md 'Measurement'): {family: (flop, bytes)}.  Bytes = every operand
+    read once and every result written once per launch (fp32): what a perfect kernel moves through HBM.
+      fwd  layer: read the input rows (M x Cin; the gather is counted at its logical size) + write y (M x Cout)
+      dX   layer: read y_l (+ dz_l when dense) + write dz_(l-1) (M x Cin) + read y_(l-1) for the fused BN-backward sums
+      dW   layer: read y_l (+ dz_l when dense) + read the input rows (M x Cin)"""
     w = {}
-    fwd = dx = 0.0
+    f_fwd = f_dx = b_fwd = b_dx = b_dw = 0.0
     for M, ch, D in ssg_layers(B, N):
         for l in range(3):
-            fwd += 2.0 * M * ch[l] * ch[l + 1]
+            cin, cout = ch[l], ch[l + 1]
+            dense = l < 2                                   # the last layer's dz comes from the small max-pooled gradient
+            f_fwd += 2.0 * M * cin * cout
+            b_fwd += 4.0 * M * (cin + cout)
+            dy_bytes = 4.0 * M * cout * (2 if dense else 1)
+            b_dw += dy_bytes + 4.0 * M * cin
             if l > 0:
-                dx += 2.0 * M * ch[l] * ch[l + 1]
+                f_dx += 2.0 * M * cin * cout
+                b_dx += dy_bytes + 4.0 * M * cin * 2
             elif D:
-                dx += 2.0 * M * D * ch[1]             # only the feature columns carry gradient
-    w[K_MLP_GEMM] = (fwd, "flop")
-    w[K_BWD_DW] = (fwd, "flop")
-    w[K_BWD_DX] = (dx, "flop")
-    w[K_FPS] = ((B * 512 * N + B * 128 * 512) * 20.0, "byte")
-    w[K_BQ] = ((B * 512 * N + B * 128 * 512) * 12.0, "byte")
-    w[K_BN_RELU_MAX] = (sum(M * ch[3] * 4.0 for M, ch, _ in ssg_layers(B, N)), "byte")
-    w[K_BWD_REDUCE] = (sum(2.0 * M * (ch[1] + ch[2]) * 4.0 for M, ch, _ in ssg_layers(B, N)), "byte")
+                f_dx += 2.0 * M * D * cout                  # only the feature columns carry gradient
+                b_dx += dy_bytes + 4.0 * M * D
+    w[K_MLP_GEMM] = (f_fwd, b_fwd)
+    w[K_BWD_DW] = (f_fwd, b_dw)
+    w[K_BWD_DX] = (f_dx, b_dx)
+    w[K_FPS] = (0.0, (B * 512 * N + B * 128 * 512) * 20.0)
+    w[K_BQ] = (0.0, (B * 512 * N + B * 128 * 512) * 12.0)
+    w[K_BN_RELU_MAX] = (0.0, sum(M * ch[3] * 4.0 for M, ch, _ in ssg_layers(B, N)))
+    w[K_BWD_REDUCE] = (0.0, sum(2.0 * M * (ch[1] + ch[2]) * 4.0 for M, ch, _ in ssg_layers(B, N)))
     return w
 
 
@@ -247,16 +258,24 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
-        work, kind = algorithmic_work(B, N)[dominant] if dominant in algorithmic_work(B, N) else (0.0, "byte")
+        flop, byts = algorithmic_work(B, N).get(dominant, (0.0, 0.0))
         per_step_s = (dom_ms / 1e3) / n_roof if dom_ms > 0 else float("nan")
-        if kind == "flop":
-            achieved = work / per_step_s / 1e12
-            roof = {"bound": "mfma", "kernel": K_NAMES[dominant], "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None}
+        # which roof bounds the family: its matrix time at the rate the instruction mix allows (exact 3-way bf16 split =
+        # 6 bf16 MFMA products per fp32 product -> 2500 / 6 TFLOP/s of algorithmic fp32 work) against its HBM time at 8 TB/s
+        f32_exact = os.environ.get("PAPC_GEMM_F32") == "1" and os.environ.get("PAPC_DW_F32") == "1"
+        mfma_peak = PEAK_MFMA_F32_TFLOPS if f32_exact else PEAK_MFMA_BF16_TFLOPS / 6.0
+        t_mfma = flop / (mfma_peak * 1e12)
+        t_hbm = byts / (PEAK_HBM_GBS * 1e9)
+        if flop > 0 and t_mfma >= t_hbm:
+            achieved = flop / per_step_s / 1e12
+            roof = {"bound": "mfma", "kernel": K_NAMES[dominant], "achieved": round(achieved, 2), "peak": round(mfma_peak, 1),
+                    "unit": "TFLOP/s", "frac": round(achieved / mfma_peak, 4), "traffic": None}
         else:
-            achieved = work / per_step_s / 1e9
+            achieved = byts / per_step_s / 1e9
             roof = {"bound": "hbm", "kernel": K_NAMES[dominant], "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+        roof["algorithmic"] = {"GFLOP_per_step": round(flop / 1e9, 2), "MB_per_step": round(byts / 1e6, 1),
+                               "mfma_floor_ms": round(t_mfma * 1e3, 3), "hbm_floor_ms": round(t_hbm * 1e3, 3)}
         roof["launches_per_step"] = dom_n // n_roof
         roof["avg_launch_ms"] = round(dom_ms / max(1, dom_n), 4)
         roof["ms_per_step"] = round(dom_ms / n_roof, 3)
@@ -274,8 +293,8 @@ def main():
             "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
                        "sampling": "batch i+1 pyramid on a side stream during batch i" if args.overlap else "in-line",
-                       "mfma": "fwd/dX GEMMs: fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, "
-                               "fp32 accumulate (PAPC_GEMM_F32=1 selects v_mfma_f32_32x32x2_f32); dW: v_mfma_f32_32x32x2_f32",
+                       "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
+                               "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
                        "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager all-reduce + Adam" if use_graph else "eager"},
             "roofline": roof,
             "cpu_baseline": cpu,
