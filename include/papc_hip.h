@@ -279,6 +279,34 @@ int papc_pfn_bwd_dw_f32(const float *features, const int32_t *num_voxels, const 
 /* ------------------------------------------------------------------------------------------------
  * Harness helpers (the reference's Adam step, PAPC/train.py:62-65,113-116, on one flat buffer)
  * ---------------------------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------------------------------
+ * Steps either side of the PillarFeatureNet
+ * ---------------------------------------------------------------------------------------------- */
+
+/* points_to_voxel (pointpillars/libs/ops/point_cloud/point_cloud_ops.py:8-53 zyx kernel, :56-103 xyz kernel, wrapper
+ * :106-166), exact and deterministic on the device: a cell becomes voxel v when its first point (lowest index) is met,
+ * points keep their input order inside a voxel (first max_points), and everything from the first point that would open
+ * voxel number max_voxels onwards is dropped (the source's `break`, :44-45).
+ *   points [N, ndim] fp32 (xyz first); voxel_size[3], coors_range[6] HOST floats (xyz, xyzxyz min/max)
+ *   voxels [max_voxels, max_points, ndim] (zero-filled here), coors [max_voxels, 3] int32 (zyx when reverse_index),
+ *   num_points [max_voxels] int32, voxel_num [1] int32 (device) -- rows >= *voxel_num stay zero.
+ *   workspace: papc_points_to_voxel_workspace(N) bytes of device memory. */
+size_t papc_points_to_voxel_workspace(int N);
+int papc_points_to_voxel_f32(const float *points, int N, int ndim, const float *voxel_size, const float *coors_range,
+                             int max_points, int max_voxels, int reverse_index, float *voxels, int32_t *coors,
+                             int32_t *num_points, int32_t *voxel_num, void *workspace, size_t workspace_bytes,
+                             papc_stream_t stream);
+
+/* PointPillarsScatter.forward (pointpillars/models/bones/pillars.py:122-142): canvas [B, C, ny, nx] (zero-filled here),
+ * canvas[b, :, y, x] = voxel_features[p, :] for coords[p] = (b, z, y, x); a repeated cell keeps the LAST pillar, like the
+ * numpy assignment of select_change (libs/functional.py:35-38).  owner [B, ny, nx] int32 is written here (winning pillar
+ * per cell, -1 = empty) and read by the backward. */
+int papc_pillar_scatter_f32(const float *voxel_features, const int32_t *coords, int P, int C, int batch_size, int ny,
+                            int nx, float *canvas, int32_t *owner, papc_stream_t stream);
+/* grad_features[p, :] = grad_canvas[b, :, y, x] if pillar p owns its cell, else 0 */
+int papc_pillar_scatter_bwd_f32(const float *grad_canvas, const int32_t *coords, const int32_t *owner, int P, int C,
+                                int batch_size, int ny, int nx, float *grad_features, papc_stream_t stream);
+
 /* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params. */
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,

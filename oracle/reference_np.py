@@ -426,3 +426,63 @@ def pillar_feature_net(features, num_voxels, coors, layer_weights, voxel_size=(0
     for i, (w, g, b) in enumerate(layer_weights):
         feats = pfn_layer(feats, w, g, b, last_layer=(i == n - 1), f64=f64)                  # :105-106
     return np.squeeze(feats)                                                                 # :108
+
+
+# --------------------------------------------------------------------------------------------
+# points_to_voxel  (pointpillars/libs/ops/point_cloud/point_cloud_ops.py) and PointPillarsScatter (bones/pillars.py:110-142)
+# --------------------------------------------------------------------------------------------
+def points_to_voxel(points, voxel_size, coors_range, max_points=35, reverse_index=True, max_voxels=20000):
+    """:106-166 with the loop of :8-53 (reverse) / :56-103 written out: sequential first-come assignment, float32
+    arithmetic like the numba-jitted source (its arrays are float32)."""
+    points = _f32(points)
+    voxel_size = np.asarray(voxel_size, dtype=points.dtype)                         # :137-138
+    coors_range = np.asarray(coors_range, dtype=points.dtype)
+    grid_size = np.round((coors_range[3:] - coors_range[:3]) / voxel_size).astype(np.int32)   # :25 / :140-141
+    shape = tuple(grid_size.tolist())
+    if reverse_index:
+        shape = shape[::-1]                                                         # :142-143
+    num_points_per_voxel = np.zeros((max_voxels,), np.int32)
+    coor_to_voxelidx = -np.ones(shape, np.int32)
+    voxels = np.zeros((max_voxels, max_points, points.shape[-1]), points.dtype)
+    coors = np.zeros((max_voxels, 3), np.int32)
+    coor = np.zeros((3,), np.int32)
+    voxel_num = 0
+    for i in range(points.shape[0]):
+        failed = False
+        for j in range(3):
+            c = np.floor((points[i, j] - coors_range[j]) / voxel_size[j])           # :35 (float32)
+            if c < 0 or c >= grid_size[j]:
+                failed = True
+                break
+            coor[2 - j if reverse_index else j] = c                                 # :39 / :87
+        if failed:
+            continue
+        voxelidx = coor_to_voxelidx[coor[0], coor[1], coor[2]]
+        if voxelidx == -1:
+            voxelidx = voxel_num
+            if voxel_num >= max_voxels:
+                break                                                               # :44-45
+            voxel_num += 1
+            coor_to_voxelidx[coor[0], coor[1], coor[2]] = voxelidx
+            coors[voxelidx] = coor
+        num = num_points_per_voxel[voxelidx]
+        if num < max_points:                                                        # :48-50
+            voxels[voxelidx, num] = points[i]
+            num_points_per_voxel[voxelidx] += 1
+    return voxels[:voxel_num], coors[:voxel_num], num_points_per_voxel[:voxel_num]
+
+
+def pillar_scatter(voxel_features, coords, batch_size, ny, nx):
+    """PointPillarsScatter.forward, pillars.py:122-142 (select_change = numpy fancy assignment: last duplicate wins)."""
+    voxel_features = _f32(voxel_features)
+    C = voxel_features.shape[1]
+    out = []
+    for b in range(batch_size):
+        canvas = np.zeros((C, nx * ny), np.float32)
+        mask = coords[:, 0] == b
+        if mask.any():
+            this = coords[mask]
+            indices = (this[:, 2] * nx + this[:, 3]).astype(np.int64)               # :131-132
+            canvas[:, indices] = voxel_features[mask].T                             # :133-136
+        out.append(canvas)
+    return np.stack(out, 0).reshape(batch_size, C, ny, nx)

@@ -211,3 +211,22 @@ def test_full_size_config3_msg_sa1(dev):
     ora = R.PointNetSetAbstractionMsg(S, radii[:1], ks[:1], 3, mlps[:1], ws[:1])
     _, ref = ora.forward(x, x, st, f64=True)
     assert_close(out[:, :64].detach().cpu().numpy(), ref, REL, "config-3 branch r=0.1 vs f64 oracle")
+
+
+@pytest.mark.parametrize("env", [
+    {"PAPC_GEMM_F32": "1", "PAPC_DW_F32": "1"},   # the exact-fp32 MFMA flavour (v_mfma_f32_32x32x2_f32) of every GEMM
+    {"PAPC_GEMM_WS": "3"},                        # the opt-in wave-specialised forward / dX GEMM
+])
+def test_alternative_kernel_flavours(dev, env):
+    """The kernel flavours are chosen once per process from the environment, so the alternatives are held to the same
+    parity tests in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_mlp.py", "-q", "-m", "gpu", "-x",
+                        "-k", "sa_forward or group_all or msg_vs or stack_backward"], cwd=root, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]

@@ -193,3 +193,26 @@ def test_golden_fp_fixture_matches_oracle():
         o, interp = R.PointNetFeaturePropagation(48, [64, 32], ws, nb).forward(x1, x2, g["points1"], g["points2"], f64=True, return_interp=True)
         assert np.array_equal(interp, g["interp_" + nb])
         assert np.array_equal(o.astype(np.float32), g["out_" + nb])
+
+
+def test_points_to_voxel_known_answers():
+    """Hand-checkable frame: first-come voxel numbering, zyx coordinates, max_points clipping, the max_voxels break."""
+    vs, cr = (1.0, 1.0, 2.0), (0.0, 0.0, 0.0, 4.0, 4.0, 2.0)
+    pts = np.array([[0.5, 0.5, 0.1, 1], [3.5, 0.5, 0.1, 2], [0.6, 0.4, 1.0, 3], [9.0, 0.0, 0.0, 4],
+                    [0.7, 0.3, 1.5, 5], [2.5, 2.5, 0.5, 6], [3.4, 0.6, 0.2, 7]], np.float32)
+    v, c, n = R.points_to_voxel(pts, vs, cr, max_points=2, reverse_index=True, max_voxels=10)
+    assert c.tolist() == [[0, 0, 0], [0, 0, 3], [0, 2, 2]]                 # zyx, in order of first appearance
+    assert n.tolist() == [2, 2, 1]                                         # the third point of cell (0,0) is clipped
+    assert v[0, :, 3].tolist() == [1, 3] and v[1, :, 3].tolist() == [2, 7] and v[2, 0, 3] == 6
+    v, c, n = R.points_to_voxel(pts, vs, cr, max_points=2, reverse_index=False, max_voxels=2)
+    assert c.tolist() == [[0, 0, 0], [3, 0, 0]]                            # xyz
+    # the break at the point that would open voxel 2 (index 5) also drops point 6 of the existing voxel 1
+    assert n.tolist() == [2, 1]
+
+
+def test_pillar_scatter_last_duplicate_wins():
+    f = np.arange(6, dtype=np.float32).reshape(3, 2)
+    coords = np.array([[0, 0, 1, 1], [1, 0, 0, 0], [0, 0, 1, 1]], np.int32)
+    out = R.pillar_scatter(f, coords, 2, 2, 2)
+    assert out.shape == (2, 2, 2, 2)
+    assert out[0, :, 1, 1].tolist() == [4, 5] and out[1, :, 0, 0].tolist() == [2, 3] and out.sum() == 4 + 5 + 2 + 3

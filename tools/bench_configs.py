@@ -79,6 +79,22 @@ def pfn_step():
 t_fb = timeit(pfn_step, n=50)
 print("config 5  PFN 12000x100: fwd %.3f ms (%.0f GB/s of the 41.5 MB algorithmic), fwd+bwd %.3f ms" % (t_f, 41.5e-3 / t_f * 1e3, t_fb))
 
+# ---- config 5 as a frame -> BEV pipeline: voxeliser + PFN + scatter (120k-point synthetic frame)
+from papc_amd.voxel import PointPillarsScatter, points_to_voxel
+rng = np.random.default_rng(0)
+fr = np.empty((120000, 4), np.float32)
+fr[:, 0] = rng.uniform(0, 69, 120000); fr[:, 1] = rng.uniform(-39, 39, 120000); fr[:, 2] = rng.uniform(-3, 1, 120000); fr[:, 3] = rng.uniform(0, 1, 120000)
+tfr = torch.from_numpy(fr).to(dev)
+KW = dict(voxel_size=(0.16, 0.16, 4.0), coors_range=(0, -39.68, -3, 69.12, 39.68, 1), max_points=100, max_voxels=12000)
+t_vox = timeit(lambda: points_to_voxel(tfr, padded=True, **KW), n=30)
+vv, cc, nn_, cnt = points_to_voxel(tfr, padded=True, **KW)
+c4 = torch.cat([torch.zeros(12000, 1, device=dev, dtype=torch.int32), cc], 1)
+scat = PointPillarsScatter([1, 64, 496, 432], num_input_features=64)
+with torch.no_grad():
+    ff = pfn(vv, nn_.clamp(min=1), c4)
+    t_sc = timeit(lambda: scat(ff, c4, 1), n=30)
+print("config 5  frame->BEV: points_to_voxel(120k pts) %.3f ms, PFN fwd %.3f ms, scatter %.3f ms" % (t_vox, t_f, t_sc))
+
 # ---- config 0: PointNet-Basic B=8 N=1024
 xb = torch.from_numpy(make_clouds(8, 1024, 6)).to(dev)
 pb = PointNet_Basic_Clas(num_classes=16).to(dev)
