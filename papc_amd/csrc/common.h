@@ -57,6 +57,18 @@ __device__ __forceinline__ float wave_sum_f32_to_lane63(float v)
     return v;
 }
 
+// sums over the two 32-lane halves of a wave: lanes 16..31 hold the sum of lanes 0..31, lanes 48..63 that of lanes 32..63
+__device__ __forceinline__ float half_sum_f32(float v)
+{
+    float t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0xB1, 0xF));  v += t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0x4E, 0xF));  v += t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0x124, 0xF)); v += t;
+    t = __int_as_float(PAPC_DPP(__float_as_int(v), 0x128, 0xF)); v += t;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false)); v += t;
+    return v;
+}
+
 __device__ __forceinline__ float readlane63_f32(float v)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));

@@ -60,6 +60,7 @@ struct GemmArgs {
     RedSrc rd;
     GmaxDst gm;
     unsigned long long *dbg;       // PAPC_GEMM_DBG=1: per-workgroup cycle counters (development aid)
+    int tl;                        // host: the transposed-accumulator epilogue is legal (16-byte aligned dense dX store)
 };
 
 constexpr int LDT = 36;  // LDS row stride (floats)
@@ -123,9 +124,17 @@ __device__ __forceinline__ float4 mask_w4(const GemmArgs &p, int n, int k, float
 // after finishing the previous one and only touches them G - 1 slots later, so the HBM latency is covered by plain
 // issue -> wait -> transform code per wave (register rings across a loop back-edge do not survive hipcc's waitcnt
 // insertion: it drains to vmcnt(0)).  Same two LDS buffers and the same single barrier per stage as the unspecialised loop.
-template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH, bool BF3, int WS>
+//
+// TL = true (dX kernels with a dense store): the MFMA operands are swapped, so the accumulator tile is held TRANSPOSED --
+// a lane owns one output ROW (m = tile row lane&31) and 16 columns in four groups of 4 consecutive ones.  The epilogue then
+// moves 16 bytes per lane per instruction (global_store_dwordx4, and dwordx4 loads of the previous layer's y for the fused
+// BN-backward sums) instead of 4: a quarter of the memory instructions, which is what the dX epilogues were bound by
+// (DESIGN.md 3.7).  The per-column sums become 16 per-lane accumulators per 32-column tile, reduced across lanes once at
+// the end of the kernel (DPP tree, fixed order).
+template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH, bool BF3, int WS, bool TL>
 __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WGN / 2) void gemm_kernel(GemmArgs p)
 {
+    static_assert(!TL || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (EPI == EPI_STORE || EPI == EPI_STORE_RED) && VEC), "TL: dense dX stores");
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
     constexpr int BKS = BF3 ? 16 : BK;        // k extent of one stage
     constexpr int KQN = BKS / 4;              // threads along k (one float4 each)
@@ -143,8 +152,10 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
     static_assert(BM == 128, "row tile is 128");
     constexpr int STAGE = (BM + BN) * ROWF;
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * WGM * BN];
+    constexpr bool TLRED = TL && EPI == EPI_STORE_RED;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * WGM * BN + (TLRED ? 4 * BN : 0)];
     float *red = smem + 2 * STAGE;
+    float *cst = red + 2 * WGM * BN;   // TLRED: previous layer's scale / shift / mean / invstd of this column block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -178,6 +189,19 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
         const int cc = cok[wn] ? col : 0;
         rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
         if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[cc]; rsh[wn] = p.rd.shift[cc]; rmu[wn] = p.rd.mean[cc]; ris[wn] = p.rd.invstd[cc]; }
+    }
+
+    constexpr int NS = TLRED ? 16 : 1;
+    float st1[WN][NS], st2[WN][NS];   // TLRED: per-lane column sums (column = the lane's r-th accumulator column)
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+        for (int r = 0; r < NS; ++r) { st1[wn][r] = 0.f; st2[wn][r] = 0.f; }
+    if (TLRED) {
+        for (int i = tid; i < BN; i += NT) {
+            const int cc = n0 + i < p.Nout ? n0 + i : 0;
+            cst[0 * BN + i] = p.rd.scale[cc]; cst[1 * BN + i] = p.rd.shift[cc]; cst[2 * BN + i] = p.rd.mean[cc]; cst[3 * BN + i] = p.rd.invstd[cc];
+        }
     }
 
     floatx16 acc[WM][WN];
@@ -313,7 +337,8 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                 for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
                     for (int wn = 0; wn < WN; ++wn)
-                        acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[wm][PA[t]], bq[wn][PB[t]], acc[wm][wn], 0, 0, 0);
+                        acc[wm][wn] = TL ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[wn][PB[t]], af[wm][PA[t]], acc[wm][wn], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[wm][PA[t]], bq[wn][PB[t]], acc[wm][wn], 0, 0, 0);
         } else {
             const float *As = smem + buf * STAGE, *Ws = As + BM * LDT;
             const int kend = min(BK, Kpad - kc_c * BK);
@@ -329,10 +354,17 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                 for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
                     for (int wn = 0; wn < WN; ++wn) {
+                        if (TL) {
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[wn].x, af[wm].x, acc[wm][wn], 0, 0, 0);
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[wn].y, af[wm].y, acc[wm][wn], 0, 0, 0);
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[wn].z, af[wm].z, acc[wm][wn], 0, 0, 0);
+                            acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[wn].w, af[wm].w, acc[wm][wn], 0, 0, 0);
+                        } else {
                         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].x, bf[wn].x, acc[wm][wn], 0, 0, 0);
                         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].y, bf[wn].y, acc[wm][wn], 0, 0, 0);
                         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].z, bf[wn].z, acc[wm][wn], 0, 0, 0);
                         acc[wm][wn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[wm].w, bf[wn].w, acc[wm][wn], 0, 0, 0);
+                        }
                     }
             }
         }
@@ -342,6 +374,50 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     // row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Straight-line stores (no per-element branch) for full tiles; the ragged last
     // tile takes the predicated path.
     auto epilogue = [&](int64_t tile_c) {
+        if (TL) {
+            // transposed accumulators: lane = output row, register r = column (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32-column tile
+            const int64_t m0 = tile_c * BM;
+            const bool full = m0 + BM <= p.M && n0 + BN <= p.Nout;   // whole tile inside the matrix: no predicates at all
+#pragma unroll
+            for (int wm = 0; wm < WM; ++wm) {
+                const int64_t m = m0 + (wgm * WM + wm) * 32 + l31;
+                const bool rok = m < p.M;
+                const int64_t mc = rok ? m : m0;
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) {
+                    const int cl0 = (wgn * WN + wn) * 32 + 4 * hi;   // column (inside the block) of accumulator 0
+                    float4 yv[4];
+                    if (EPI == EPI_STORE_RED) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int col = n0 + cl0 + 8 * q;
+                            yv[q] = ld4(p.rd.y + mc * p.ldy + (col < p.Nout ? col : 0));
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = n0 + cl0 + 8 * q;
+                        const float4 v = make_float4(acc[wm][wn][4 * q], acc[wm][wn][4 * q + 1], acc[wm][wn][4 * q + 2], acc[wm][wn][4 * q + 3]);
+                        if (EPI == EPI_STORE_RED) {
+                            const float4 sc = *reinterpret_cast<const float4 *>(&cst[0 * BN + cl0 + 8 * q]);
+                            const float4 sh = *reinterpret_cast<const float4 *>(&cst[1 * BN + cl0 + 8 * q]);
+                            const float4 mu = *reinterpret_cast<const float4 *>(&cst[2 * BN + cl0 + 8 * q]);
+                            const float4 is = *reinterpret_cast<const float4 *>(&cst[3 * BN + cl0 + 8 * q]);
+                            // rows / columns outside the matrix carry v = 0 (zero operand rows / zero weight rows): they add nothing
+                            float pp;
+                            pp = fmaf(sc.x, yv[q].x, sh.x) > 0.f ? v.x : 0.f; st1[wn][4 * q + 0] += pp; st2[wn][4 * q + 0] = fmaf(pp, (yv[q].x - mu.x) * is.x, st2[wn][4 * q + 0]);
+                            pp = fmaf(sc.y, yv[q].y, sh.y) > 0.f ? v.y : 0.f; st1[wn][4 * q + 1] += pp; st2[wn][4 * q + 1] = fmaf(pp, (yv[q].y - mu.y) * is.y, st2[wn][4 * q + 1]);
+                            pp = fmaf(sc.z, yv[q].z, sh.z) > 0.f ? v.z : 0.f; st1[wn][4 * q + 2] += pp; st2[wn][4 * q + 2] = fmaf(pp, (yv[q].z - mu.z) * is.z, st2[wn][4 * q + 2]);
+                            pp = fmaf(sc.w, yv[q].w, sh.w) > 0.f ? v.w : 0.f; st1[wn][4 * q + 3] += pp; st2[wn][4 * q + 3] = fmaf(pp, (yv[q].w - mu.w) * is.w, st2[wn][4 * q + 3]);
+                        }
+                        if (full || (rok && col < p.Nout)) *reinterpret_cast<float4 *>(p.y + m * p.ldy + col) = v;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[wm][wn][r] = 0.f;
+                }
+            }
+            return;
+        }
 
             const int64_t m0 = tile_c * BM;
             const bool full = m0 + BM <= p.M;
@@ -626,14 +702,22 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     // one pipeline step: issue a new stage into `si`, compute the current stage from LDS, then finish the OLDEST in-flight
     // stage `sc` (the next one to compute) into the other LDS buffer.  DEPTH 1: si == sc; DEPTH 2: the two sets alternate, so
     // every stage's loads get two MFMA phases to land.
+    unsigned long long t_is = 0, t_mf = 0, t_co = 0, t_ep = 0, t_ba = 0, n_st = 0;
     auto step = [&](Stg &si, Stg &sc) -> bool {
         if (!have) return false;
+        const unsigned long long c0 = p.dbg ? __builtin_readcyclecounter() : 0;
         issue(si);
+        const unsigned long long c1 = p.dbg ? __builtin_readcyclecounter() : 0;
         mfma_stage(buf, kc_c);
+        const unsigned long long c2 = p.dbg ? __builtin_readcyclecounter() : 0;
         // ---- consume the next stage's loads: transform, write the other LDS buffer
         if (sc.ok) consume(sc, smem + (buf ^ 1) * STAGE);
+        unsigned long long c3 = c2;
+        if (p.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = __builtin_readcyclecounter(); }
         if (kc_c == n_kc - 1) epilogue(tile_c);
+        const unsigned long long c4 = p.dbg ? __builtin_readcyclecounter() : 0;
         lds_barrier();  // LDS-only: the epilogue's global stores and the idx prefetch stay in flight across it
+        if (p.dbg) { const unsigned long long c5 = __builtin_readcyclecounter(); t_is += c1 - c0; t_mf += c2 - c1; t_co += c3 - c2; t_ep += c4 - c3; t_ba += c5 - c4; ++n_st; }
         buf ^= 1;
         tile_c = sc.tile;
         kc_c = sc.kci;
@@ -643,9 +727,27 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     if (!WS) {
         if (DEPTH == 2) { while (step(sb, sa) && step(sa, sb)) {} }
         else { while (step(sa, sa)) {} }
+        if (p.dbg && blockIdx.y == 0 && tid == 0) {
+            unsigned long long *d = p.dbg + (int64_t)blockIdx.x * 32;
+            d[0] = t_is; d[1] = t_mf; d[2] = t_co; d[3] = t_ep; d[4] = n_st; d[5] = t_ba;
+        }
     }
 
     if ((EPI == EPI_STORE || EPI == EPI_STORE_RED || EPI == EPI_STORE_GMAX) && p.stats) {
+        if (TLRED) {
+            // per-lane column sums -> sums over the 32 rows of each half wave (fixed DPP tree); lanes 31 / 63 hold them
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                for (int r = 0; r < NS; ++r) {
+                    const float a = half_sum_f32(st1[wn][r]), b = half_sum_f32(st2[wn][r]);
+                    if (l31 == 31 && !producer) {
+                        const int cl = (wgn * WN + wn) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        red[(0 * WGM + wgm) * BN + cl] = a;
+                        red[(1 * WGM + wgm) * BN + cl] = b;
+                    }
+                }
+        } else {
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             s1[wn] += __shfl_xor(s1[wn], 32);
@@ -654,6 +756,7 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                 red[(0 * WGM + wgm) * BN + (wgn * WN + wn) * 32 + l31] = s1[wn];
                 red[(1 * WGM + wgm) * BN + (wgn * WN + wn) * 32 + l31] = s2[wn];
             }
+        }
         }
         __syncthreads();
         for (int i = tid; i < 2 * BN; i += NT) {
@@ -697,13 +800,25 @@ static int gemm_ws()   // producer groups of the wave-specialised 128x128 kernel
     if (v < 0) { const char *e = getenv("PAPC_GEMM_WS"); v = e ? atoi(e) : 0; if (v != 3) v = 0; }   // opt-in: see DESIGN.md 3.7
     return v;
 }
+static unsigned long long *g_dbg = nullptr;
+static void dbg_report0(const GemmArgs &p, int amode, int epi, unsigned gx, int waves)
+{
+    hipDeviceSynchronize();
+    static unsigned long long h[512 * 4 * 8];
+    hipMemcpy(h, g_dbg, sizeof(h), hipMemcpyDeviceToHost);
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    for (unsigned b = 0; b < gx; ++b) for (int i = 0; i < 6; ++i) c[i] += (double)h[b * 32 + i];
+    const double n = c[4] > 0 ? c[4] : 1;
+    fprintf(stderr, "[gemm dbg0] amode %d epi %d waves %d M %lld K %d N %d: stages/wg %.0f | wave 0 cyc/stage: issue %.0f mfma %.0f consume %.0f epilogue %.0f barrier %.0f\n",
+            amode, epi, waves, (long long)p.M, p.Kin, p.Nout, n / gx, c[0] / n, c[1] / n, c[2] / n, c[3] / n, c[5] / n);
+}
 #define GEMM_LAUNCH(a, b, c, d)                                                                                        \
     do {                                                                                                               \
-        if (gemm_f32_exact()) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false, 0>), grid, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0>), grid, dim3(a * b * 64), 0, st, p); \
+        if (gemm_f32_exact()) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false, 0, TL>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0, TL>), grid, dim3(a * b * 64), 0, st, p); \
+        if (dbg_on) dbg_report0(p, AMODE, EPI, gx, a * b);                                                             \
     } while (0)
 
-static unsigned long long *g_dbg = nullptr;
 static void dbg_report(const GemmArgs &p, int amode, int epi, unsigned gx)
 {
     hipDeviceSynchronize();
@@ -721,7 +836,7 @@ static void dbg_report(const GemmArgs &p, int amode, int epi, unsigned gx)
             amode, epi, (long long)p.M, p.Kin, p.Nout, n / gx, c[0] / n, c[1] / n, c[2] / n, pr[0][0] / n, pr[0][1] / n, pr[0][2] / n, pr[0][3] / n);
 }
 
-template <int AMODE, int EPI, bool VEC>
+template <int AMODE, int EPI, bool VEC, bool TL>
 static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
 {
     GemmArgs p = p_in;
@@ -748,11 +863,14 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
         dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
         if (!gemm_f32_exact() && gemm_ws() == 3)        // 4 consumer + 12 producer waves on the same 128x128 tile
         {
-            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2, 1, true, 3>), grid, dim3(1024), 0, st, p);
+            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2, 1, true, 3, TL>), grid, dim3(1024), 0, st, p);
             if (dbg_on) dbg_report(p, AMODE, EPI, gx);
         }
         else if (!gemm_f32_exact() && gemm_waves8(AMODE, EPI))   // same 128x128 tile on 8 waves of 64x32: 4 waves per SIMD
-            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0>), grid, dim3(512), 0, st, p);
+        {
+            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL>), grid, dim3(512), 0, st, p);
+            if (dbg_on) dbg_report0(p, AMODE, EPI, gx, 8);
+        }
         else
             GEMM_LAUNCH(2, 2, 2, 2);
     } else if (p.Nout > 32) {
@@ -768,7 +886,11 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
 template <int AMODE, int EPI>
 static int launch_gemm(const GemmArgs &p, bool vec, hipStream_t st)
 {
-    return vec ? launch_gemm_v<AMODE, EPI, true>(p, st) : launch_gemm_v<AMODE, EPI, false>(p, st);
+    constexpr bool TLOK = (AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (EPI == EPI_STORE || EPI == EPI_STORE_RED);
+    if constexpr (TLOK) {
+        if (vec && p.tl) return launch_gemm_v<AMODE, EPI, true, true>(p, st);
+    }
+    return vec ? launch_gemm_v<AMODE, EPI, true, false>(p, st) : launch_gemm_v<AMODE, EPI, false, false>(p, st);
 }
 
 static void fill_group(GroupSrc &g, const papc_group_src *s)
@@ -922,6 +1044,12 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
         p.rd.y = next_red->y; p.rd.mean = next_red->mean; p.rd.invstd = next_red->invstd; p.rd.scale = next_red->scale;
         p.rd.shift = next_red->shift; p.stats = next_red->red_partial;
     }
+    static int tl_on = -1;
+    // opt-in (PAPC_GEMM_TL=1): measured on MI355X the transposed epilogue itself is 30-40 % shorter, but the kernel's load-issue
+    // phase grows by more (9140-9180 vs 9220-9260 clouds/s end to end), so the column-lane epilogue stays the default
+    if (tl_on < 0) { const char *e = getenv("PAPC_GEMM_TL"); tl_on = (e && e[0] == '1') ? 1 : 0; }
+    // (with the fused BN-backward sums only the 64-column tile has the registers for the 32 per-lane accumulators)
+    p.tl = tl_on && !scatter && dx && aligned16(dx) && Cin % 4 == 0 && (!next_red || (aligned16(next_red->y) && Cin <= 64));
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DX, st);
     if (next_red) {

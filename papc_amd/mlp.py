@@ -53,6 +53,7 @@ import os
 _FUSE_RED = os.environ.get("PAPC_NO_RED") != "1"            # A/B switch for the BN-backward reduce fused into the dX epilogue
 _FUSE_GMAX = os.environ.get("PAPC_NO_GMAX") != "1"          # A/B switch for the fused neighbourhood-max epilogue
 _RESIDENT_WGS = int(os.environ.get("PAPC_PARTS", "512"))   # persistent-grid size (tuning knob shared with the C side)
+_DW_WGS = int(os.environ.get("PAPC_DW_WGS", "512"))         # workgroups of one dW launch (row chunks x output tiles)
 
 
 def _dw_rows_per_chunk(M, cout, cin):
@@ -60,7 +61,7 @@ def _dw_rows_per_chunk(M, cout, cin):
     no tail round; chunks of >= 256 rows."""
     wide = 128 < cin <= 160
     tiles = ((cout + 127) // 128) * (1 if wide else (cin + 127) // 128)
-    want = max(1, _RESIDENT_WGS // tiles)
+    want = max(1, _DW_WGS // tiles)
     rpc = (M + want - 1) // want
     rpc = max(256, ((rpc + 63) // 64) * 64)
     return rpc

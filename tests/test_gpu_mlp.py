@@ -216,6 +216,7 @@ def test_full_size_config3_msg_sa1(dev):
 @pytest.mark.parametrize("env", [
     {"PAPC_GEMM_F32": "1", "PAPC_DW_F32": "1"},   # the exact-fp32 MFMA flavour (v_mfma_f32_32x32x2_f32) of every GEMM
     {"PAPC_GEMM_WS": "3"},                        # the opt-in wave-specialised forward / dX GEMM
+    {"PAPC_GEMM_TL": "1"},                        # the opt-in transposed-accumulator dX epilogue
 ])
 def test_alternative_kernel_flavours(dev, env):
     """The kernel flavours are chosen once per process from the environment, so the alternatives are held to the same
