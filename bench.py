@@ -179,11 +179,20 @@ def main():
         return loss
 
     def capture():
+        """Returns True when the graph was captured; on any capture failure the bench falls back to eager launches."""
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=torch.cuda.current_stream()):
-            graph_state["loss"] = fwd_bwd()
+        try:
+            # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+            with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                graph_state["loss"] = fwd_bwd()
+        except Exception as e:   # noqa: BLE001
+            print("[bench] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), file=sys.stderr)
+            graph_state["g"], graph_state["loss"] = None, None
+            torch.cuda.synchronize()
+            return False
         graph_state["g"] = g
+        return True
 
     def step():
         if graph_state["g"] is None:
@@ -221,11 +230,11 @@ def main():
                                                                          100.0 * ms / max(tot, 1e-9)), file=sys.stderr)
     if use_graph:
         loss = None                               # drop the last eager autograd graph before capturing
-        capture()                                 # event profiler off: nothing but kernels, memsets and copies in the graph
+        use_graph = capture()                     # event profiler off: nothing but kernels, memsets and copies in the graph
         for _ in range(2):
             loss = step()
         torch.cuda.synchronize()
-    else:
+    if not use_graph:
         lib.papc_prof_enable(1 << dominant)       # eager timed region: event pairs only around the dominant family
         lib.papc_prof_reset()
 
