@@ -111,6 +111,43 @@ __device__ __forceinline__ unsigned wave_min_u32_to_lane63(unsigned v)
     t = PAPC_DPPU(v, 0x143, 0xC); v = t < v ? t : v;
     return v;
 }
+// ---- the same reductions as single fused DPP instructions (inline asm).  hipcc compiles the builtin forms above to
+// v_mov_b32 + s_nop + v_mov_b32_dpp + (canonicalising v_max_f32) + v_max per step, ~5 dependent issue slots; here a step
+// is `s_nop 1` (the VALU-write -> DPP-read hazard) + one v_max_u32_dpp / v_min_u32_dpp.  Unsigned compares: callers pass
+// the bit patterns of NON-NEGATIVE floats, which order like the floats and need no canonicalisation.
+#define PAPC_DPP_STEP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+__device__ __forceinline__ unsigned row_max_u32_fused(unsigned v)   // every lane of a 16-lane row ends with the row max
+{
+    PAPC_DPP_STEP("v_max_u32_dpp", v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    PAPC_DPP_STEP("v_max_u32_dpp", v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    PAPC_DPP_STEP("v_max_u32_dpp", v, "row_ror:4 row_mask:0xf bank_mask:0xf");
+    PAPC_DPP_STEP("v_max_u32_dpp", v, "row_ror:8 row_mask:0xf bank_mask:0xf");
+    return v;
+}
+__device__ __forceinline__ unsigned row_min_u32_fused(unsigned v)
+{
+    PAPC_DPP_STEP("v_min_u32_dpp", v, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    PAPC_DPP_STEP("v_min_u32_dpp", v, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    PAPC_DPP_STEP("v_min_u32_dpp", v, "row_ror:4 row_mask:0xf bank_mask:0xf");
+    PAPC_DPP_STEP("v_min_u32_dpp", v, "row_ror:8 row_mask:0xf bank_mask:0xf");
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32_fused_to_lane63(unsigned v)   // lane 63 (all of row 3) holds the wave max
+{
+    v = row_max_u32_fused(v);
+    PAPC_DPP_STEP("v_max_u32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    PAPC_DPP_STEP("v_max_u32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::"v"(v));
+    return v;
+}
+__device__ __forceinline__ unsigned wave_min_u32_fused_to_lane63(unsigned v)
+{
+    v = row_min_u32_fused(v);
+    PAPC_DPP_STEP("v_min_u32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    PAPC_DPP_STEP("v_min_u32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::"v"(v));
+    return v;
+}
 __device__ __forceinline__ unsigned readlane63_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ float readlane0_f32(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
 __device__ __forceinline__ unsigned readlane0_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 0); }

@@ -70,30 +70,46 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
                 o[0] = cx; o[1] = cy; o[2] = cz;
             }
         }
-        float bestd = -1.0f;
-        int bestj = 0;
+        // Running distances live as the BIT PATTERNS of non-negative floats: unsigned min / max / compare then equal the float
+        // ones and need neither canonicalisation (v_max_f32 x,x,x before every fminf) nor a serial compare-select chain.
+        u32 du[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const float dx = x[j] - cx, dy = y[j] - cy, dz = z[j] - cz;
             const float dd = (dx * dx + dy * dy) + dz * dz;  // sum((xyz - centroid) ** 2, -1)  (:86)
-            d[j] = __builtin_fminf(dd, d[j]);               // where(dist < distance, dist, distance) (:87-92)
-            if (d[j] > bestd) { bestd = d[j]; bestj = j; }  // strict >: lowest j (= lowest index) on ties
+            const u32 a = __float_as_uint(dd), bq = __float_as_uint(d[j]);
+            du[j] = a < bq ? a : bq;                          // where(dist < distance, dist, distance) (:87-92)
+            d[j] = __uint_as_float(du[j]);
         }
+        // per-thread argmax as a max tree + "lowest j holding the max" (strict first-maximum rule, :93)
+        u32 bmax = du[0];
+#pragma unroll
+        for (int j = 1; j < PPT; ++j) bmax = du[j] > bmax ? du[j] : bmax;
+        int bestj = PPT - 1;
+#pragma unroll
+        for (int j = PPT - 2; j >= 0; --j) bestj = du[j] == bmax ? j : bestj;
+        const float bestd = __uint_as_float(bmax);
         // wave argmax in two 32-bit DPP passes (64-bit compares are quarter rate): max distance, then the
         // LOWEST index among the lanes holding it -- argmax(distance, -1) returns the first maximum (:93)
-        const float mw = readlane63_f32(wave_max_f32_to_lane63(bestd));
-        const u32 iw = readlane63_u32(wave_min_u32_to_lane63(bestd == mw ? (u32)(bestj * T + tid) : 0xFFFFFFFFu));
+        // (bestd >= 0 here: its bit pattern orders like the float, so the reductions run on unsigned integers)
+        const u32 bd = __float_as_uint(bestd);
+        const u32 mwb = readlane63_u32(wave_max_u32_fused_to_lane63(bd));
+        const float mw = __uint_as_float(mwb);
+        const u32 iw = readlane63_u32(wave_min_u32_fused_to_lane63(bd == mwb ? (u32)(bestj * T + tid) : 0xFFFFFFFFu));
         if (NW == 1) {
             far = (int)iw;
         } else {
             if (lane == 0) keys2[(it & 1) * 16 + wave] = make_uint2(__float_as_uint(mw), iw);
             __syncthreads();
             // every wave combines the <=16 per-wave results with a 16-lane row reduce (same two passes)
-            uint2 kv = make_uint2(0xBF800000u /* -1.0f */, 0xFFFFFFFFu);
+            uint2 kv = make_uint2(0u /* +0.0f: below every real maximum's bit pattern or tied with index 0xFFFFFFFF */, 0xFFFFFFFFu);
             if (lane < NW) kv = keys2[(it & 1) * 16 + lane];
-            const float km = __uint_as_float(kv.x);
-            const float bm = readlane0_f32(row_max_f32(km));
-            far = (int)readlane0_u32(row_min_u32(km == bm ? kv.y : 0xFFFFFFFFu));
+            u32 bm = row_max_u32_fused(kv.x);
+            asm volatile("s_nop 1" ::"v"(bm));
+            bm = readlane0_u32(bm);
+            u32 fi = row_min_u32_fused(kv.x == bm ? kv.y : 0xFFFFFFFFu);
+            asm volatile("s_nop 1" ::"v"(fi));
+            far = (int)readlane0_u32(fi);
         }
     }
 }
