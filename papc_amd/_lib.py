@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpapc_hip.so")
+LIB_PATH = os.environ.get("PAPC_LIB") or os.path.join(_HERE, "libpapc_hip.so")   # PAPC_LIB: A/B a second build of the library
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int

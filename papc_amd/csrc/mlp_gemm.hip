@@ -153,6 +153,10 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     static_assert(BM == 128, "row tile is 128");
     constexpr int STAGE = (BM + BN) * ROWF;
     constexpr bool TLRED = TL && EPI == EPI_STORE_RED;
+#ifndef PAPC_GEMM_EARLY
+#define PAPC_GEMM_EARLY 1
+#endif
+    constexpr bool EARLY = PAPC_GEMM_EARLY && DEPTH == 1;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * WGM * BN + (TLRED ? 4 * BN : 0)];
     float *red = smem + 2 * STAGE;
     float *cst = red + 2 * WGM * BN;   // TLRED: previous layer's scale / shift / mean / invstd of this column block
@@ -311,7 +315,7 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     int64_t tile_c = sa.tile;  // tile / chunk of the stage being computed
     int kc_c = sa.kci;
     if (have && !WS) consume(sa, smem);
-    if (DEPTH == 2) issue(sa);
+    if (DEPTH == 2 || (EARLY && !WS)) issue(sa);
     if (!WS) __syncthreads();
 
     // ---- MFMAs of one stage from LDS buffer `buf` (kc = its k-chunk index)
@@ -706,12 +710,16 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     auto step = [&](Stg &si, Stg &sc) -> bool {
         if (!have) return false;
         const unsigned long long c0 = p.dbg ? __builtin_readcyclecounter() : 0;
-        issue(si);
+        if (!EARLY) issue(si);
         const unsigned long long c1 = p.dbg ? __builtin_readcyclecounter() : 0;
         mfma_stage(buf, kc_c);
         const unsigned long long c2 = p.dbg ? __builtin_readcyclecounter() : 0;
         // ---- consume the next stage's loads: transform, write the other LDS buffer
+        const int64_t nx_tile = sc.tile; const int nx_kc = sc.kci; const bool nx_ok = sc.ok;
         if (sc.ok) consume(sc, smem + (buf ^ 1) * STAGE);
+        // EARLY: the stage after next is issued right here, into the registers consume() just released -- its loads then have
+        // the epilogue, the barrier and the whole next MFMA phase to land (one register set, no ring for hipcc to drain)
+        if (EARLY) issue(si);
         unsigned long long c3 = c2;
         if (p.dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c3 = __builtin_readcyclecounter(); }
         if (kc_c == n_kc - 1) epilogue(tile_c);
@@ -719,9 +727,9 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
         lds_barrier();  // LDS-only: the epilogue's global stores and the idx prefetch stay in flight across it
         if (p.dbg) { const unsigned long long c5 = __builtin_readcyclecounter(); t_is += c1 - c0; t_mf += c2 - c1; t_co += c3 - c2; t_ep += c4 - c3; t_ba += c5 - c4; ++n_st; }
         buf ^= 1;
-        tile_c = sc.tile;
-        kc_c = sc.kci;
-        have = sc.ok;
+        tile_c = nx_tile;
+        kc_c = nx_kc;
+        have = nx_ok;
         return true;
     };
     if (!WS) {
