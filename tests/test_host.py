@@ -56,3 +56,37 @@ def test_layer_constructors_mirror_reference_signatures():
     assert len(sa.mlp_convs) == 3 and sa.mlp_convs[0].weight.shape == (64, 3, 1, 1)
     msg = PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]])
     assert msg.conv_blocks[0][0].weight.shape == (32, 3, 1, 1)
+
+
+def test_checkpoint_exchange_with_reference_layout(tmp_path):
+    """*.pdparams round trip (plain pickle of name -> ndarray): Linear weights are [in, out] on the reference side, BN
+    statistics are _mean / _variance, SA layers are absent from a reference checkpoint."""
+    import pickle
+    import numpy as np
+    import torch
+    from papc_amd import checkpoint as C
+    from papc_amd.models import PointNet2_SSG_Clas
+    torch.manual_seed(0)
+    m = PointNet2_SSG_Clas(num_classes=16)
+    with torch.no_grad():
+        m.bn1.running_mean.uniform_(-1, 1); m.bn1.running_var.uniform_(0.5, 2)
+    path = str(tmp_path / "model.pdparams")
+    C.save_pdparams(m, path)
+    st = C.load_pdparams(path)
+    assert st["fc1.weight"].shape == (1024, 512)                       # paddle layout [in, out]
+    assert "bn1._mean" in st and "bn1._variance" in st and not any("running" in k for k in st)
+    m2 = PointNet2_SSG_Clas(num_classes=16)
+    missing, unexpected = C.import_state(m2, st, strict=True)
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(a, b), k
+    # a reference-made checkpoint: only the registered head layers, plus paddle's bookkeeping key
+    ref = {k: v for k, v in st.items() if not k.startswith("sa")}
+    ref["StructuredToParameterName@@"] = {}
+    with open(path, "wb") as f:
+        pickle.dump(ref, f, protocol=2)
+    m3 = PointNet2_SSG_Clas(num_classes=16)
+    missing, unexpected = C.import_state(m3, C.load_pdparams(path))
+    assert missing and all(k.startswith("sa") for k in missing) and not unexpected
+    assert torch.equal(m3.fc2.weight, m.fc2.weight) and torch.equal(m3.bn1.running_var, m.bn1.running_var)
