@@ -30,6 +30,26 @@ def _bn_buffers(bns):
     return [(bn.running_mean, bn.running_var) for bn in bns]
 
 
+def _pad_features(feats, params, xyz_first):
+    """The gather kernels move features as float4: a feature count that is not a multiple of 4 (e.g. the 3 normal /
+    xyz channels the segmentation nets feed to SA1) would fall to the element-wise path, ~10x slower.  Pad the features with
+    zero channels and the first conv weight with matching zero columns instead (a view-level change: same result, the
+    gradient flows back to the real columns through the concatenation)."""
+    D = feats.shape[2]
+    pad = (-D) % 4
+    if pad == 0:
+        return feats, params, D
+    feats = torch.nn.functional.pad(feats, (0, pad))
+    w = params[0]
+    w2 = w.reshape(w.shape[0], -1)
+    z = w2.new_zeros(w2.shape[0], pad)
+    if xyz_first:   # columns [xyz(3), feats(D)] -> [xyz, feats, 0]
+        w_pad = torch.cat([w2, z], 1)
+    else:           # columns [feats(D), xyz(3)] -> [feats, 0, xyz]
+        w_pad = torch.cat([w2[:, :D], z, w2[:, D:]], 1)
+    return feats, [w_pad] + list(params[1:]), D + pad
+
+
 class PointNetSetAbstraction(nn.Module):
     def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all, reference_quirks=False, init_dist=1.0):
         super().__init__()
@@ -83,10 +103,12 @@ class PointNetSetAbstraction(nn.Module):
             else:
                 _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)
                 idx = F_._ball_query_raw([self.radius], [K], xyz, new_xyz)[0]
+        params = _stack_params(self.mlp_convs, self.mlp_bns)
+        if feats is not None:
+            feats, params, D = _pad_features(feats, params, True)
         spec = StackSpec(B, N, S, K, D, xyz_first=True, eps=self.mlp_bns[0].eps, momentum=0.9,
                          cut_gather_grad=self.reference_quirks)
-        out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx,
-                             _stack_params(self.mlp_convs, self.mlp_bns))       # :214-219
+        out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx, params)   # :214-219
         new_points = out.view(B, S, -1).transpose(1, 2)                         # [B,D',S]
         return new_xyz.transpose(1, 2), new_points                              # :220-221
 
@@ -125,11 +147,15 @@ class PointNetSetAbstractionMsg(nn.Module):
         _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)             # :258 (one FPS for all radii)
         idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz)   # :260-262, one scan
         outs = []
+        feats_in = feats
         for i, K in enumerate(self.nsample_list):
-            spec = StackSpec(B, N, S, K, D, xyz_first=False, eps=self.bn_blocks[i][0].eps, momentum=0.9,
+            params = _stack_params(self.conv_blocks[i], self.bn_blocks[i])
+            Dp = D
+            if feats_in is not None:
+                feats, params, Dp = _pad_features(feats_in, params, False)
+            spec = StackSpec(B, N, S, K, Dp, xyz_first=False, eps=self.bn_blocks[i][0].eps, momentum=0.9,
                              cut_gather_grad=self.reference_quirks)             # feats first, then xyz (:267)
-            o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats, idxs[i],
-                               _stack_params(self.conv_blocks[i], self.bn_blocks[i]))   # :271-276
+            o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats, idxs[i], params)   # :271-276
             outs.append(o.view(B, S, -1))
         new_points_concat = torch.cat(outs, dim=2).transpose(1, 2)              # :280  [B,D',S]
         return new_xyz.transpose(1, 2), new_points_concat
