@@ -274,8 +274,10 @@ def grad_targets_of(params):
     kernels) and hands autograd ``None``: no per-parameter AccumulateGrad add kernels."""
     tg = []
     for p in params:
-        g = getattr(p, "grad", None)
-        if not (isinstance(p, torch.nn.Parameter) and p.requires_grad and g is not None and g.is_contiguous()
+        if not isinstance(p, torch.nn.Parameter):   # e.g. a zero-padded view of a weight: gradients go back through autograd
+            return None
+        g = p.grad
+        if not (p.requires_grad and g is not None and g.is_contiguous()
                 and g.dtype == torch.float32 and g.shape == p.shape):
             return None
         tg.append(g)
