@@ -307,6 +307,14 @@ int papc_pillar_scatter_f32(const float *voxel_features, const int32_t *coords, 
 int papc_pillar_scatter_bwd_f32(const float *grad_canvas, const int32_t *coords, const int32_t *owner, int P, int C,
                                 int batch_size, int ny, int nx, float *grad_features, papc_stream_t stream);
 
+/* Axis-aligned bitmask NMS: nms_gpu of pointpillars/libs/ops/non_max_suppression/nms_gpu.py:130-164 (CUDA twin
+ * libs/ops/cc/nms/nms_kernel.cu.cc:38-157), all on the device.  dets [N,5] = (x1, y1, x2, y2, score) fp32, N <= 65536.
+ * keep [N] int32 receives the ORIGINAL indices of the kept boxes in descending-score order (ties: higher index first, the
+ * order of a stable argsort reversed), num_out [1] their count.  workspace: papc_nms_workspace(N) bytes. */
+size_t papc_nms_workspace(int N);
+int papc_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *keep, int32_t *num_out, void *workspace,
+                 size_t workspace_bytes, papc_stream_t stream);
+
 /* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params. */
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,

@@ -486,3 +486,91 @@ def pillar_scatter(voxel_features, coords, batch_size, ny, nx):
             canvas[:, indices] = voxel_features[mask].T                             # :133-136
         out.append(canvas)
     return np.stack(out, 0).reshape(batch_size, C, ny, nx)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# axis-aligned bitmask NMS
+# ---------------------------------------------------------------------------------------------------------------------
+def nms_iou(a, b):
+    """iou_device, non_max_suppression/nms_gpu.py:22-34: fp32, boxes are inclusive pixel ranges (the "+1")."""
+    f = np.float32
+    one, zero = f(1.0), f(0.0)
+    left, right = max(a[0], b[0]), min(a[2], b[2])
+    top, bottom = max(a[1], b[1]), min(a[3], b[3])
+    width = max(f(f(right - left) + one), zero)
+    height = max(f(f(bottom - top) + one), zero)
+    inter = f(width * height)
+    sa = f(f(f(a[2] - a[0]) + one) * f(f(a[3] - a[1]) + one))
+    sb = f(f(f(b[2] - b[0]) + one) * f(f(b[3] - b[1]) + one))
+    return f(inter / f(f(sa + sb) - inter))
+
+
+def nms_mask(boxes, thresh):
+    """nms_kernel, nms_gpu.py:73-108: mask[i, j // 64] bit (j % 64) = IoU(i, j) > thresh for j after i (score-sorted boxes)."""
+    n = boxes.shape[0]
+    col_blocks = (n + 63) // 64
+    mask = np.zeros((n, col_blocks), np.uint64)
+    thresh = np.float32(thresh)
+    b = boxes.astype(np.float32)
+    for i in range(n):
+        for j in range(i + 1, n):                                    # start = tx + 1 on the diagonal block (:96-98)
+            if nms_iou(b[i], b[j]) > thresh:
+                mask[i, j // 64] |= np.uint64(1) << np.uint64(j % 64)
+    return mask
+
+
+def nms_postprocess(keep_out, mask_host, boxes_num):
+    """nms_gpu.py:111-127 (the sequential sweep).  Returns the number kept; keep_out[:n] = kept sorted positions."""
+    col_blocks = (boxes_num + 63) // 64
+    remv = np.zeros(col_blocks, np.uint64)
+    num_to_keep = 0
+    for i in range(boxes_num):
+        nblock, inblock = i // 64, i % 64
+        if not (remv[nblock] & (np.uint64(1) << np.uint64(inblock))):
+            keep_out[num_to_keep] = i
+            num_to_keep += 1
+            for j in range(nblock, col_blocks):
+                remv[j] |= mask_host[i * col_blocks + j]
+    return num_to_keep
+
+
+def nms_gpu(dets, nms_overlap_thresh):
+    """nms_gpu, nms_gpu.py:130-164.  dets [N,5] = (x1,y1,x2,y2,score).  Returns the kept ORIGINAL indices, best score first.
+    The source sorts with ``scores.argsort()[::-1]`` (numpy's default sort, tie order unspecified); the restatement and the
+    HIP path both use the stable sort reversed (ties: higher index first)."""
+    dets = np.asarray(dets, np.float32)
+    n = dets.shape[0]
+    if n == 0:
+        return []
+    order = dets[:, 4].argsort(kind="stable")[::-1]
+    boxes = dets[order]
+    mask = nms_mask(boxes, nms_overlap_thresh)
+    keep = np.zeros(n, np.int32)
+    num = nms_postprocess(keep, mask.reshape(-1), n)
+    return list(order[keep[:num]])
+
+
+def nms_vectorised(dets, thresh):
+    """Same result as nms_gpu with each kept row's IoUs computed by numpy fp32 array ops (for sizes the loops cannot reach)."""
+    dets = np.asarray(dets, np.float32)
+    n = dets.shape[0]
+    if n == 0:
+        return []
+    order = dets[:, 4].argsort(kind="stable")[::-1]
+    b = dets[order]
+    one = np.float32(1.0)
+    area = ((b[:, 2] - b[:, 0]) + one) * ((b[:, 3] - b[:, 1]) + one)
+    removed = np.zeros(n, bool)
+    keep = []
+    thr = np.float32(thresh)
+    for i in range(n):                                       # rows of removed boxes are never read by the sweep: skip them
+        if removed[i]:
+            continue
+        keep.append(i)
+        r = b[i + 1:]
+        w = np.maximum((np.minimum(b[i, 2], r[:, 2]) - np.maximum(b[i, 0], r[:, 0])) + one, np.float32(0))
+        h = np.maximum((np.minimum(b[i, 3], r[:, 3]) - np.maximum(b[i, 1], r[:, 1])) + one, np.float32(0))
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            removed[i + 1:] |= inter / ((area[i] + area[i + 1:]) - inter) > thr
+    return list(order[np.asarray(keep, np.int64)])

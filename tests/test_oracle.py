@@ -216,3 +216,25 @@ def test_pillar_scatter_last_duplicate_wins():
     out = R.pillar_scatter(f, coords, 2, 2, 2)
     assert out.shape == (2, 2, 2, 2)
     assert out[0, :, 1, 1].tolist() == [4, 5] and out[1, :, 0, 0].tolist() == [2, 3] and out.sum() == 4 + 5 + 2 + 3
+
+
+def test_nms_known_answers():
+    """nms_gpu restatement: hand-checked cases + literal bitmask path == vectorised path."""
+    # two heavy overlaps + one far box: IoU(a,b) = (10*11)/(121+121-110) = 0.833 with the +1 convention
+    dets = np.array([[0, 0, 10, 10, 0.9], [1, 0, 11, 10, 0.8], [100, 100, 110, 110, 0.7]], np.float32)
+    assert np.isclose(R.nms_iou(dets[0], dets[1]), 110.0 / 132.0)
+    assert [int(i) for i in R.nms_gpu(dets, 0.5)] == [0, 2]
+    assert [int(i) for i in R.nms_gpu(dets, 0.9)] == [0, 1, 2]
+    assert R.nms_gpu(np.zeros((0, 5), np.float32), 0.5) == []
+    # touching boxes still overlap by one pixel column under the +1 convention
+    t = np.array([[0, 0, 9, 9, 1.0], [9, 0, 18, 9, 0.5]], np.float32)
+    assert np.isclose(R.nms_iou(t[0], t[1]), 10.0 / 190.0)
+    rng = np.random.default_rng(3)
+    for n in (1, 64, 65, 150):
+        xy = rng.uniform(0, 60, (n, 2)); wh = rng.uniform(1, 30, (n, 2))
+        d = np.concatenate([xy, xy + wh, np.round(rng.uniform(0, 1, (n, 1)) * 16) / 16], 1).astype(np.float32)
+        a = [int(i) for i in R.nms_gpu(d, 0.4)]
+        b = [int(i) for i in R.nms_vectorised(d, 0.4)]
+        assert a == b and len(a) >= 1
+        m = R.nms_mask(d[d[:, 4].argsort(kind="stable")[::-1]], 0.4)
+        assert m.shape == (n, (n + 63) // 64)
