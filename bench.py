@@ -100,6 +100,7 @@ def main():
 
     from papc_amd import _lib
     from papc_amd.distributed import FlatAdam, FlatParams, init_from_env
+    from papc_amd.head import softmax_cross_entropy
     from papc_amd.models import PointNet2_SSG_Clas
     from papc_amd.synthetic import make_clouds, make_labels, make_start_idx
 
@@ -158,7 +159,7 @@ def main():
         # the FC head and their backward are small-grid kernels, so the 32 FPS workgroups run on idle CUs instead of
         # displacing workgroups of the chip-filling persistent MFMA grids
         logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap else None))
-        loss = F.cross_entropy(logits, y)
+        loss = softmax_cross_entropy(logits, y)
         loss.backward()
         scale = flat.allreduce_grads()
         opt.step(scale)
@@ -174,7 +175,7 @@ def main():
     def fwd_bwd():
         flat.zero_grad()
         logits = model(x, (s1, s2))
-        loss = F.cross_entropy(logits, y)
+        loss = softmax_cross_entropy(logits, y)
         loss.backward()
         return loss
 

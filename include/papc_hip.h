@@ -307,6 +307,26 @@ int papc_pillar_scatter_f32(const float *voxel_features, const int32_t *coords, 
 int papc_pillar_scatter_bwd_f32(const float *grad_canvas, const int32_t *coords, const int32_t *owner, int P, int C,
                                 int batch_size, int ny, int nx, float *grad_features, papc_stream_t stream);
 
+/* Classifier head (classify/pointnet2/pointnet2.py:17-23, :37-39 / :51-57, :71-73): one launch per layer each way.
+ * papc_head_fc_f32: out = [dropout(relu(bn_train(]x W^T + bias[)))]  for x [B,Cin], W [Cout,Cin] (nn.Linear as [out,in]), B <= 256,
+ * Cin % 4 == 0.  has_bn: train-mode BatchNorm1D over the B rows (biased variance, eps), running_mean/var updated with `momentum`
+ * (new = (1-m) old + m batch, unbiased variance; nullable), num_batches_tracked[0] += 1 (nullable); y [B,Cout] (linear output),
+ * mean/invstd [Cout] are saved for the backward.  Dropout p = drop_p in upscale_in_train mode from a counter-based hash of
+ * rng_state = {seed, counter} (device int64[2]; null or drop_p == 0: none); keep [B,Cout] (uint8, nullable) receives the mask;
+ * rng_bump (nullable, the same int64[2]): counter += 1 at the end of this launch -- pass it on the head's last layer.
+ * papc_head_bwd_f32 for layer l: g = gnext . wnext (gnext [B,Cn] = dY of layer l+1, wnext [Cn,Cout]; wnext null: g = gnext),
+ * has_bn: dropout/ReLU/BN backward from the saved forward -> dY_l (written to dy when non-null; dgamma, dbeta), else dY_l = g;
+ * x non-null: dw [Cout,Cin] = dY_l^T x, db [Cout] = column sums.  accumulate != 0 adds into dw/db/dgamma/dbeta.
+ * papc_softmax_xent_f32: loss[0] = mean cross-entropy of logits [B,C] with int64 labels, dlogits = (softmax - onehot)/B. */
+int papc_head_fc_f32(const float *x, const float *w, const float *bias, const float *gamma, const float *beta, int B, int Cin, int Cout,
+                     int has_bn, float eps, float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                     float drop_p, const int64_t *rng_state, int layer_tag, int64_t *rng_bump, float *y, float *mean, float *invstd,
+                     uint8_t *keep, float *out, papc_stream_t stream);
+int papc_head_bwd_f32(const float *gnext, const float *wnext, int Cn, const float *out, const float *y, const float *mean,
+                      const float *invstd, const float *gamma, float drop_p, int has_bn, const float *x, int B, int Cin, int Cout,
+                      float *dy, float *dw, float *db, float *dgamma, float *dbeta, int accumulate, papc_stream_t stream);
+int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int C, float *loss, float *dlogits, papc_stream_t stream);
+
 /* Axis-aligned bitmask NMS: nms_gpu of pointpillars/libs/ops/non_max_suppression/nms_gpu.py:130-164 (CUDA twin
  * libs/ops/cc/nms/nms_kernel.cu.cc:38-157), all on the device.  dets [N,5] = (x1, y1, x2, y2, score) fp32, N <= 65536.
  * keep [N] int32 receives the ORIGINAL indices of the kept boxes in descending-score order (ties: higher index first, the

@@ -82,6 +82,10 @@ SIGNATURES = {
     "papc_points_to_voxel_f32": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_pillar_scatter_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     "papc_pillar_scatter_bwd_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "papc_head_fc_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_f, c_p, c_i, c_p, c_p, c_p, c_p,
+                               c_p, c_p, c_p]),
+    "papc_head_bwd_f32": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "papc_softmax_xent_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "papc_nms_workspace": (ctypes.c_size_t, [c_i]),
     "papc_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_adam_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),

@@ -1,0 +1,391 @@
+// head.hip -- the classifier head behind the set-abstraction pyramid, for gfx950.
+//
+// Reference: /root/reference/PAPC/models/classify/pointnet2/pointnet2.py:17-23, :37-39 (SSG) and :51-57, :71-73 (MSG):
+//   x = drop1(relu(bn1(fc1(x))));  x = drop2(relu(bn2(fc2(x))));  x = fc3(x)      then softmax cross-entropy (mean).
+// B (the batch) is tens of rows, so every library op of this chain is a launch-latency-sized kernel (~60 of them, 9 % of the
+// training step).  Here a layer is ONE launch forward and ONE launch backward:
+//   forward   workgroup = 32 output channels x all B rows.  Linear on v_mfma_f32_32x32x2_f32 (fp32 products, fp32 accumulate)
+//             with the K range split over the 8 waves and summed in fixed order through LDS; train-mode BatchNorm statistics
+//             are column-local, so the same workgroup normalises, applies ReLU and dropout and updates the running statistics.
+//   backward  workgroup = 32 channels of layer l: g = dY_{l+1} . W_{l+1} (this tile's columns), dropout/ReLU/BN backward
+//             (again column-local) -> dY_l, then dW_l rows = dY_l^T . X_l, all in the one launch.
+// Dropout uses a counter-based hash of (seed, step counter, layer, element) read from device memory, so a captured hipGraph
+// draws fresh masks on every replay.
+#include "common.h"
+
+namespace papc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HT = 512;             // threads (8 waves)
+constexpr int HW = 8;               // waves: K split
+constexpr int HROWS_MAX = 256;      // batch rows a workgroup can hold in LDS
+constexpr int TP = 33;              // LDS tile pitch (floats)
+
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t counter, uint32_t tag, uint32_t idx)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (counter + 1) + ((uint64_t)tag << 40) + idx;   // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0,1)
+}
+
+// acc[] += A[rows r0.., k] * Bm[cols c0.., k] over the wave's share of K; both operands K-contiguous (row-major [*, K]).
+// lane: row/col = lane & 31, k half = lane >> 5; float4 loads give 4 MFMA steps (any k pairing is valid: the sum is over k).
+__device__ __forceinline__ void mfma_kcontig(f32x16 &acc, const float *__restrict__ A, int a_rows, int a_r0, const float *__restrict__ Bm,
+                                             int b_rows, int b_r0, int K, int wave, int lane)
+{
+    const int r = lane & 31, h = lane >> 5;
+    const int ar = a_r0 + r, br = b_r0 + r;
+    const bool a_ok = ar < a_rows, b_ok = br < b_rows;
+    const float *ap = A + (int64_t)(a_ok ? ar : 0) * K;
+    const float *bp = Bm + (int64_t)(b_ok ? br : 0) * K;
+    const int nblk = (K + 7) >> 3;
+    for (int blk = wave; blk < nblk; blk += HW) {
+        const int k = blk * 8 + 4 * h;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (k < K) {               // K % 4 == 0
+            a = *reinterpret_cast<const float4 *>(ap + k);
+            b = *reinterpret_cast<const float4 *>(bp + k);
+        }
+        if (!a_ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!b_ok) b = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+}
+
+// acc[] += G[rows r0.., n] * Wn[n, cols c0..] over the wave's share of n < Cn: G [rows, Cn] row-major (K-contiguous), Wn [Cn, ldw]
+__device__ __forceinline__ void mfma_g_times_w(f32x16 &acc, const float *__restrict__ G, int g_rows, int g_r0, const float *__restrict__ Wn,
+                                               int Cn, int ldw, int c0, int wave, int lane)
+{
+    const int r = lane & 31, h = lane >> 5;
+    const int gr = g_r0 + r, col = c0 + r;
+    const bool g_ok = gr < g_rows, c_ok = col < ldw;
+    const float *gp = G + (int64_t)(g_ok ? gr : 0) * Cn;
+    const float *wp = Wn + (c_ok ? col : 0);
+    const int nblk = (Cn + 7) >> 3;
+    for (int blk = wave; blk < nblk; blk += HW) {
+        const int n = blk * 8 + 4 * h;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (n < Cn) {              // Cn % 4 == 0
+            a = *reinterpret_cast<const float4 *>(gp + n);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[i] = wp[(int64_t)(n + i) * ldw];
+        }
+        if (!g_ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!c_ok) b[0] = b[1] = b[2] = b[3] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
+    }
+}
+
+// the 8 waves' partial 32x32 tiles -> tile[(row0 + r) * TP + c] summed in wave order (deterministic)
+__device__ __forceinline__ void reduce_waves_to_tile(const f32x16 &acc, float *red, float *tile, int row0, int wave, int lane, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        red[(wave * 32 + row) * TP + (lane & 31)] = acc[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < 1024; e += HT) {
+        const int row = e >> 5, c = e & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < HW; ++w) s += red[(w * 32 + row) * TP + c];
+        tile[(row0 + row) * TP + c] = s;
+    }
+    __syncthreads();
+}
+
+struct HeadFwd {
+    const float *x, *w, *bias, *gamma, *beta;
+    int B, Cin, Cout, has_bn;
+    float eps, momentum;
+    float *running_mean, *running_var;
+    int64_t *num_batches_tracked;
+    float drop_p;
+    const int64_t *rng_state;     // [seed, counter] on the device (null: no dropout)
+    int layer_tag;
+    int64_t *rng_bump;            // non-null: counter += 1 after this launch's reads (last layer of the head)
+    float *y, *mean, *invstd, *out;
+    uint8_t *keep;
+};
+
+__global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
+{
+    extern __shared__ float smem[];
+    float *red = smem;                          // [8*32][TP]
+    float *tile = smem + HW * 32 * TP;          // [Bpad][TP]
+    __shared__ float s_mean[32], s_scale[32], s_shift[32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c0 = blockIdx.x * 32;
+    const int nrb = (a.B + 31) >> 5;
+    for (int rb = 0; rb < nrb; ++rb) {
+        f32x16 acc = {0};
+        mfma_kcontig(acc, a.x, a.B, rb * 32, a.w, a.Cout, c0, a.Cin, wave, lane);
+        reduce_waves_to_tile(acc, red, tile, rb * 32, wave, lane, tid);
+    }
+    const int ncol = min(32, a.Cout - c0);
+    if (tid < 32) {
+        const int c = c0 + tid;
+        if (tid < ncol) {
+            const float bv = a.bias ? a.bias[c] : 0.f;
+            if (a.has_bn) {
+                float s = 0.f;
+                for (int b = 0; b < a.B; ++b) { tile[b * TP + tid] += bv; s += tile[b * TP + tid]; }
+                const float mean = s / (float)a.B;
+                float v = 0.f;
+                for (int b = 0; b < a.B; ++b) { const float d = tile[b * TP + tid] - mean; v += d * d; }
+                const float var = v / (float)a.B;
+                const float invstd = 1.0f / sqrtf(var + a.eps);
+                a.mean[c] = mean;
+                a.invstd[c] = invstd;
+                if (a.running_mean) {     // nn.BatchNorm1D train step: unbiased variance into the running estimate
+                    const float unb = a.B > 1 ? v / (float)(a.B - 1) : var;
+                    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+                    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+                }
+                s_mean[tid] = mean;
+                s_scale[tid] = invstd * a.gamma[c];
+                s_shift[tid] = a.beta[c];
+            } else {
+                for (int b = 0; b < a.B; ++b) tile[b * TP + tid] += bv;
+            }
+        }
+        if (tid == 0 && blockIdx.x == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
+    }
+    __syncthreads();
+    uint64_t seed = 0, counter = 0;
+    const bool drop = a.rng_state != nullptr && a.drop_p > 0.f;
+    if (drop) { seed = (uint64_t)a.rng_state[0]; counter = (uint64_t)a.rng_state[1]; }
+    const float keep_scale = drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    for (int e = tid; e < a.B * 32; e += HT) {
+        const int b = e >> 5, t = e & 31;
+        if (t >= ncol) continue;
+        const int64_t o = (int64_t)b * a.Cout + c0 + t;
+        const float yv = tile[b * TP + t];
+        if (a.y) a.y[o] = yv;
+        float v = yv;
+        if (a.has_bn) {
+            v = (yv - s_mean[t]) * s_scale[t] + s_shift[t];
+            v = fmaxf(v, 0.f);
+            bool k = true;
+            if (drop) k = hash_uniform(seed, counter, (uint32_t)a.layer_tag, (uint32_t)o) >= a.drop_p;
+            if (a.keep) a.keep[o] = k ? 1 : 0;
+            v = k ? v * keep_scale : 0.f;
+        }
+        a.out[o] = v;
+    }
+    if (a.rng_bump && blockIdx.x == 0 && tid == 0) a.rng_bump[1] += 1;   // stream order: every reader of this step is done or is this launch
+}
+
+struct HeadBwd {
+    const float *gnext;           // [B, Cn]: dY of the next layer (or dlogits)
+    const float *wnext;           // [Cn, Cout] next layer's weight, or null: g = gnext itself (then Cn == Cout)
+    int Cn;
+    const float *out, *y, *mean, *invstd, *gamma;   // this layer's saved forward (has_bn)
+    float keep_scale;
+    int has_bn;
+    const float *x;               // this layer's input [B, Cin], or null: no weight gradient
+    int B, Cin, Cout;
+    float *dy;                    // [B, Cout] or null
+    float *dw, *db, *dgamma, *dbeta;
+    int accumulate;
+};
+
+__global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
+{
+    extern __shared__ float smem[];
+    float *red = smem;                          // [8*32][TP]
+    float *gt = smem + HW * 32 * TP;            // [Bpad][TP]  g -> masked g -> dY (in place)
+    float *xh = gt + ((a.B + 31) & ~31) * TP;   // [Bpad][TP]  x-hat
+    __shared__ float s_k1[32], s_k2[32], s_k3[32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c0 = blockIdx.x * 32;
+    const int nrb = (a.B + 31) >> 5;
+    const int Bpad = nrb * 32;
+    const int ncol = min(32, a.Cout - c0);
+    if (a.wnext) {
+        for (int rb = 0; rb < nrb; ++rb) {
+            f32x16 acc = {0};
+            mfma_g_times_w(acc, a.gnext, a.B, rb * 32, a.wnext, a.Cn, a.Cout, c0, wave, lane);
+            reduce_waves_to_tile(acc, red, gt, rb * 32, wave, lane, tid);
+        }
+    } else {
+        for (int e = tid; e < Bpad * 32; e += HT) {
+            const int b = e >> 5, t = e & 31;
+            gt[b * TP + t] = (b < a.B && t < ncol) ? a.gnext[(int64_t)b * a.Cout + c0 + t] : 0.f;
+        }
+        __syncthreads();
+    }
+    if (a.has_bn) {
+        for (int e = tid; e < Bpad * 32; e += HT) {
+            const int b = e >> 5, t = e & 31;
+            float g = 0.f, h = 0.f;
+            if (b < a.B && t < ncol) {
+                const int64_t o = (int64_t)b * a.Cout + c0 + t;
+                g = a.out[o] > 0.f ? gt[b * TP + t] * a.keep_scale : 0.f;      // dropout (upscale_in_train) + ReLU backward
+                h = (a.y[o] - a.mean[c0 + t]) * a.invstd[c0 + t];
+            }
+            gt[b * TP + t] = g;
+            xh[b * TP + t] = h;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float sg = 0.f, sgx = 0.f;
+            for (int b = 0; b < a.B; ++b) { sg += gt[b * TP + tid]; sgx += gt[b * TP + tid] * xh[b * TP + tid]; }
+            if (tid < ncol) {
+                const int c = c0 + tid;
+                a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + sg;
+                a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + sgx;
+                s_k1[tid] = a.gamma[c] * a.invstd[c];
+            } else {
+                s_k1[tid] = 0.f;
+            }
+            s_k2[tid] = sg / (float)a.B;
+            s_k3[tid] = sgx / (float)a.B;
+        }
+        __syncthreads();
+        for (int e = tid; e < Bpad * 32; e += HT) {
+            const int b = e >> 5, t = e & 31;
+            float d = 0.f;
+            if (b < a.B && t < ncol) d = s_k1[t] * ((gt[b * TP + t] - s_k2[t]) - xh[b * TP + t] * s_k3[t]);
+            gt[b * TP + t] = d;
+        }
+        __syncthreads();
+    }
+    if (a.dy) {
+        for (int e = tid; e < a.B * 32; e += HT) {
+            const int b = e >> 5, t = e & 31;
+            if (t < ncol) a.dy[(int64_t)b * a.Cout + c0 + t] = gt[b * TP + t];
+        }
+    }
+    if (!a.x) return;
+    if (tid < ncol && a.db) {
+        float s = 0.f;
+        for (int b = 0; b < a.B; ++b) s += gt[b * TP + tid];
+        a.db[c0 + tid] = (a.accumulate ? a.db[c0 + tid] : 0.f) + s;
+    }
+    // dW[c0 + r, k] = sum_b dY[b, c0 + r] * X[b, k]: MFMA with the batch as K; one wave per 32-column block of Cin
+    const int r = lane & 31, h = lane >> 5;
+    for (int kb = wave; kb * 32 < a.Cin; kb += HW) {
+        const int kcol = kb * 32 + r;
+        const bool k_ok = kcol < a.Cin;
+        f32x16 acc = {0};
+        for (int b0 = 0; b0 < Bpad; b0 += 2) {
+            const int b = b0 + h;
+            const float av = gt[b * TP + r];                                           // rows >= B hold zeros
+            const float bv = (k_ok && b < a.B) ? a.x[(int64_t)b * a.Cin + kcol] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (row < ncol && k_ok) {
+                const int64_t o = (int64_t)(c0 + row) * a.Cin + kcol;
+                a.dw[o] = (a.accumulate ? a.dw[o] : 0.f) + acc[i];
+            }
+        }
+    }
+}
+
+// mean softmax cross-entropy + its gradient: loss = mean_b (logsumexp(z_b) - z_b[label_b]); dz = (softmax(z) - onehot) / B
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restrict__ z, const int64_t *__restrict__ label, int B, int C,
+                                                           float *__restrict__ loss, float *__restrict__ dz)
+{
+    __shared__ float part[256];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float *row = z + (int64_t)b * C;
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
+        const float lse = m + logf(s);
+        const int64_t y = label[b];
+        if (y >= 0 && y < C) acc += lse - row[y];
+        const float inv = 1.0f / (s * (float)B);
+        for (int c = 0; c < C; ++c) {
+            float g = expf(row[c] - m) * inv;
+            if (c == y) g -= 1.0f / (float)B;
+            dz[(int64_t)b * C + c] = g;
+        }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
+}
+
+}  // namespace papc
+
+using namespace papc;
+
+extern "C" {
+
+int papc_head_fc_f32(const float *x, const float *w, const float *bias, const float *gamma, const float *beta, int B, int Cin, int Cout,
+                     int has_bn, float eps, float momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                     float drop_p, const int64_t *rng_state, int layer_tag, int64_t *rng_bump, float *y, float *mean, float *invstd,
+                     uint8_t *keep, float *out, papc_stream_t stream)
+{
+    PAPC_REQUIRE(x && w && out, PAPC_E_INVALID, "papc_head_fc_f32: null pointer");
+    PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_fc_f32: B=%d not in [1, %d]", B, HROWS_MAX);
+    PAPC_REQUIRE(Cin >= 4 && Cin % 4 == 0 && Cout >= 1, PAPC_E_INVALID, "papc_head_fc_f32: Cin=%d must be a multiple of 4", Cin);
+    PAPC_REQUIRE(!has_bn || (gamma && beta && mean && invstd && y), PAPC_E_INVALID, "papc_head_fc_f32: BatchNorm needs gamma/beta/mean/invstd/y");
+    PAPC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, PAPC_E_INVALID, "papc_head_fc_f32: drop_p=%f", (double)drop_p);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    HeadFwd a{x, w, bias, gamma, beta, B, Cin, Cout, has_bn, eps, momentum, running_mean, running_var, num_batches_tracked,
+              drop_p, rng_state, layer_tag, rng_bump, y, mean, invstd, out, keep};
+    const int Bpad = (B + 31) & ~31;
+    const size_t lds = (size_t)(HW * 32 + Bpad) * TP * sizeof(float);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("papc_head_fc_f32: hipFuncSetAttribute");
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)cdiv(Cout, 32)), dim3(HT), lds, st, a);
+    return check_launch("papc_head_fc_f32");
+}
+
+int papc_head_bwd_f32(const float *gnext, const float *wnext, int Cn, const float *out, const float *y, const float *mean,
+                      const float *invstd, const float *gamma, float drop_p, int has_bn, const float *x, int B, int Cin, int Cout,
+                      float *dy, float *dw, float *db, float *dgamma, float *dbeta, int accumulate, papc_stream_t stream)
+{
+    PAPC_REQUIRE(gnext, PAPC_E_INVALID, "papc_head_bwd_f32: null pointer");
+    PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_bwd_f32: B=%d not in [1, %d]", B, HROWS_MAX);
+    PAPC_REQUIRE(Cout >= 1 && (!wnext || (Cn >= 4 && Cn % 4 == 0)), PAPC_E_INVALID, "papc_head_bwd_f32: Cn=%d must be a multiple of 4", Cn);
+    PAPC_REQUIRE(wnext || Cn == Cout, PAPC_E_INVALID, "papc_head_bwd_f32: without wnext, gnext must be [B, Cout]");
+    PAPC_REQUIRE(!has_bn || (out && y && mean && invstd && gamma && dgamma && dbeta), PAPC_E_INVALID, "papc_head_bwd_f32: BatchNorm backward needs the saved forward");
+    PAPC_REQUIRE(!x || (dw && Cin >= 1), PAPC_E_INVALID, "papc_head_bwd_f32: x without dw");
+    PAPC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, PAPC_E_INVALID, "papc_head_bwd_f32: drop_p=%f", (double)drop_p);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    HeadBwd a{gnext, wnext, Cn, out, y, mean, invstd, gamma, 1.0f / (1.0f - drop_p), has_bn, x, B, Cin, Cout, dy, dw, db, dgamma, dbeta, accumulate};
+    const int Bpad = (B + 31) & ~31;
+    const size_t lds = (size_t)(HW * 32 + 2 * Bpad) * TP * sizeof(float);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("papc_head_bwd_f32: hipFuncSetAttribute");
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)cdiv(Cout, 32)), dim3(HT), lds, st, a);
+    return check_launch("papc_head_bwd_f32");
+}
+
+int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int C, float *loss, float *dlogits, papc_stream_t stream)
+{
+    PAPC_REQUIRE(logits && labels && loss && dlogits, PAPC_E_INVALID, "papc_softmax_xent_f32: null pointer");
+    PAPC_REQUIRE(B >= 1 && C >= 1, PAPC_E_INVALID, "papc_softmax_xent_f32: B=%d C=%d", B, C);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, st, logits, labels, B, C, loss, dlogits);
+    return check_launch("papc_softmax_xent_f32");
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Classifier head of the PointNet++ classifiers as fused HIP launches (csrc/head.hip).
+
+Reference: PAPC/models/classify/pointnet2/pointnet2.py:17-23, :37-39 (SSG) / :51-57, :71-73 (MSG)
+    x = drop1(relu(bn1(fc1(x)))); x = drop2(relu(bn2(fc2(x)))); x = fc3(x)
+One launch per layer forward, one per layer backward (+ one for the input gradient); the library-op chain it replaces is ~60
+launch-latency-sized kernels per training step.  The ``nn.Linear`` / ``nn.BatchNorm1d`` / ``nn.Dropout`` modules stay the parameter
+holders (state_dict unchanged); eval mode and shapes outside the kernel's limits run the modules themselves.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .mlp import grad_targets_of
+
+MAX_ROWS = 256
+
+
+class HeadSpec:
+    """Per-model state of the fused head: dropout RNG state on the device, export of the dropout masks for tests."""
+
+    def __init__(self):
+        self.rng_state = None          # int64 [2] = (seed, counter), device
+        self.export_masks = False
+        self.masks = None              # (keep1, keep2) uint8 tensors of the last forward when export_masks
+        self.grad_targets = None
+
+    def state(self, device):
+        if self.rng_state is None or self.rng_state.device != device:
+            self.rng_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        return self.rng_state
+
+
+def usable(x, fc1, fc2, fc3, training):
+    return (training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= MAX_ROWS
+            and fc1.in_features % 4 == 0 and fc1.out_features % 4 == 0 and fc2.out_features % 4 == 0
+            and fc3.out_features % 4 == 0 and fc1.bias is not None and fc2.bias is not None and fc3.bias is not None)
+
+
+class _Head(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, bns, drops, x0, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3):
+        lib = _lib.load()
+        x0 = x0.contiguous()
+        B = x0.shape[0]
+        dev = x0.device
+        st = stream_ptr()
+        rng = spec.state(dev)
+        saved = []
+        x = x0
+        keeps = []
+        for li, (w, b, g, be, bn, p) in enumerate(((w1, b1, g1, be1, bns[0], drops[0]), (w2, b2, g2, be2, bns[1], drops[1]))):
+            cout, cin = w.shape
+            y = torch.empty(B, cout, device=dev, dtype=torch.float32)
+            out = torch.empty_like(y)
+            mean = torch.empty(cout, device=dev, dtype=torch.float32)
+            invstd = torch.empty_like(mean)
+            keep = torch.empty(B, cout, device=dev, dtype=torch.uint8) if spec.export_masks else None
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            track = bn.track_running_stats and bn.running_mean is not None
+            check(lib.papc_head_fc_f32(ptr(x), ptr(w), ptr(b), ptr(g), ptr(be), B, cin, cout, 1, float(bn.eps), mom,
+                                       ptr(bn.running_mean) if track else 0, ptr(bn.running_var) if track else 0,
+                                       ptr(bn.num_batches_tracked) if track and bn.num_batches_tracked is not None else 0,
+                                       float(p), ptr(rng), li + 1, 0, ptr(y), ptr(mean), ptr(invstd), ptr(keep), ptr(out), st),
+                  "papc_head_fc_f32")
+            saved += [y, mean, invstd, out]
+            keeps.append(keep)
+            x = out
+        cout, cin = w3.shape
+        logits = torch.empty(B, cout, device=dev, dtype=torch.float32)
+        check(lib.papc_head_fc_f32(ptr(x), ptr(w3), ptr(b3), 0, 0, B, cin, cout, 0, 0.0, 0.0, 0, 0, 0, 0.0, 0, 3, ptr(rng),
+                                   0, 0, 0, 0, ptr(logits), st), "papc_head_fc_f32")
+        spec.masks = tuple(keeps) if spec.export_masks else None
+        ctx.spec = spec
+        ctx.drops = drops
+        ctx.save_for_backward(x0, w1, g1, w2, g2, w3, *saved)
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        lib = _lib.load()
+        x0, w1, g1, w2, g2, w3, y1, mean1, invstd1, x1, y2, mean2, invstd2, x2 = ctx.saved_tensors
+        spec = ctx.spec
+        p1, p2 = ctx.drops
+        B = x0.shape[0]
+        dev = x0.device
+        st = stream_ptr()
+        glogits = glogits.contiguous().float()
+        tg = spec.grad_targets
+        acc = 1 if tg is not None else 0
+        if tg is None:
+            shapes = [w1.shape, (w1.shape[0],), (w1.shape[0],), (w1.shape[0],), w2.shape, (w2.shape[0],), (w2.shape[0],),
+                      (w2.shape[0],), w3.shape, (w3.shape[0],)]
+            tg = [torch.empty(s, device=dev, dtype=torch.float32) for s in shapes]
+        dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dw3, db3 = tg
+        c1, c0 = w1.shape
+        c2 = w2.shape[0]
+        c3 = w3.shape[0]
+        dy2 = torch.empty(B, c2, device=dev, dtype=torch.float32)
+        dy1 = torch.empty(B, c1, device=dev, dtype=torch.float32)
+        need_dx = ctx.needs_input_grad[3]
+        dx0 = torch.empty(B, c0, device=dev, dtype=torch.float32) if need_dx else None
+        f = lib.papc_head_bwd_f32
+        check(f(ptr(glogits), 0, c3, 0, 0, 0, 0, 0, 0.0, 0, ptr(x2), B, c2, c3, 0, ptr(dw3), ptr(db3), 0, 0, acc, st), "papc_head_bwd_f32")
+        check(f(ptr(glogits), ptr(w3), c3, ptr(x2), ptr(y2), ptr(mean2), ptr(invstd2), ptr(g2), float(p2), 1, ptr(x1), B, c1, c2,
+                ptr(dy2), ptr(dw2), ptr(db2), ptr(dg2), ptr(dbe2), acc, st), "papc_head_bwd_f32")
+        check(f(ptr(dy2), ptr(w2), c2, ptr(x1), ptr(y1), ptr(mean1), ptr(invstd1), ptr(g1), float(p1), 1, ptr(x0), B, c0, c1,
+                ptr(dy1), ptr(dw1), ptr(db1), ptr(dg1), ptr(dbe1), acc, st), "papc_head_bwd_f32")
+        if need_dx:
+            check(f(ptr(dy1), ptr(w1), c1, 0, 0, 0, 0, 0, 0.0, 0, 0, B, 0, c0, ptr(dx0), 0, 0, 0, 0, 0, st), "papc_head_bwd_f32")
+        grads = (None,) * 10 if acc else tuple(tg)
+        return (None, None, None, dx0) + grads
+
+
+def classifier_head(spec, x, fc1, bn1, drop1, fc2, bn2, drop2, fc3):
+    """logits = fc3(drop2(relu(bn2(fc2(drop1(relu(bn1(fc1(x)))))))))  in train mode, fused."""
+    params = (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias)
+    if spec.grad_targets is None and torch.is_grad_enabled():
+        spec.grad_targets = grad_targets_of(params)
+    return _Head.apply(spec, (bn1, bn2), (float(drop1.p), float(drop2.p)), x, *params)
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous().float()
+        labels = labels.contiguous().long()
+        B, C = logits.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        dz = torch.empty_like(logits)
+        check(_lib.load().papc_softmax_xent_f32(ptr(logits), ptr(labels), B, C, ptr(loss), ptr(dz), stream_ptr()), "papc_softmax_xent_f32")
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return dz * g, None
+
+
+def softmax_cross_entropy(logits, labels):
+    """Mean softmax cross-entropy of logits [B, C] with int64 labels [B] (paddle ``F.cross_entropy`` / torch default), one launch
+    that also produces the gradient."""
+    if not logits.is_cuda:
+        raise _lib.PapcError("softmax_cross_entropy needs CUDA (ROCm) tensors: there is no CPU fallback")
+    return _SoftmaxXent.apply(logits, labels.reshape(-1))

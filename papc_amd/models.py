@@ -13,7 +13,11 @@ import torch.nn.functional as F
 
 from .layers import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg, _bn_buffers,
                      _stack_params)
+from . import head as _head
 from .mlp import StackSpec, shared_mlp_max
+
+import os
+_FUSED_HEAD = os.environ.get("PAPC_NO_FUSED_HEAD") != "1"     # A/B switch: fused classifier head (head.py) vs the library-op chain
 
 
 def _starts(start_idx, n):
@@ -23,7 +27,21 @@ def _starts(start_idx, n):
     return list(start_idx)
 
 
-class PointNet2_SSG_Clas(nn.Module):
+class _ClasHead:
+    """fc1/bn1/drop1/fc2/bn2/drop2/fc3 (pointnet2.py:37-39): fused launches in train mode on the GPU (head.py), the modules otherwise."""
+
+    def _head(self, x):
+        spec = self.__dict__.get("_head_spec")
+        if spec is None:
+            spec = self.__dict__["_head_spec"] = _head.HeadSpec()
+        if _FUSED_HEAD and _head.usable(x, self.fc1, self.fc2, self.fc3, self.training):
+            return _head.classifier_head(spec, x, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3)
+        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
+        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
+        return self.fc3(x)
+
+
+class PointNet2_SSG_Clas(nn.Module, _ClasHead):
     def __init__(self, name_scope='PointNet2_SSG_Clas_', num_classes=16, normal_channel=False, reference_quirks=False):
         super().__init__()
         in_channel = 6 if normal_channel else 3
@@ -75,12 +93,10 @@ class PointNet2_SSG_Clas(nn.Module):
             after_sa2()
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
-        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
-        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
-        return self.fc3(x)
+        return self._head(x)
 
 
-class PointNet2_MSG_Clas(nn.Module):
+class PointNet2_MSG_Clas(nn.Module, _ClasHead):
     def __init__(self, name_scope='PointNet2_MSG_Clas_', num_classes=16, normal_channel=False, reference_quirks=False):
         super().__init__()
         in_channel = 3 if normal_channel else 0
@@ -111,9 +127,7 @@ class PointNet2_MSG_Clas(nn.Module):
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1])
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
-        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
-        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
-        return self.fc3(x)
+        return self._head(x)
 
 
 class PointNet_Basic_Clas(nn.Module):

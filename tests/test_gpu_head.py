@@ -1,0 +1,140 @@
+"""GPU parity: fused classifier head (csrc/head.hip) vs a float64 restatement of pointnet2.py:37-39 with the same dropout masks."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _modules(c0, c1, c2, c3, seed):
+    torch.manual_seed(seed)
+    fc1, bn1, fc2, bn2, fc3 = nn.Linear(c0, c1), nn.BatchNorm1d(c1), nn.Linear(c1, c2), nn.BatchNorm1d(c2), nn.Linear(c2, c3)
+    for bn in (bn1, bn2):
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+            bn.running_mean.uniform_(-0.1, 0.1)
+            bn.running_var.uniform_(0.8, 1.2)
+    return fc1, bn1, nn.Dropout(0.4), fc2, bn2, nn.Dropout(0.5), fc3
+
+
+def _ref64(x0, mods, keeps, glogits):
+    fc1, bn1, d1, fc2, bn2, d2, fc3 = mods
+    P = lambda t: t.detach().double().cpu().requires_grad_(True)
+    prm = [P(t) for t in (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias)]
+    x = P(x0)
+    h = x
+    stats = []
+    for (w, b, g, be), keep, p in ((prm[0:4], keeps[0], d1.p), (prm[4:8], keeps[1], d2.p)):
+        y = h @ w.t() + b
+        mean, var = y.mean(0), y.var(0, unbiased=False)
+        stats.append((mean.detach(), y.var(0, unbiased=True).detach()))
+        h = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * g + be) * keep.double().cpu() / (1.0 - p)
+    logits = h @ prm[8].t() + prm[9]
+    logits.backward(glogits.double().cpu())
+    return logits.detach(), x.grad, [t.grad for t in prm], stats
+
+
+@pytest.mark.parametrize("B,c3,accumulate", [(32, 40, False), (32, 40, True), (7, 16, False), (100, 40, True), (256, 8, False)])
+def test_head_matches_float64(B, c3, accumulate):
+    from papc_amd import head
+    mods = [m.cuda() for m in _modules(1024, 512, 256, c3, 3 + B)]
+    fc1, bn1, d1, fc2, bn2, d2, fc3 = mods
+    params = [fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias]
+    g0 = None
+    if accumulate:
+        g0 = []
+        for p in params:
+            p.grad = torch.randn_like(p) * 0.01
+            g0.append(p.grad.clone())
+    rm0 = [bn1.running_mean.clone(), bn1.running_var.clone(), bn2.running_mean.clone(), bn2.running_var.clone()]
+    x0 = torch.randn(B, 1024, device="cuda", requires_grad=True)
+    glog = torch.randn(B, c3, device="cuda")
+    spec = head.HeadSpec()
+    spec.export_masks = True
+    assert head.usable(x0, fc1, fc2, fc3, True)
+    logits = head.classifier_head(spec, x0, fc1, bn1, d1, fc2, bn2, d2, fc3)
+    keeps = spec.masks
+    logits.backward(glog)
+    torch.cuda.synchronize()
+    for k, p in zip(keeps, (0.4, 0.5)):
+        frac = k.float().mean().item()
+        assert abs(frac - (1 - p)) < 6.0 * (p * (1 - p) / k.numel()) ** 0.5 + 1e-3
+    want_logits, want_dx, want_g, stats = _ref64(x0, mods, keeps, glog)
+
+    def close(got, want, tol=1e-5):
+        got = got.detach().double().cpu()
+        scale = want.abs().max().item() + 1e-30
+        err = (got - want).abs().max().item() / scale
+        assert err <= tol, err
+
+    close(logits, want_logits)
+    close(x0.grad, want_dx, 2e-5)
+    for i, (p, w) in enumerate(zip(params, want_g)):
+        got = p.grad - g0[i] if accumulate else p.grad
+        if i in (1, 5):      # a bias feeding a train-mode BN: gradient is rounding noise around 0 in both implementations
+            assert got.abs().max().item() <= 1e-4 * (glog.abs().max().item() + 1)
+        else:
+            close(got, w, 5e-5 if accumulate else 2e-5)
+    m = 0.1
+    for (mean, unb), (rm, rv), bn in zip(stats, ((rm0[0], rm0[1]), (rm0[2], rm0[3])), (bn1, bn2)):
+        close(bn.running_mean, (1 - m) * rm.double().cpu() + m * mean)
+        close(bn.running_var, (1 - m) * rv.double().cpu() + m * unb)
+        assert int(bn.num_batches_tracked.item()) == 1
+
+
+def test_head_masks_advance_and_seed():
+    from papc_amd import head
+    mods = [m.cuda() for m in _modules(1024, 512, 256, 40, 1)]
+    x0 = torch.randn(32, 1024, device="cuda")
+    spec = head.HeadSpec()
+    spec.export_masks = True
+    head.classifier_head(spec, x0, *mods)
+    a = [k.clone() for k in spec.masks]
+    head.classifier_head(spec, x0, *mods)
+    b = [k.clone() for k in spec.masks]
+    assert int(spec.rng_state[1].item()) == 2
+    for ka, kb in zip(a, b):
+        assert (ka != kb).float().mean().item() > 0.3            # fresh masks every step
+    assert (a[0][:, :256] != a[1]).float().mean().item() > 0.3   # layers draw different streams
+    spec2 = head.HeadSpec()
+    spec2.export_masks = True
+    spec2.rng_state = torch.tensor([int(spec.rng_state[0].item()), 0], dtype=torch.int64, device="cuda")
+    head.classifier_head(spec2, x0, *mods)
+    assert all((k1 == k2).all() for k1, k2 in zip(a, spec2.masks))   # same (seed, counter) -> same masks
+
+
+@pytest.mark.parametrize("B,C", [(32, 40), (5, 16), (300, 7)])
+def test_softmax_cross_entropy(B, C):
+    from papc_amd.head import softmax_cross_entropy
+    torch.manual_seed(B)
+    z = (torch.randn(B, C, device="cuda") * 3).requires_grad_(True)
+    y = torch.randint(0, C, (B,), device="cuda")
+    loss = softmax_cross_entropy(z, y)
+    (loss * 1.7).backward()
+    z64 = z.detach().double().cpu().requires_grad_(True)
+    want = F.cross_entropy(z64, y.cpu())
+    (want * 1.7).backward()
+    assert abs(loss.item() - want.item()) <= 1e-5 * abs(want.item())
+    assert (z.grad.double().cpu() - z64.grad).abs().max().item() <= 1e-5 * z64.grad.abs().max().item()
+
+
+def test_model_uses_fused_head_and_trains():
+    """The SSG classifier routes its head through head.hip in train mode; eval mode and the A/B switch use the modules."""
+    from papc_amd.models import PointNet2_SSG_Clas
+    from papc_amd.head import softmax_cross_entropy
+    torch.manual_seed(0)
+    model = PointNet2_SSG_Clas(num_classes=40).cuda().train()
+    x = torch.randn(4, 3, 1024, device="cuda")
+    y = torch.randint(0, 40, (4,), device="cuda")
+    logits = model(x)
+    assert model._head_spec.rng_state is not None and int(model._head_spec.rng_state[1].item()) == 1
+    loss = softmax_cross_entropy(logits, y)
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad)
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    assert out.shape == (4, 40) and int(model._head_spec.rng_state[1].item()) == 1
