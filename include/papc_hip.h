@@ -145,8 +145,9 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
                       const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
                       int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
                       papc_stream_t stream);
-/* out[g,c] = relu(scale*(scale >= 0 ? gmax : gmin) + shift), argmax[g,c] = the matching row offset */
-int papc_bn_select_max_f32(const float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
+/* out[g,c] = relu(scale*(scale >= 0 ? gmax : gmin) + shift), argmax[g,c] = the matching row offset.  On return gmax holds the
+ * SELECTED raw value (ysel: y at the argmax) -- pass it to papc_bn_bwd_reduce_f32 (MAX) so the backward need not gather y. */
+int papc_bn_select_max_f32(float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
                            const float *scale, const float *shift, int64_t G, int C, float *out, int32_t *argmax,
                            papc_stream_t stream);
 
@@ -177,7 +178,8 @@ int papc_bn_relu_f32(const float *y, const float *scale, const float *shift, int
 
 /* Per-channel reductions of the BN+ReLU backward: with p = dz * (scale*y+shift > 0),
  * partial[t] = (sum p, sum p*xhat) over the t-th of n_parts contiguous row ranges, xhat = (y-mean)*invstd.
- * DENSE: dz [M,C]; MAX: gout [M/K,C] + argmax.  red_partial [n_parts,2,C] (caller picks n_parts <= 1024). */
+ * DENSE: dz [M,C]; MAX: gout [M/K,C] + argmax, and dz = NULL (y is gathered at the argmax) or dz = ysel [M/K,C], the raw y at
+ * the argmax as left in gmax by papc_bn_select_max_f32.  red_partial [n_parts,2,C] (caller picks n_parts <= 1024). */
 int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, const int32_t *argmax, int K,
                            const float *y, const float *mean, const float *invstd, const float *scale,
                            const float *shift, int64_t M, int C, int n_parts, float *red_partial,
@@ -334,6 +336,10 @@ int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int
 size_t papc_nms_workspace(int N);
 int papc_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *keep, int32_t *num_out, void *workspace,
                  size_t workspace_bytes, papc_stream_t stream);
+
+/* count <= 8 row-major fp32 matrices transposed in one launch: dst[i] [cols[i], rows[i]] = src[i] [rows[i], cols[i]]^T.  The four
+ * arrays are HOST arrays (read during the call); the matrices are device memory.  Used for the W^T operands of a stack's dX GEMMs. */
+int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream);
 
 /* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params. */
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void bn_select_max_kernel(const float *__restrict__ gmax, const float *__restrict__ gmin,
+__global__ __launch_bounds__(256) void bn_select_max_kernel(float *__restrict__ gmax, const float *__restrict__ gmin,
                                                             const int32_t *__restrict__ amax, const int32_t *__restrict__ amin,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
                                                             int64_t total, int C, float *__restrict__ out, int32_t *__restrict__ argmax)
@@ -106,7 +106,9 @@ __global__ __launch_bounds__(256) void bn_select_max_kernel(const float *__restr
         const int c = (int)(e % C);
         const float sc = scale[c], sh = shift[c];
         const bool up = sc >= 0.f;   // relu(sc*y+sh) is non-decreasing in y for sc >= 0, non-increasing otherwise
-        out[e] = fmaxf(fmaf(sc, up ? gmax[e] : gmin[e], sh), 0.f);
+        const float sel = up ? gmax[e] : gmin[e];
+        out[e] = fmaxf(fmaf(sc, sel, sh), 0.f);
+        gmax[e] = sel;               // the raw pre-BN value behind out[e]: the backward reductions read it instead of gathering y
         if (argmax) argmax[e] = up ? amax[e] : amin[e];
     }
 }
@@ -160,10 +162,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
             for (int64_t u = u0 + rl; u < u1; u += RL) {
                 if (MAXMODE) {
                     const Vec<V> g = Vec<V>::load(gout + u * C + c);
+                    Vec<V> ys;
+                    if (dz) {        // MAX mode: dz carries ysel [M/K, C], the raw y at the argmax (papc_bn_select_max_f32)
+                        ys = Vec<V>::load(dz + u * C + c);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < V; ++i) ys[i] = y[(u * K + argmax[u * C + c + i]) * (int64_t)C + c + i];
+                    }
 #pragma unroll
                     for (int i = 0; i < V; ++i) {
-                        const int am = argmax[u * C + c + i];
-                        const float yv = y[(u * K + am) * (int64_t)C + c + i];
+                        const float yv = ys[i];
                         const float z = fmaf(sc[i], yv, sh[i]);
                         const float p = z > 0.f ? g[i] : 0.f;
                         a1[i] += p;
@@ -235,8 +243,18 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
     const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
     const int64_t i = (int64_t)blockIdx.x * 64 + el;
     float s = 0.f;
-    if (i < n)
-        for (int t = cl; t < n_chunks; t += 16) s += part[(int64_t)t * ld + i];
+    if (i < n) {
+        for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {     // 8 loads in flight per lane; summed in chunk order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + 16 * j;
+                v[j] = part[(int64_t)(t < n_chunks ? t : t0) * ld + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (t0 + 16 * j < n_chunks) ? v[j] : 0.f;
+        }
+    }
     red[cl][el] = s;
     __syncthreads();
     if (cl == 0 && i < n) {
@@ -244,6 +262,41 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
         for (int g = 1; g < 16; ++g) s += red[g][el];
         float *o = i < n1 ? out + i : out2 + (i - n1);  // elements [0,n1) -> out, [n1,n) -> out2
         *o = accumulate ? *o + s : s;
+    }
+}
+
+// few chunks of many elements (the group_all layers): a lane owns 4 consecutive elements, the 4 waves of a workgroup split the
+// chunks; n1, ld multiples of 4 and 16-byte aligned pointers
+__global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float *__restrict__ part, int n_chunks, int64_t n, int64_t ld,
+                                                                   float *__restrict__ out, int64_t n1, float *__restrict__ out2,
+                                                                   int accumulate)
+{
+    __shared__ float4 red[4][64];
+    const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + el) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        for (int t0 = cl; t0 < n_chunks; t0 += 4 * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + 4 * j;
+                v[j] = *reinterpret_cast<const float4 *>(part + (int64_t)(t < n_chunks ? t : t0) * ld + i);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (t0 + 4 * j < n_chunks) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+            }
+        }
+    }
+    red[cl][el] = s;
+    __syncthreads();
+    if (cl == 0 && i < n) {
+#pragma unroll
+        for (int g = 1; g < 4; ++g) { const float4 r = red[g][el]; s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w; }
+        float4 *o = reinterpret_cast<float4 *>(i < n1 ? out + i : out2 + (i - n1));
+        if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+        *o = s;
     }
 }
 
@@ -262,7 +315,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 
 static inline unsigned ew_grid(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 256 * 16)); }
 
+// up to 8 small row-major matrices transposed in one launch (the W^T operands of a stack's dX GEMMs)
+struct TransposeBatch {
+    const float *src[8];
+    float *dst[8];
+    int rows[8], cols[8];
+};
+
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch t)
+{
+    __shared__ float tile[32][33];
+    const int m = blockIdx.y;
+    const int rows = t.rows[m], cols = t.cols[m];
+    const int tiles_c = (cols + 31) >> 5, tiles = ((rows + 31) >> 5) * tiles_c;
+    const float *__restrict__ src = t.src[m];
+    float *__restrict__ dst = t.dst[m];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int tl = blockIdx.x; tl < tiles; tl += gridDim.x) {
+        const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + ty + 8 * i, c = c0 + tx;
+            tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;
+            if (r < rows && c < cols) dst[(int64_t)c * rows + r] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace papc
+
 
 using namespace papc;
 
@@ -295,7 +382,7 @@ int papc_bn_relu_max_f32(const float *y, const float *scale, const float *shift,
     return check_launch("papc_bn_relu_max_f32");
 }
 
-int papc_bn_select_max_f32(const float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
+int papc_bn_select_max_f32(float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
                            const float *scale, const float *shift, int64_t G, int C, float *out, int32_t *argmax,
                            papc_stream_t stream)
 {
@@ -334,7 +421,7 @@ int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, cons
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, false>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
     } else {
         PAPC_REQUIRE(gout && argmax && K >= 1 && M % K == 0, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: MAX needs gout/argmax and K | M");
-        const bool v4 = (C % 4 == 0) && aligned16(gout) && aligned16(mean) && aligned16(invstd) && aligned16(scale) && aligned16(shift);
+        const bool v4 = (C % 4 == 0) && aligned16(gout) && (!dz || aligned16(dz)) && aligned16(mean) && aligned16(invstd) && aligned16(scale) && aligned16(shift);
         if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, true>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
     }
@@ -360,7 +447,12 @@ int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, in
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
     const int64_t n = n1 + n2;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, ld, out1, n1, out2, accumulate);
+    const bool wide = n_chunks <= 64 && n >= 16384 && n1 % 4 == 0 && n2 % 4 == 0 && ld % 4 == 0 && aligned16(partial) && aligned16(out1) &&
+                      (n2 == 0 || aligned16(out2));
+    if (wide)
+        hipLaunchKernelGGL(reduce_partials_wide_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, partial, n_chunks, n, ld, out1, n1, out2, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, ld, out1, n1, out2, accumulate);
     return check_launch("papc_reduce_partials2_f32");
 }
 
@@ -372,6 +464,23 @@ int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, floa
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, n, out, n, (float *)nullptr, accumulate);
     return check_launch("papc_reduce_partials_f32");
+}
+
+int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream)
+{
+    PAPC_REQUIRE(src && dst && rows && cols, PAPC_E_INVALID, "papc_transpose_batch_f32: null pointer");
+    PAPC_REQUIRE(count >= 1 && count <= 8, PAPC_E_INVALID, "papc_transpose_batch_f32: count=%d not in [1, 8]", count);
+    TransposeBatch t{};
+    int max_tiles = 1;
+    for (int i = 0; i < count; ++i) {
+        PAPC_REQUIRE(src[i] && dst[i] && rows[i] >= 1 && cols[i] >= 1, PAPC_E_INVALID, "papc_transpose_batch_f32: bad entry %d", i);
+        t.src[i] = src[i]; t.dst[i] = dst[i]; t.rows[i] = rows[i]; t.cols[i] = cols[i];
+        max_tiles = std::max(max_tiles, (int)(cdiv(rows[i], 32) * cdiv(cols[i], 32)));
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)std::min(max_tiles, 512), (unsigned)count), dim3(256), 0, st, t);
+    return check_launch("papc_transpose_batch_f32");
 }
 
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,

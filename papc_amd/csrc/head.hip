@@ -42,19 +42,30 @@ __device__ __forceinline__ void mfma_kcontig(f32x16 &acc, const float *__restric
     const float *ap = A + (int64_t)(a_ok ? ar : 0) * K;
     const float *bp = Bm + (int64_t)(b_ok ? br : 0) * K;
     const int nblk = (K + 7) >> 3;
-    for (int blk = wave; blk < nblk; blk += HW) {
-        const int k = blk * 8 + 4 * h;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (k < K) {               // K % 4 == 0
-            a = *reinterpret_cast<const float4 *>(ap + k);
-            b = *reinterpret_cast<const float4 *>(bp + k);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int NB = 8;
+    // a wave owns a CONTIGUOUS k range (its consecutive 32-byte pieces share cache lines); NB blocks per trip: all 2*NB loads
+    // in flight before the first MFMA
+    const int per = (nblk + HW - 1) / HW, blk_end = min(nblk, (wave + 1) * per);
+    for (int blk0 = wave * per; blk0 < blk_end; blk0 += NB) {
+        float4 a[NB], b[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int k = (blk0 + j < blk_end ? blk0 + j : nblk) * 8 + 4 * h;        // K % 4 == 0
+            const int kc = k < K ? k : 0;
+            a[j] = *reinterpret_cast<const float4 *>(ap + kc);
+            b[j] = *reinterpret_cast<const float4 *>(bp + kc);
         }
-        if (!a_ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!b_ok) b = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int k = (blk0 + j < blk_end ? blk0 + j : nblk) * 8 + 4 * h;
+            const float4 av = (k < K && a_ok) ? a[j] : zero4;
+            const float4 bv = (k < K && b_ok) ? b[j] : zero4;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+        }
     }
 }
 
@@ -68,21 +79,29 @@ __device__ __forceinline__ void mfma_g_times_w(f32x16 &acc, const float *__restr
     const float *gp = G + (int64_t)(g_ok ? gr : 0) * Cn;
     const float *wp = Wn + (c_ok ? col : 0);
     const int nblk = (Cn + 7) >> 3;
-    for (int blk = wave; blk < nblk; blk += HW) {
-        const int n = blk * 8 + 4 * h;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (n < Cn) {              // Cn % 4 == 0
-            a = *reinterpret_cast<const float4 *>(gp + n);
+    const int per = (nblk + HW - 1) / HW, blk_end = min(nblk, (wave + 1) * per);
+    for (int blk0 = wave * per; blk0 < blk_end; blk0 += 2) {  // contiguous n range per wave, 2 blocks per trip, loads first
+        float4 a[2];
+        float b[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) b[i] = wp[(int64_t)(n + i) * ldw];
+        for (int j = 0; j < 2; ++j) {
+            const int n = (blk0 + j < blk_end ? blk0 + j : nblk) * 8 + 4 * h;        // Cn % 4 == 0
+            const int nc = n < Cn ? n : 0;
+            a[j] = *reinterpret_cast<const float4 *>(gp + nc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[j][i] = wp[(int64_t)(nc + i) * ldw];
         }
-        if (!g_ok) a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!c_ok) b[0] = b[1] = b[2] = b[3] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = (blk0 + j < blk_end ? blk0 + j : nblk) * 8 + 4 * h;
+            const bool ok = n < Cn;
+            const float4 av = (ok && g_ok) ? a[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool bk = ok && c_ok;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bk ? b[j][0] : 0.f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bk ? b[j][1] : 0.f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bk ? b[j][2] : 0.f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bk ? b[j][3] : 0.f, acc, 0, 0, 0);
+        }
     }
 }
 
@@ -134,31 +153,41 @@ __global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
         reduce_waves_to_tile(acc, red, tile, rb * 32, wave, lane, tid);
     }
     const int ncol = min(32, a.Cout - c0);
-    if (tid < 32) {
-        const int c = c0 + tid;
-        if (tid < ncol) {
-            const float bv = a.bias ? a.bias[c] : 0.f;
-            if (a.has_bn) {
-                float s = 0.f;
-                for (int b = 0; b < a.B; ++b) { tile[b * TP + tid] += bv; s += tile[b * TP + tid]; }
-                const float mean = s / (float)a.B;
-                float v = 0.f;
-                for (int b = 0; b < a.B; ++b) { const float d = tile[b * TP + tid] - mean; v += d * d; }
-                const float var = v / (float)a.B;
-                const float invstd = 1.0f / sqrtf(var + a.eps);
-                a.mean[c] = mean;
-                a.invstd[c] = invstd;
-                if (a.running_mean) {     // nn.BatchNorm1D train step: unbiased variance into the running estimate
-                    const float unb = a.B > 1 ? v / (float)(a.B - 1) : var;
-                    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-                    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
-                }
-                s_mean[tid] = mean;
-                s_scale[tid] = invstd * a.gamma[c];
-                s_shift[tid] = a.beta[c];
-            } else {
-                for (int b = 0; b < a.B; ++b) tile[b * TP + tid] += bv;
+    {   // 8 threads per channel: bias, then mean and centred second moment in two passes over the LDS column
+        __shared__ float s_part[8][32];
+        const int t = tid & 31, q = tid >> 5;             // q < 16; the upper 8 groups idle
+        const bool act = q < 8 && t < ncol;
+        const float bv = (act && a.bias) ? a.bias[c0 + t] : 0.f;
+        float sacc = 0.f;
+        if (act) for (int b = q; b < a.B; b += 8) { const float v = tile[b * TP + t] + bv; tile[b * TP + t] = v; sacc += v; }
+        if (q < 8) s_part[q][t] = sacc;
+        __syncthreads();
+        float mean = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mean += s_part[i][t];
+        mean /= (float)a.B;
+        __syncthreads();
+        float vacc = 0.f;
+        if (act && a.has_bn) for (int b = q; b < a.B; b += 8) { const float d = tile[b * TP + t] - mean; vacc += d * d; }
+        if (q < 8) s_part[q][t] = vacc;
+        __syncthreads();
+        if (tid < ncol && a.has_bn) {
+            const int c = c0 + tid;
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v += s_part[i][tid];
+            const float var = v / (float)a.B;
+            const float invstd = 1.0f / sqrtf(var + a.eps);
+            a.mean[c] = mean;
+            a.invstd[c] = invstd;
+            if (a.running_mean) {     // nn.BatchNorm1D train step: unbiased variance into the running estimate
+                const float unb = a.B > 1 ? v / (float)(a.B - 1) : var;
+                a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
             }
+            s_mean[tid] = mean;
+            s_scale[tid] = invstd * a.gamma[c];
+            s_shift[tid] = a.beta[c];
         }
         if (tid == 0 && blockIdx.x == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
     }
@@ -244,8 +273,10 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
             for (int b = 0; b < a.B; ++b) { sg += gt[b * TP + tid]; sgx += gt[b * TP + tid] * xh[b * TP + tid]; }
             if (tid < ncol) {
                 const int c = c0 + tid;
-                a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + sg;
-                a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + sgx;
+                if (blockIdx.y == 0) {
+                    a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + sg;
+                    a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + sgx;
+                }
                 s_k1[tid] = a.gamma[c] * a.invstd[c];
             } else {
                 s_k1[tid] = 0.f;
@@ -262,37 +293,51 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
         }
         __syncthreads();
     }
-    if (a.dy) {
+    const bool first = blockIdx.y == 0;          // the column-split workgroups recompute dY; only the first one publishes it
+    if (a.dy && first) {
         for (int e = tid; e < a.B * 32; e += HT) {
             const int b = e >> 5, t = e & 31;
             if (t < ncol) a.dy[(int64_t)b * a.Cout + c0 + t] = gt[b * TP + t];
         }
     }
     if (!a.x) return;
-    if (tid < ncol && a.db) {
+    if (first && tid < ncol && a.db) {
         float s = 0.f;
         for (int b = 0; b < a.B; ++b) s += gt[b * TP + tid];
         a.db[c0 + tid] = (a.accumulate ? a.db[c0 + tid] : 0.f) + s;
     }
-    // dW[c0 + r, k] = sum_b dY[b, c0 + r] * X[b, k]: MFMA with the batch as K; one wave per 32-column block of Cin
+    // dW[c0 + r, k] = sum_b dY[b, c0 + r] * X[b, k]: MFMA with the batch as K; one wave per 32-column block of Cin, the
+    // column blocks dealt round-robin over (blockIdx.y, wave)
     const int r = lane & 31, h = lane >> 5;
-    for (int kb = wave; kb * 32 < a.Cin; kb += HW) {
+    for (int kb = blockIdx.y * HW + wave; kb * 32 < a.Cin; kb += HW * gridDim.y) {
         const int kcol = kb * 32 + r;
         const bool k_ok = kcol < a.Cin;
+        const float *xp = a.x + (k_ok ? kcol : 0);
         f32x16 acc = {0};
-        for (int b0 = 0; b0 < Bpad; b0 += 2) {
-            const int b = b0 + h;
-            const float av = gt[b * TP + r];                                           // rows >= B hold zeros
-            const float bv = (k_ok && b < a.B) ? a.x[(int64_t)b * a.Cin + kcol] : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        float prev[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {          // the accumulate target: issued before the MFMA chain, consumed after it
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            prev[i] = (a.accumulate && row < ncol && k_ok) ? a.dw[(int64_t)(c0 + row) * a.Cin + kcol] : 0.f;
+        }
+        for (int b0 = 0; b0 < Bpad; b0 += 32) {
+            float bv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int b = b0 + 2 * j + h;
+                bv[j] = xp[(int64_t)(b < a.B ? b : 0) * a.Cin];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int b = b0 + 2 * j + h;
+                const float av = gt[b * TP + r];                                       // rows >= B hold zeros
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, (k_ok && b < a.B) ? bv[j] : 0.f, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (row < ncol && k_ok) {
-                const int64_t o = (int64_t)(c0 + row) * a.Cin + kcol;
-                a.dw[o] = (a.accumulate ? a.dw[o] : 0.f) + acc[i];
-            }
+            if (row < ncol && k_ok) a.dw[(int64_t)(c0 + row) * a.Cin + kcol] = prev[i] + acc[i];
         }
     }
 }
@@ -374,7 +419,8 @@ int papc_head_bwd_f32(const float *gnext, const float *wnext, int Cn, const floa
     const size_t lds = (size_t)(HW * 32 + 2 * Bpad) * TP * sizeof(float);
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return check_launch("papc_head_bwd_f32: hipFuncSetAttribute");
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)cdiv(Cout, 32)), dim3(HT), lds, st, a);
+    const int nsplit = x ? std::min(8, std::max(1, (int)cdiv(cdiv(Cin, 32), HW))) : 1;   // dW column blocks: one per wave where possible
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)cdiv(Cout, 32), (unsigned)nsplit), dim3(HT), lds, st, a);
     return check_launch("papc_head_bwd_f32");
 }
 

@@ -150,7 +150,8 @@ class SharedMLPMax(torch.autograd.Function):
         ctx.feats_needs_grad = feats is not None and feats.requires_grad and not spec.cut_gather_grad
         ctx.x_needs_grad = plain and x_rows.requires_grad
         ctx.cin0 = cin0
-        ctx.save_for_backward(xyz, new_xyz, feats, idx, x_rows, argmax, *params, *ys, *consts)
+        ysel = gbuf_f[0] if (spec.pool and gm_ref is not None) else None   # raw y at the argmax (left in gmax by select_max)
+        ctx.save_for_backward(xyz, new_xyz, feats, idx, x_rows, argmax, ysel, *params, *ys, *consts)
         return out
 
     @staticmethod
@@ -159,10 +160,10 @@ class SharedMLPMax(torch.autograd.Function):
         st = stream_ptr()
         spec, L = ctx.spec, ctx.L
         saved = ctx.saved_tensors
-        xyz, new_xyz, feats, idx, x_rows, argmax = saved[:6]
-        params = saved[6:6 + 4 * L]
-        ys = saved[6 + 4 * L: 6 + 5 * L]
-        consts = saved[6 + 5 * L: 6 + 6 * L]
+        xyz, new_xyz, feats, idx, x_rows, argmax, ysel = saved[:7]
+        params = saved[7:7 + 4 * L]
+        ys = saved[7 + 4 * L: 7 + 5 * L]
+        consts = saved[7 + 5 * L: 7 + 6 * L]
         plain = x_rows is not None
         dev = gout.device
         M = spec.M
@@ -175,11 +176,25 @@ class SharedMLPMax(torch.autograd.Function):
         dz = None
         fused_red = None
         gemm_parts = lib.papc_mlp_gemm_parts(M)
+        # W^T operands of every dX GEMM of the stack: one batched transpose launch
+        need_wt = [l for l in range(L) if l > 0 or (plain and ctx.x_needs_grad) or ((not plain) and ctx.feats_needs_grad)]
+        wts = {}
+        for g0 in range(0, len(need_wt), 8):
+            grp_l = need_wt[g0:g0 + 8]
+            n = len(grp_l)
+            srcs, dsts, rws, cls = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+            for i, l in enumerate(grp_l):
+                w = params[4 * l]
+                cout = w.shape[0]
+                cin = ctx.cin0 if l == 0 else params[4 * (l - 1)].shape[0]
+                assert w.is_contiguous()
+                wts[l] = torch.empty(cin, cout, device=dev, dtype=torch.float32)
+                srcs[i], dsts[i], rws[i], cls[i] = w.data_ptr(), wts[l].data_ptr(), cout, cin
+            check(lib.papc_transpose_batch_f32(srcs, dsts, rws, cls, n, st), "papc_transpose_batch_f32")
         for l in range(L - 1, -1, -1):
             w = params[4 * l]
             cout = w.shape[0]
             cin = ctx.cin0 if l == 0 else params[4 * (l - 1)].shape[0]
-            w2 = w.reshape(cout, cin)
             cst = consts[l]
             c12 = torch.empty(2, cout, device=dev, dtype=torch.float32)
             tgt = spec.grad_targets[4 * l: 4 * l + 4] if spec.grad_targets is not None else None
@@ -201,7 +216,8 @@ class SharedMLPMax(torch.autograd.Function):
             dy.c1, dy.c2 = c12[0].data_ptr(), c12[1].data_ptr()
             if fused_red is None:   # (sum p, sum p*xhat): separate pass, unless the dX kernel of layer l+1 already produced it
                 red, red_parts = torch.empty(n_parts, 2, cout, device=dev, dtype=torch.float32), n_parts
-                check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
+                red_dz = ptr(ysel) if dy.dz_mode == DZ_MAX else dy.dz
+                check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, red_dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
                                                  dy.shift, M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
             else:
                 red, red_parts = fused_red, gemm_parts
@@ -238,7 +254,7 @@ class SharedMLPMax(torch.autograd.Function):
             # ---- dX
             fused_red = None
             if l > 0:
-                wt = w2.t().contiguous()
+                wt = wts[l]
                 dz_prev = torch.empty(M, cin, device=dev, dtype=torch.float32)
                 # the dX kernel also accumulates layer l-1's BN-backward reductions over the dz it produces
                 nr_ref = None
@@ -254,11 +270,11 @@ class SharedMLPMax(torch.autograd.Function):
                       "papc_mlp_bwd_dx_f32")
                 dz = dz_prev
             elif plain and ctx.x_needs_grad:
-                wt = w2.t().contiguous()
+                wt = wts[l]
                 grad_x = torch.empty(M, cin, device=dev, dtype=torch.float32)
                 check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(grad_x), None, None, st), "papc_mlp_bwd_dx_f32")
             elif (not plain) and ctx.feats_needs_grad:
-                wt = w2.t().contiguous()
+                wt = wts[l]
                 grad_feats = torch.zeros(spec.B, spec.N, spec.D, device=dev, dtype=torch.float32)
                 sc = ScatterDst()
                 sc.grad_feats, sc.idx = grad_feats.data_ptr(), ptr(idx)
