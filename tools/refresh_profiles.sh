@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collect the round's profile evidence on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
+# then summarise locally with tools/refresh_profiles_local.sh.  PMC passes are separate runs with --kernel-trace only.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+mkdir -p $O
+timeout 400 python bench.py > $O/bench_line.json 2> $O/bench_line.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o run -- python bench.py --no-cpu-baseline --steps 50 --warmup 10 > $O/prof_stats.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_$c.log 2>&1
+done
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_sq.log 2>&1
+find $O -name "*.csv" | head -30
+tail -c 300 $O/bench_line.json

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Turn gpurun_out/ of tools/refresh_profiles.sh into the committed summaries under profiles/ (round tag = $1, default r01).
+R=${1:-r01}
+O=gpurun_out
+P=profiles
+cp $O/prof_stats/run_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
+grep "^{" $O/bench_line.json > $P/${R}_bench_line.json
+{
+  echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, with --kernel-trace only) of: python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2"
+  echo "# values are KB per dispatch as reported; FETCH_SIZE must be DOUBLED on gfx950 (MI355X_MICROARCH.md, HBM section) -- calibrated in this repo on"
+  echo "# bn_relu_max / bn_bwd_reduce-type streaming kernels whose traffic is known exactly (reported 131 MB vs 268 MB streamed)."
+  echo "# kernel names: gemm_kernel<AMODE, EPI, VEC, WGM, WGN, WM, WN, DEPTH, BF3, WS, TL>; dw_ws_kernel<XMODE, DYMODE, NTO, NTI>; dw_kernel<...> = f32-MFMA dW (gather layers)"
+  python tools/pmc_summary.py $O/pmc_FETCH_SIZE 24
+  python tools/pmc_summary.py $O/pmc_WRITE_SIZE 24
+} > $P/${R}_bench_pmc_fetch_write.txt
+{
+  echo "# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE (one pass, --kernel-trace only) of:"
+  echo "#   python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2     (sums over all dispatches of the run)"
+  echo "# matrix-pipe utilisation of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs): the counter advances 32 per"
+  echo "# v_mfma_f32_32x32x16_bf16 and 64 per v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs."
+  python tools/pmc_table.py $O/pmc_sq 30
+} > $P/${R}_bench_pmc_sq.txt
+wc -l $P/${R}_*
