@@ -337,6 +337,23 @@ size_t papc_nms_workspace(int N);
 int papc_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *keep, int32_t *num_out, void *workspace,
                  size_t workspace_bytes, papc_stream_t stream);
 
+/* Backward of a max-pooled LAST layer without reading its dense output y [M,Cout] (the largest tensor of a stack).  With the BN+ReLU
+ * backward expanded, dy = s*p - e*y + f (s = scale, e = s*c2*invstd, f = e*mean - s*c1; c1, c2 from papc_bn_bwd_finalize_f32) and
+ * y = A W^T + b, A = relu(bn(y_prev)):      dX = (s*p) W - A (W^T E W) + (f - e*b) W.
+ * p is non-zero only at the argmax row of each (group, channel), so the first product is a GEMM over a sparse operand that is built
+ * from [M/K, Cout] arrays, and the second one is a GEMM over the layer's INPUT (Cin channels).
+ * papc_bn_max_prep_f32: psel [G,Co] = s*[s*ysel+shift > 0]*gout (ysel: papc_bn_select_max_f32), wcat [Ci, Co+Ci] = [W^T | -W^T E W],
+ * hbias [Ci] = (f - e*b) W, e [Co], q [Co] = f - e*b.   (w [Co,Ci]; bias may be NULL.)
+ * papc_mlp_bwd_dx_max_f32: dx [M,Cin] = [P | relu(bn_scale*x + bn_shift)] . wcat^T + hbias, P[m,c] = (m%K == argmax[m/K,c]) ? psel : 0;
+ * x [M,ldx] is the previous layer's pre-BN output; next_red as in papc_mlp_bwd_dx_f32.  Needs Cout % 16 == 0, Cin % 4 == 0 and 16-byte
+ * aligned operands (PAPC_E_UNSUPPORTED otherwise: use papc_mlp_bwd_dx_f32). */
+int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scale, const float *shift, const float *mean,
+                         const float *invstd, const float *c1, const float *c2, const float *w, const float *bias, int64_t G, int Co,
+                         int Ci, float *psel, float *wcat, float *hbias, float *e_out, float *q_out, papc_stream_t stream);
+int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, int64_t ldx, const float *bn_scale,
+                            const float *bn_shift, const float *wcat, const float *hbias, int64_t M, int Cin, int Cout, float *dx,
+                            const papc_bwd_red *next_red, papc_stream_t stream);
+
 /* count <= 8 row-major fp32 matrices transposed in one launch: dst[i] [cols[i], rows[i]] = src[i] [rows[i], cols[i]]^T.  The four
  * arrays are HOST arrays (read during the call); the matrices are device memory.  Used for the W^T operands of a stack's dX GEMMs. */
 int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream);

@@ -315,6 +315,60 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
 
 static inline unsigned ew_grid(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 256 * 16)); }
 
+// ---------------------------------------------------------------------------------------------------
+// Max-pooled last layer, backward without its dense output y (papc_mlp_bwd_dx_max_f32):
+//   dy = s*p - e*y + f            with s = scale, e = s*c2*invstd, f = e*mean - s*c1   (the BN+ReLU backward, expanded)
+//   y  = A W^T + b                A = relu(bn(y_prev)) [M, Ci], W [Co, Ci]
+//   dX = dy W = (s*p) W - A (W^T E W) + (f - e*b) W
+// p is non-zero only at the argmax row of each (group, channel): psel[g, c] = s_c * [s_c*ysel + shift_c > 0] * gout[g, c].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_max_psel_kernel(const float *__restrict__ gout, const float *__restrict__ ysel,
+                                                          const float *__restrict__ scale, const float *__restrict__ shift, int64_t total,
+                                                          int C, float *__restrict__ psel)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const float sc = scale[c];
+        psel[e] = fmaf(sc, ysel[e], shift[c]) > 0.f ? sc * gout[e] : 0.f;
+    }
+}
+
+// block n (< Ci): row n of wcat [Ci, Co + Ci] = [ W^T | -W^T E W ], hbias[n] = sum_c q_c W[c, n], q = f - e*b; block 0 also writes e, q
+__global__ __launch_bounds__(256) void bn_max_wcat_kernel(const float *__restrict__ w, const float *__restrict__ bias,
+                                                          const float *__restrict__ scale, const float *__restrict__ mean,
+                                                          const float *__restrict__ invstd, const float *__restrict__ c1,
+                                                          const float *__restrict__ c2, int Co, int Ci, float *__restrict__ wcat,
+                                                          float *__restrict__ hbias, float *__restrict__ e_out, float *__restrict__ q_out)
+{
+    extern __shared__ float sm[];          // [Co] e_c * W[c, n]   then [256] reduction scratch (doubles)
+    float *ewn = sm;
+    double *red = reinterpret_cast<double *>(sm + ((Co + 1) & ~1));
+    const int n = blockIdx.x, tid = threadIdx.x;
+    double hacc = 0.0;
+    for (int c = tid; c < Co; c += 256) {
+        const float s = scale[c];
+        const float e = s * c2[c] * invstd[c];
+        const float q = e * (mean[c] - (bias ? bias[c] : 0.f)) - s * c1[c];
+        const float wv = w[(int64_t)c * Ci + n];
+        ewn[c] = e * wv;
+        hacc += (double)q * (double)wv;
+        wcat[(int64_t)n * (Co + Ci) + c] = wv;
+        if (n == 0) { e_out[c] = e; q_out[c] = q; }
+    }
+    red[tid] = hacc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) hbias[n] = (float)red[0];
+    for (int j = tid; j < Ci; j += 256) {
+        double g = 0.0;
+        for (int c = 0; c < Co; ++c) g += (double)ewn[c] * (double)w[(int64_t)c * Ci + j];
+        wcat[(int64_t)n * (Co + Ci) + Co + j] = (float)(-g);
+    }
+}
+
 // up to 8 small row-major matrices transposed in one launch (the W^T operands of a stack's dX GEMMs)
 struct TransposeBatch {
     const float *src[8];
@@ -464,6 +518,21 @@ int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, floa
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, n, out, n, (float *)nullptr, accumulate);
     return check_launch("papc_reduce_partials_f32");
+}
+
+int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scale, const float *shift, const float *mean,
+                         const float *invstd, const float *c1, const float *c2, const float *w, const float *bias, int64_t G, int Co,
+                         int Ci, float *psel, float *wcat, float *hbias, float *e_out, float *q_out, papc_stream_t stream)
+{
+    PAPC_REQUIRE(gout && ysel && scale && shift && mean && invstd && c1 && c2 && w && psel && wcat && hbias && e_out && q_out, PAPC_E_INVALID,
+                 "papc_bn_max_prep_f32: null pointer");
+    PAPC_REQUIRE(G >= 1 && Co >= 1 && Ci >= 1 && Co <= 8192, PAPC_E_INVALID, "papc_bn_max_prep_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_REDUCE, st);
+    hipLaunchKernelGGL(bn_max_psel_kernel, dim3(ew_grid(G * Co)), dim3(256), 0, st, gout, ysel, scale, shift, G * Co, Co, psel);
+    const size_t lds = (size_t)((Co + 1) & ~1) * sizeof(float) + 256 * sizeof(double);
+    hipLaunchKernelGGL(bn_max_wcat_kernel, dim3((unsigned)Ci), dim3(256), lds, st, w, bias, scale, mean, invstd, c1, c2, Co, Ci, wcat, hbias, e_out, q_out);
+    return check_launch("papc_bn_max_prep_f32");
 }
 
 int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream)

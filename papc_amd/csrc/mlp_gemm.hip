@@ -184,7 +184,7 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
         s1[wn] = 0.f; s2[wn] = 0.f;
         const int col = n0 + (wgn * WN + wn) * 32 + l31;
         cok[wn] = col < p.Nout;
-        biasv[wn] = ((EPI == EPI_STORE || EPI == EPI_STORE_GMAX) && p.bias) ? p.bias[cok[wn] ? col : 0] : 0.f;
+        biasv[wn] = ((EPI == EPI_STORE || EPI == EPI_STORE_GMAX || EPI == EPI_STORE_RED) && p.bias) ? p.bias[cok[wn] ? col : 0] : 0.f;
     }
     float rsc[WN], rsh[WN], rmu[WN], ris[WN];  // EPI_STORE_RED: previous layer's BN constants of this lane's columns
 #pragma unroll
@@ -529,7 +529,7 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                                 for (int r = 0; r < 16; ++r) {
                                     const int ro = (r & 3) + 8 * (r >> 2);
                                     if (full || rb + ro < p.M) {
-                                        const float v = acc[wm][wn][r];
+                                        const float v = acc[wm][wn][r] + biasv[wn];   // (bias: the A_MAXCAT dX only, else 0)
                                         yp[(int64_t)ro * p.ldy] = v;
                                         const float pp = fmaf(rsc[wn], yv[wi][r], rsh[wn]) > 0.f ? v : 0.f;
                                         s1[wn] += pp;
@@ -800,6 +800,7 @@ static bool gemm_waves8(int amode, int epi)   // 8-wave flavour of the 128x128 t
     if (v < 0) { const char *e = getenv("PAPC_GEMM_WAVES"); v = e ? atoi(e) : 0; }
     if (v == 4) return false;
     if (v == 8) return true;
+    if (amode == A_MAXCAT) { static int m = -1; if (m < 0) { const char *e = getenv("PAPC_MAXCAT_WAVES"); m = e ? atoi(e) : 8; } return m == 8; }
     return !(amode == A_DY_MAX && epi == EPI_STORE_RED);   // measured per kernel (MI355X): only that one is faster on 4 waves (178 vs 223 us)
 }
 static int gemm_ws()   // producer groups of the wave-specialised 128x128 kernel (0 = unspecialised)
@@ -1067,6 +1068,34 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
         return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_SCATTER>(p, vec, st) : launch_gemm<A_DY_MAX, EPI_SCATTER>(p, vec, st);
     }
     return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_STORE>(p, vec, st) : launch_gemm<A_DY_MAX, EPI_STORE>(p, vec, st);
+}
+
+int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, int64_t ldx, const float *bn_scale,
+                            const float *bn_shift, const float *wcat, const float *hbias, int64_t M, int Cin, int Cout, float *dx,
+                            const papc_bwd_red *next_red, papc_stream_t stream)
+{
+    PAPC_REQUIRE(psel && argmax && x && bn_scale && bn_shift && wcat && hbias && dx, PAPC_E_INVALID, "papc_mlp_bwd_dx_max_f32: null pointer");
+    PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1 && K >= 1 && M % K == 0, PAPC_E_INVALID, "papc_mlp_bwd_dx_max_f32: bad sizes");
+    PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_mlp_bwd_dx_max_f32: M=%lld >= 2^31 rows", (long long)M);
+    PAPC_REQUIRE(Cout % 16 == 0 && Cin % 4 == 0 && ldx % 4 == 0 && aligned16(psel) && aligned16(argmax) && aligned16(x) && aligned16(bn_scale) &&
+                     aligned16(bn_shift) && aligned16(wcat) && aligned16(dx),
+                 PAPC_E_UNSUPPORTED, "papc_mlp_bwd_dx_max_f32: needs Cout %% 16 == 0, Cin %% 4 == 0 and 16-byte aligned operands");
+    GemmArgs p;
+    memset(&p, 0, sizeof(p));
+    p.a.x = x; p.a.ldx = ldx; p.a.sc = bn_scale; p.a.sh = bn_shift; p.a.vec = 1;
+    p.a.d.gout = psel; p.a.d.argmax = argmax; p.a.d.K = K; p.a.d.divK = make_fastdiv((uint32_t)K); p.a.d.C = Cout;
+    // GEMM view: rows M, reduction over the concatenated Cout + Cin channels, outputs Cin; weights wcat [Cin][Cout + Cin]
+    p.w = wcat; p.ldw = Cout + Cin; p.bias = hbias; p.M = M; p.Kin = Cout + Cin; p.Nout = Cin; p.y = dx; p.ldy = Cin;
+    if (next_red) {
+        PAPC_REQUIRE(next_red->y && next_red->mean && next_red->invstd && next_red->scale && next_red->shift && next_red->red_partial,
+                     PAPC_E_INVALID, "papc_mlp_bwd_dx_max_f32: null pointer in next_red");
+        p.rd.y = next_red->y; p.rd.mean = next_red->mean; p.rd.invstd = next_red->invstd; p.rd.scale = next_red->scale;
+        p.rd.shift = next_red->shift; p.stats = next_red->red_partial;
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_DX, st);
+    if (next_red) return launch_gemm_v<A_MAXCAT, EPI_STORE_RED, true, false>(p, st);
+    return launch_gemm_v<A_MAXCAT, EPI_STORE, true, false>(p, st);
 }
 
 }  // extern "C"

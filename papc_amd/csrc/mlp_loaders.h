@@ -19,7 +19,11 @@
 
 namespace papc {
 
-enum { A_PLAIN = PAPC_A_PLAIN, A_BNRELU = PAPC_A_BNRELU, A_GROUP = PAPC_A_GROUP, A_DY_DENSE = 3, A_DY_MAX = 4 };
+enum { A_PLAIN = PAPC_A_PLAIN, A_BNRELU = PAPC_A_BNRELU, A_GROUP = PAPC_A_GROUP, A_DY_DENSE = 3, A_DY_MAX = 4, A_MAXCAT = 5 };
+// A_MAXCAT (dX of a max-pooled last layer without reading its output y, see papc_mlp_bwd_dx_max_f32): the operand row is the
+// concatenation [ P (d.C columns) | relu(bn(x)) (Kin - d.C columns) ] where P[m, c] = (m % K == argmax[m / K, c]) ? psel[m / K, c] : 0
+// is the sparse max-backward gradient (psel = d.gout, already masked and scaled) and x / sc / sh are the layer's BN+ReLU input.
+// d.C is a multiple of 16, so a 16-wide k stage lies entirely in one of the two regions.
 
 // unsigned 32-bit division by an invariant (Granlund-Montgomery round-up form)
 struct FastDiv {
@@ -112,6 +116,12 @@ __device__ __forceinline__ RowCtx make_row(const ASrc &a, int64_t m64, int64_t M
         r.p0 = a.d.y + (int64_t)r.m * a.d.C;
         r.p1 = a.d.gout + (int64_t)r.grp * a.d.C;
         r.p2 = a.d.argmax + (int64_t)r.grp * a.d.C;
+    } else if (AMODE == A_MAXCAT) {
+        r.grp = (int)fdiv((uint32_t)r.m, a.d.divK);
+        r.kin = r.m - r.grp * a.d.K;
+        r.p0 = a.x + (int64_t)r.m * a.ldx - a.d.C;      // indexed with the concatenated k (>= d.C in the dense region)
+        r.p1 = a.d.gout + (int64_t)r.grp * a.d.C;
+        r.p2 = a.d.argmax + (int64_t)r.grp * a.d.C;
     }
     return r;
 }
@@ -137,6 +147,9 @@ __device__ __forceinline__ KConst make_kconst(const ASrc &a, int k, int Kin)
     if (AMODE == A_BNRELU) {
         if (VEC) { const int kk = k < Kin ? k : 0; c.c0 = ld4(a.sc + kk); c.c1 = ld4(a.sh + kk); }
         else { c.c0 = ld4s_or_zero(a.sc, k, Kin); c.c1 = ld4s_or_zero(a.sh, k, Kin); }
+    } else if (AMODE == A_MAXCAT) {   // VEC only: BN+ReLU constants of the dense region (unused in the sparse one)
+        const int kk = (k >= a.d.C && k < Kin) ? k - a.d.C : 0;
+        c.c0 = ld4(a.sc + kk); c.c1 = ld4(a.sh + kk);
     } else if (AMODE == A_DY_DENSE || AMODE == A_DY_MAX) {
         if (VEC) {
             const int kk = k < Kin ? k : 0;
@@ -178,6 +191,10 @@ __device__ __forceinline__ Raw3 fetch_a4(const ASrc &a, const RowCtx &r, int k, 
         const int kk = k < Kin ? k : 0;
         if (AMODE == A_PLAIN || AMODE == A_BNRELU) {
             w.p = ld4(r.p0 + kk);
+        } else if (AMODE == A_MAXCAT) {   // one value load (psel | x) and one int4 (argmax | a valid dummy), both unconditional
+            const bool sp = kk < a.d.C;
+            w.p = ld4((sp ? r.p1 : r.p0) + kk);
+            w.r = *reinterpret_cast<const int4 *>(reinterpret_cast<const int32_t *>(r.p2) + (sp ? kk : 0));
         } else if (AMODE == A_GROUP) {
             const GroupSrc &g = a.g;
             if (kk < g.D) {
@@ -247,6 +264,14 @@ __device__ __forceinline__ float4 finish_a4(const ASrc &a, const RowCtx &r, int 
         v.y = ky ? fmaxf(fmaf(kc.c0.y, w.p.y, kc.c1.y), 0.f) : 0.f;
         v.z = kz ? fmaxf(fmaf(kc.c0.z, w.p.z, kc.c1.z), 0.f) : 0.f;
         v.w = kw ? fmaxf(fmaf(kc.c0.w, w.p.w, kc.c1.w), 0.f) : 0.f;
+    } else if (AMODE == A_MAXCAT) {
+        if (k < a.d.C) {              // uniform over the stage
+            v.x = (w.r.x == r.kin) ? w.p.x : 0.f; v.y = (w.r.y == r.kin) ? w.p.y : 0.f;
+            v.z = (w.r.z == r.kin) ? w.p.z : 0.f; v.w = (w.r.w == r.kin) ? w.p.w : 0.f;
+        } else {
+            v.x = fmaxf(fmaf(kc.c0.x, w.p.x, kc.c1.x), 0.f); v.y = fmaxf(fmaf(kc.c0.y, w.p.y, kc.c1.y), 0.f);
+            v.z = fmaxf(fmaf(kc.c0.z, w.p.z, kc.c1.z), 0.f); v.w = fmaxf(fmaf(kc.c0.w, w.p.w, kc.c1.w), 0.f);
+        }
     } else if (AMODE == A_GROUP) {   // feats pass through (q = 0: p - 0 is exact); xyz columns: grouped_xyz - new_xyz (:147)
         v.x = w.p.x - w.q.x; v.y = w.p.y - w.q.y; v.z = w.p.z - w.q.z; v.w = w.p.w - w.q.w;
     } else {

@@ -53,6 +53,7 @@ import os
 _FUSE_RED = os.environ.get("PAPC_NO_RED") != "1"            # A/B switch for the BN-backward reduce fused into the dX epilogue
 _FUSE_GMAX = os.environ.get("PAPC_NO_GMAX") != "1"          # A/B switch for the fused neighbourhood-max epilogue
 _RESIDENT_WGS = int(os.environ.get("PAPC_PARTS", "512"))   # persistent-grid size (tuning knob shared with the C side)
+_SPARSE_MAX = os.environ.get("PAPC_SPARSE_MAX", "0") == "1"   # dX of the max-pooled last layer without reading its output y (papc_mlp_bwd_dx_max_f32)
 _DW_WGS = int(os.environ.get("PAPC_DW_WGS", "512"))         # workgroups of one dW launch (row chunks x output tiles)
 
 
@@ -178,6 +179,12 @@ class SharedMLPMax(torch.autograd.Function):
         gemm_parts = lib.papc_mlp_gemm_parts(M)
         # W^T operands of every dX GEMM of the stack: one batched transpose launch
         need_wt = [l for l in range(L) if l > 0 or (plain and ctx.x_needs_grad) or ((not plain) and ctx.feats_needs_grad)]
+        # last layer under the max: its dX can be formed from the [G, C] max-backward arrays and the layer's INPUT, without its output
+        cL, cLi = params[4 * (L - 1)].shape[0], (params[4 * (L - 2)].shape[0] if L > 1 else 0)
+        sparse_max = (_SPARSE_MAX and spec.pool and L > 1 and ysel is not None and M >= 32768 and cL % 16 == 0 and cLi % 4 == 0
+                      and cL + cLi <= 512)
+        if sparse_max:
+            need_wt.remove(L - 1)
         wts = {}
         for g0 in range(0, len(need_wt), 8):
             grp_l = need_wt[g0:g0 + 8]
@@ -254,7 +261,7 @@ class SharedMLPMax(torch.autograd.Function):
             # ---- dX
             fused_red = None
             if l > 0:
-                wt = wts[l]
+                wt = wts.get(l)
                 dz_prev = torch.empty(M, cin, device=dev, dtype=torch.float32)
                 # the dX kernel also accumulates layer l-1's BN-backward reductions over the dz it produces
                 nr_ref = None
@@ -266,8 +273,23 @@ class SharedMLPMax(torch.autograd.Function):
                     nr.mean, nr.invstd, nr.scale, nr.shift = (pc[i].data_ptr() for i in range(4))
                     nr.red_partial = fused_red.data_ptr()
                     nr_ref = ctypes.byref(nr)
-                check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dz_prev), None, nr_ref, st),
-                      "papc_mlp_bwd_dx_f32")
+                if sparse_max and l == L - 1:
+                    G = M // spec.K
+                    psel = torch.empty(G, cout, device=dev, dtype=torch.float32)
+                    wcat = torch.empty(cin, cout + cin, device=dev, dtype=torch.float32)
+                    hb = torch.empty(cin, device=dev, dtype=torch.float32)
+                    eq = torch.empty(2, cout, device=dev, dtype=torch.float32)
+                    check(lib.papc_bn_max_prep_f32(ptr(gout), ptr(ysel), cst[2].data_ptr(), cst[3].data_ptr(), cst[0].data_ptr(),
+                                                   cst[1].data_ptr(), c12[0].data_ptr(), c12[1].data_ptr(), ptr(w), ptr(params[4 * l + 1]),
+                                                   G, cout, cin, ptr(psel), ptr(wcat), ptr(hb), eq[0].data_ptr(), eq[1].data_ptr(), st),
+                          "papc_bn_max_prep_f32")
+                    pc = consts[l - 1]
+                    check(lib.papc_mlp_bwd_dx_max_f32(ptr(psel), ptr(argmax), spec.K, ys[l - 1].data_ptr(), cin, pc[2].data_ptr(),
+                                                      pc[3].data_ptr(), ptr(wcat), ptr(hb), M, cin, cout, ptr(dz_prev), nr_ref, st),
+                          "papc_mlp_bwd_dx_max_f32")
+                else:
+                    check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dz_prev), None, nr_ref, st),
+                          "papc_mlp_bwd_dx_f32")
                 dz = dz_prev
             elif plain and ctx.x_needs_grad:
                 wt = wts[l]
