@@ -336,6 +336,13 @@ int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int
 size_t papc_nms_workspace(int N);
 int papc_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *keep, int32_t *num_out, void *workspace,
                  size_t workspace_bytes, papc_stream_t stream);
+/* Rotated boxes, nms_gpu.py:179-653 (numba.cuda in the reference; typing follows that source: fp32 clipping, fp64 area and quotient).
+ * papc_rotate_nms_f32: rotate_nms_gpu (:453-488), dets [N,6] = (x, y, x_d, y_d, angle, score); outputs and workspace as papc_nms_f32.
+ * papc_rotate_iou_f32: rotate_iou_gpu / rotate_iou_gpu_eval (:524-653), boxes [N,5], query_boxes [K,5] = (x, y, x_d, y_d, angle) ->
+ * iou [N,K]; criterion -1: intersection over union, 0: over area(query), 1: over area(box), 2: the intersection area. */
+int papc_rotate_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *keep, int32_t *num_out, void *workspace,
+                        size_t workspace_bytes, papc_stream_t stream);
+int papc_rotate_iou_f32(const float *boxes, const float *query_boxes, int N, int K, int criterion, float *iou, papc_stream_t stream);
 
 /* Backward of a max-pooled LAST layer without reading its dense output y [M,Cout] (the largest tensor of a stack).  With the BN+ReLU
  * backward expanded, dy = s*p - e*y + f (s = scale, e = s*c2*invstd, f = e*mean - s*c1; c1, c2 from papc_bn_bwd_finalize_f32) and

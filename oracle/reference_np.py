@@ -574,3 +574,148 @@ def nms_vectorised(dets, thresh):
         with np.errstate(divide="ignore", invalid="ignore"):
             removed[i + 1:] |= inter / ((area[i] + area[i + 1:]) - inter) > thr
     return list(order[np.asarray(keep, np.int64)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rotated-box IoU / NMS, nms_gpu.py:179-653 (numba.cuda in the reference)
+# Typing follows the numba source: fp32 for corners / clipping, Python-float (fp64) for the area accumulator and the quotient.
+# ---------------------------------------------------------------------------------------------------------------------
+_f = np.float32
+
+
+def rbbox_to_corners(rbbox):
+    """:366-389.  rbbox = (x, y, x_d, y_d, angle) -> 8 floats, clockwise corners rotated clockwise."""
+    a_cos, a_sin = _f(np.cos(_f(rbbox[4]))), _f(np.sin(_f(rbbox[4])))
+    hx, hy = _f(_f(rbbox[2]) / _f(2)), _f(_f(rbbox[3]) / _f(2))
+    cx = [-hx, -hx, hx, hx]
+    cy = [-hy, hy, hy, -hy]
+    c = np.zeros(8, np.float32)
+    for i in range(4):
+        c[2 * i] = _f(_f(_f(a_cos * cx[i]) + _f(a_sin * cy[i])) + _f(rbbox[0]))
+        c[2 * i + 1] = _f(_f(_f(-a_sin * cx[i]) + _f(a_cos * cy[i])) + _f(rbbox[1]))
+    return c
+
+
+def _point_in_quadrilateral(px, py, c):
+    """:323-339"""
+    ab0, ab1, ad0, ad1 = _f(c[2] - c[0]), _f(c[3] - c[1]), _f(c[6] - c[0]), _f(c[7] - c[1])
+    ap0, ap1 = _f(px - c[0]), _f(py - c[1])
+    abab = _f(_f(ab0 * ab0) + _f(ab1 * ab1)); abap = _f(_f(ab0 * ap0) + _f(ab1 * ap1))
+    adad = _f(_f(ad0 * ad0) + _f(ad1 * ad1)); adap = _f(_f(ad0 * ap0) + _f(ad1 * ap1))
+    return abab >= abap and abap >= 0 and adad >= adap and adap >= 0
+
+
+def _line_segment_intersection(p1, p2, i, j):
+    """:235-278.  Returns the intersection point or None."""
+    A0, A1, B0, B1 = p1[2 * i], p1[2 * i + 1], p1[2 * ((i + 1) % 4)], p1[2 * ((i + 1) % 4) + 1]
+    C0, C1, D0, D1 = p2[2 * j], p2[2 * j + 1], p2[2 * ((j + 1) % 4)], p2[2 * ((j + 1) % 4) + 1]
+    BA0, BA1, DA0, CA0, DA1, CA1 = _f(B0 - A0), _f(B1 - A1), _f(D0 - A0), _f(C0 - A0), _f(D1 - A1), _f(C1 - A1)
+    acd = _f(DA1 * CA0) > _f(CA1 * DA0)
+    bcd = _f(_f(D1 - B1) * _f(C0 - B0)) > _f(_f(C1 - B1) * _f(D0 - B0))
+    if acd != bcd:
+        abc = _f(CA1 * BA0) > _f(BA1 * CA0)
+        abd = _f(DA1 * BA0) > _f(BA1 * DA0)
+        if abc != abd:
+            DC0, DC1 = _f(D0 - C0), _f(D1 - C1)
+            ABBA = _f(_f(A0 * B1) - _f(B0 * A1)); CDDC = _f(_f(C0 * D1) - _f(D0 * C1))
+            DH = _f(_f(BA1 * DC0) - _f(BA0 * DC1))
+            Dx = _f(_f(ABBA * DC0) - _f(BA0 * CDDC)); Dy = _f(_f(ABBA * DC1) - _f(BA1 * CDDC))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return _f(Dx / DH), _f(Dy / DH)
+    return None
+
+
+def rotate_inter(rbbox1, rbbox2):
+    """inter(), :392-406 (quadrilateral_intersection :342-363, sort_vertex_in_convex_polygon :195-232, area :185-192).  The source's
+    scratch holds 8 points; degenerate overlaps can produce more candidates (it would write past the array) -- here, as in the HIP
+    kernel, up to 16 are kept."""
+    c1, c2 = rbbox_to_corners(rbbox1), rbbox_to_corners(rbbox2)
+    pts = []
+    for i in range(4):
+        if _point_in_quadrilateral(c1[2 * i], c1[2 * i + 1], c2):
+            pts.append([c1[2 * i], c1[2 * i + 1]])
+        if _point_in_quadrilateral(c2[2 * i], c2[2 * i + 1], c1):
+            pts.append([c2[2 * i], c2[2 * i + 1]])
+    for i in range(4):
+        for j in range(4):
+            t = _line_segment_intersection(c1, c2, i, j)
+            if t is not None:
+                pts.append([t[0], t[1]])
+    pts = pts[:16]
+    n = len(pts)
+    if n > 0:
+        ctr0, ctr1 = _f(0), _f(0)
+        for q in pts:
+            ctr0 = _f(ctr0 + q[0]); ctr1 = _f(ctr1 + q[1])
+        ctr0 = _f(ctr0 / _f(n)); ctr1 = _f(ctr1 / _f(n))
+        vs = []
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for q in pts:
+                v0, v1 = _f(q[0] - ctr0), _f(q[1] - ctr1)
+                d = _f(np.sqrt(_f(_f(v0 * v0) + _f(v1 * v1))))
+                v0, v1 = _f(v0 / d), _f(v1 / d)
+                if v1 < 0:
+                    v0 = _f(_f(-2) - v0)
+                vs.append(v0)
+        for i in range(1, n):                       # insertion sort exactly as written (:218-232)
+            if vs[i - 1] > vs[i]:
+                temp, tq = vs[i], pts[i]
+                j = i
+                while j > 0 and vs[j - 1] > temp:
+                    vs[j] = vs[j - 1]; pts[j] = pts[j - 1]
+                    j -= 1
+                vs[j] = temp; pts[j] = tq
+    area = 0.0
+    for i in range(n - 2):
+        a, b, c = pts[0], pts[i + 1], pts[i + 2]
+        num = _f(_f(_f(a[0] - c[0]) * _f(b[1] - c[1])) - _f(_f(a[1] - c[1]) * _f(b[0] - c[0])))
+        area += abs(float(num) / 2.0)
+    return area
+
+
+def rotate_iou_eval(rbox1, rbox2, criterion=-1):
+    """devRotateIoU :409-414 / devRotateIoUEval :562-574"""
+    area1, area2 = _f(_f(rbox1[2]) * _f(rbox1[3])), _f(_f(rbox2[2]) * _f(rbox2[3]))
+    ai = rotate_inter(rbox1, rbox2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if criterion == -1:
+            return np.float64(ai) / (np.float64(_f(area1 + area2)) - ai)
+        if criterion == 0:
+            return np.float64(ai) / np.float64(area1)
+        if criterion == 1:
+            return np.float64(ai) / np.float64(area2)
+    return np.float64(ai)
+
+
+def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1):
+    """:618-653 (criterion -1 = rotate_iou_gpu :524-559): iou[n, k] = devRotateIoUEval(query[k], boxes[n])."""
+    boxes, query_boxes = np.asarray(boxes, np.float32), np.asarray(query_boxes, np.float32)
+    out = np.zeros((boxes.shape[0], query_boxes.shape[0]), np.float32)
+    for n in range(boxes.shape[0]):
+        for k in range(query_boxes.shape[0]):
+            out[n, k] = np.float32(rotate_iou_eval(query_boxes[k], boxes[n], criterion))
+    return out
+
+
+def rotate_nms_gpu(dets, nms_overlap_thresh, return_ious=False):
+    """:453-488.  dets [N,6] = (x, y, x_d, y_d, angle, score) -> kept original indices, best score first (stable sort reversed)."""
+    dets = np.asarray(dets, np.float32)
+    n = dets.shape[0]
+    if n == 0:
+        return ([], {}) if return_ious else []
+    order = dets[:, 5].argsort(kind="stable")[::-1]
+    b = dets[order]
+    col_blocks = (n + 63) // 64
+    mask = np.zeros((n, col_blocks), np.uint64)
+    thr = np.float64(np.float32(nms_overlap_thresh))
+    ious = {}
+    for i in range(n):
+        for j in range(i + 1, n):
+            v = rotate_iou_eval(b[i, :5], b[j, :5], -1)
+            ious[(i, j)] = float(v)
+            if v > thr:
+                mask[i, j // 64] |= np.uint64(1) << np.uint64(j % 64)
+    keep = np.zeros(n, np.int32)
+    num = nms_postprocess(keep, mask.reshape(-1), n)
+    res = list(order[keep[:num]])
+    return (res, ious) if return_ious else res

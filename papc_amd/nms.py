@@ -34,3 +34,49 @@ def nms_gpu(dets, nms_overlap_thresh, device_id=0):
     if not torch.is_tensor(dets):
         dets = torch.as_tensor(dets, dtype=torch.float32).to("cuda:%d" % device_id)
     return nms_gpu_tensor(dets, nms_overlap_thresh).tolist()
+
+
+def rotate_nms_gpu_tensor(dets, nms_overlap_thresh):
+    """dets [N,6] = (x, y, x_d, y_d, angle, score) fp32 CUDA tensor -> int64 tensor of kept original indices, best score first."""
+    if not dets.is_cuda:
+        raise _lib.PapcError("rotate_nms_gpu needs a CUDA (ROCm) tensor: there is no CPU fallback")
+    assert dets.dim() == 2 and dets.shape[1] == 6, "dets must be [N, 6]"
+    N = int(dets.shape[0])
+    if N == 0:
+        return torch.empty(0, dtype=torch.int64, device=dets.device)
+    dets = dets.contiguous().float()
+    lib = _lib.load()
+    ws_bytes = int(lib.papc_nms_workspace(N))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dets.device)
+    keep = torch.empty(N, dtype=torch.int32, device=dets.device)
+    num = torch.empty(1, dtype=torch.int32, device=dets.device)
+    check(lib.papc_rotate_nms_f32(ptr(dets), N, float(nms_overlap_thresh), ptr(keep), ptr(num), ptr(ws), ws_bytes, stream_ptr()),
+          "papc_rotate_nms_f32")
+    return keep[:int(num.item())].long()
+
+
+def rotate_nms_gpu(dets, nms_overlap_thresh, device_id=0):
+    """nms_gpu.py:453-488: numpy or tensor ``dets`` [N,6] in, python list of kept indices out."""
+    if not torch.is_tensor(dets):
+        dets = torch.as_tensor(dets, dtype=torch.float32).to("cuda:%d" % device_id)
+    return rotate_nms_gpu_tensor(dets, nms_overlap_thresh).tolist()
+
+
+def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
+    """nms_gpu.py:618-653 (``rotate_iou_gpu`` :524-559 is criterion -1).  boxes [N,5], query_boxes [K,5] = (x, y, x_d, y_d, angle)
+    -> iou [N,K] (tensor in -> tensor out, numpy in -> numpy out like the source)."""
+    as_np = not torch.is_tensor(boxes)
+    dev = "cuda:%d" % device_id
+    b = torch.as_tensor(boxes, dtype=torch.float32).to(dev).contiguous() if as_np else boxes.contiguous().float()
+    q = torch.as_tensor(query_boxes, dtype=torch.float32).to(b.device).contiguous()
+    if not b.is_cuda:
+        raise _lib.PapcError("rotate_iou_gpu needs CUDA (ROCm) tensors: there is no CPU fallback")
+    N, K = int(b.shape[0]), int(q.shape[0])
+    iou = torch.zeros(N, K, dtype=torch.float32, device=b.device)
+    if N and K:
+        check(_lib.load().papc_rotate_iou_f32(ptr(b), ptr(q), N, K, int(criterion), ptr(iou), stream_ptr()), "papc_rotate_iou_f32")
+    return iou.cpu().numpy() if as_np else iou
+
+
+def rotate_iou_gpu(boxes, query_boxes, device_id=0):
+    return rotate_iou_gpu_eval(boxes, query_boxes, -1, device_id)

@@ -238,3 +238,27 @@ def test_nms_known_answers():
         assert a == b and len(a) >= 1
         m = R.nms_mask(d[d[:, 4].argsort(kind="stable")[::-1]], 0.4)
         assert m.shape == (n, (n + 63) // 64)
+
+
+def test_rotate_iou_known_answers():
+    """Rotated-box IoU restatement (nms_gpu.py:179-414) against hand-computed overlaps."""
+    sq = np.array([0, 0, 2, 2, 0], np.float32)
+    assert abs(R.rotate_iou_eval(sq, sq) - 1.0) < 1e-6                                   # identical boxes
+    shifted = np.array([1, 0, 2, 2, 0], np.float32)                                      # overlap 1 x 2 of two 2 x 2 squares
+    assert abs(R.rotate_inter(sq, shifted) - 2.0) < 1e-6
+    assert abs(R.rotate_iou_eval(sq, shifted) - 2.0 / 6.0) < 1e-6
+    assert abs(R.rotate_iou_eval(sq, shifted, 0) - 0.5) < 1e-6 and abs(R.rotate_iou_eval(sq, shifted, 2) - 2.0) < 1e-6
+    far = np.array([10, 10, 2, 2, 0.3], np.float32)
+    assert R.rotate_iou_eval(sq, far) == 0.0
+    diamond = np.array([0, 0, 2, 2, np.pi / 4], np.float32)                              # 45 degrees: regular octagon, area 8(sqrt2 - 1)
+    assert abs(R.rotate_inter(sq, diamond) - 8.0 * (np.sqrt(2.0) - 1.0)) < 1e-5
+    quarter = np.array([0, 0, 4, 1, np.pi / 2], np.float32)                              # 4x1 bar against itself rotated 90 degrees: 1x1
+    bar = np.array([0, 0, 4, 1, 0], np.float32)
+    assert abs(R.rotate_inter(bar, quarter) - 1.0) < 1e-5
+    inner = np.array([0.2, -0.1, 0.5, 0.3, 1.0], np.float32)                             # box inside a box: intersection = the small one
+    assert abs(R.rotate_inter(np.array([0, 0, 4, 4, 0.2], np.float32), inner) - 0.15) < 1e-6
+    m = R.rotate_iou_gpu_eval(np.stack([sq, shifted]), np.stack([sq, far, shifted]))
+    assert m.shape == (2, 3) and abs(m[0, 0] - 1) < 1e-6 and m[0, 1] == 0 and abs(m[1, 0] - 1 / 3) < 1e-6 and abs(m[0, 2] - 1 / 3) < 1e-6
+    dets = np.array([[0, 0, 2, 2, 0, 0.9], [0.1, 0, 2, 2, 0.05, 0.8], [5, 5, 2, 2, 1.0, 0.7], [5, 5.2, 2, 2, 1.1, 0.95]], np.float32)
+    assert [int(i) for i in R.rotate_nms_gpu(dets, 0.5)] == [3, 0]
+    assert [int(i) for i in R.rotate_nms_gpu(dets, 0.99)] == [3, 0, 1, 2]
