@@ -31,7 +31,7 @@ class HeadSpec:
 
 
 def usable(x, fc1, fc2, fc3, training):
-    return (training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= MAX_ROWS
+    return (training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 2 <= x.shape[0] <= MAX_ROWS   # (one row: BatchNorm1d itself refuses to train)
             and fc1.in_features % 4 == 0 and fc1.out_features % 4 == 0 and fc2.out_features % 4 == 0
             and fc3.out_features % 4 == 0 and fc1.bias is not None and fc2.bias is not None and fc3.bias is not None)
 
