@@ -472,6 +472,85 @@ __global__ __launch_bounds__(768, 3) void dw_ws_kernel(DwArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dW of a first layer fed by coordinates only (GROUP input with D = 0: Cin = 3; SA1 of the SSG / MSG classifiers).  A 128x32 MFMA
+// tile would carry 3 useful columns, so this is a streaming reduction instead: a lane owns 4 output channels (float4 loads of dz and
+// y), 16 lanes cover a 64-channel row, and each lane keeps 4 x 3 running sums of dY[m, c] * (xyz_j - centre)[m]; the 256-thread
+// workgroup reduces its row slots in LDS in fixed order.  HBM-bound on the (dz, y) stream.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dw_xyz_kernel(DwArgs p)
+{
+    __shared__ float red[256 * 12];
+    const int tid = threadIdx.x;
+    const int CQ = p.Cout >> 2;              // channel quads per row (<= 64)
+    const int RSL = 256 / CQ;                // row slots of the workgroup
+    const int cq = tid % CQ, slot = tid / CQ;
+    const bool act = slot < RSL;
+    const int c = cq * 4;
+    const DySrc &d = p.dy.d;
+    const float4 ksc = ld4(d.scale + c), ksh = ld4(d.shift + c), kmu = ld4(d.mean + c);
+    const float4 is = ld4(d.invstd + c), c1 = ld4(d.c1 + c), c2 = ld4(d.c2 + c);
+    const float4 kA = make_float4(ksc.x * c1.x, ksc.y * c1.y, ksc.z * c1.z, ksc.w * c1.w);
+    const float4 kB = make_float4(ksc.x * c2.x * is.x, ksc.y * c2.y * is.y, ksc.z * c2.z * is.z, ksc.w * c2.w * is.w);
+    const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
+    const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
+    float a[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i][0] = a[i][1] = a[i][2] = 0.f;
+    auto dyv = [&](float dz, float y, float sc, float sh, float mu, float A, float Bp) {
+        const float z = fmaf(sc, y, sh);
+        const float pp = z > 0.f ? dz : 0.f;
+        return fmaf(sc, pp, -fmaf(Bp, y - mu, A));
+    };
+    constexpr int U = 4;                     // rows in flight per lane
+    if (act) {
+        for (int64_t m0 = mbeg + slot; m0 < mend; m0 += (int64_t)U * RSL) {
+            float4 vy[U], vz[U], vx[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = m0 + (int64_t)u * RSL;
+                ok[u] = m < mend;
+                const int64_t mc = ok[u] ? m : mbeg;
+                vy[u] = ld4(d.y + mc * p.Cout + c);
+                vz[u] = ld4(d.dz + mc * p.Cout + c);
+                const RowCtx r = make_row<A_GROUP>(p.x, mc, p.M);
+                const Raw3 w = fetch_a4<A_GROUP, true>(p.x, r, 0, 3);
+                vx[u] = finish_a4<A_GROUP, true>(p.x, r, 0, 3, KConst{}, w);     // (x - cx, y - cy, z - cz, 0); zero for a no-hit row
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                const float g0 = dyv(vz[u].x, vy[u].x, ksc.x, ksh.x, kmu.x, kA.x, kB.x);
+                const float g1 = dyv(vz[u].y, vy[u].y, ksc.y, ksh.y, kmu.y, kA.y, kB.y);
+                const float g2 = dyv(vz[u].z, vy[u].z, ksc.z, ksh.z, kmu.z, kA.z, kB.z);
+                const float g3 = dyv(vz[u].w, vy[u].w, ksc.w, ksh.w, kmu.w, kA.w, kB.w);
+                a[0][0] = fmaf(g0, vx[u].x, a[0][0]); a[0][1] = fmaf(g0, vx[u].y, a[0][1]); a[0][2] = fmaf(g0, vx[u].z, a[0][2]);
+                a[1][0] = fmaf(g1, vx[u].x, a[1][0]); a[1][1] = fmaf(g1, vx[u].y, a[1][1]); a[1][2] = fmaf(g1, vx[u].z, a[1][2]);
+                a[2][0] = fmaf(g2, vx[u].x, a[2][0]); a[2][1] = fmaf(g2, vx[u].y, a[2][1]); a[2][2] = fmaf(g2, vx[u].z, a[2][2]);
+                a[3][0] = fmaf(g3, vx[u].x, a[3][0]); a[3][1] = fmaf(g3, vx[u].y, a[3][1]); a[3][2] = fmaf(g3, vx[u].z, a[3][2]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[tid * 12 + i * 3 + j] = act ? a[i][j] : 0.f;
+    __syncthreads();
+    // thread t < Cout * 3: (channel, column); sum over the row slots in slot order
+    float *out = p.dw_partial + (int64_t)blockIdx.x * p.part_ld;
+    for (int t = tid; t < p.Cout * 3; t += 256) {
+        const int ch = t / 3, j = t - ch * 3;
+        const int q = ch >> 2, i = ch & 3;
+        float sacc = 0.f;
+        for (int sl = 0; sl < RSL; ++sl) sacc += red[(sl * CQ + q) * 12 + i * 3 + j];
+        out[(int64_t)ch * 3 + gk(p.x.g, j)] = sacc;       // internal xyz column j -> the caller's weight column (D = 0: identity)
+    }
+    if (p.db_partial) {
+        for (int t = tid; t < p.Cout; t += 256) p.db_partial[(int64_t)blockIdx.x * p.part_ld + t] = 0.f;   // exact (see dw_ws_kernel)
+    }
+}
+
 static bool dw_f32_exact()
 {
     static int v = -1;
@@ -567,6 +646,13 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);
     const bool dense = dy->dz_mode == PAPC_DZ_DENSE;
+    static int xyz_on = -1;
+    if (xyz_on < 0) { const char *e = getenv("PAPC_DW_XYZ"); xyz_on = (e && e[0] == '0') ? 0 : 1; }
+    if (xyz_on && a_mode == A_GROUP && dense && vec && grp->D == 0 && Cin == 3 && Cout % 4 == 0 && Cout >= 4 && Cout <= 256) {
+        // coordinates-only first layer: streaming reduction instead of a 3-of-32-column MFMA tile
+        hipLaunchKernelGGL(dw_xyz_kernel, dim3((unsigned)cdiv(M, rows_per_chunk)), dim3(256), 0, st, p);
+        return check_launch("papc_mlp_bwd_dw_f32");
+    }
     switch (a_mode) {
     case A_PLAIN: return dense ? launch_dw<A_PLAIN, A_DY_DENSE>(p, vec, st) : launch_dw<A_PLAIN, A_DY_MAX>(p, vec, st);
     case A_BNRELU: return dense ? launch_dw<A_BNRELU, A_DY_DENSE>(p, vec, st) : launch_dw<A_BNRELU, A_DY_MAX>(p, vec, st);
