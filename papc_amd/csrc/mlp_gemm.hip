@@ -131,12 +131,14 @@ __device__ __forceinline__ float4 mask_w4(const GemmArgs &p, int n, int k, float
 // BN-backward sums) instead of 4: a quarter of the memory instructions, which is what the dX epilogues were bound by
 // (DESIGN.md 3.7).  The per-column sums become 16 per-lane accumulators per 32-column tile, reduced across lanes once at
 // the end of the kernel (DPP tree, fixed order).
-template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH, bool BF3, int WS, bool TL>
+template <int AMODE, int EPI, bool VEC, int WGM, int WGN, int WM, int WN, int DEPTH, bool BF3, int WS, bool TL, int KB = 1>
 __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WGN / 2) void gemm_kernel(GemmArgs p)
 {
     static_assert(!TL || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (EPI == EPI_STORE || EPI == EPI_STORE_RED) && VEC), "TL: dense dX stores");
     constexpr int BM = WGM * WM * 32, BN = WGN * WN * 32;
-    constexpr int BKS = BF3 ? 16 : BK;        // k extent of one stage
+    static_assert(KB == 1 || (BF3 && !WS && KB == 2), "KB: k blocks of 16 per stage (split-bf16 kernel)");
+    constexpr int BKS = BF3 ? 16 * KB : BK;   // k extent of one stage (KB = 2: half as many, fatter stages for the latency-bound
+                                              // few-row-tile problems that run one workgroup per CU anyway)
     constexpr int KQN = BKS / 4;              // threads along k (one float4 each)
     constexpr int NC = WGM * WGN * 64;        // threads that own accumulators (4 or 8 waves)
     constexpr int NT = (1 + WS) * NC;         // threads per workgroup
@@ -145,7 +147,8 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     constexpr int NAI = BM / RPI;             // A float4 loads per thread per stage
     constexpr int NWL = (BN + RPI - 1) / RPI; // weight float4 loads per thread per stage
     constexpr bool WPART = BN < RPI;          // only the first BN row-threads carry a weight row (wave-uniform)
-    constexpr int ROWB = 112;                 // BF3 LDS row stride in bytes
+    constexpr int PLB = 32 * KB;              // bytes of one bf16 plane of a row
+    constexpr int ROWB = 3 * PLB + 16;        // BF3 LDS row stride in bytes (an odd number of 16-byte slots: 112 / 208)
     constexpr int ROWF = BF3 ? ROWB / 4 : LDT;
     constexpr bool WMAP = (AMODE == A_GROUP);
     constexpr bool NMAP = (EPI == EPI_SCATTER);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                 uint2 q0, q1, q2;
                 split3(finish_a4<AMODE, VEC>(p.a, s.rows[i], s.kf, p.Kin, s.kc, s.ra[i]), q0, q1, q2);
                 char *d = Ab + (r0 + RPI * i) * ROWB + kq * 2;
-                *reinterpret_cast<uint2 *>(d) = q0; *reinterpret_cast<uint2 *>(d + 32) = q1; *reinterpret_cast<uint2 *>(d + 64) = q2;
+                *reinterpret_cast<uint2 *>(d) = q0; *reinterpret_cast<uint2 *>(d + PLB) = q1; *reinterpret_cast<uint2 *>(d + 2 * PLB) = q2;
             }
             if (wrow) {
 #pragma unroll
@@ -289,7 +292,7 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                     uint2 q0, q1, q2;
                     split3(mask_w4(p, n0 + r0 + RPI * i, s.kf, s.rw[i]), q0, q1, q2);
                     char *d = Wb + (r0 + RPI * i) * ROWB + kq * 2;
-                    *reinterpret_cast<uint2 *>(d) = q0; *reinterpret_cast<uint2 *>(d + 32) = q1; *reinterpret_cast<uint2 *>(d + 64) = q2;
+                    *reinterpret_cast<uint2 *>(d) = q0; *reinterpret_cast<uint2 *>(d + PLB) = q1; *reinterpret_cast<uint2 *>(d + 2 * PLB) = q2;
                 }
             }
             return;
@@ -322,27 +325,30 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
     auto mfma_stage = [&](int buf, int kc_c) {
         if (BF3) {
             const char *Ab = reinterpret_cast<const char *>(smem + buf * STAGE), *Wb = Ab + BM * ROWB;
-            bf16x8 af[WM][3], bq[WN][3];
-#pragma unroll
-            for (int wm = 0; wm < WM; ++wm)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    af[wm][pl] = *reinterpret_cast<const bf16x8 *>(Ab + ((wgm * WM + wm) * 32 + l31) * ROWB + pl * 32 + hi * 16);
-#pragma unroll
-            for (int wn = 0; wn < WN; ++wn)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    bq[wn][pl] = *reinterpret_cast<const bf16x8 *>(Wb + ((wgn * WN + wn) * 32 + l31) * ROWB + pl * 32 + hi * 16);
             // smallest terms first; consecutive MFMAs go to different accumulators
             constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int kb = 0; kb < KB; ++kb) {
+                bf16x8 af[WM][3], bq[WN][3];
 #pragma unroll
                 for (int wm = 0; wm < WM; ++wm)
 #pragma unroll
-                    for (int wn = 0; wn < WN; ++wn)
-                        acc[wm][wn] = TL ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[wn][PB[t]], af[wm][PA[t]], acc[wm][wn], 0, 0, 0)
-                                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[wm][PA[t]], bq[wn][PB[t]], acc[wm][wn], 0, 0, 0);
+                    for (int pl = 0; pl < 3; ++pl)
+                        af[wm][pl] = *reinterpret_cast<const bf16x8 *>(Ab + ((wgm * WM + wm) * 32 + l31) * ROWB + pl * PLB + kb * 32 + hi * 16);
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        bq[wn][pl] = *reinterpret_cast<const bf16x8 *>(Wb + ((wgn * WN + wn) * 32 + l31) * ROWB + pl * PLB + kb * 32 + hi * 16);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int wm = 0; wm < WM; ++wm)
+#pragma unroll
+                        for (int wn = 0; wn < WN; ++wn)
+                            acc[wm][wn] = TL ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[wn][PB[t]], af[wm][PA[t]], acc[wm][wn], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[wm][PA[t]], bq[wn][PB[t]], acc[wm][wn], 0, 0, 0);
+            }
         } else {
             const float *As = smem + buf * STAGE, *Ws = As + BM * LDT;
             const int kend = min(BK, Kpad - kc_c * BK);
@@ -824,6 +830,7 @@ static void dbg_report0(const GemmArgs &p, int amode, int epi, unsigned gx, int 
 #define GEMM_LAUNCH(a, b, c, d)                                                                                        \
     do {                                                                                                               \
         if (gemm_f32_exact()) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false, 0, TL>), grid, dim3(256), 0, st, p); \
+        else if (kb2) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0, TL, 2>), grid, dim3(a * b * 64), 0, st, p); \
         else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0, TL>), grid, dim3(a * b * 64), 0, st, p); \
         if (dbg_on) dbg_report0(p, AMODE, EPI, gx, a * b);                                                             \
     } while (0)
@@ -860,8 +867,15 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
     // few row tiles (group_all layers: M = B*N ~ 4096): 128-wide column tiles would leave most CUs idle, so use
     // 64- (or 32-) wide ones to get >= ~256 workgroups; the A tile is then re-read from L2 by more workgroups
     const int64_t wg128 = (int64_t)gx * cdiv(p.Nout, 128);
-    if (p.Nout > 64 && wg128 < 192 && (int64_t)gx * cdiv(p.Nout, 64) < 1024) {
-        if ((int64_t)gx * cdiv(p.Nout, 64) >= 192 || p.Nout <= 64) {
+    // few row tiles also means ONE tile per workgroup: the k loop is a serial chain of load -> transform -> MFMA stages with nothing
+    // to overlap it, so those problems take 32-wide k stages (half as many): kb2
+    static int kb_env = -1;
+    if (kb_env < 0) { const char *e = getenv("PAPC_GEMM_KB"); kb_env = e ? atoi(e) : 0; }
+    const bool kb2 = kb_env != 1 && !TL && gx <= 64;
+    static int minwg = -1;
+    if (minwg < 0) { const char *e = getenv("PAPC_GEMM_MINWG"); minwg = e ? atoi(e) : 192; }
+    if (p.Nout > 64 && wg128 < minwg && (int64_t)gx * cdiv(p.Nout, 64) < 1024) {
+        if ((int64_t)gx * cdiv(p.Nout, 64) >= minwg || p.Nout <= 64) {
             dim3 grid(gx, (unsigned)cdiv(p.Nout, 64));
             GEMM_LAUNCH(2, 2, 2, 1);
         } else {
@@ -877,7 +891,8 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
         }
         else if (!gemm_f32_exact() && gemm_waves8(AMODE, EPI))   // same 128x128 tile on 8 waves of 64x32: 4 waves per SIMD
         {
-            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL>), grid, dim3(512), 0, st, p);
+            if (kb2) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL, 2>), grid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL>), grid, dim3(512), 0, st, p);
             if (dbg_on) dbg_report0(p, AMODE, EPI, gx, 8);
         }
         else
