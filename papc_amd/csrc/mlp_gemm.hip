@@ -871,7 +871,7 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
     // to overlap it, so those problems take 32-wide k stages (half as many): kb2
     static int kb_env = -1;
     if (kb_env < 0) { const char *e = getenv("PAPC_GEMM_KB"); kb_env = e ? atoi(e) : 0; }
-    const bool kb2 = kb_env != 1 && !TL && gx <= 64;
+    const bool kb2 = !TL && (kb_env == 2 || (kb_env != 1 && gx <= 64));   // PAPC_GEMM_KB=1: never, =2: always (experiment)
     static int minwg = -1;
     if (minwg < 0) { const char *e = getenv("PAPC_GEMM_MINWG"); minwg = e ? atoi(e) : 192; }
     if (p.Nout > 64 && wg128 < minwg && (int64_t)gx * cdiv(p.Nout, 64) < 1024) {
