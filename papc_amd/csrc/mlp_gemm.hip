@@ -20,6 +20,8 @@
 //     suffices (writes of stage s go to the buffer last read in stage s-1, which every wave left before the
 //     previous barrier).  Two workgroups per CU: one computes while the other writes / stores.
 #include "mlp_loaders.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace papc {
 
@@ -55,7 +57,8 @@ struct GemmArgs {
     const float *bias;
     int64_t M; int Kin; int Nout;
     float *y; int64_t ldy;
-    float *stats;                  // [gridDim.x][2][Nout] or null
+    float *stats;                  // [parts][2][Nout] or null
+    int parts;                     // rows of `stats` the caller reduces (>= gridDim.x; the surplus rows are written as zeros)
     ScatterDst sc;
     RedSrc rd;
     GmaxDst gm;
@@ -65,7 +68,8 @@ struct GemmArgs {
 
 constexpr int LDT = 36;  // LDS row stride (floats)
 constexpr int BK = 32;
-constexpr int GEMM_MAX_PARTS = 512;  // one residency wave: 256 CUs x 2 workgroups
+constexpr int GEMM_MAX_PARTS = 768;  // rows of the per-workgroup partial buffers: up to 256 CUs x 3 resident workgroups (a kernel that
+                                     // fits fewer per CU launches fewer and zero-fills the rows it does not own)
 
 // The thread's float4 of the weight tile: row n (output channel), internal channels k..k+3.  fetch_w4 ONLY issues
 // loads (unconditional, clamped indices) so they stay in flight across the MFMA phase; mask_w4 zeroes the
@@ -778,7 +782,10 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
             float t = 0.f;
 #pragma unroll
             for (int g = 0; g < WGM; ++g) t += red[(which * WGM + g) * BN + c];
-            if (n0 + c < p.Nout) p.stats[((int64_t)blockIdx.x * 2 + which) * p.Nout + n0 + c] = t;
+            if (n0 + c < p.Nout) {
+                p.stats[((int64_t)blockIdx.x * 2 + which) * p.Nout + n0 + c] = t;
+                for (int r = blockIdx.x + gridDim.x; r < p.parts; r += gridDim.x) p.stats[((int64_t)r * 2 + which) * p.Nout + n0 + c] = 0.f;
+            }
         }
     }
 }
@@ -827,12 +834,38 @@ static void dbg_report0(const GemmArgs &p, int amode, int epi, unsigned gx, int 
     fprintf(stderr, "[gemm dbg0] amode %d epi %d waves %d M %lld K %d N %d: stages/wg %.0f | wave 0 cyc/stage: issue %.0f mfma %.0f consume %.0f epilogue %.0f barrier %.0f\n",
             amode, epi, waves, (long long)p.M, p.Kin, p.Nout, n / gx, c[0] / n, c[1] / n, c[2] / n, c[3] / n, c[5] / n);
 }
-#define GEMM_LAUNCH(a, b, c, d)                                                                                        \
+
+// persistent grid = one residency wave of THIS kernel: CUs x resident workgroups per CU (registers / LDS), capped by the row tiles
+static unsigned persist_grid(const void *kern, int threads, unsigned parts)
+{
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> cache;
+    static int ncu = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        else ncu = 256;
+    }
+    auto it = cache.find(kern);
+    int per_cu;
+    if (it == cache.end()) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n < 1) n = 2;
+        per_cu = std::min(n, 3);
+        cache[kern] = per_cu;
+        if (getenv("PAPC_GEMM_OCC")) fprintf(stderr, "[gemm occ] kernel %p threads %d: %d resident workgroups per CU (API %d), %d CUs\n", kern, threads, per_cu, n, ncu);
+    } else {
+        per_cu = it->second;
+    }
+    return std::min<unsigned>(parts, (unsigned)(ncu * per_cu));
+}
+#define GEMM_GO(KERN, THREADS)                                                                                         \
     do {                                                                                                               \
-        if (gemm_f32_exact()) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false, 0, TL>), grid, dim3(256), 0, st, p); \
-        else if (kb2) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0, TL, 2>), grid, dim3(a * b * 64), 0, st, p); \
-        else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0, TL>), grid, dim3(a * b * 64), 0, st, p); \
-        if (dbg_on) dbg_report0(p, AMODE, EPI, gx, a * b);                                                             \
+        auto kfn = KERN;                                                                                               \
+        grid.x = persist_grid(reinterpret_cast<const void *>(kfn), THREADS, gx);                                       \
+        hipLaunchKernelGGL(kfn, grid, dim3(THREADS), 0, st, p);                                                        \
     } while (0)
 
 static void dbg_report(const GemmArgs &p, int amode, int epi, unsigned gx)
@@ -852,6 +885,14 @@ static void dbg_report(const GemmArgs &p, int amode, int epi, unsigned gx)
             amode, epi, (long long)p.M, p.Kin, p.Nout, n / gx, c[0] / n, c[1] / n, c[2] / n, pr[0][0] / n, pr[0][1] / n, pr[0][2] / n, pr[0][3] / n);
 }
 
+#define GEMM_LAUNCH(a, b, c, d)                                                                                        \
+    do {                                                                                                               \
+        if (gemm_f32_exact()) GEMM_GO((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, false, 0, TL>), 256);                \
+        else if (kb2) GEMM_GO((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0, TL, 2>), a * b * 64);               \
+        else GEMM_GO((gemm_kernel<AMODE, EPI, VEC, a, b, c, d, 1, true, 0, TL>), a * b * 64);                           \
+        if (dbg_on) dbg_report0(p, AMODE, EPI, gx, a * b);                                                             \
+    } while (0)
+
 template <int AMODE, int EPI, bool VEC, bool TL>
 static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
 {
@@ -864,6 +905,7 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
         p.dbg = g_dbg;
     }
     const unsigned gx = (unsigned)gemm_parts(p.M);
+    p.parts = (int)gx;
     // few row tiles (group_all layers: M = B*N ~ 4096): 128-wide column tiles would leave most CUs idle, so use
     // 64- (or 32-) wide ones to get >= ~256 workgroups; the A tile is then re-read from L2 by more workgroups
     const int64_t wg128 = (int64_t)gx * cdiv(p.Nout, 128);
@@ -886,13 +928,13 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
         dim3 grid(gx, (unsigned)cdiv(p.Nout, 128));
         if (!gemm_f32_exact() && gemm_ws() == 3)        // 4 consumer + 12 producer waves on the same 128x128 tile
         {
-            hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2, 1, true, 3, TL>), grid, dim3(1024), 0, st, p);
+            GEMM_GO((gemm_kernel<AMODE, EPI, VEC, 2, 2, 2, 2, 1, true, 3, TL>), 1024);
             if (dbg_on) dbg_report(p, AMODE, EPI, gx);
         }
         else if (!gemm_f32_exact() && gemm_waves8(AMODE, EPI))   // same 128x128 tile on 8 waves of 64x32: 4 waves per SIMD
         {
-            if (kb2) hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL, 2>), grid, dim3(512), 0, st, p);
-            else hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL>), grid, dim3(512), 0, st, p);
+            if (kb2) GEMM_GO((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL, 2>), 512);
+            else GEMM_GO((gemm_kernel<AMODE, EPI, VEC, 2, 4, 2, 1, 1, true, 0, TL>), 512);
             if (dbg_on) dbg_report0(p, AMODE, EPI, gx, 8);
         }
         else
