@@ -23,6 +23,26 @@ template <> struct Vec<1> {
     __device__ float operator[](int) const { return v; }
 };
 
+// this lane's share (rows tl, tl + 64, ...) of the [n_tiles][2][C] partial rows of channel c, summed in row order; the loads of 8
+// rows are issued before the first add (the rows are a dependent chain of ~0.5 us loads otherwise)
+__device__ __forceinline__ void sum_partial_rows(const float *__restrict__ part, int n_tiles, int C, int c, int tl, double &s1, double &s2)
+{
+    for (int t0 = tl; t0 < n_tiles; t0 += 64 * 8) {
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + 64 * j;
+            const int64_t o = (int64_t)(t < n_tiles ? t : t0) * 2 * C + c;
+            a[j] = part[o];
+            b[j] = part[o + C];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (t0 + 64 * j < n_tiles) { s1 += (double)a[j]; s2 += (double)b[j]; }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // stats partials [n_tiles][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
 // ---------------------------------------------------------------------------------------------------
@@ -35,11 +55,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 channels x 64 part-lanes
     const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int t = tl; t < n_tiles; t += 64) {
-            s1 += (double)part[((int64_t)t * 2 + 0) * C + c];
-            s2 += (double)part[((int64_t)t * 2 + 1) * C + c];
-        }
+    if (c < C) sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
     r1[tl][cl] = s1; r2[tl][cl] = s2;
     __syncthreads();
     for (int h = 32; h >= 1; h >>= 1) {  // fixed-shape tree over the 64 part-lanes (deterministic)
@@ -215,11 +231,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
     const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 channels x 64 part-lanes
     const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int t = tl; t < n_tiles; t += 64) {
-            s1 += (double)part[((int64_t)t * 2 + 0) * C + c];
-            s2 += (double)part[((int64_t)t * 2 + 1) * C + c];
-        }
+    if (c < C) sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
     r1[tl][cl] = s1; r2[tl][cl] = s2;
     __syncthreads();
     for (int h = 32; h >= 1; h >>= 1) {  // fixed-shape tree over the 64 part-lanes (deterministic)
