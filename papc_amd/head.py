@@ -114,8 +114,7 @@ class _Head(torch.autograd.Function):
 def classifier_head(spec, x, fc1, bn1, drop1, fc2, bn2, drop2, fc3):
     """logits = fc3(drop2(relu(bn2(fc2(drop1(relu(bn1(fc1(x)))))))))  in train mode, fused."""
     params = (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias)
-    if spec.grad_targets is None and torch.is_grad_enabled():
-        spec.grad_targets = grad_targets_of(params)
+    spec.grad_targets = grad_targets_of(params) if torch.is_grad_enabled() else None   # per forward: see mlp.shared_mlp_max
     return _Head.apply(spec, (bn1, bn2), (float(drop1.p), float(drop2.p)), x, *params)
 
 

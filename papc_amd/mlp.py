@@ -323,6 +323,7 @@ def grad_targets_of(params):
 
 
 def shared_mlp_max(spec, bn_buffers, xyz, new_xyz, feats, idx, params, x_rows=None):
-    if spec.grad_targets is None and torch.is_grad_enabled():
-        spec.grad_targets = grad_targets_of(params)
+    # re-evaluated on every forward: a cached list would go stale when the optimizer replaces the .grad tensors
+    # (e.g. zero_grad(set_to_none=True)) and gradients would silently land in orphaned buffers
+    spec.grad_targets = grad_targets_of(params) if torch.is_grad_enabled() else None
     return SharedMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)

@@ -191,3 +191,30 @@ def test_hipgraph_replay_matches_eager(dev):
     scale = float(grad_e.abs().max())
     assert float((flat.grad - grad_e).abs().max()) <= 2e-4 * scale
     assert not torch.equal(m.sa1.mlp_bns[0].running_mean, bn_e)   # the running statistics keep moving under replay
+
+
+def test_grad_targets_follow_the_optimizer():
+    """In-place gradient accumulation must track the CURRENT .grad tensors: zero_grad(set_to_none=False) keeps them (kernels add in
+    place), zero_grad(set_to_none=True) drops them (gradients go back through autograd) -- switching between the two must not
+    leave gradients in orphaned buffers."""
+    import torch
+    from papc_amd.models import PointNet2_SSG_Clas
+    from papc_amd.head import softmax_cross_entropy
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    model = PointNet2_SSG_Clas(num_classes=16).to(dev).train()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    x = torch.randn(4, 3, 512, device=dev)
+    y = torch.randint(0, 16, (4,), device=dev)
+    for mode in (True, False, False, True, True):
+        opt.zero_grad(set_to_none=mode)
+        before = {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        loss = softmax_cross_entropy(model(x), y)
+        loss.backward()
+        for n, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+            if n.endswith("weight") and ("conv" in n or "fc" in n or "mlp" in n.lower()):
+                assert float(p.grad.abs().max()) > 0, (n, mode)
+        opt.step()
