@@ -129,7 +129,8 @@ typedef struct papc_group_src {
  * bn_scale/bn_shift [Cin] fold the previous layer's train-mode BN (from papc_bn_finalize_f32).
  * stats_partial (may be NULL): [papc_mlp_gemm_parts(M), 2, Cout] per-workgroup column sums and sums of
  * squares of y (deterministic, no atomics) for this layer's batch statistics. */
-/* rows of stats_partial written by papc_mlp_gemm_f32 for M rows (= its persistent grid size) */
+/* rows of stats_partial written by papc_mlp_gemm_f32 for M rows: min(row tiles, 768).  The kernel launches one residency wave of
+ * its own occupancy (<= that many workgroups) and writes the rows no workgroup owns as zeros. */
 int papc_mlp_gemm_parts(int64_t M);
 /* gmax (optional; last layer of a stack): fuse the neighbourhood max (paddle.max(new_points, 2), :219) into the
  * epilogue.  Per group of K consecutive rows the kernel writes max and min of y and the first row offset attaining

@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     assert lib.papc_mlp_gemm_f32(0, None, 0, None, None, None, None, None, 1, 1, 1, None, None, None, None) == -1
     assert lib.papc_mlp_gemm_gmax_ok(524288, 128, 32) == 1 and lib.papc_mlp_gemm_gmax_ok(524288, 128, 16) == 0 and lib.papc_mlp_gemm_gmax_ok(4096, 1024, 128) == 1
     assert lib.papc_pfn_num_blocks(12000) == 1024 and lib.papc_pfn_num_blocks(8) == 2
-    assert lib.papc_mlp_gemm_parts(524288) == 512 and lib.papc_mlp_gemm_parts(300) == 3
+    assert lib.papc_mlp_gemm_parts(524288) == 768 and lib.papc_mlp_gemm_parts(300) == 3   # rows of the partial buffers: min(row tiles, 3 x 256 CUs)
     with pytest.raises(_lib.PapcError):
         _lib.check(-1, "x")
 
