@@ -284,8 +284,24 @@ def main():
             achieved = byts / per_step_s / 1e9
             roof = {"bound": "hbm", "kernel": K_NAMES[dominant], "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
-        roof["traffic_note"] = ("PMC FETCH_SIZE x2 + WRITE_SIZE are collected offline in separate passes (profiles/r01_bench_pmc_fetch_write.txt): "
-                                "dW family 2.62 GB/step measured vs 2.35 GB algorithmic")
+        # HBM traffic of the family from the PMC counters: they need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
+        # separately, --kernel-trace only), so they are collected offline (tools/refresh_profiles.sh) and read back from the
+        # committed per-family summary of the latest round
+        roof["traffic_note"] = "no profiles/*_bench_pmc_family.json found"
+        import glob
+        fams = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_bench_pmc_family.json")))
+        if fams:
+            try:
+                with open(fams[-1]) as fh:
+                    rec = json.load(fh).get(K_NAMES[dominant])
+                if rec:
+                    roof["traffic"] = round(rec["traffic_MB_per_launch"] * 1e6)     # bytes per launch, like `achieved`
+                    roof["traffic_note"] = ("%s: 2 x FETCH_SIZE + WRITE_SIZE per launch of the family (separate rocprofv3 --pmc passes, gfx950 "
+                                            "FETCH_SIZE correction x2), %.1f MB against %.1f MB algorithmic per launch"
+                                            % (os.path.join("profiles", os.path.basename(fams[-1])), rec["traffic_MB_per_launch"],
+                                               byts / 1e6 / max(1, dom_n // n_roof)))
+            except (OSError, ValueError, KeyError) as e:
+                roof["traffic_note"] = "could not read %s: %s" % (fams[-1], e)
         roof["algorithmic"] = {"GFLOP_per_step": round(flop / 1e9, 2), "MB_per_step": round(byts / 1e6, 1),
                                "mfma_floor_ms": round(t_mfma * 1e3, 3), "hbm_floor_ms": round(t_hbm * 1e3, 3)}
         roof["launches_per_step"] = dom_n // n_roof

@@ -1,0 +1,47 @@
+"""Per kernel family: HBM traffic per launch from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; unit KB).
+    python tools/pmc_family.py <fetch dir> <write dir> > profiles/rNN_bench_pmc_family.json
+FETCH_SIZE is doubled (gfx950 under-reports wide streaming reads by 2x: MI355X_MICROARCH.md, HBM section; calibrated in this repo on
+streaming kernels of known traffic).  Families are the library's profiling families (papc_prof_*, include/papc_hip.h)."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    n = re.sub(r"^void ", "", name).replace("papc::", "")
+    if n.startswith(("dw_ws_kernel", "dw_kernel", "dw_xyz_kernel")):
+        return "bwd_dw_gemm"
+    m = re.match(r"gemm_kernel<(\d+),", n)
+    if m:
+        return "mlp_gemm_fwd" if int(m.group(1)) <= 2 else "bwd_dx_gemm"
+    if n.startswith("fps_kernel"):
+        return "fps"
+    if n.startswith("ball_query"):
+        return "ball_query"
+    return None
+
+
+def collect(d):
+    agg = defaultdict(lambda: [0, 0.0])
+    with open(d + "/run_counter_collection.csv") as f:
+        for r in csv.DictReader(f):
+            fam = family(r["Kernel_Name"])
+            if fam:
+                agg[fam][0] += 1
+                agg[fam][1] += float(r["Counter_Value"])
+    return agg
+
+
+fetch, write = collect(sys.argv[1]), collect(sys.argv[2])
+out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --no-cpu-baseline "
+               "--no-graph --steps 6 --warmup 2`; bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches"}
+for fam in sorted(set(fetch) | set(write)):
+    nf, kf = fetch.get(fam, [0, 0.0])
+    nw, kw = write.get(fam, [0, 0.0])
+    n = max(nf, nw, 1)
+    out[fam] = {"launches_profiled": n, "fetch_MB_per_launch_x2": round(2 * kf * 1024 / n / 1e6, 2),
+                "write_MB_per_launch": round(kw * 1024 / n / 1e6, 2),
+                "traffic_MB_per_launch": round((2 * kf + kw) * 1024 / n / 1e6, 2)}
+print(json.dumps(out, indent=1))

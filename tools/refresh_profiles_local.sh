@@ -20,4 +20,5 @@ grep "^{" $O/bench_line.json > $P/${R}_bench_line.json
   echo "# v_mfma_f32_32x32x16_bf16 and 64 per v_mfma_f32_32x32x2_f32 (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs."
   python tools/pmc_table.py $O/pmc_sq 30
 } > $P/${R}_bench_pmc_sq.txt
+python tools/pmc_family.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $P/${R}_bench_pmc_family.json
 wc -l $P/${R}_*
