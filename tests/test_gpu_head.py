@@ -37,10 +37,14 @@ def _ref64(x0, mods, keeps, glogits):
     return logits.detach(), x.grad, [t.grad for t in prm], stats
 
 
-@pytest.mark.parametrize("B,c3,accumulate", [(32, 40, False), (32, 40, True), (7, 16, False), (100, 40, True), (256, 8, False)])
-def test_head_matches_float64(B, c3, accumulate):
+@pytest.mark.parametrize("B,c3,accumulate,dims", [(32, 40, False, None), (32, 40, True, None), (7, 16, False, None), (100, 40, True, None),
+                                                  (256, 8, False, None),
+                                                  (5, 12, False, (132, 72, 40)),      # ragged widths: partial 32-channel tiles, k tails
+                                                  (33, 4, True, (36, 100, 68))])
+def test_head_matches_float64(B, c3, accumulate, dims):
     from papc_amd import head
-    mods = [m.cuda() for m in _modules(1024, 512, 256, c3, 3 + B)]
+    c0, c1, c2 = dims if dims else (1024, 512, 256)
+    mods = [m.cuda() for m in _modules(c0, c1, c2, c3, 3 + B)]
     fc1, bn1, d1, fc2, bn2, d2, fc3 = mods
     params = [fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias]
     g0 = None
@@ -50,7 +54,7 @@ def test_head_matches_float64(B, c3, accumulate):
             p.grad = torch.randn_like(p) * 0.01
             g0.append(p.grad.clone())
     rm0 = [bn1.running_mean.clone(), bn1.running_var.clone(), bn2.running_mean.clone(), bn2.running_var.clone()]
-    x0 = torch.randn(B, 1024, device="cuda", requires_grad=True)
+    x0 = torch.randn(B, c0, device="cuda", requires_grad=True)
     glog = torch.randn(B, c3, device="cuda")
     spec = head.HeadSpec()
     spec.export_masks = True
