@@ -345,6 +345,20 @@ int papc_rotate_nms_f32(const float *dets, int N, float nms_overlap_thresh, int3
                         size_t workspace_bytes, papc_stream_t stream);
 int papc_rotate_iou_f32(const float *boxes, const float *query_boxes, int N, int K, int criterion, float *iou, papc_stream_t stream);
 
+/* First layer of a GROUPED stack with the linear map taken before the gather (pointnet2_basic_layers.py:146-153 + conv1 :215-217):
+ * a row is [xyz_j - centre | feats_j], so y[m] = P[j] + W_x (xyz_j - centre) + b with P = feats W_f^T [B*N, C] computed once per
+ * SOURCE POINT by the caller (a B*N-row GEMM) instead of once per (group, neighbour) row.
+ * papc_lingather_fwd_f32: y [M,C] and the per-workgroup column sums / sums of squares stats_partial [papc_lingather_parts(M), 2, C]
+ * (feed papc_bn_finalize_f32 with that row count).  w [C, ldw] is the layer weight, its xyz columns are xcol0..xcol0+2; grp gives
+ * xyz / new_xyz / idx / N / S / K (feats, D unused); bias may be NULL.  C % 4 == 0.
+ * papc_lingather_bwd_f32: from the layer's dense dY source (papc_bwd_dy, DENSE), G [B*N, C] += sum of dY rows per source point
+ * (pre-zeroed by the caller, float atomics) and dwx_partial [papc_lingather_parts(M), C, 3] = partial sums of dY^T (xyz_j - centre);
+ * the caller finishes with grad_feats = G W_f, dW_f = G^T feats, dW_x = sum of the partials. */
+int papc_lingather_parts(int64_t M);
+int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, const float *w, int ldw, int xcol0, const float *bias, int C,
+                           float *y, float *stats_partial, papc_stream_t stream);
+int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream);
+
 /* Backward of a max-pooled LAST layer without reading its dense output y [M,Cout] (the largest tensor of a stack).  With the BN+ReLU
  * backward expanded, dy = s*p - e*y + f (s = scale, e = s*c2*invstd, f = e*mean - s*c1; c1, c2 from papc_bn_bwd_finalize_f32) and
  * y = A W^T + b, A = relu(bn(y_prev)):      dX = (s*p) W - A (W^T E W) + (f - e*b) W.

@@ -88,6 +88,9 @@ SIGNATURES = {
     "papc_softmax_xent_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "papc_nms_workspace": (ctypes.c_size_t, [c_i]),
     "papc_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
+    "papc_lingather_parts": (c_i, [c_l]),
+    "papc_lingather_fwd_f32": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
+    "papc_lingather_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "papc_bn_max_prep_f32": (c_i, [c_p] * 10 + [c_l, c_i, c_i] + [c_p] * 6),
     "papc_mlp_bwd_dx_max_f32": (c_i, [c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
     "papc_transpose_batch_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p]),

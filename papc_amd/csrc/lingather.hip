@@ -1,0 +1,253 @@
+// lingather.hip -- first layer of a grouped stack with the linear map taken BEFORE the gather, for gfx950.
+//
+// Reference: PAPC/models/layers/pointnet2_basic_layers.py:146-153 (grouped_xyz_norm / index_points(points, idx) / concat) feeding
+// conv1 of the stack (:215-217).  A row of that layer's input is [ xyz_j - centre (3) | feats_j (D) ] for neighbour j of a group, so
+//     y[m, :] = W_x (xyz_j - centre) + W_f feats_j + b  =  P[j, :] + W_x (xyz_j - centre) + b,     P = feats W_f^T  [B*N, C].
+// W_f feats_j depends on the SOURCE POINT only: every point sits in S*K/N (16 for SA2 of the SSG classifier) neighbourhoods, so the
+// D-wide product is computed once per point (a B*N-row library GEMM) instead of once per (group, neighbour) row, and the layer
+// itself becomes a streaming gather-add: one P row (C floats, L2-resident table) + a rank-3 update per output row.
+// Backward, with G[j, :] = sum over the rows m that gathered point j of dY[m, :]:
+//     grad_feats = G W_f,   dW_f = G^T feats   (B*N-row GEMMs),   dW_x[c, t] = sum_m dY[m, c] (xyz_j - centre)[t]  (streamed here).
+// Both kernels are HBM-bound on the [M, C] activation stream (write y | read dz, y).
+#include "mlp_loaders.h"
+
+namespace papc {
+
+struct LinGatherArgs {
+    const float *P;             // [B*N, C]
+    const float *xyz; int64_t sb, sn, sc;
+    const float *new_xyz;       // [B*S, 3]
+    const int32_t *idx;         // [B*S*K]
+    const float *w; int ldw, xcol0;   // layer weight [C, ldw]; xyz columns xcol0 .. xcol0+2
+    const float *bias;          // [C] or null
+    int B, N, S, K, C;
+    int64_t M;
+    float *y;                   // fwd: [M, C]
+    float *stats;               // fwd: [gridDim.x][2][C] column sums / sums of squares of y
+    DySrc d;                    // bwd: dz, y, BN constants (DENSE)
+    float *G;                   // bwd: [B*N, C], pre-zeroed, atomically accumulated
+    float *dwx;                 // bwd: [gridDim.x][C][3]
+    int rows_per_wg;
+};
+
+constexpr int LG_T = 256;
+
+struct LgRow {
+    int j;            // source point (or -1: no-hit sentinel -> zero input row)
+    int b;
+    float dx, dy, dz; // xyz_j - centre
+};
+
+__device__ __forceinline__ LgRow lg_row(const LinGatherArgs &a, int64_t m)
+{
+    LgRow r;
+    const int g = (int)(m / a.K);
+    r.b = g / a.S;
+    int j = a.idx[m];
+    if (j < 0 || j >= a.N) { r.j = -1; r.dx = r.dy = r.dz = 0.f; return r; }
+    r.j = j;
+    const float *p = a.xyz + (int64_t)r.b * a.sb + (int64_t)j * a.sn;
+    const float *c = a.new_xyz + (int64_t)g * 3;
+    r.dx = p[0] - c[0]; r.dy = p[a.sc] - c[1]; r.dz = p[2 * a.sc] - c[2];      // grouped_xyz - new_xyz (:147)
+    return r;
+}
+
+// y = P[j] + W_x d + b, per-workgroup column statistics; thread = (row slot, channel quad)
+__global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
+{
+    __shared__ float red[LG_T * 8];
+    const int tid = threadIdx.x;
+    const int CQ = a.C >> 2, RSL = LG_T / CQ;
+    const int cq = tid % CQ, slot = tid / CQ;
+    const bool act = slot < RSL;
+    const int c = cq * 4;
+    float4 w0, w1, w2, bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        const float *wp = a.w + (int64_t)c * a.ldw + a.xcol0;
+        w0 = make_float4(wp[0], wp[a.ldw], wp[2 * a.ldw], wp[3 * a.ldw]);
+        w1 = make_float4(wp[1], wp[a.ldw + 1], wp[2 * a.ldw + 1], wp[3 * a.ldw + 1]);
+        w2 = make_float4(wp[2], wp[a.ldw + 2], wp[2 * a.ldw + 2], wp[3 * a.ldw + 2]);
+        if (a.bias) bv = ld4(a.bias + c);
+    }
+    const int64_t mbeg = (int64_t)blockIdx.x * a.rows_per_wg, mend = min(a.M, mbeg + a.rows_per_wg);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    constexpr int U = 4;
+    if (act) {
+        for (int64_t m0 = mbeg + slot; m0 < mend; m0 += (int64_t)U * RSL) {
+            LgRow r[U];
+            float4 pv[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = m0 + (int64_t)u * RSL;
+                ok[u] = m < mend;
+                r[u] = lg_row(a, ok[u] ? m : mbeg);
+                pv[u] = ld4(a.P + ((int64_t)r[u].b * a.N + (r[u].j < 0 ? 0 : r[u].j)) * a.C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                float4 v = r[u].j < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : pv[u];
+                v.x = fmaf(r[u].dz, w2.x, fmaf(r[u].dy, w1.x, fmaf(r[u].dx, w0.x, v.x + bv.x)));
+                v.y = fmaf(r[u].dz, w2.y, fmaf(r[u].dy, w1.y, fmaf(r[u].dx, w0.y, v.y + bv.y)));
+                v.z = fmaf(r[u].dz, w2.z, fmaf(r[u].dy, w1.z, fmaf(r[u].dx, w0.z, v.z + bv.z)));
+                v.w = fmaf(r[u].dz, w2.w, fmaf(r[u].dy, w1.w, fmaf(r[u].dx, w0.w, v.w + bv.w)));
+                *reinterpret_cast<float4 *>(a.y + (m0 + (int64_t)u * RSL) * a.C + c) = v;
+                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+                s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
+            }
+        }
+    }
+    float *rd = red + tid * 8;
+    rd[0] = act ? s1.x : 0.f; rd[1] = act ? s1.y : 0.f; rd[2] = act ? s1.z : 0.f; rd[3] = act ? s1.w : 0.f;
+    rd[4] = act ? s2.x : 0.f; rd[5] = act ? s2.y : 0.f; rd[6] = act ? s2.z : 0.f; rd[7] = act ? s2.w : 0.f;
+    __syncthreads();
+    for (int t = tid; t < 2 * a.C; t += LG_T) {       // (which, channel): sum over the row slots in slot order
+        const int which = t / a.C, ch = t - which * a.C;
+        float sacc = 0.f;
+        for (int sl = 0; sl < RSL; ++sl) sacc += red[(sl * CQ + (ch >> 2)) * 8 + which * 4 + (ch & 3)];
+        a.stats[((int64_t)blockIdx.x * 2 + which) * a.C + ch] = sacc;
+    }
+}
+
+// dY rows -> G[j] (atomic), dW_x partial sums.  Lane = channel, so one atomic instruction of a wave covers 64 consecutive floats of a
+// G row (the quad-per-lane mapping of the forward kernel would issue four quarter-dense atomics instead).  Ball-query padding
+// repeats each group's first neighbour, often for half of the nsample slots: those rows are summed in a register per group and
+// flushed with one atomic.
+__global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
+{
+    __shared__ float red[LG_T * 3];
+    const int tid = threadIdx.x;
+    const int RSL = LG_T / a.C;                   // C <= 256 (host-checked)
+    const int ch = tid % a.C, slot = tid / a.C;
+    const bool act = slot < RSL;
+    const DySrc &d = a.d;
+    const float ksc = d.scale[ch], ksh = d.shift[ch], kmu = d.mean[ch];
+    const float kA = ksc * d.c1[ch], kB = ksc * d.c2[ch] * d.invstd[ch];
+    const int64_t mbeg = (int64_t)blockIdx.x * a.rows_per_wg, mend = min(a.M, mbeg + a.rows_per_wg);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    float dsum = 0.f;                             // pending sum of padding duplicates ...
+    int dgrp = -1, djf = -1, dbat = 0;            // ... of group dgrp (first neighbour djf, cloud dbat)
+    constexpr int U = 8;
+    if (act) {
+        for (int64_t m0 = mbeg + slot; m0 < mend; m0 += (int64_t)U * RSL) {
+            LgRow r[U];
+            float vy[U], vz[U];
+            int jf[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = m0 + (int64_t)u * RSL;
+                ok[u] = m < mend;
+                const int64_t mc = ok[u] ? m : mbeg;
+                r[u] = lg_row(a, mc);
+                jf[u] = a.idx[(mc / a.K) * a.K];
+                vy[u] = d.y[mc * a.C + ch];
+                vz[u] = d.dz[mc * a.C + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u] || r[u].j < 0) continue;
+                const int64_t m = m0 + (int64_t)u * RSL;
+                const float z = fmaf(ksc, vy[u], ksh);
+                const float pp = z > 0.f ? vz[u] : 0.f;
+                const float g = fmaf(ksc, pp, -fmaf(kB, vy[u] - kmu, kA));
+                acc0 = fmaf(g, r[u].dx, acc0); acc1 = fmaf(g, r[u].dy, acc1); acc2 = fmaf(g, r[u].dz, acc2);
+                const int grp = (int)(m / a.K);
+                if (r[u].j == jf[u] && m != (int64_t)grp * a.K) {       // a padding duplicate of the group's first neighbour
+                    if (grp != dgrp) {
+                        if (dgrp >= 0 && djf >= 0 && djf < a.N) unsafeAtomicAdd(a.G + ((int64_t)dbat * a.N + djf) * a.C + ch, dsum);
+                        dsum = 0.f; dgrp = grp; djf = jf[u]; dbat = r[u].b;
+                    }
+                    dsum += g;
+                } else {
+                    unsafeAtomicAdd(a.G + ((int64_t)r[u].b * a.N + r[u].j) * a.C + ch, g);
+                }
+            }
+        }
+        if (dgrp >= 0 && djf >= 0 && djf < a.N) unsafeAtomicAdd(a.G + ((int64_t)dbat * a.N + djf) * a.C + ch, dsum);
+    }
+    red[tid * 3 + 0] = act ? acc0 : 0.f; red[tid * 3 + 1] = act ? acc1 : 0.f; red[tid * 3 + 2] = act ? acc2 : 0.f;
+    __syncthreads();
+    float *out = a.dwx + (int64_t)blockIdx.x * a.C * 3;
+    for (int t = tid; t < a.C * 3; t += LG_T) {
+        const int c = t / 3, k = t - c * 3;
+        float sacc = 0.f;
+        for (int sl = 0; sl < RSL; ++sl) sacc += red[(sl * a.C + c) * 3 + k];
+        out[t] = sacc;
+    }
+}
+
+}  // namespace papc
+
+using namespace papc;
+
+static int lg_check(const papc_group_src *g, int B, int C, const char *who)
+{
+    PAPC_REQUIRE(g && g->xyz && g->new_xyz && g->idx, PAPC_E_INVALID, "%s: group source needs xyz, new_xyz and idx", who);
+    PAPC_REQUIRE(B >= 1 && g->N >= 1 && g->S >= 1 && g->K >= 1, PAPC_E_INVALID, "%s: bad B/N/S/K", who);
+    PAPC_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, PAPC_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in [4, 1024]", who, C);
+    PAPC_REQUIRE((int64_t)B * g->S * g->K < (1ll << 31), PAPC_E_UNSUPPORTED, "%s: >= 2^31 rows", who);
+    return 0;
+}
+
+static void lg_fill(LinGatherArgs &a, const papc_group_src *g, int B, int C)
+{
+    a.xyz = g->xyz; a.sb = g->sb; a.sn = g->sn; a.sc = g->sc; a.new_xyz = g->new_xyz; a.idx = g->idx;
+    a.B = B; a.N = g->N; a.S = g->S; a.K = g->K; a.C = C; a.M = (int64_t)B * g->S * g->K;
+}
+
+extern "C" {
+
+// workgroups (= rows of the partial buffers): the kernels are chains of dependent loads (neighbour index -> point), so they want
+// many resident waves -- 8 workgroups of 256 threads per CU
+int papc_lingather_parts(int64_t M)
+{
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("PAPC_LG_PARTS"); cap = e ? atoi(e) : 2048; if (cap < 1 || cap > 8192) cap = 2048; }
+    return (int)std::min<int64_t>(cap, std::max<int64_t>(1, (M + 127) / 128));
+}
+
+int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, const float *w, int ldw, int xcol0, const float *bias, int C,
+                           float *y, float *stats_partial, papc_stream_t stream)
+{
+    int rc = lg_check(grp, B, C, "papc_lingather_fwd_f32");
+    if (rc) return rc;
+    PAPC_REQUIRE(P && w && y && stats_partial, PAPC_E_INVALID, "papc_lingather_fwd_f32: null pointer");
+    PAPC_REQUIRE(aligned16(P) && aligned16(y) && (!bias || aligned16(bias)) && ldw >= xcol0 + 3 && xcol0 >= 0, PAPC_E_INVALID,
+                 "papc_lingather_fwd_f32: alignment / weight columns");
+    LinGatherArgs a;
+    memset(&a, 0, sizeof(a));
+    lg_fill(a, grp, B, C);
+    a.P = P; a.w = w; a.ldw = ldw; a.xcol0 = xcol0; a.bias = bias; a.y = y; a.stats = stats_partial;
+    const int parts = papc_lingather_parts(a.M);
+    a.rows_per_wg = (int)((a.M + parts - 1) / parts);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MLP_GEMM, st);
+    hipLaunchKernelGGL(lingather_fwd_kernel, dim3((unsigned)parts), dim3(LG_T), 0, st, a);
+    return check_launch("papc_lingather_fwd_f32");
+}
+
+int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream)
+{
+    int rc = lg_check(grp, B, C, "papc_lingather_bwd_f32");
+    if (rc) return rc;
+    PAPC_REQUIRE(dy && dy->dz_mode == PAPC_DZ_DENSE && dy->dz && dy->y && dy->mean && dy->invstd && dy->scale && dy->shift && dy->c1 && dy->c2,
+                 PAPC_E_INVALID, "papc_lingather_bwd_f32: needs a dense dY source");
+    PAPC_REQUIRE(G && dwx_partial, PAPC_E_INVALID, "papc_lingather_bwd_f32: null pointer");
+    PAPC_REQUIRE(C <= LG_T, PAPC_E_UNSUPPORTED, "papc_lingather_bwd_f32: C=%d > %d", C, LG_T);
+    LinGatherArgs a;
+    memset(&a, 0, sizeof(a));
+    lg_fill(a, grp, B, C);
+    a.d.dz = dy->dz; a.d.y = dy->y; a.d.mean = dy->mean; a.d.invstd = dy->invstd; a.d.scale = dy->scale; a.d.shift = dy->shift;
+    a.d.c1 = dy->c1; a.d.c2 = dy->c2; a.d.C = C;
+    a.G = G; a.dwx = dwx_partial;
+    const int parts = papc_lingather_parts(a.M);
+    a.rows_per_wg = (int)((a.M + parts - 1) / parts);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_DW, st);
+    hipLaunchKernelGGL(lingather_bwd_kernel, dim3((unsigned)parts), dim3(LG_T), 0, st, a);
+    return check_launch("papc_lingather_bwd_f32");
+}
+
+}  // extern "C"

@@ -53,6 +53,7 @@ import os
 _FUSE_RED = os.environ.get("PAPC_NO_RED") != "1"            # A/B switch for the BN-backward reduce fused into the dX epilogue
 _FUSE_GMAX = os.environ.get("PAPC_NO_GMAX") != "1"          # A/B switch for the fused neighbourhood-max epilogue
 _RESIDENT_WGS = int(os.environ.get("PAPC_PARTS", "512"))   # persistent-grid size (tuning knob shared with the C side)
+_LIN_GATHER = os.environ.get("PAPC_LIN_GATHER", "1") == "1"    # first grouped layer: linear map per source point, then gather-add (lingather.hip)
 _SPARSE_MAX = os.environ.get("PAPC_SPARSE_MAX", "0") == "1"   # dX of the max-pooled last layer without reading its output y (papc_mlp_bwd_dx_max_f32)
 _DW_WGS = int(os.environ.get("PAPC_DW_WGS", "512"))         # workgroups of one dW launch (row chunks x output tiles)
 
@@ -94,6 +95,8 @@ class SharedMLPMax(torch.autograd.Function):
         prev_y, prev_sc, prev_sh = None, None, None
         cin = x_rows.shape[1] if plain else spec.D + 3
         cin0 = cin
+        lin0 = (_LIN_GATHER and not plain and idx is not None and feats is not None and L >= 2 and spec.D % 4 == 0 and spec.D >= 16
+                and params[0].shape[0] % 4 == 0 and params[0].shape[0] <= 256 and feats.is_contiguous())
         for l in range(L):
             w, b, gamma, beta = params[4 * l: 4 * l + 4]
             cout = w.shape[0]
@@ -101,6 +104,7 @@ class SharedMLPMax(torch.autograd.Function):
             assert w2.is_contiguous()
             y = torch.empty(M, cout, device=dev, dtype=torch.float32)
             stats = torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
+            parts_l = parts
             gm_ref = None
             if l == L - 1 and spec.pool and _FUSE_GMAX and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
                 # last layer: the neighbourhood max is reduced in the GEMM epilogue (per-group max/min of the raw output)
@@ -115,6 +119,14 @@ class SharedMLPMax(torch.autograd.Function):
             if l == 0 and plain:
                 check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(x_rows), cin, None, None, None, ptr(w2), ptr(b), M, cin, cout,
                                             ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
+            elif l == 0 and lin0:
+                # W_f feats_j depends on the source point only: one [B*N, D] x [D, cout] product, then a streaming gather-add
+                wf = (w2[:, 3:] if spec.xyz_first else w2[:, :spec.D]).contiguous()
+                P = torch.mm(feats.reshape(-1, spec.D), wf.t())
+                parts_l = lib.papc_lingather_parts(M)
+                stats = torch.empty(parts_l, 2, cout, device=dev, dtype=torch.float32)
+                check(lib.papc_lingather_fwd_f32(ptr(P), ctypes.byref(grp), spec.B, ptr(w2), cin, 0 if spec.xyz_first else spec.D,
+                                                 ptr(b), cout, ptr(y), ptr(stats), st), "papc_lingather_fwd_f32")
             elif l == 0:
                 check(lib.papc_mlp_gemm_f32(A_GROUP, None, 0, ctypes.byref(grp), None, None, ptr(w2), ptr(b), M, cin, cout,
                                             ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
@@ -123,7 +135,7 @@ class SharedMLPMax(torch.autograd.Function):
                                             cout, ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
             cst = torch.empty(4, cout, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
             rm, rv = (bn_buffers[l] if bn_buffers is not None else (None, None))
-            check(lib.papc_bn_finalize_f32(ptr(stats), parts, M, cout, ptr(gamma), ptr(beta), spec.eps, spec.momentum,
+            check(lib.papc_bn_finalize_f32(ptr(stats), parts_l, M, cout, ptr(gamma), ptr(beta), spec.eps, spec.momentum,
                                            cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(),
                                            ptr(rm), ptr(rv), st), "papc_bn_finalize_f32")
             ys.append(y)
@@ -151,6 +163,7 @@ class SharedMLPMax(torch.autograd.Function):
         ctx.feats_needs_grad = feats is not None and feats.requires_grad and not spec.cut_gather_grad
         ctx.x_needs_grad = plain and x_rows.requires_grad
         ctx.cin0 = cin0
+        ctx.lin0 = lin0
         ysel = gbuf_f[0] if (spec.pool and gm_ref is not None) else None   # raw y at the argmax (left in gmax by select_max)
         ctx.save_for_backward(xyz, new_xyz, feats, idx, x_rows, argmax, ysel, *params, *ys, *consts)
         return out
@@ -185,6 +198,8 @@ class SharedMLPMax(torch.autograd.Function):
                       and cL + cLi <= 512)
         if sparse_max:
             need_wt.remove(L - 1)
+        if ctx.lin0 and 0 in need_wt:
+            need_wt.remove(0)
         wts = {}
         for g0 in range(0, len(need_wt), 8):
             grp_l = need_wt[g0:g0 + 8]
@@ -230,6 +245,48 @@ class SharedMLPMax(torch.autograd.Function):
                 red, red_parts = fused_red, gemm_parts
             check(lib.papc_bn_bwd_finalize_f32(ptr(red), red_parts, M, cout, dgamma_p, dbeta_p,
                                                c12[0].data_ptr(), c12[1].data_ptr(), int(inplace), st), "papc_bn_bwd_finalize_f32")
+            if l == 0 and ctx.lin0:
+                # G[j] = sum of the dY rows that gathered point j (+ the xyz columns of dW, streamed); the D-wide products run on B*N rows
+                BN_ = spec.B * spec.N
+                parts_l = lib.papc_lingather_parts(M)
+                dwx_part = torch.empty(parts_l, cout * 3, device=dev, dtype=torch.float32)
+                Gs = torch.zeros(BN_, cout, device=dev, dtype=torch.float32)
+                check(lib.papc_lingather_bwd_f32(ctypes.byref(dy), ctypes.byref(grp), spec.B, cout, ptr(Gs), ptr(dwx_part), st),
+                      "papc_lingather_bwd_f32")
+                dwx = torch.empty(cout, 3, device=dev, dtype=torch.float32)
+                check(lib.papc_reduce_partials_f32(ptr(dwx_part), parts_l, cout * 3, ptr(dwx), 0, st), "papc_reduce_partials_f32")
+                # dW_f = G^T feats on the library's own dW kernel (K = B*N rows: rocBLAS picks an unsplit 32x32 kernel, 108 us):
+                # G plays dY with BN constants that make dY = dz (scale 1, shift huge -> ReLU mask always on, c1 = c2 = 0)
+                one = torch.ones(cout, device=dev, dtype=torch.float32)
+                zero = torch.zeros(cout, device=dev, dtype=torch.float32)
+                big = torch.full((cout,), 1e30, device=dev, dtype=torch.float32)
+                dyg = BwdDy()
+                dyg.dz_mode, dyg.dz, dyg.gout, dyg.argmax, dyg.K = DZ_DENSE, Gs.data_ptr(), None, None, 1
+                dyg.y = Gs.data_ptr()
+                dyg.mean, dyg.invstd, dyg.scale, dyg.shift = zero.data_ptr(), one.data_ptr(), one.data_ptr(), big.data_ptr()
+                dyg.c1, dyg.c2 = zero.data_ptr(), zero.data_ptr()
+                rpc_g = _dw_rows_per_chunk(BN_, cout, spec.D)
+                n_chunks_g = (BN_ + rpc_g - 1) // rpc_g
+                pld_g = cout * spec.D + cout
+                part_g = torch.empty(n_chunks_g, pld_g, device=dev, dtype=torch.float32)
+                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dyg), A_PLAIN, ptr(feats), spec.D, None, None, None, BN_, spec.D, cout, rpc_g,
+                                              part_g.data_ptr(), part_g.data_ptr() + 4 * cout * spec.D, pld_g, st), "papc_mlp_bwd_dw_f32")
+                dwf = torch.empty(cout, spec.D, device=dev, dtype=torch.float32)
+                dbf = torch.empty(cout, device=dev, dtype=torch.float32)
+                check(lib.papc_reduce_partials2_f32(ptr(part_g), n_chunks_g, pld_g, cout * spec.D, ptr(dwf), cout, ptr(dbf), 0, st),
+                      "papc_reduce_partials2_f32")
+                dw = torch.cat([dwx, dwf], 1) if spec.xyz_first else torch.cat([dwf, dwx], 1)
+                if inplace:
+                    tgt[0].add_(dw.reshape(tgt[0].shape))      # (db: a bias feeding a train-mode BN has gradient exactly 0)
+                else:
+                    grads[0] = dw.reshape(w.shape)
+                    grads[1] = torch.zeros(cout, device=dev, dtype=torch.float32)
+                    grads[2] = dgb[0]
+                    grads[3] = dgb[1]
+                if ctx.feats_needs_grad:
+                    wf = (w.reshape(cout, cin)[:, 3:] if spec.xyz_first else w.reshape(cout, cin)[:, :spec.D]).contiguous()
+                    grad_feats = torch.mm(Gs, wf).reshape(spec.B, spec.N, spec.D)
+                break
             # ---- dW, db
             rpc = _dw_rows_per_chunk(M, cout, cin)
             n_chunks = (M + rpc - 1) // rpc
