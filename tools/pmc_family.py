@@ -11,8 +11,10 @@ from collections import defaultdict
 
 def family(name):
     n = re.sub(r"^void ", "", name).replace("papc::", "")
-    if n.startswith(("dw_ws_kernel", "dw_kernel", "dw_xyz_kernel")):
+    if n.startswith(("dw_ws_kernel", "dw_kernel", "dw_xyz_kernel", "lingather_bwd_kernel")):
         return "bwd_dw_gemm"
+    if n.startswith("lingather_fwd_kernel"):
+        return "mlp_gemm_fwd"
     m = re.match(r"gemm_kernel<(\d+),", n)
     if m:
         return "mlp_gemm_fwd" if int(m.group(1)) <= 2 else "bwd_dx_gemm"
