@@ -114,9 +114,15 @@ __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
 // G row (the quad-per-lane mapping of the forward kernel would issue four quarter-dense atomics instead).  Ball-query padding
 // repeats each group's first neighbour, often for half of the nsample slots: those rows are summed in a register per group and
 // flushed with one atomic.
+constexpr int LG_ROWS = 256;                    // rows a workgroup stages metadata for at a time
 __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
 {
     __shared__ float red[LG_T * 3];
+    // per-row metadata, fetched ONCE per row by one thread (the 2 x C/64 waves that work on a row would otherwise each repeat the
+    // same eight loads: the kernel was bound by memory instructions, not by bytes or by the atomics)
+    __shared__ int s_j[LG_ROWS], s_b[LG_ROWS], s_grp[LG_ROWS];
+    __shared__ float s_dx[LG_ROWS], s_dy[LG_ROWS], s_dz[LG_ROWS];
+    __shared__ unsigned char s_dup[LG_ROWS];
     const int tid = threadIdx.x;
     const int RSL = LG_T / a.C;                   // C <= 256 (host-checked)
     const int ch = tid % a.C, slot = tid / a.C;
@@ -128,45 +134,53 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
     float dsum = 0.f;                             // pending sum of padding duplicates ...
     int dgrp = -1, djf = -1, dbat = 0;            // ... of group dgrp (first neighbour djf, cloud dbat)
-    constexpr int U = 8;
-    if (act) {
-        for (int64_t m0 = mbeg + slot; m0 < mend; m0 += (int64_t)U * RSL) {
-            LgRow r[U];
+    for (int64_t base = mbeg; base < mend; base += LG_ROWS) {
+        const int nrows = (int)min((int64_t)LG_ROWS, mend - base);
+        __syncthreads();
+        for (int rr = tid; rr < nrows; rr += LG_T) {
+            const int64_t m = base + rr;
+            const LgRow r = lg_row(a, m);
+            const int grp = (int)(m / a.K);
+            const int jf = a.idx[(int64_t)grp * a.K];
+            s_j[rr] = r.j; s_b[rr] = r.b; s_grp[rr] = grp; s_dx[rr] = r.dx; s_dy[rr] = r.dy; s_dz[rr] = r.dz;
+            s_dup[rr] = (r.j == jf && m != (int64_t)grp * a.K) ? 1 : 0;
+        }
+        __syncthreads();
+        if (!act) continue;
+        constexpr int U = 8;
+        for (int r0 = slot; r0 < nrows; r0 += U * RSL) {
             float vy[U], vz[U];
-            int jf[U];
-            bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t m = m0 + (int64_t)u * RSL;
-                ok[u] = m < mend;
-                const int64_t mc = ok[u] ? m : mbeg;
-                r[u] = lg_row(a, mc);
-                jf[u] = a.idx[(mc / a.K) * a.K];
-                vy[u] = d.y[mc * a.C + ch];
-                vz[u] = d.dz[mc * a.C + ch];
+                const int rr = min(r0 + u * RSL, nrows - 1);
+                vy[u] = d.y[(base + rr) * a.C + ch];
+                vz[u] = d.dz[(base + rr) * a.C + ch];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (!ok[u] || r[u].j < 0) continue;
-                const int64_t m = m0 + (int64_t)u * RSL;
+                const int rr = r0 + u * RSL;
+                if (rr >= nrows) continue;
+                const int j = s_j[rr];
+                if (j < 0) continue;
                 const float z = fmaf(ksc, vy[u], ksh);
                 const float pp = z > 0.f ? vz[u] : 0.f;
                 const float g = fmaf(ksc, pp, -fmaf(kB, vy[u] - kmu, kA));
-                acc0 = fmaf(g, r[u].dx, acc0); acc1 = fmaf(g, r[u].dy, acc1); acc2 = fmaf(g, r[u].dz, acc2);
-                const int grp = (int)(m / a.K);
-                if (r[u].j == jf[u] && m != (int64_t)grp * a.K) {       // a padding duplicate of the group's first neighbour
+                acc0 = fmaf(g, s_dx[rr], acc0); acc1 = fmaf(g, s_dy[rr], acc1); acc2 = fmaf(g, s_dz[rr], acc2);
+                if (s_dup[rr]) {                  // a padding duplicate of the group's first neighbour
+                    const int grp = s_grp[rr];
                     if (grp != dgrp) {
                         if (dgrp >= 0 && djf >= 0 && djf < a.N) unsafeAtomicAdd(a.G + ((int64_t)dbat * a.N + djf) * a.C + ch, dsum);
-                        dsum = 0.f; dgrp = grp; djf = jf[u]; dbat = r[u].b;
+                        dsum = 0.f; dgrp = grp; djf = j; dbat = s_b[rr];
                     }
                     dsum += g;
                 } else {
-                    unsafeAtomicAdd(a.G + ((int64_t)r[u].b * a.N + r[u].j) * a.C + ch, g);
+                    unsafeAtomicAdd(a.G + ((int64_t)s_b[rr] * a.N + j) * a.C + ch, g);
                 }
             }
         }
-        if (dgrp >= 0 && djf >= 0 && djf < a.N) unsafeAtomicAdd(a.G + ((int64_t)dbat * a.N + djf) * a.C + ch, dsum);
     }
+    if (act && dgrp >= 0 && djf >= 0 && djf < a.N) unsafeAtomicAdd(a.G + ((int64_t)dbat * a.N + djf) * a.C + ch, dsum);
+    __syncthreads();
     red[tid * 3 + 0] = act ? acc0 : 0.f; red[tid * 3 + 1] = act ? acc1 : 0.f; red[tid * 3 + 2] = act ? acc2 : 0.f;
     __syncthreads();
     float *out = a.dwx + (int64_t)blockIdx.x * a.C * 3;
