@@ -406,6 +406,15 @@ int papc_prof_enable(unsigned mask);
 int papc_prof_reset(void);
 int papc_prof_read(int kernel, double *total_ms, int64_t *launches);
 
+/* ------------------------------------------------------------------------------------------------
+ * Tuning knobs.  Every PAPC_* environment variable (README.md) is read ONCE, when the library is
+ * loaded; entry points never call getenv.  papc_knob_set / papc_knob_get let a tuning harness flip
+ * one at run time (process-wide, not thread-safe against concurrent launches).  Unknown names and
+ * out-of-range values are PAPC_E_INVALID.
+ * ---------------------------------------------------------------------------------------------- */
+int papc_knob_set(const char *name, int value);
+int papc_knob_get(const char *name, int *value);
+
 #ifdef __cplusplus
 }
 #endif

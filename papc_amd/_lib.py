@@ -97,6 +97,8 @@ SIGNATURES = {
     "papc_rotate_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_rotate_iou_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "papc_adam_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "papc_knob_set": (c_i, [ctypes.c_char_p, c_i]),
+    "papc_knob_get": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
     "papc_prof_enable": (c_i, [ctypes.c_uint]),
     "papc_prof_reset": (c_i, []),
     "papc_prof_read": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_l)]),

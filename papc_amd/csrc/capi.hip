@@ -7,6 +7,8 @@
 
 #include "common.h"
 
+#define GEMM_PARTS_DEFAULT 768
+
 namespace papc {
 
 static thread_local char g_err[512] = "";
@@ -28,6 +30,44 @@ int check_launch(const char *what)
     }
     return PAPC_OK;
 }
+
+// ---- knobs --------------------------------------------------------------------------------------
+struct KnobDef { const char *name; int def, lo, hi; };
+static const KnobDef g_knob_defs[KNOB_COUNT] = {
+    {"PAPC_LG_PARTS", 2048, 1, 8192},      // workgroups of the gather-add kernels
+    {"PAPC_DW_F32", 0, 0, 1},              // dW on the exact-f32 MFMA
+    {"PAPC_DW_DBG", 0, 0, 1},
+    {"PAPC_DW_XYZ", 1, 0, 1},              // streamed dW of a coordinates-only first layer
+    {"PAPC_PARTS", GEMM_PARTS_DEFAULT, 1, 1024},   // rows of the per-workgroup partial buffers
+    {"PAPC_GEMM_F32", 0, 0, 1},            // forward / dX GEMMs on the exact-f32 MFMA
+    {"PAPC_GEMM_WAVES", 0, 0, 8},
+    {"PAPC_MAXCAT_WAVES", 8, 4, 8},
+    {"PAPC_GEMM_WS", 0, 0, 3},
+    {"PAPC_GEMM_OCC", 0, 0, 1},
+    {"PAPC_GEMM_DBG", 0, 0, 1},
+    {"PAPC_GEMM_KB", 0, 0, 2},
+    {"PAPC_GEMM_MINWG", 192, 1, 4096},
+    {"PAPC_GEMM_TL", 0, 0, 1},
+    {"PAPC_FPS_THREADS", 0, 0, 1024},
+    {"PAPC_FPS_THREADS_SMALL", 0, 0, 1024},
+    {"PAPC_STREAM", 1, 0, 1},              // row-streaming GEMM (mlp_stream.hip) where a flavour fits
+    {"PAPC_STREAM_MINTILES", 2048, 1, 1 << 30},   // ... for problems with at least this many 32-row tiles
+    {"PAPC_STREAM_CK", 0, 0, 8},           // k blocks per prefetch chunk (0 = per shape)
+    {"PAPC_STREAM_ASM", 1, 0, 1},          // operand loads hidden from hipcc's waitcnt pass (hand-counted vmcnt)
+};
+static int g_knobs[KNOB_COUNT];
+static int knob_parse(int id, const char *e)
+{
+    const KnobDef &d = g_knob_defs[id];
+    if (!e || !*e) return d.def;
+    const int v = atoi(e);
+    return (v < d.lo || v > d.hi) ? d.def : v;
+}
+static const bool g_knobs_loaded = [] {
+    for (int i = 0; i < KNOB_COUNT; ++i) g_knobs[i] = knob_parse(i, getenv(g_knob_defs[i].name));
+    return true;
+}();
+int knob(int id) { return g_knobs[id]; }
 
 // ---- profiler: event pairs per enabled kernel family, resolved lazily in papc_prof_read ---------
 struct ProfState {
@@ -91,6 +131,29 @@ extern "C" {
 int papc_version(void) { return 100; /* 0.1.0 */ }
 
 const char *papc_last_error_string(void) { return papc::g_err; }
+
+int papc_knob_set(const char *name, int value)
+{
+    PAPC_REQUIRE(name, PAPC_E_INVALID, "papc_knob_set: null name");
+    for (int i = 0; i < papc::KNOB_COUNT; ++i)
+        if (!strcmp(name, papc::g_knob_defs[i].name)) {
+            PAPC_REQUIRE(value >= papc::g_knob_defs[i].lo && value <= papc::g_knob_defs[i].hi, PAPC_E_INVALID,
+                         "papc_knob_set: %s = %d outside [%d, %d]", name, value, papc::g_knob_defs[i].lo, papc::g_knob_defs[i].hi);
+            papc::g_knobs[i] = value;
+            return PAPC_OK;
+        }
+    papc::set_error("papc_knob_set: unknown knob %s", name);
+    return PAPC_E_INVALID;
+}
+
+int papc_knob_get(const char *name, int *value)
+{
+    PAPC_REQUIRE(name && value, PAPC_E_INVALID, "papc_knob_get: null argument");
+    for (int i = 0; i < papc::KNOB_COUNT; ++i)
+        if (!strcmp(name, papc::g_knob_defs[i].name)) { *value = papc::g_knobs[i]; return PAPC_OK; }
+    papc::set_error("papc_knob_get: unknown knob %s", name);
+    return PAPC_E_INVALID;
+}
 
 int papc_prof_enable(unsigned mask)
 {

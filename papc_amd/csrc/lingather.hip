@@ -217,8 +217,7 @@ extern "C" {
 // many resident waves -- 8 workgroups of 256 threads per CU
 int papc_lingather_parts(int64_t M)
 {
-    static int cap = -1;
-    if (cap < 0) { const char *e = getenv("PAPC_LG_PARTS"); cap = e ? atoi(e) : 2048; if (cap < 1 || cap > 8192) cap = 2048; }
+    const int cap = knob(KNOB_LG_PARTS);
     return (int)std::min<int64_t>(cap, std::max<int64_t>(1, (M + 127) / 128));
 }
 

@@ -553,9 +553,7 @@ __global__ __launch_bounds__(256) void dw_xyz_kernel(DwArgs p)
 
 static bool dw_f32_exact()
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PAPC_DW_F32"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
+    return knob(KNOB_DW_F32) == 1;
 }
 
 static unsigned long long *g_dw_dbg = nullptr;
@@ -573,8 +571,7 @@ template <int XMODE, int DYMODE, bool VEC>
 static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
 {
     DwArgs p = p_in;
-    static int dbg_on = -1;
-    if (dbg_on < 0) { const char *e = getenv("PAPC_DW_DBG"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+    const int dbg_on = knob(KNOB_DW_DBG);
     if (dbg_on) {
         if (!g_dw_dbg) hipMalloc(&g_dw_dbg, 32 * sizeof(unsigned long long));
         hipMemsetAsync(g_dw_dbg, 0, 32 * sizeof(unsigned long long), st);
@@ -646,8 +643,7 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);
     const bool dense = dy->dz_mode == PAPC_DZ_DENSE;
-    static int xyz_on = -1;
-    if (xyz_on < 0) { const char *e = getenv("PAPC_DW_XYZ"); xyz_on = (e && e[0] == '0') ? 0 : 1; }
+    const int xyz_on = knob(KNOB_DW_XYZ);
     if (xyz_on && a_mode == A_GROUP && dense && vec && grp->D == 0 && Cin == 3 && Cout % 4 == 0 && Cout >= 4 && Cout <= 256) {
         // coordinates-only first layer: streaming reduction instead of a 3-of-32-column MFMA tile
         hipLaunchKernelGGL(dw_xyz_kernel, dim3((unsigned)cdiv(M, rows_per_chunk)), dim3(256), 0, st, p);

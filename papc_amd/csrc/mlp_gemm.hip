@@ -19,57 +19,14 @@
 //     to the other LDS buffer after them, so HBM/L2 latency hides under the matrix pipe and one barrier per stage
 //     suffices (writes of stage s go to the buffer last read in stage s-1, which every wave left before the
 //     previous barrier).  Two workgroups per CU: one computes while the other writes / stores.
-#include "mlp_loaders.h"
+#include "mlp_gemm.h"
 #include <mutex>
 #include <unordered_map>
 
 namespace papc {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2, EPI_STORE_GMAX = 3 };
-
-// EPI_STORE_RED (dX only): besides storing dz_prev = dX, accumulate the BN-backward reductions of the PREVIOUS layer
-// (p = dz_prev * [scale*y_prev + shift > 0]; sum p and sum p*xhat per channel) into the stats partials, so no separate
-// pass has to re-read dz_prev.
-struct RedSrc {
-    const float *y; const float *mean, *invstd, *scale, *shift;  // previous layer: pre-BN output [M,Nout] and BN constants
-};
-
-struct ScatterDst {
-    float *gf; const int32_t *idx; int N, S, K, D;
-    FastDiv divSK, divK;
-};
-
-// EPI_STORE_GMAX (last forward layer): besides y and the statistics partials, write per group of K consecutive rows the
-// max and min of y and the first row offset attaining each.  relu(scale*y+shift) is monotone in y (direction = sign of
-// scale), so max_k relu(bn(y)) = relu(scale * (scale >= 0 ? max y : min y) + shift): the neighbourhood max
-// (pointnet2_basic_layers.py:219) no longer needs a separate pass over y.  K in {32, 64, 128}, M % 128 == 0.
-struct GmaxDst {
-    float *gmax, *gmin; int32_t *amax, *amin; int K;
-};
-
-struct GemmArgs {
-    ASrc a;
-    const float *w; int64_t ldw;  // weights [Nout][Kin]
-    int wmap;                      // map internal k -> weight column with gk() (GROUP forward)
-    int nmap;                      // map internal n -> weight row with gk() (GROUP dX)
-    const float *bias;
-    int64_t M; int Kin; int Nout;
-    float *y; int64_t ldy;
-    float *stats;                  // [parts][2][Nout] or null
-    int parts;                     // rows of `stats` the caller reduces (>= gridDim.x; the surplus rows are written as zeros)
-    ScatterDst sc;
-    RedSrc rd;
-    GmaxDst gm;
-    unsigned long long *dbg;       // PAPC_GEMM_DBG=1: per-workgroup cycle counters (development aid)
-    int tl;                        // host: the transposed-accumulator epilogue is legal (16-byte aligned dense dX store)
-};
-
 constexpr int LDT = 36;  // LDS row stride (floats)
 constexpr int BK = 32;
-constexpr int GEMM_MAX_PARTS = 768;  // rows of the per-workgroup partial buffers: up to 256 CUs x 3 resident workgroups (a kernel that
-                                     // fits fewer per CU launches fewer and zero-fills the rows it does not own)
 
 // The thread's float4 of the weight tile: row n (output channel), internal channels k..k+3.  fetch_w4 ONLY issues
 // loads (unconditional, clamped indices) so they stay in flight across the MFMA phase; mask_w4 zeroes the
@@ -792,9 +749,7 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
 
 static int gemm_max_parts()
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PAPC_PARTS"); v = e ? atoi(e) : GEMM_MAX_PARTS; if (v < 1 || v > 1024) v = GEMM_MAX_PARTS; }
-    return v;
+    return knob(KNOB_PARTS);
 }
 static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128, gemm_max_parts()); }
 
@@ -803,24 +758,19 @@ static int gemm_parts(int64_t M) { return (int)std::min<int64_t>((M + 127) / 128
 // DEPTH = 1 is instantiated.
 static bool gemm_f32_exact()
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PAPC_GEMM_F32"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
+    return knob(KNOB_GEMM_F32) == 1;
 }
 static bool gemm_waves8(int amode, int epi)   // 8-wave flavour of the 128x128 tile (PAPC_GEMM_WAVES=4|8 forces one; default per epilogue)
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PAPC_GEMM_WAVES"); v = e ? atoi(e) : 0; }
+    const int v = knob(KNOB_GEMM_WAVES);
     if (v == 4) return false;
     if (v == 8) return true;
-    if (amode == A_MAXCAT) { static int m = -1; if (m < 0) { const char *e = getenv("PAPC_MAXCAT_WAVES"); m = e ? atoi(e) : 8; } return m == 8; }
+    if (amode == A_MAXCAT) return knob(KNOB_MAXCAT_WAVES) == 8;
     return !(amode == A_DY_MAX && epi == EPI_STORE_RED);   // measured per kernel (MI355X): only that one is faster on 4 waves (178 vs 223 us)
 }
 static int gemm_ws()   // producer groups of the wave-specialised 128x128 kernel (0 = unspecialised)
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("PAPC_GEMM_WS"); v = e ? atoi(e) : 0; if (v != 3) v = 0; }   // opt-in: see DESIGN.md 3.7
-    return v;
+    return knob(KNOB_GEMM_WS) == 3 ? 3 : 0;   // opt-in: see DESIGN.md 3.7
 }
 static unsigned long long *g_dbg = nullptr;
 static void dbg_report0(const GemmArgs &p, int amode, int epi, unsigned gx, int waves)
@@ -855,7 +805,7 @@ static unsigned persist_grid(const void *kern, int threads, unsigned parts)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, 0) != hipSuccess || n < 1) n = 2;
         per_cu = std::min(n, 3);
         cache[kern] = per_cu;
-        if (getenv("PAPC_GEMM_OCC")) fprintf(stderr, "[gemm occ] kernel %p threads %d: %d resident workgroups per CU (API %d), %d CUs\n", kern, threads, per_cu, n, ncu);
+        if (knob(KNOB_GEMM_OCC)) fprintf(stderr, "[gemm occ] kernel %p threads %d: %d resident workgroups per CU (API %d), %d CUs\n", kern, threads, per_cu, n, ncu);
     } else {
         per_cu = it->second;
     }
@@ -897,8 +847,7 @@ template <int AMODE, int EPI, bool VEC, bool TL>
 static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
 {
     GemmArgs p = p_in;
-    static int dbg_on = -1;
-    if (dbg_on < 0) { const char *e = getenv("PAPC_GEMM_DBG"); dbg_on = (e && e[0] == '1') ? 1 : 0; }
+    const int dbg_on = knob(KNOB_GEMM_DBG);
     if (dbg_on) {
         if (!g_dbg) hipMalloc(&g_dbg, 512 * 4 * 8 * sizeof(unsigned long long));
         hipMemsetAsync(g_dbg, 0, 512 * 4 * 8 * sizeof(unsigned long long), st);
@@ -911,11 +860,9 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
     const int64_t wg128 = (int64_t)gx * cdiv(p.Nout, 128);
     // few row tiles also means ONE tile per workgroup: the k loop is a serial chain of load -> transform -> MFMA stages with nothing
     // to overlap it, so those problems take 32-wide k stages (half as many): kb2
-    static int kb_env = -1;
-    if (kb_env < 0) { const char *e = getenv("PAPC_GEMM_KB"); kb_env = e ? atoi(e) : 0; }
+    const int kb_env = knob(KNOB_GEMM_KB);
     const bool kb2 = !TL && (kb_env == 2 || (kb_env != 1 && gx <= 64));   // PAPC_GEMM_KB=1: never, =2: always (experiment)
-    static int minwg = -1;
-    if (minwg < 0) { const char *e = getenv("PAPC_GEMM_MINWG"); minwg = e ? atoi(e) : 192; }
+    const int minwg = knob(KNOB_GEMM_MINWG);
     if (p.Nout > 64 && wg128 < minwg && (int64_t)gx * cdiv(p.Nout, 64) < 1024) {
         if ((int64_t)gx * cdiv(p.Nout, 64) >= minwg || p.Nout <= 64) {
             dim3 grid(gx, (unsigned)cdiv(p.Nout, 64));
@@ -952,6 +899,13 @@ static int launch_gemm_v(const GemmArgs &p_in, hipStream_t st)
 template <int AMODE, int EPI>
 static int launch_gemm(const GemmArgs &p, bool vec, hipStream_t st)
 {
+    if constexpr (AMODE != A_GROUP && EPI != EPI_SCATTER) {
+        // the big streaming shapes (M >> K, N) run barrier-free with the weights resident in LDS: mlp_stream.hip
+        GemmArgs q = p;
+        q.parts = gemm_parts(p.M);
+        const int rc = stream_gemm_try(q, AMODE, EPI, vec, st);
+        if (rc != 0) return rc < 0 ? rc : PAPC_OK;
+    }
     constexpr bool TLOK = (AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (EPI == EPI_STORE || EPI == EPI_STORE_RED);
     if constexpr (TLOK) {
         if (vec && p.tl) return launch_gemm_v<AMODE, EPI, true, true>(p, st);
@@ -1110,10 +1064,9 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
         p.rd.y = next_red->y; p.rd.mean = next_red->mean; p.rd.invstd = next_red->invstd; p.rd.scale = next_red->scale;
         p.rd.shift = next_red->shift; p.stats = next_red->red_partial;
     }
-    static int tl_on = -1;
     // opt-in (PAPC_GEMM_TL=1): measured on MI355X the transposed epilogue itself is 30-40 % shorter, but the kernel's load-issue
     // phase grows by more (9140-9180 vs 9220-9260 clouds/s end to end), so the column-lane epilogue stays the default
-    if (tl_on < 0) { const char *e = getenv("PAPC_GEMM_TL"); tl_on = (e && e[0] == '1') ? 1 : 0; }
+    const int tl_on = knob(KNOB_GEMM_TL);
     // (with the fused BN-backward sums only the 64-column tile has the registers for the 32 per-lane accumulators)
     p.tl = tl_on && !scatter && dx && aligned16(dx) && Cin % 4 == 0 && (!next_red || (aligned16(next_red->y) && Cin <= 64));
     hipStream_t st = as_stream(stream);

@@ -1,0 +1,478 @@
+// mlp_stream.hip -- barrier-free "row streaming" form of the pointwise-MLP GEMMs (gfx950).
+//
+//   forward  : y[M,Cout]  = A(x)[M,Cin] . w[Cout,Cin]^T + bias      (+ per-channel sum / sum-of-squares partials, + group max)
+//   backward : dX[M,Cin]  = dY[M,Cout] . w[Cout,Cin]                 (dY recomputed in the load, + BN-backward sums of the layer below)
+//
+// Same contract as gemm_kernel (mlp_gemm.hip) -- nn.Conv2D(cin,cout,1) + the BatchNorm2D statistics of
+// /root/reference/PAPC/models/layers/pointnet2_basic_layers.py:189,215-219 on channel-contiguous rows -- for the shapes that
+// dominate a training step: M in the hundreds of thousands, K and N between 32 and 256.  What the tiled kernel is bound by on
+// those shapes is not bytes but its per-stage sequence (issue -> wait -> transform -> LDS write -> barrier -> MFMA):
+// two lock-stepped workgroups per CU cannot fill each other's gaps.  This kernel removes the sequence instead of tuning it:
+//
+//   * The weights are split into their three bf16 planes ONCE per (persistent) workgroup and stay in LDS for all of its rows
+//     (N tile x K x 6 bytes: 25-100 KB).  After that prologue there is no barrier and no LDS write in the main loop.
+//   * A wave owns whole 32-row tiles.  The fp32 row-major operand already has the MFMA A-fragment shape -- lane (row = lane & 31,
+//     half = lane >> 5) needs the 8 consecutive channels 16 kb + 8 half .. + 7 of its row, i.e. two 16-byte loads -- so the operand
+//     goes global -> VGPR directly (each 128-byte line is fetched once; both halves of a row are touched by the same instruction
+//     pair), is transformed (BN+ReLU of the previous layer / the BN+ReLU+max backward) and split in registers, and meets the
+//     weight fragments read from LDS in v_mfma_f32_32x32x16_bf16 (six products per block, fp32 accumulate: the exact 3-way split
+//     of mlp_loaders.h).  No A tile in LDS, no transposes.
+//   * Waves are independent streams: 8 per CU (2 per SIMD), each with its own prefetch -- the operand loads of k chunk c + 2 are
+//     issued when chunk c has been consumed, into the registers it frees, and waited for with a COUNTED s_waitcnt (only the
+//     younger chunk's loads may remain outstanding; loads return in order, so `vmcnt(#younger loads)` is exact).  The loads are
+//     inline asm so hipcc's waitcnt pass, which drains such rings to vmcnt(0) at every loop back-edge, does not see them;
+//     the destination registers are tied ("+v") through the load and named again by the wait (cdna guide 5.7, form ii).
+//     One wave's epilogue / load wait overlaps the other seven's MFMAs by ordinary wave scheduling.
+//   * Epilogue from the accumulator layout (lane = column): every store instruction writes two full 128-byte row segments; the
+//     BN statistics are two running sums per lane; the neighbourhood max (EPI_STORE_GMAX) is a running max / min / first-offset
+//     per lane over the K/32 consecutive tiles of a group, which one wave processes back to back (no exchange between waves).
+#include "mlp_gemm.h"
+#include <type_traits>
+#include <utility>
+
+namespace papc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+// one 16-byte operand load: address = wave-uniform base (SGPR pair) + per-lane byte offset + immediate
+template <bool ASM, int OFF, bool FIRST>
+__device__ __forceinline__ void gload4(f32x4 &d, unsigned voff, const char *sbase)
+{
+    if constexpr (ASM) {
+        // FIRST: the base may have been produced by v_readfirstlane (VALU write of an SGPR -> VMEM read: 5 wait states)
+        if constexpr (FIRST) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+        else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+    } else {
+        d = *reinterpret_cast<const f32x4 *>(sbase + voff + OFF);
+    }
+}
+template <bool ASM, int N>
+__device__ __forceinline__ void wait_vm()
+{
+    if constexpr (ASM) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+}
+template <bool ASM>
+__device__ __forceinline__ void touch(f32x4 &d)
+{
+    if constexpr (ASM) asm volatile("" : "+v"(d));
+}
+
+struct StreamGeo {
+    int n_units;     // units of U consecutive 32-row tiles
+    int ushift;      // U = 1 << ushift
+    int kgshift;     // DY_MAX: rows per group = 1 << kgshift (>= 32)
+};
+
+// AMODE: A_PLAIN, A_BNRELU, A_DY_DENSE, A_DY_MAX.  EPI: EPI_STORE, EPI_STORE_GMAX (forward), EPI_STORE_RED (dX).
+// KB16 = K / 16 k blocks, CK blocks per prefetch chunk, WN 32-column tiles per wave (N tile = 32 WN columns per workgroup).
+template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM>
+__global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo geo)
+{
+    constexpr int NW = 8;
+    constexpr int K = KB16 * 16;
+    constexpr int NT = WN * 32;
+    constexpr int NCH = KB16 / CK;
+    static_assert(KB16 % CK == 0 && NCH >= 2 && NCH % 2 == 0, "an even number of chunks per tile");
+    constexpr bool DY = (AMODE == A_DY_DENSE || AMODE == A_DY_MAX);
+    constexpr int NLD = (AMODE == A_DY_MAX) ? 6 : (AMODE == A_DY_DENSE ? 4 : 2);   // 16-byte loads per lane and k block
+    constexpr int CL = CK * NLD;                                                      // ... per chunk
+    static_assert(CL <= 60, "vmcnt is a 6-bit field");
+    constexpr int ROWB = 6 * K + 16;          // LDS bytes of one weight row: [plane 0 | plane 1 | plane 2] bf16 + 16 (odd number of 16-B slots)
+    constexpr int NCST = (AMODE == A_BNRELU) ? 2 : (DY ? 5 : 0);
+    constexpr int W_BYTES = NT * ROWB;
+    constexpr int CST_BYTES = NCST * K * 4;
+    constexpr int RED_BYTES = 2 * NW * NT * 4;
+    constexpr int SMEM = (W_BYTES + CST_BYTES) > RED_BYTES ? (W_BYTES + CST_BYTES) : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    char *cstb = smem + W_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.y * NT;
+    const int ldx = (int)(DY ? p.a.d.C : p.a.ldx);     // row stride (floats) of the streamed operand(s)
+
+    // ---- prologue: weights -> three bf16 planes in LDS (once per workgroup); folded per-channel constants
+    {
+        const float *wb = p.w + (int64_t)n0 * p.ldw;
+        for (int i = tid; i < NT * (K / 4); i += NW * 64) {
+            const int n = i / (K / 4), k4 = (i - n * (K / 4)) * 4;
+            uint2 q0, q1, q2;
+            split3(ld4(wb + (int64_t)n * p.ldw + k4), q0, q1, q2);
+            char *d = smem + n * ROWB + k4 * 2;
+            *reinterpret_cast<uint2 *>(d) = q0;
+            *reinterpret_cast<uint2 *>(d + 2 * K) = q1;
+            *reinterpret_cast<uint2 *>(d + 4 * K) = q2;
+        }
+        float *cf = reinterpret_cast<float *>(cstb);
+        for (int k = tid; k < K; k += NW * 64) {
+            if (AMODE == A_BNRELU) {
+                cf[k] = p.a.sc[k]; cf[K + k] = p.a.sh[k];
+            } else if (DY) {
+                // dy = sc (p - c1 - xhat c2), p = dz [sc y + sh > 0], xhat = (y - mean) invstd   ==   sc p - (A + Bp (y - mean))
+                const float sc = p.a.d.scale[k];
+                cf[k] = sc; cf[K + k] = p.a.d.shift[k]; cf[2 * K + k] = p.a.d.mean[k];
+                cf[3 * K + k] = sc * p.a.d.c1[k];
+                cf[4 * K + k] = sc * p.a.d.c2[k] * p.a.d.invstd[k];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- this wave's tiles: units gw, gw + TW, ...; U consecutive tiles per unit
+    const int TW = (int)gridDim.x * NW;
+    const int gw = (int)blockIdx.x * NW + wave;
+    const int U = 1 << geo.ushift;
+    const int my_units = geo.n_units > gw ? (geo.n_units - gw + TW - 1) / TW : 0;
+    const int my_tiles = my_units << geo.ushift;
+    auto tile_row0 = [&](int j) -> int {   // first row of this wave's j-th tile (clamped to its last one: the prefetch runs ahead)
+        const int jj = j < my_tiles ? j : my_tiles - 1;
+        const int u = gw + (jj >> geo.ushift) * TW;
+        return ((u << geo.ushift) + (jj & (U - 1))) * 32;
+    };
+    struct SB { const char *p0, *p1, *p2; };
+    auto bases = [&](int row0) -> SB {
+        SB s;
+        s.p1 = nullptr; s.p2 = nullptr;
+        if (DY) {
+            s.p0 = reinterpret_cast<const char *>(p.a.d.y + (int64_t)row0 * ldx);
+            if (AMODE == A_DY_DENSE) s.p1 = reinterpret_cast<const char *>(p.a.d.dz + (int64_t)row0 * ldx);
+            else {
+                const int64_t g = row0 >> geo.kgshift;
+                s.p1 = reinterpret_cast<const char *>(p.a.d.gout + g * ldx);
+                s.p2 = reinterpret_cast<const char *>(p.a.d.argmax + g * ldx);
+            }
+        } else {
+            s.p0 = reinterpret_cast<const char *>(p.a.x + (int64_t)row0 * ldx);
+        }
+        return s;
+    };
+    const unsigned voff_row = (unsigned)((l31 * ldx + 8 * hi) * 4);   // this lane's row and k half inside a tile
+    const unsigned voff_grp = (unsigned)(8 * hi * 4);                  // ... inside a per-group row (DY_MAX: gout / argmax)
+
+    f32x4 buf[2][CL];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < CL; ++i) buf[b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // issue the loads of chunk `ci` (compile-time) of the tile whose bases are `s` into buffer `bi`
+    auto issue = [&](auto bi_, auto ci_, const SB &s) {
+        constexpr int bi = decltype(bi_)::value, ci = decltype(ci_)::value;
+        sfor<0, CK>([&](auto blk_) {
+            constexpr int blk = decltype(blk_)::value;
+            constexpr int off = (ci * CK + blk) * 64;
+            gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 0], voff_row, s.p0);
+            gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 1], voff_row, s.p0);
+            if constexpr (AMODE == A_DY_DENSE) {
+                gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 2], voff_row, s.p1);
+                gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 3], voff_row, s.p1);
+            }
+            if constexpr (AMODE == A_DY_MAX) {
+                gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 2], voff_grp, s.p1);
+                gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 3], voff_grp, s.p1);
+                gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 4], voff_grp, s.p2);
+                gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 5], voff_grp, s.p2);
+            }
+        });
+    };
+    auto touch_buf = [&](auto bi_) {
+        constexpr int bi = decltype(bi_)::value;
+        sfor<0, CL>([&](auto i_) { touch<ASM>(buf[bi][decltype(i_)::value]); });
+    };
+
+    floatx16 acc[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[wn][r] = 0.f;
+
+    const char *wl = smem + l31 * ROWB + hi * 16;        // this lane's weight-fragment row (tile 0, plane 0, k block 0)
+    const char *cl = cstb + hi * 32;                     // this lane's constants (k block 0)
+    int kin = 0;                                         // DY_MAX: this lane's row offset inside its group
+
+    // MFMAs of chunk `ci` from buffer `bi`
+    auto compute = [&](auto bi_, auto ci_) {
+        constexpr int bi = decltype(bi_)::value, ci = decltype(ci_)::value;
+        sfor<0, CK>([&](auto blk_) {
+            constexpr int blk = decltype(blk_)::value;
+            constexpr int kb = ci * CK + blk;
+            const f32x4 *r = &buf[bi][blk * NLD];
+            float v[8];
+            if constexpr (AMODE == A_PLAIN) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i] = r[0][i]; v[4 + i] = r[1][i]; }
+            } else if constexpr (AMODE == A_BNRELU) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(cl + kb * 64), s1 = *reinterpret_cast<const f32x4 *>(cl + kb * 64 + 16);
+                const f32x4 h0 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64), h1 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64 + 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = fmaxf(fmaf(s0[i], r[0][i], h0[i]), 0.f);
+                    v[4 + i] = fmaxf(fmaf(s1[i], r[1][i], h1[i]), 0.f);
+                }
+            } else {
+                f32x4 c[5][2];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    c[q][0] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64);
+                    c[q][1] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64 + 16);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float y = r[h][i];
+                        float dz = r[2 + h][i];
+                        if constexpr (AMODE == A_DY_MAX) dz = (__float_as_int(r[4 + h][i]) == kin) ? dz : 0.f;
+                        const float z = fmaf(c[0][h][i], y, c[1][h][i]);
+                        const float pp = z > 0.f ? dz : 0.f;
+                        v[4 * h + i] = fmaf(-c[4][h][i], y - c[2][h][i], fmaf(c[0][h][i], pp, -c[3][h][i]));
+                    }
+            }
+            uint2 a0, a1, a2, b0, b1, b2;
+            split3(make_float4(v[0], v[1], v[2], v[3]), a0, a1, a2);
+            split3(make_float4(v[4], v[5], v[6], v[7]), b0, b1, b2);
+            bf16x8 af[3];
+            af[0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+            af[1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+            af[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+            bf16x8 bq[WN][3];
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    bq[wn][pl] = *reinterpret_cast<const bf16x8 *>(wl + wn * 32 * ROWB + pl * 2 * K + kb * 32);
+            // smallest terms first; consecutive MFMAs go to different accumulators
+            constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn)
+                    acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]], bq[wn][PB[t]], acc[wn], 0, 0, 0);
+        });
+    };
+
+    // ---- per-lane epilogue state: this lane's columns are n0 + 32 wn + l31 for every tile
+    float s1[WN], s2[WN], biasv[WN];
+    float rsc[WN], rsh[WN], rmu[WN], ris[WN];
+    float gmx[WN], gmn[WN];
+    int gix[WN], gin[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const int col = n0 + wn * 32 + l31;
+        s1[wn] = 0.f; s2[wn] = 0.f;
+        biasv[wn] = p.bias ? p.bias[col] : 0.f;
+        rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
+        if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[col]; rsh[wn] = p.rd.shift[col]; rmu[wn] = p.rd.mean[col]; ris[wn] = p.rd.invstd[col]; }
+        gmx[wn] = -INFINITY; gmn[wn] = INFINITY; gix[wn] = 0; gin[wn] = 0;
+    }
+
+    // epilogue of the tile starting at row0 (sub = its index inside the unit).  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 hi.
+    auto epilogue = [&](int row0, int sub) {
+        const int64_t ldy = p.ldy;
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) {
+            const int col = n0 + wn * 32 + l31;
+            float *yp = p.y + (int64_t)(row0 + 4 * hi) * ldy + col;
+            if (EPI == EPI_STORE_RED) {
+                const float *qp = p.rd.y + (int64_t)(row0 + 4 * hi) * ldy + col;
+                float yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = qp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[wn][r] + biasv[wn];
+                    yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = v;
+                    const float pp = fmaf(rsc[wn], yv[r], rsh[wn]) > 0.f ? v : 0.f;
+                    s1[wn] += pp;
+                    s2[wn] = fmaf(pp, (yv[r] - rmu[wn]) * ris[wn], s2[wn]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    const float v = acc[wn][r] + biasv[wn];
+                    yp[(int64_t)ro * ldy] = v;
+                    s1[wn] += v;
+                    s2[wn] = fmaf(v, v, s2[wn]);
+                    if (EPI == EPI_STORE_GMAX) {
+                        const int off = sub * 32 + ro + 4 * hi;
+                        if (v > gmx[wn]) { gmx[wn] = v; gix[wn] = off; }
+                        if (v < gmn[wn]) { gmn[wn] = v; gin[wn] = off; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[wn][r] = 0.f;
+            if (EPI == EPI_STORE_GMAX && sub == U - 1) {
+                // close the group: merge the two half-waves (first offset wins ties), lanes 0-31 write
+                float vmx = gmx[wn], vmn = gmn[wn];
+                int imx = gix[wn], imn = gin[wn];
+                const float omx = __shfl_xor(vmx, 32), omn = __shfl_xor(vmn, 32);
+                const int oix = __shfl_xor(imx, 32), oin = __shfl_xor(imn, 32);
+                if (omx > vmx || (omx == vmx && oix < imx)) { vmx = omx; imx = oix; }
+                if (omn < vmn || (omn == vmn && oin < imn)) { vmn = omn; imn = oin; }
+                if (hi == 0) {
+                    const int64_t g = (int64_t)(row0 >> 5) >> geo.ushift;
+                    p.gm.gmax[g * p.Nout + col] = vmx; p.gm.amax[g * p.Nout + col] = imx;
+                    p.gm.gmin[g * p.Nout + col] = vmn; p.gm.amin[g * p.Nout + col] = imn;
+                }
+                gmx[wn] = -INFINITY; gmn[wn] = INFINITY; gix[wn] = 0; gin[wn] = 0;
+            }
+        }
+    };
+
+    // ---- main loop.  Chunk c of the flat (tile, chunk) sequence lives in buffer c & 1 and is prefetched two chunks ahead.
+    if (my_tiles > 0) {
+        int row0 = tile_row0(0);
+        SB sa = bases(row0);
+        issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sa);
+        issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sa);
+        wait_vm<ASM, CL>();
+        touch_buf(std::integral_constant<int, 0>{});
+        for (int j = 0; j < my_tiles; ++j) {
+            const int row0n = tile_row0(j + 1);
+            const SB sn = bases(row0n);
+            if (AMODE == A_DY_MAX) kin = (row0 & ((1 << geo.kgshift) - 1)) + l31;
+            sfor<0, NCH>([&](auto c_) {
+                constexpr int c = decltype(c_)::value;
+                constexpr int bi = c & 1;
+                if constexpr (c > 0) {   // (chunk 0 was waited for before the previous tile's stores went out)
+                    wait_vm<ASM, CL>();
+                    touch_buf(std::integral_constant<int, bi>{});
+                }
+                compute(std::integral_constant<int, bi>{}, c_);
+                if constexpr (c + 2 < NCH) issue(std::integral_constant<int, bi>{}, std::integral_constant<int, c + 2>{}, sa);
+                else issue(std::integral_constant<int, bi>{}, std::integral_constant<int, c + 2 - NCH>{}, sn);
+            });
+            // chunk 0 of the next tile: in flight since chunk NCH - 2 was consumed; only chunk 1's loads are younger.  Waiting
+            // here, BEFORE the stores, keeps fresh stores out of every counted wait (vmcnt counts them too).
+            wait_vm<ASM, CL>();
+            touch_buf(std::integral_constant<int, 0>{});
+            epilogue(row0, j & (U - 1));
+            row0 = row0n;
+            sa = sn;
+        }
+        wait_vm<ASM, 0>();
+        touch_buf(std::integral_constant<int, 0>{});
+        touch_buf(std::integral_constant<int, 1>{});
+    }
+
+    // ---- BN statistics (or BN-backward sums): one deterministic partial row per row-workgroup
+    if (p.stats) {
+        __syncthreads();   // every wave has left the weights: the reduction scratch may overwrite them
+        float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn) {
+            s1[wn] += __shfl_xor(s1[wn], 32);
+            s2[wn] += __shfl_xor(s2[wn], 32);
+            if (hi == 0) {
+                red[(0 * NW + wave) * NT + wn * 32 + l31] = s1[wn];
+                red[(1 * NW + wave) * NT + wn * 32 + l31] = s2[wn];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * NT; i += NW * 64) {
+            const int which = i / NT, c = i - which * NT;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[(which * NW + w) * NT + c];
+            p.stats[((int64_t)blockIdx.x * 2 + which) * p.Nout + n0 + c] = t;
+            for (int r = blockIdx.x + gridDim.x; r < p.parts; r += gridDim.x) p.stats[((int64_t)r * 2 + which) * p.Nout + n0 + c] = 0.f;
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+static int stream_ncu()
+{
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        else ncu = 256;
+    }
+    return ncu;
+}
+
+template <int AMODE, int EPI, int KB16, int WN>
+static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
+{
+    // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
+    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : 2;
+    const int ncb = p.Nout / (32 * WN);
+    // one workgroup per CU in total (weights + 8 waves of up to 256 registers fill it); column blocks of the same rows are
+    // gridDim.x apart in the flat id, i.e. on the same XCD when gridDim.x % 8 == 0: the second reader of a row finds it in L2
+    int gx = std::max(8, (stream_ncu() / ncb) & ~7);
+    gx = std::min(gx, std::max(1, (geo.n_units + 7) / 8));
+    if (gx > p.parts) gx = p.parts;
+    dim3 grid((unsigned)gx, (unsigned)ncb);
+    if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true>), grid, dim3(512), 0, st, p, geo);
+    else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);
+    const int rc = check_launch("mlp stream gemm");
+    return rc ? rc : 1;
+}
+
+template <int AMODE, int EPI>
+static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
+{
+    const int kb = p.Kin / 16;
+    // N tile: as many columns as the weights' LDS image allows (6 K + 16 bytes per column, <= ~100 KB), at most 128
+    const int nt = p.Kin > 128 ? 64 : 128;
+    const int wn = std::min(p.Nout, nt) / 32;
+    if (p.Nout % (32 * wn) != 0) return 0;
+#define STREAM_CASE(KB, WNN) if (kb == KB && wn == WNN) return stream_go<AMODE, EPI, KB, WNN>(p, geo, st)
+    STREAM_CASE(2, 2); STREAM_CASE(2, 4);
+    STREAM_CASE(4, 2); STREAM_CASE(4, 4);
+    STREAM_CASE(8, 2); STREAM_CASE(8, 4);
+    if constexpr (AMODE == A_DY_DENSE || AMODE == A_DY_MAX || AMODE == A_BNRELU) { STREAM_CASE(16, 2); }
+#undef STREAM_CASE
+    return 0;
+}
+
+static int ilog2_exact(int v)
+{
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
+}
+
+int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t st)
+{
+    if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !vec) return 0;
+    if (p.M % 32 != 0 || p.M / 32 < knob(KNOB_STREAM_MINTILES)) return 0;
+    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > 256 || p.Nout % 64 != 0) return 0;
+    if (p.wmap || p.nmap || p.ldy != p.Nout) return 0;
+    if (!(p.stats || epi == EPI_STORE)) return 0;
+    StreamGeo geo;
+    geo.ushift = 0; geo.kgshift = 5;
+    if (epi == EPI_STORE_GMAX) {
+        const int s = ilog2_exact(p.gm.K);
+        if (s < 5 || p.M % p.gm.K != 0) return 0;
+        geo.ushift = s - 5;
+    }
+    if (amode == A_DY_MAX) {
+        const int s = ilog2_exact(p.a.d.K);
+        if (s < 5) return 0;
+        geo.kgshift = s;
+    }
+    geo.n_units = (int)((p.M / 32) >> geo.ushift);
+    if (amode == A_BNRELU && epi == EPI_STORE) return stream_pick<A_BNRELU, EPI_STORE>(p, geo, st);
+    if (amode == A_BNRELU && epi == EPI_STORE_GMAX) return stream_pick<A_BNRELU, EPI_STORE_GMAX>(p, geo, st);
+    if (amode == A_PLAIN && epi == EPI_STORE) return stream_pick<A_PLAIN, EPI_STORE>(p, geo, st);
+    if (amode == A_DY_DENSE && epi == EPI_STORE_RED) return stream_pick<A_DY_DENSE, EPI_STORE_RED>(p, geo, st);
+    if (amode == A_DY_MAX && epi == EPI_STORE_RED) return stream_pick<A_DY_MAX, EPI_STORE_RED>(p, geo, st);
+    return 0;
+}
+
+}  // namespace papc

@@ -359,8 +359,8 @@ int papc_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, in
     // up to 512 threads (two waves per SIMD hide each other's DPP/LDS latency; more waves only add barrier cost)
     int T = 64;
     while (T < 512 && T * 8 < N) T *= 2;
-    const char *env = getenv(N <= 1024 ? "PAPC_FPS_THREADS_SMALL" : "PAPC_FPS_THREADS");   // tuning knobs (small / large clouds)
-    if (env) { int t = atoi(env); if (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) T = t; }
+    { const int t = knob(N <= 1024 ? KNOB_FPS_THREADS_SMALL : KNOB_FPS_THREADS);   // tuning knobs (small / large clouds)
+      if (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) T = t; }
     int ppt = 1;
     while ((int64_t)T * ppt < N) ppt *= 2;
     while (ppt > 16 && T < 1024) { T *= 2; ppt = 1; while ((int64_t)T * ppt < N) ppt *= 2; }
