@@ -23,7 +23,8 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-mat
           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function"]
 # per-file extra flags
 NOSLP = ["-fno-slp-vectorize"]
-EXTRA = {"mlp_gemm.hip": NOSLP, "mlp_dw.hip": NOSLP, "sampling.hip": NOSLP, "bn_ops.hip": NOSLP, "pfn.hip": NOSLP, "interp.hip": NOSLP, "nms.hip": NOSLP, "head.hip": NOSLP, "lingather.hip": NOSLP}  # packed f32 VALU (v_pk_add_f32 ...) is slower than scalar beside MFMAs
+RES = ["-Rpass-analysis=kernel-resource-usage"]
+EXTRA = {"mlp_stream.hip": NOSLP + RES, "mlp_gemm.hip": NOSLP, "mlp_dw.hip": NOSLP, "sampling.hip": NOSLP, "bn_ops.hip": NOSLP, "pfn.hip": NOSLP, "interp.hip": NOSLP, "nms.hip": NOSLP, "head.hip": NOSLP, "lingather.hip": NOSLP}  # packed f32 VALU (v_pk_add_f32 ...) is slower than scalar beside MFMAs
 
 
 def _hipcc():
@@ -31,6 +32,20 @@ def _hipcc():
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
             return c
     return "hipcc"
+
+
+def _check_no_spills(remarks):
+    """mlp_stream.hip loads its operands with inline asm that hipcc's register allocator cannot see in flight: a spilled
+    (or scratch-backed) register of such a kernel would be copied before its load has landed.  Refuse to build one."""
+    import re
+    name = None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"(VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name and "stream_kernel" in name and "Lb1E" in name and int(m.group(2)) != 0 and "SGPRs Spill" not in m.group(1):
+            raise RuntimeError("mlp_stream.hip: %s has %s = %s (asm-loaded registers must not spill)" % (name, m.group(1), m.group(2)))
 
 
 def _newest(paths):
@@ -42,13 +57,14 @@ def build(force=False, verbose=True):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + [__file__]
     hdr_time = _newest(hdrs)
+    extra_env = os.environ.get("PAPC_BUILD_DEFS", "").split()   # development aid: e.g. PAPC_BUILD_DEFS="-DPAPC_STREAM_WAIT0"
     jobs = []
     objs = []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
-            cmd = [_hipcc(), "-c", s, "-o", o] + COMMON + EXTRA.get(os.path.basename(s), [])
+            cmd = [_hipcc(), "-c", s, "-o", o] + COMMON + EXTRA.get(os.path.basename(s), []) + extra_env
             jobs.append((s, cmd))
 
     def run(job):
@@ -59,6 +75,9 @@ def build(force=False, verbose=True):
     if jobs:
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for s, rc, out in ex.map(run, jobs):
+                if os.path.basename(s) == "mlp_stream.hip":
+                    _check_no_spills(out)
+                    out = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l)
                 if verbose and out.strip():
                     print(out)
                 if rc != 0:

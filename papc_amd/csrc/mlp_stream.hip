@@ -343,22 +343,28 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             const int row0n = tile_row0(j + 1);
             const SB sn = bases(row0n);
             if (AMODE == A_DY_MAX) kin = (row0 & ((1 << geo.kgshift) - 1)) + l31;
+            // LATE1: the epilogue of the dX kernels issues compiler-visible loads (the layer below's y).  hipcc's own counted waits for
+            // them proved unsound on hardware while asm loads it cannot see are in flight (late data landed in registers it had
+            // already reused: wrong rows, timing dependent), so for that epilogue nothing hidden is outstanding: chunk 1 of the next
+            // tile is issued AFTER the epilogue instead of before it (it still has chunk 0's whole compute phase to land).
+            constexpr bool LATE1 = (EPI == EPI_STORE_RED);
             sfor<0, NCH>([&](auto c_) {
                 constexpr int c = decltype(c_)::value;
                 constexpr int bi = c & 1;
                 if constexpr (c > 0) {   // (chunk 0 was waited for before the previous tile's stores went out)
-                    wait_vm<ASM, CL>();
+                    wait_vm<ASM, CL>();   // (LATE1: chunk 1 was issued behind the epilogue's stores; chunk 2's loads are still the only younger ones)
                     touch_buf(std::integral_constant<int, bi>{});
                 }
                 compute(std::integral_constant<int, bi>{}, c_);
                 if constexpr (c + 2 < NCH) issue(std::integral_constant<int, bi>{}, std::integral_constant<int, c + 2>{}, sa);
-                else issue(std::integral_constant<int, bi>{}, std::integral_constant<int, c + 2 - NCH>{}, sn);
+                else if constexpr (!(LATE1 && c == NCH - 1)) issue(std::integral_constant<int, bi>{}, std::integral_constant<int, c + 2 - NCH>{}, sn);
             });
             // chunk 0 of the next tile: in flight since chunk NCH - 2 was consumed; only chunk 1's loads are younger.  Waiting
             // here, BEFORE the stores, keeps fresh stores out of every counted wait (vmcnt counts them too).
-            wait_vm<ASM, CL>();
+            wait_vm<ASM, LATE1 ? 0 : CL>();
             touch_buf(std::integral_constant<int, 0>{});
             epilogue(row0, j & (U - 1));
+            if constexpr (LATE1) issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sn);
             row0 = row0n;
             sa = sn;
         }
@@ -409,7 +415,7 @@ template <int AMODE, int EPI, int KB16, int WN>
 static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
-    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : 2;
+    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || (AMODE == A_DY_DENSE && WN == 4) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : 2;
     const int ncb = p.Nout / (32 * WN);
     // one workgroup per CU in total (weights + 8 waves of up to 256 registers fill it); column blocks of the same rows are
     // gridDim.x apart in the flat id, i.e. on the same XCD when gridDim.x % 8 == 0: the second reader of a row finds it in L2
