@@ -104,10 +104,22 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     // ---- prologue: weights -> three bf16 planes in LDS (once per workgroup); folded per-channel constants
     {
         const float *wb = p.w + (int64_t)n0 * p.ldw;
-        for (int i = tid; i < NT * (K / 4); i += NW * 64) {
+        // all of the thread's pieces are loaded before the first is used: one exposed L2 round trip, not NI of them
+        constexpr int NI = NT * (K / 4) / (NW * 64);
+        static_assert(NT * (K / 4) % (NW * 64) == 0, "whole float4 pieces per thread");
+        float4 wv[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int i = tid + q * NW * 64;
+            const int n = i / (K / 4), k4 = (i - n * (K / 4)) * 4;
+            wv[q] = ld4(wb + (int64_t)n * p.ldw + k4);
+        }
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int i = tid + q * NW * 64;
             const int n = i / (K / 4), k4 = (i - n * (K / 4)) * 4;
             uint2 q0, q1, q2;
-            split3(ld4(wb + (int64_t)n * p.ldw + k4), q0, q1, q2);
+            split3(wv[q], q0, q1, q2);
             char *d = smem + n * ROWB + k4 * 2;
             *reinterpret_cast<uint2 *>(d) = q0;
             *reinterpret_cast<uint2 *>(d + 2 * K) = q1;
