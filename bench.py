@@ -91,8 +91,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config: 32)")
     ap.add_argument("--npoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="compute batch i+1's sampling pyramid on a side stream while "
-                    "batch i runs its small-grid kernels (SA3 + FC head, forward and backward)")
+    ap.add_argument("--overlap", dest="overlap", action="store_true", default=True,
+                    help="(default) software-pipelined sampling: batch i+1's pyramid (FPS + ball query: weight-independent, a serial "
+                    "chain on 32 of the 256 CUs) runs on a side stream / graph branch beside batch i's MLP kernels")
+    ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="sample in-line at the head of every step")
+    ap.add_argument("--fork", choices=["start", "sa2"], default="sa2", help="where the step forks the next batch's sampling branch")
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
@@ -155,10 +158,11 @@ def main():
             plan, ev = state["plan"], state["ev"]
             main.wait_event(ev)
         flat.zero_grad()
-        # the next batch's pyramid is enqueued on the side stream when the main stream reaches SA3: the group_all layer,
-        # the FC head and their backward are small-grid kernels, so the 32 FPS workgroups run on idle CUs instead of
-        # displacing workgroups of the chip-filling persistent MFMA grids
-        logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap else None))
+        # the next batch's pyramid is enqueued on the side stream beside this batch's MLP kernels (--fork sa2: only once the
+        # main stream reaches SA3 -- the group_all layer, the FC head and their backward are small-grid kernels)
+        if args.overlap and args.fork == "start":
+            launch_plan()
+        logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap and args.fork == "sa2" else None))
         loss = softmax_cross_entropy(logits, y)
         loss.backward()
         scale = flat.allreduce_grads()
@@ -169,38 +173,67 @@ def main():
     # Python and the GPU idles ~12 % of the step between them.  zero_grad + forward + loss + backward are captured once
     # (static buffers: the allocations made during capture live in the graph's private pool) and replayed; the gradient
     # all-reduce and the Adam kernel (whose bias correction takes the step count as a host scalar) stay eager launches.
-    use_graph = not args.no_graph and not args.overlap
-    graph_state = {"g": None, "loss": None}
+    # With --overlap the sampling of the NEXT batch is a second branch of the same graph (forked from the capturing stream,
+    # joined at the end): two graphs alternate, one reading the plan buffers the other one fills.
+    use_graph = not args.no_graph
+    graph_state = {"g": None, "loss": None, "i": 0}
 
-    def fwd_bwd():
+    def fwd_bwd(plan_in=None, plan_out=None):
         flat.zero_grad()
-        logits = model(x, (s1, s2))
+
+        def fork():
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                p = model.plan_sampling(x, (s1, s2))
+                for dst_lvl, src_lvl in zip(plan_out, p):
+                    for d, s_ in zip(dst_lvl, src_lvl):
+                        d.copy_(s_)
+
+        if plan_out is not None and args.fork == "start":
+            fork()
+        logits = model(x, (s1, s2), plan=plan_in, after_sa2=(fork if plan_out is not None and args.fork == "sa2" else None))
         loss = softmax_cross_entropy(logits, y)
         loss.backward()
+        if plan_out is not None:
+            main.wait_stream(side)                 # join: the branch is part of this step
         return loss
 
     def capture():
-        """Returns True when the graph was captured; on any capture failure the bench falls back to eager launches."""
+        """Returns True when the graph(s) were captured; on any capture failure the bench falls back to eager launches."""
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
         try:
-            # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
-            with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                graph_state["loss"] = fwd_bwd()
+            if args.overlap:
+                p0 = model.plan_sampling(x, (s1, s2))
+                bufs = [tuple(tuple(t.clone() for t in lvl) for lvl in p0) for _ in range(2)]
+                torch.cuda.synchronize()
+                gs, losses = [], []
+                for i in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+                    with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                        losses.append(fwd_bwd(bufs[i], bufs[1 - i]))
+                    gs.append(g)
+                graph_state["g"], graph_state["loss"] = gs, losses
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                    loss = fwd_bwd()
+                graph_state["g"], graph_state["loss"] = [g], [loss]
         except Exception as e:   # noqa: BLE001
             print("[bench] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), file=sys.stderr)
             graph_state["g"], graph_state["loss"] = None, None
             torch.cuda.synchronize()
             return False
-        graph_state["g"] = g
         return True
 
     def step():
         if graph_state["g"] is None:
             return step_eager()
-        graph_state["g"].replay()
+        i = graph_state["i"] % len(graph_state["g"])
+        graph_state["i"] += 1
+        graph_state["g"][i].replay()
         opt.step(flat.allreduce_grads())
-        return graph_state["loss"]
+        return graph_state["loss"][i]
 
     use_dist = dist.is_initialized()
 
@@ -320,7 +353,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
-                       "sampling": "batch i+1 pyramid on a side stream during batch i" if args.overlap else "in-line",
+                       "sampling": ("software-pipelined: batch i+1's FPS + ball-query pyramid runs as a second branch (side stream) of "
+                                    "batch i's step, fork at %s; every timed step computes one full pyramid" % args.fork) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
                        "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager all-reduce + Adam" if use_graph else "eager"},
