@@ -187,9 +187,22 @@ int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, cons
                            papc_stream_t stream);
 
 /* Reduce red_partial -> dgamma[c] = sum p*xhat, dbeta[c] = sum p, and the two per-channel constants of
- * dy = scale*(p - c1 - xhat*c2): c1 = dbeta/M, c2 = dgamma/M.  accumulate != 0 adds into dgamma/dbeta. */
+ * dy = scale*(p - c1 - xhat*c2): c1 = dbeta/M, c2 = dgamma/M.  bit 0 of accumulate adds into dgamma/dbeta; bit 1: eval-mode BN (below). */
 int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, int C, float *dgamma,
                              float *dbeta, float *c1, float *c2, int accumulate, papc_stream_t stream);
+
+/* Eval-mode BatchNorm (the source's registered norms under model.eval(): PointNet-Basic's mlp_1/mlp_2,
+ * pointnet_base.py:8-24, PFNLayer.norm, pillars.py:24): mean / invstd / scale / shift from the RUNNING statistics,
+ * the four vectors papc_bn_finalize_f32 derives from a batch.  The backward of such a layer passes
+ * `accumulate | 2` to papc_bn_bwd_finalize_f32 (c1 = c2 = 0: no batch-mean terms). */
+int papc_bn_eval_consts_f32(const float *running_mean, const float *running_var, const float *gamma, const float *beta,
+                            float eps, int C, float *mean, float *invstd, float *scale, float *shift,
+                            papc_stream_t stream);
+
+/* Backward of a max over groups of K consecutive rows (PFNLayer's paddle.max(x, axis=1), pillars.py:34, when the
+ * activations x are themselves an output): dx [G*K,C] = gout [G,C] at row argmax [G,C] of each group, 0 elsewhere. */
+int papc_group_max_bwd_f32(const float *gout, const int32_t *argmax, int64_t G, int K, int C, float *dx,
+                           papc_stream_t stream);
 
 typedef struct papc_bwd_dy {
     int dz_mode;           /* PAPC_DZ_* */
@@ -257,7 +270,8 @@ int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, in
  * w is [C,9] ([out,in]; paddle's Linear stores [in,out]).  C <= 64. */
 /* decoration only (pillars.py:82-102): out [P,T,9] = masked [x,y,z,r, xyz-mean, x-cx, y-cy] rows */
 int papc_pfn_decorate_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
-                          float vx, float vy, float x_offset, float y_offset, float *out, papc_stream_t stream);
+                          float vx, float vy, float x_offset, float y_offset, int with_distance, float *out,
+                          papc_stream_t stream);
 int papc_pfn_stats_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
                        float vx, float vy, float x_offset, float y_offset, const float *w, int C,
                        float *stats_partial, int *n_blocks_out, papc_stream_t stream);
@@ -380,9 +394,10 @@ int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, con
  * arrays are HOST arrays (read during the call); the matrices are device memory.  Used for the W^T operands of a stack's dX GEMMs. */
 int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream);
 
-/* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params. */
+/* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params.  The betas are doubles:
+ * 1 - beta and the bias corrections are formed in double on the host (as float, 1 - 0.999f is already 1.3e-5 off). */
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
-                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       float lr, double beta1, double beta2, float eps, float weight_decay, int step,
                        float grad_scale, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

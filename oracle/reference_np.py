@@ -386,8 +386,9 @@ def get_paddings_indicator(actual_num, max_num):
     return np.asarray(actual_num).astype(np.int64)[:, None] > np.arange(max_num, dtype=np.int64)[None, :]
 
 
-def pillar_decorate(features, num_voxels, coors, vx, vy, x_offset, y_offset):
-    """pillars.py:79-102 -> masked 9-channel rows [P,T,9] (fp32, op order as written)."""
+def pillar_decorate(features, num_voxels, coors, vx, vy, x_offset, y_offset, with_distance=False):
+    """pillars.py:79-102 -> masked 9-channel rows [P,T,9] (fp32, op order as written); with_distance (:92-94) appends
+    paddle.norm(features[:, :, :3], 2, 2, keepdim=True) as a 10th channel."""
     features = _f32(features)
     nv = np.asarray(num_voxels).astype(np.float32).reshape(-1, 1, 1)
     points_mean = features[:, :, :3].sum(axis=1, keepdims=True, dtype=np.float32) / nv      # :82
@@ -397,7 +398,11 @@ def pillar_decorate(features, num_voxels, coors, vx, vy, x_offset, y_offset):
     cy = np.asarray(coors)[:, 2].astype(np.float32)[:, None]
     f_center[:, :, 0] = features[:, :, 0] - (cx * np.float32(vx) + np.float32(x_offset))     # :87
     f_center[:, :, 1] = features[:, :, 1] - (cy * np.float32(vy) + np.float32(y_offset))     # :88
-    feats = np.concatenate([features, f_cluster, f_center], axis=-1)                         # :91-95
+    ls = [features, f_cluster, f_center]                                                     # :91
+    if with_distance:                                                                        # :92-94
+        sq = features[:, :, :3] * features[:, :, :3]
+        ls.append(np.sqrt((sq[:, :, 0:1] + sq[:, :, 1:2]) + sq[:, :, 2:3]).astype(np.float32))
+    feats = np.concatenate(ls, axis=-1)                                                      # :95
     mask = get_paddings_indicator(num_voxels, feats.shape[1])                                # :99-100
     feats = feats * mask[..., None].astype(np.float32)                                       # :101-102
     return feats

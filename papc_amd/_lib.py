@@ -68,11 +68,13 @@ SIGNATURES = {
     "papc_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_p]),
     "papc_bn_bwd_reduce_f32": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p]),
     "papc_bn_bwd_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
+    "papc_bn_eval_consts_f32": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "papc_group_max_bwd_f32": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_p]),
     "papc_mlp_bwd_dx_f32": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_mlp_bwd_dw_f32": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "papc_reduce_partials2_f32": (c_i, [c_p, c_i, c_l, c_l, c_p, c_l, c_p, c_i, c_p]),
     "papc_reduce_partials_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p]),
-    "papc_pfn_decorate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "papc_pfn_decorate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_p, c_p]),
     "papc_pfn_stats_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p]),
     "papc_pfn_apply_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "papc_pfn_num_blocks": (c_i, [c_i]),
@@ -96,7 +98,7 @@ SIGNATURES = {
     "papc_transpose_batch_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_rotate_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_rotate_iou_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
-    "papc_adam_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
+    "papc_adam_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, ctypes.c_double, ctypes.c_double, c_f, c_f, c_i, c_f, c_p]),
     "papc_knob_set": (c_i, [ctypes.c_char_p, c_i]),
     "papc_knob_get": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
     "papc_prof_enable": (c_i, [ctypes.c_uint]),

@@ -22,10 +22,24 @@ import torch.nn as nn
 _SKIP = ("StructuredToParameterName@@",)
 
 
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """A checkpoint is data from somewhere else: only numpy's array reconstruction helpers and plain containers may be
+    instantiated while reading it (a stock ``pickle.load`` would run any callable the file names)."""
+
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+                ("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("collections", "OrderedDict"), ("_codecs", "encode")}   # (protocol-2 pickles carry array bytes as latin-1 text)
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("checkpoint names %s.%s: only numpy arrays and plain containers are accepted" % (module, name))
+
+
 def load_pdparams(path):
-    """*.pdparams -> {name: numpy array} (plain pickle; nothing from paddle is imported)."""
+    """*.pdparams -> {name: numpy array} (pickle restricted to numpy arrays; nothing from paddle is imported)."""
     with open(path, "rb") as f:
-        obj = pickle.load(f)
+        obj = _ArraysOnlyUnpickler(f).load()
     if not isinstance(obj, dict):
         raise ValueError("%s does not hold a state dict" % path)
     out = {}
@@ -46,7 +60,16 @@ def _module_of(model, param_name):
     return mod
 
 
-def _to_reference_name(name):
+def _to_reference_name(name, model=None):
+    """this package's state_dict key -> the reference's.  A model may carry ``reference_names`` (own module prefix -> the
+    source's, e.g. PointNet_Basic_Clas: ``convs.0`` -> ``mlp_1.0``, pointnet_base.py:7-25) where its containers are laid out
+    differently from the source's nn.Sequential holders."""
+    ref = getattr(model, "reference_names", None) if model is not None else None
+    if ref:
+        for own, theirs in ref.items():
+            if name.startswith(own + "."):
+                name = theirs + name[len(own):]
+                break
     return name.replace("running_mean", "_mean").replace("running_var", "_variance")
 
 
@@ -59,7 +82,7 @@ def export_state(model):
         a = t.detach().cpu().numpy()
         if name.endswith(".weight") and isinstance(_module_of(model, name), nn.Linear):
             a = np.ascontiguousarray(a.T)
-        out[_to_reference_name(name)] = a
+        out[_to_reference_name(name, model)] = a
     return out
 
 
@@ -76,7 +99,7 @@ def import_state(model, state, strict=False):
     missing = []
     with torch.no_grad():
         for name, dst in own.items():
-            key = _to_reference_name(name)
+            key = _to_reference_name(name, model)
             if key not in state:
                 missing.append(name)
                 continue

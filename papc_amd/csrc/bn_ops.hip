@@ -240,10 +240,41 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
     }
     if (tl == 0 && c < C) {
         s1 = r1[0][cl]; s2 = r2[0][cl];
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
-        c1[c] = (float)(s1 / (double)M);
-        c2[c] = (float)(s2 / (double)M);
+        if (dbeta) dbeta[c] = (accumulate & 1) ? dbeta[c] + (float)s1 : (float)s1;
+        if (dgamma) dgamma[c] = (accumulate & 1) ? dgamma[c] + (float)s2 : (float)s2;
+        // bit 1 of `accumulate`: the BatchNorm ran on its RUNNING statistics (eval mode): the batch-mean terms of its backward vanish
+        const bool eval_bn = (accumulate & 2) != 0;
+        c1[c] = eval_bn ? 0.f : (float)(s1 / (double)M);
+        c2[c] = eval_bn ? 0.f : (float)(s2 / (double)M);
+    }
+}
+
+// eval-mode BatchNorm constants from the running statistics: the same four vectors bn_finalize_kernel derives from a batch
+__global__ void bn_eval_consts_kernel(const float *__restrict__ rmean, const float *__restrict__ rvar, const float *__restrict__ gamma,
+                                      const float *__restrict__ beta, float eps, int C, float *mean, float *invstd, float *scale, float *shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = (double)rmean[c];
+    const double is = 1.0 / sqrt((double)rvar[c] + (double)eps);
+    const double sc = (gamma ? (double)gamma[c] : 1.0) * is;
+    mean[c] = (float)mu;
+    invstd[c] = (float)is;
+    scale[c] = (float)sc;
+    shift[c] = (float)((beta ? (double)beta[c] : 0.0) - mu * sc);
+}
+
+// backward of out[g,c] = max_k x[g*K+k, c] (first maximum wins): dx[g*K+k, c] = (k == argmax[g,c]) ? gout[g,c] : 0, written densely
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(const float *__restrict__ gout, const int32_t *__restrict__ argmax, int64_t G,
+                                                            int K, int C, float *__restrict__ dx)
+{
+    const int64_t total = G * K * (int64_t)C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const int64_t m = e / C;
+        const int64_t g = m / K;
+        const int k = (int)(m - g * K);
+        dx[e] = (argmax[g * C + c] == k) ? gout[g * C + c] : 0.f;
     }
 }
 
@@ -313,13 +344,13 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float *
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
-                                                   float *__restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float wd, float bc1, float bc2, float gscale)
+                                                   float *__restrict__ v, int64_t n, float lr, float b1, float b2, float omb1, float omb2,
+                                                   float eps, float wd, float bc1, float bc2, float gscale)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float gi = g[i] * gscale + wd * p[i];  // L2 regularisation folded into the gradient (paddle weight_decay=float)
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float mi = b1 * m[i] + omb1 * gi;       // omb = 1 - beta formed in double on the host: 1.f - 0.999f is off by 1.3e-5
+        const float vi = b2 * v[i] + omb2 * gi * gi;
         m[i] = mi; v[i] = vi;
         p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
     }
@@ -505,6 +536,29 @@ int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, i
     return check_launch("papc_bn_bwd_finalize_f32");
 }
 
+int papc_bn_eval_consts_f32(const float *running_mean, const float *running_var, const float *gamma, const float *beta, float eps, int C,
+                            float *mean, float *invstd, float *scale, float *shift, papc_stream_t stream)
+{
+    PAPC_REQUIRE(running_mean && running_var && mean && invstd && scale && shift, PAPC_E_INVALID, "papc_bn_eval_consts_f32: null pointer");
+    PAPC_REQUIRE(C >= 1, PAPC_E_INVALID, "papc_bn_eval_consts_f32: C=%d", C);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(bn_eval_consts_kernel, dim3((unsigned)cdiv(C, 256)), dim3(256), 0, st, running_mean, running_var, gamma, beta, eps, C,
+                       mean, invstd, scale, shift);
+    return check_launch("papc_bn_eval_consts_f32");
+}
+
+int papc_group_max_bwd_f32(const float *gout, const int32_t *argmax, int64_t G, int K, int C, float *dx, papc_stream_t stream)
+{
+    PAPC_REQUIRE(gout && argmax && dx, PAPC_E_INVALID, "papc_group_max_bwd_f32: null pointer");
+    PAPC_REQUIRE(G >= 1 && K >= 1 && C >= 1, PAPC_E_INVALID, "papc_group_max_bwd_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    const int64_t total = G * K * (int64_t)C;
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3((unsigned)std::min<int64_t>(cdiv(total, 256), 8192)), dim3(256), 0, st, gout, argmax, G, K, C, dx);
+    return check_launch("papc_group_max_bwd_f32");
+}
+
 int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, int64_t n1, float *out1, int64_t n2,
                               float *out2, int accumulate, papc_stream_t stream)
 {
@@ -565,16 +619,17 @@ int papc_transpose_batch_f32(const float *const *src, float *const *dst, const i
 }
 
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
-                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       float lr, double beta1, double beta2, float eps, float weight_decay, int step,
                        float grad_scale, papc_stream_t stream)
 {
     PAPC_REQUIRE(param && grad && exp_avg && exp_avg_sq, PAPC_E_INVALID, "papc_adam_step_f32: null pointer");
     PAPC_REQUIRE(n >= 1 && step >= 1, PAPC_E_INVALID, "papc_adam_step_f32: bad n/step");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2, grad_scale);
+    // everything that depends on the betas only is formed in double here (the optimiser's hyper-parameters are doubles on the host)
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step)), bc2 = (float)(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, (float)beta1, (float)beta2,
+                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc1, bc2, grad_scale);
     return check_launch("papc_adam_step_f32");
 }
 

@@ -27,6 +27,7 @@ struct PfnArgs {
     // backward
     const float *gout; const int32_t *amax; const float *mean, *invstd, *c1, *c2;
     float *red; float *dwp;
+    int with_dist;   // PFN_DECORATE only: also write ||xyz|| as a 10th channel (pillars.py:92-94)
 };
 
 enum { PFN_STATS = 0, PFN_APPLY = 1, PFN_BWD_RED = 2, PFN_BWD_DW = 3, PFN_DECORATE = 4 };
@@ -62,7 +63,8 @@ __device__ __forceinline__ void pfn_stage(const PfnArgs &a, int p, float *rows, 
             const float4 v = f[h];
             *reinterpret_cast<float4 *>(r) = make_float4(v.x * mk, v.y * mk, v.z * mk, v.w * mk);
             *reinterpret_cast<float4 *>(r + 4) = make_float4((v.x - mx) * mk, (v.y - my) * mk, (v.z - mz) * mk, (v.x - pcx) * mk);
-            *reinterpret_cast<float4 *>(r + 8) = make_float4((v.y - pcy) * mk, 0.f, 0.f, 0.f);
+            // (slot 9: points_dist = paddle.norm(features[:, :, :3], 2, 2) of the with_distance variant, :92-94)
+            *reinterpret_cast<float4 *>(r + 8) = make_float4((v.y - pcy) * mk, sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z) * mk, 0.f, 0.f);
         }
     }
 }
@@ -106,9 +108,10 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_kernel(PfnArgs a)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (MODE == PFN_DECORATE) {
-            for (int e = lane; e < a.T * 9; e += 64) {
-                const int t = e / 9, k = e - t * 9;
-                a.out[((int64_t)p * a.T + t) * 9 + k] = rows[t * PFN_LD + k];
+            const int nc = a.with_dist ? 10 : 9;
+            for (int e = lane; e < a.T * nc; e += 64) {
+                const int t = e / nc, k = e - t * nc;
+                a.out[((int64_t)p * a.T + t) * nc + k] = rows[t * PFN_LD + k];
             }
         } else if (MODE == PFN_STATS) {
             for (int t = 0; t < a.T; ++t) {
@@ -204,7 +207,7 @@ extern "C" {
 int papc_pfn_num_blocks(int P) { return P >= 1 ? pfn_blocks(P) : 0; }
 
 int papc_pfn_decorate_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
-                          float vx, float vy, float x_offset, float y_offset, float *out, papc_stream_t stream)
+                          float vx, float vy, float x_offset, float y_offset, int with_distance, float *out, papc_stream_t stream)
 {
     const float dummy = 0.f;
     int rc = pfn_check("papc_pfn_decorate_f32", features, num_voxels, coors, P, T, &dummy, 1);
@@ -213,6 +216,7 @@ int papc_pfn_decorate_f32(const float *features, const int32_t *num_voxels, cons
     PfnArgs a;
     memset(&a, 0, sizeof(a));
     a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
+    a.with_dist = with_distance ? 1 : 0;
     a.C = 1; a.out = out;
     return launch_pfn<PFN_DECORATE>(a, as_stream(stream), "papc_pfn_decorate_f32");
 }

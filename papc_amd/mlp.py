@@ -23,11 +23,15 @@ DZ_DENSE, DZ_MAX = 0, 1
 class StackSpec:
     """Static description of one stack invocation (not a tensor; passed through autograd untouched)."""
 
-    def __init__(self, B, N, S, K, D, xyz_first, eps=1e-5, momentum=0.9, cut_gather_grad=False, pool=True):
+    def __init__(self, B, N, S, K, D, xyz_first, eps=1e-5, momentum=0.9, cut_gather_grad=False, pool=True, eval_bn=False):
         self.B, self.N, self.S, self.K, self.D = B, N, S, K, D
         # pool=False: no max over K -- the stack returns relu(bn_L(.)) for every row (PointNetFeaturePropagation's
         # Conv1D stack, pointnet2_basic_layers.py:330-333)
         self.pool = bool(pool)
+        # eval_bn=True: the BatchNorms normalise with their RUNNING statistics and leave them untouched (a registered norm of the
+        # source under model.eval(): pointnet_base.py:8-24, pillars.py:24); needs bn_buffers.  The SA / FP layers never set it: the
+        # source keeps their norms in plain lists, so .eval() never reaches them (pointnet2_basic_layers.py:185-191).
+        self.eval_bn = bool(eval_bn)
         self.xyz_first = bool(xyz_first)
         self.eps, self.momentum = float(eps), float(momentum)
         self.cut_gather_grad = cut_gather_grad
@@ -95,7 +99,9 @@ class SharedMLPMax(torch.autograd.Function):
         prev_y, prev_sc, prev_sh = None, None, None
         cin = x_rows.shape[1] if plain else spec.D + 3
         cin0 = cin
-        lin0 = (_LIN_GATHER and not plain and idx is not None and feats is not None and L >= 2 and spec.D % 4 == 0 and spec.D >= 16
+        ev = spec.eval_bn
+        assert not ev or bn_buffers is not None, "eval_bn needs the running statistics"
+        lin0 = (_LIN_GATHER and not ev and not plain and idx is not None and feats is not None and L >= 2 and spec.D % 4 == 0 and spec.D >= 16
                 and params[0].shape[0] % 4 == 0 and params[0].shape[0] <= 256 and feats.is_contiguous())
         for l in range(L):
             w, b, gamma, beta = params[4 * l: 4 * l + 4]
@@ -103,10 +109,10 @@ class SharedMLPMax(torch.autograd.Function):
             w2 = w.reshape(cout, cin)
             assert w2.is_contiguous()
             y = torch.empty(M, cout, device=dev, dtype=torch.float32)
-            stats = torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
+            stats = None if ev else torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
             parts_l = parts
             gm_ref = None
-            if l == L - 1 and spec.pool and _FUSE_GMAX and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
+            if l == L - 1 and spec.pool and _FUSE_GMAX and not ev and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
                 # last layer: the neighbourhood max is reduced in the GEMM epilogue (per-group max/min of the raw output)
                 G_ = M // spec.K
                 gbuf_f = torch.empty(2, G_, cout, device=dev, dtype=torch.float32)
@@ -135,9 +141,13 @@ class SharedMLPMax(torch.autograd.Function):
                                             cout, ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
             cst = torch.empty(4, cout, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
             rm, rv = (bn_buffers[l] if bn_buffers is not None else (None, None))
-            check(lib.papc_bn_finalize_f32(ptr(stats), parts_l, M, cout, ptr(gamma), ptr(beta), spec.eps, spec.momentum,
-                                           cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(),
-                                           ptr(rm), ptr(rv), st), "papc_bn_finalize_f32")
+            if ev:
+                check(lib.papc_bn_eval_consts_f32(ptr(rm), ptr(rv), ptr(gamma), ptr(beta), spec.eps, cout, cst[0].data_ptr(),
+                                                  cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), st), "papc_bn_eval_consts_f32")
+            else:
+                check(lib.papc_bn_finalize_f32(ptr(stats), parts_l, M, cout, ptr(gamma), ptr(beta), spec.eps, spec.momentum,
+                                               cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(),
+                                               ptr(rm), ptr(rv), st), "papc_bn_finalize_f32")
             ys.append(y)
             consts.append(cst)
             prev_y, prev_sc, prev_sh = y, cst[2], cst[3]
@@ -244,7 +254,8 @@ class SharedMLPMax(torch.autograd.Function):
             else:
                 red, red_parts = fused_red, gemm_parts
             check(lib.papc_bn_bwd_finalize_f32(ptr(red), red_parts, M, cout, dgamma_p, dbeta_p,
-                                               c12[0].data_ptr(), c12[1].data_ptr(), int(inplace), st), "papc_bn_bwd_finalize_f32")
+                                               c12[0].data_ptr(), c12[1].data_ptr(), int(inplace) | (2 if spec.eval_bn else 0), st),
+                  "papc_bn_bwd_finalize_f32")
             if l == 0 and ctx.lin0:
                 # G[j] = sum of the dY rows that gathered point j (+ the xyz columns of dW, streamed); the D-wide products run on B*N rows
                 BN_ = spec.B * spec.N
@@ -311,6 +322,8 @@ class SharedMLPMax(torch.autograd.Function):
                 db = torch.empty(cout, device=dev, dtype=torch.float32)
                 check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, ptr(dw), cout, ptr(db), 0, st),
                       "papc_reduce_partials2_f32")
+                if spec.eval_bn:      # no batch-mean term removes the bias direction: db = sum_m dy = scale * sum_m p (tiny [C] op)
+                    db = cst[2] * dgb[1]
                 grads[4 * l + 0] = dw.reshape(w.shape)
                 grads[4 * l + 1] = db
                 grads[4 * l + 2] = dgb[0]
@@ -382,5 +395,5 @@ def grad_targets_of(params):
 def shared_mlp_max(spec, bn_buffers, xyz, new_xyz, feats, idx, params, x_rows=None):
     # re-evaluated on every forward: a cached list would go stale when the optimizer replaces the .grad tensors
     # (e.g. zero_grad(set_to_none=True)) and gradients would silently land in orphaned buffers
-    spec.grad_targets = grad_targets_of(params) if torch.is_grad_enabled() else None
+    spec.grad_targets = grad_targets_of(params) if (torch.is_grad_enabled() and not spec.eval_bn) else None
     return SharedMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)

@@ -134,6 +134,11 @@ class PointNet_Basic_Clas(nn.Module):
     """Shared pointwise Conv1D+BN+ReLU stack (3->64->64->64->128->1024) -> max over N -> FC head.
     The five conv layers and the max are one SharedMLPMax node (group = one cloud, K = N)."""
 
+    # checkpoint exchange: the source holds these layers in two nn.Sequential containers, mlp_1 = [conv, bn, relu] x 2 and
+    # mlp_2 = [conv, bn, relu] x 3 (pointnet_base.py:7-25); papc_amd.checkpoint maps the names
+    reference_names = {"convs.0": "mlp_1.0", "bns.0": "mlp_1.1", "convs.1": "mlp_1.3", "bns.1": "mlp_1.4", "convs.2": "mlp_2.0",
+                       "bns.2": "mlp_2.1", "convs.3": "mlp_2.3", "bns.3": "mlp_2.4", "convs.4": "mlp_2.6", "bns.4": "mlp_2.7"}
+
     def __init__(self, num_classes=10, max_points=1024):
         super().__init__()
         chans = [3, 64, 64, 64, 128, max_points]
@@ -147,7 +152,9 @@ class PointNet_Basic_Clas(nn.Module):
         B, _, N = x.shape
         xyz = x.transpose(1, 2)                                   # rows (b,n) read straight from the planar input
         zero = torch.zeros(B, 1, 3, device=x.device, dtype=torch.float32)
-        spec = StackSpec(B, N, 1, N, 0, xyz_first=True, eps=self.bns[0].eps, momentum=0.9)
+        # the norms are registered layers in the source (nn.Sequential mlp_1 / mlp_2): model.eval() normalises with the running
+        # statistics and leaves them untouched
+        spec = StackSpec(B, N, 1, N, 0, xyz_first=True, eps=self.bns[0].eps, momentum=0.9, eval_bn=not self.training)
         ps = []
         for conv, bn in zip(self.convs, self.bns):
             ps += [conv.weight, conv.bias, bn.weight, bn.bias]

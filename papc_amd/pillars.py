@@ -4,9 +4,12 @@ Mirrors /root/reference/PAPC/models/detect/pointpillars/models/bones/pillars.py:
 ``PillarFeatureNet`` :43-108 (caller: models/detectors/pointpillars.py:137 ``self.pfn(voxels, num_points, coors)``).
 
 The shipped configuration (``num_filters: [64]``, pointpillars_kitti_car_xy16.yaml:56) is a single last PFNLayer:
-that path is two fused HIP passes (papc_pfn_stats_f32 / papc_pfn_apply_f32) plus their backward.  Longer
-``num_filters`` chains run layer by layer on the generic MFMA row-GEMM kernels (forward only for non-last
-layers).  ``use_norm=False`` is not built.
+that path is two fused HIP passes (papc_pfn_stats_f32 / papc_pfn_apply_f32) plus their backward.  Everything else the
+constructors allow -- the source's DEFAULT ``num_filters=(64, 128)`` chain, ``use_norm=False`` (Linear with bias, no norm,
+:25-27), ``with_distance=True`` (:57-58, :92-94) -- runs layer by layer on the generic row kernels, differentiable end to
+end: the decoration kernel, then per layer the MFMA row GEMM + BN/ReLU stack node (``pool=False``), the group max with its
+backward (papc_group_max_bwd_f32) and the concat of :39-41.  ``model.eval()`` switches the norms to their running statistics
+(they are registered layers in the source).
 
 paddle's ``nn.Linear.weight`` is ``[in,out]``; here the weight is torch-style ``[out,in]`` (transpose when
 importing a paddle checkpoint).  BatchNorm1D(momentum=0.01) in paddle weighs the RUNNING value by 0.01.
@@ -21,7 +24,7 @@ from .mlp import StackSpec, shared_mlp_max
 
 class _PFNFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, geom, features, num_voxels, coors, w, gamma, beta, rmean, rvar, eps, momentum):
+    def forward(ctx, geom, features, num_voxels, coors, w, gamma, beta, rmean, rvar, eps, momentum, training=True):
         lib = _lib.load()
         st = stream_ptr()
         P, T, _ = features.shape
@@ -29,18 +32,23 @@ class _PFNFused(torch.autograd.Function):
         vx, vy, xo, yo = geom
         dev = features.device
         nb = lib.papc_pfn_num_blocks(P)
-        stats = torch.empty(nb, 2, C, device=dev, dtype=torch.float32)
-        check(lib.papc_pfn_stats_f32(ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(w), C, ptr(stats),
-                                     None, st), "papc_pfn_stats_f32")
         cst = torch.empty(4, C, device=dev, dtype=torch.float32)
-        check(lib.papc_bn_finalize_f32(ptr(stats), nb, P * T, C, ptr(gamma), ptr(beta), eps, momentum, cst[0].data_ptr(),
-                                       cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), ptr(rmean), ptr(rvar), st),
-              "papc_bn_finalize_f32")
+        if training:
+            stats = torch.empty(nb, 2, C, device=dev, dtype=torch.float32)
+            check(lib.papc_pfn_stats_f32(ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(w), C, ptr(stats),
+                                         None, st), "papc_pfn_stats_f32")
+            check(lib.papc_bn_finalize_f32(ptr(stats), nb, P * T, C, ptr(gamma), ptr(beta), eps, momentum, cst[0].data_ptr(),
+                                           cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), ptr(rmean), ptr(rvar), st),
+                  "papc_bn_finalize_f32")
+        else:   # eval: running statistics, left untouched (self.norm is a registered BatchNorm1D in the source, :24)
+            check(lib.papc_bn_eval_consts_f32(ptr(rmean), ptr(rvar), ptr(gamma), ptr(beta), eps, C, cst[0].data_ptr(),
+                                              cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), st), "papc_bn_eval_consts_f32")
         out = torch.empty(P, C, device=dev, dtype=torch.float32)
         argmax = torch.empty(P, C, device=dev, dtype=torch.int32)
         check(lib.papc_pfn_apply_f32(ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(w), C,
                                      cst[2].data_ptr(), cst[3].data_ptr(), ptr(out), ptr(argmax), st), "papc_pfn_apply_f32")
         ctx.geom = geom
+        ctx.training = bool(training)
         ctx.save_for_backward(features, num_voxels, coors, w, cst, argmax)
         return out
 
@@ -62,13 +70,111 @@ class _PFNFused(torch.autograd.Function):
         dgb = torch.empty(2, C, device=dev, dtype=torch.float32)
         c12 = torch.empty(2, C, device=dev, dtype=torch.float32)
         check(lib.papc_bn_bwd_finalize_f32(ptr(red), nb, P * T, C, dgb[0].data_ptr(), dgb[1].data_ptr(), c12[0].data_ptr(),
-                                           c12[1].data_ptr(), 0, st), "papc_bn_bwd_finalize_f32")
+                                           c12[1].data_ptr(), 0 if ctx.training else 2, st), "papc_bn_bwd_finalize_f32")
         dwp = torch.empty(nb, C, 9, device=dev, dtype=torch.float32)
         check(lib.papc_pfn_bwd_dw_f32(*geo, ptr(gout), ptr(argmax), *bn, c12[0].data_ptr(), c12[1].data_ptr(), ptr(dwp), st),
               "papc_pfn_bwd_dw_f32")
         dw = torch.empty(C, 9, device=dev, dtype=torch.float32)
         check(lib.papc_reduce_partials_f32(ptr(dwp), nb, C * 9, ptr(dw), 0, st), "papc_reduce_partials_f32")
-        return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None
+        return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None, None
+
+
+class _GroupMax(torch.autograd.Function):
+    """max over the K rows of each group of NON-NEGATIVE activations (x = relu(.)): [G*K, C] -> [G, C] (pillars.py:34).
+    Forward: papc_bn_relu_max_f32 with unit constants (relu is the identity on x >= 0); backward: papc_group_max_bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, x, G, K):
+        lib = _lib.load()
+        C = x.shape[1]
+        dev = x.device
+        one = torch.ones(C, device=dev, dtype=torch.float32)
+        zero = torch.zeros(C, device=dev, dtype=torch.float32)
+        out = torch.empty(G, C, device=dev, dtype=torch.float32)
+        argmax = torch.empty(G, C, device=dev, dtype=torch.int32)
+        check(lib.papc_bn_relu_max_f32(ptr(x), ptr(one), ptr(zero), G, K, C, ptr(out), ptr(argmax), stream_ptr()), "papc_bn_relu_max_f32")
+        ctx.save_for_backward(argmax)
+        ctx.K = K
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (argmax,) = ctx.saved_tensors
+        G, C = argmax.shape
+        gout = gout.contiguous().float()
+        dx = torch.empty(G * ctx.K, C, device=gout.device, dtype=torch.float32)
+        check(_lib.load().papc_group_max_bwd_f32(ptr(gout), ptr(argmax), G, ctx.K, C, ptr(dx), stream_ptr()), "papc_group_max_bwd_f32")
+        return dx, None, None
+
+
+class _LinearReLU(torch.autograd.Function):
+    """relu(rows @ w^T + b) without a norm (PFNLayer(use_norm=False): Linear with bias + the Empty norm, pillars.py:25-27,:30-32) on the
+    MFMA row kernels.  The backward reuses the BN-aware kernels with identity constants (scale 1, shift 0, mean 0, invstd 1,
+    c1 = c2 = 0): their dY is then exactly gout * [y > 0]."""
+
+    @staticmethod
+    def forward(ctx, rows, w, b):
+        lib = _lib.load()
+        st = stream_ptr()
+        M, cin = rows.shape
+        cout = w.shape[0]
+        dev = rows.device
+        y = torch.empty(M, cout, device=dev, dtype=torch.float32)
+        check(lib.papc_mlp_gemm_f32(0, ptr(rows), cin, None, None, None, ptr(w), ptr(b), M, cin, cout, ptr(y), None, None, st),
+              "papc_mlp_gemm_f32")
+        ident = torch.zeros(4, cout, device=dev, dtype=torch.float32)    # mean 0, invstd / scale 1, shift 0
+        ident[1].fill_(1.0)
+        ident[2].fill_(1.0)
+        x = torch.empty(M, cout, device=dev, dtype=torch.float32)
+        check(lib.papc_bn_relu_f32(ptr(y), ident[2].data_ptr(), ident[3].data_ptr(), M, cout, ptr(x), st), "papc_bn_relu_f32")
+        ctx.save_for_backward(rows, w, y, ident)
+        ctx.needs = (rows.requires_grad, )
+        return x
+
+    @staticmethod
+    def backward(ctx, gout):
+        from ._lib import BwdDy
+        from .mlp import _dw_rows_per_chunk
+        import ctypes
+        lib = _lib.load()
+        st = stream_ptr()
+        rows, w, y, ident = ctx.saved_tensors
+        M, cin = rows.shape
+        cout = w.shape[0]
+        dev = rows.device
+        gout = gout.contiguous().float()
+        zero2 = torch.zeros(2, cout, device=dev, dtype=torch.float32)
+        dy = BwdDy()
+        dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = 0, gout.data_ptr(), None, None, 1
+        dy.y = y.data_ptr()
+        dy.mean, dy.invstd, dy.scale, dy.shift = ident[0].data_ptr(), ident[1].data_ptr(), ident[2].data_ptr(), ident[3].data_ptr()
+        dy.c1, dy.c2 = zero2[0].data_ptr(), zero2[1].data_ptr()
+        rpc = _dw_rows_per_chunk(M, cout, cin)
+        n_chunks = (M + rpc - 1) // rpc
+        pld = cout * cin + cout
+        part = torch.empty(n_chunks, pld, device=dev, dtype=torch.float32)
+        check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), 0, ptr(rows), cin, None, None, None, M, cin, cout, rpc, part.data_ptr(),
+                                      part.data_ptr() + 4 * cout * cin, pld, st), "papc_mlp_bwd_dw_f32")
+        dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
+        dbz = torch.empty(cout, device=dev, dtype=torch.float32)
+        check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, ptr(dw), cout, ptr(dbz), 0, st), "papc_reduce_partials2_f32")
+        # the dW kernel writes the bias gradient of a BN-fed conv (exactly 0); without a norm it is the column sum of dY:
+        # (sum p, sum p*xhat) from the BN-backward reduce with the identity constants -> its first row
+        n_parts = min(512, (M + 127) // 128)
+        red = torch.empty(n_parts, 2, cout, device=dev, dtype=torch.float32)
+        check(lib.papc_bn_bwd_reduce_f32(0, ptr(gout), None, None, 1, ptr(y), ident[0].data_ptr(), ident[1].data_ptr(), ident[2].data_ptr(),
+                                         ident[3].data_ptr(), M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
+        dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)
+        c12 = torch.empty(2, cout, device=dev, dtype=torch.float32)
+        check(lib.papc_bn_bwd_finalize_f32(ptr(red), n_parts, M, cout, dgb[0].data_ptr(), dgb[1].data_ptr(), c12[0].data_ptr(),
+                                           c12[1].data_ptr(), 2, st), "papc_bn_bwd_finalize_f32")
+        db = dgb[1]
+        dx = None
+        if ctx.needs[0]:
+            wt = w.t().contiguous()
+            dx = torch.empty(M, cin, device=dev, dtype=torch.float32)
+            check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(dx), None, None, st), "papc_mlp_bwd_dx_f32")
+        return dx, dw, db
 
 
 class PFNLayer(nn.Module):
@@ -81,45 +187,43 @@ class PFNLayer(nn.Module):
         if not self.last_vfe:
             out_channels = out_channels // 2                                                   # :18-19
         self.units = out_channels
-        if not use_norm:
-            raise NotImplementedError("PFNLayer(use_norm=False) is not built (the shipped config uses use_norm=True)")
-        self.linear = nn.Linear(in_channels, out_channels, bias=False)                         # :23
-        self.norm = nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.01)                      # :24 (paddle momentum)
+        self.use_norm = bool(use_norm)
+        if use_norm:
+            self.linear = nn.Linear(in_channels, out_channels, bias=False)                     # :23
+            self.norm = nn.BatchNorm1d(out_channels, eps=1e-3, momentum=0.01)                  # :24 (paddle momentum)
+        else:
+            self.linear = nn.Linear(in_channels, out_channels, bias=True)                      # :26
+            self.norm = nn.Identity()                                                          # :27 (libs.nn.Empty)
+
+    def activations(self, rows):
+        """relu(norm(linear(rows))) for rows [M, Cin] -> [M, C] (:30-32), differentiable."""
+        C = self.units
+        if not self.use_norm:
+            return _LinearReLU.apply(rows, self.linear.weight, self.linear.bias)
+        M = rows.shape[0]
+        spec = StackSpec(1, M, M, 1, 0, True, eps=self.norm.eps, momentum=self.norm.momentum, pool=False,
+                         eval_bn=not self.training)
+        zero_b = torch.zeros(C, device=rows.device, dtype=torch.float32)
+        return shared_mlp_max(spec, [(self.norm.running_mean, self.norm.running_var)], None, None, None, None,
+                              [self.linear.weight, zero_b, self.norm.weight, self.norm.bias], x_rows=rows)
 
     def forward(self, inputs):
         """inputs [P,T,Cin] -> [P,1,C] (last layer, :36-37) or [P,T,2C] (concat with the tiled max, :39-41)."""
         P, T, Cin = inputs.shape
         C = self.units
         rows = inputs.reshape(P * T, Cin).contiguous().float()
-        if self.last_vfe:
-            spec = StackSpec(P, T, 1, T, 0, True, eps=self.norm.eps, momentum=self.norm.momentum)
+        if self.last_vfe and self.use_norm:
+            # the max is the only output: one fused node, the [P*T, C] activations are never materialised
+            spec = StackSpec(P, T, 1, T, 0, True, eps=self.norm.eps, momentum=self.norm.momentum, eval_bn=not self.training)
             zero_b = torch.zeros(C, device=rows.device, dtype=torch.float32)
             out = shared_mlp_max(spec, [(self.norm.running_mean, self.norm.running_var)], None, None, None, None,
                                  [self.linear.weight, zero_b, self.norm.weight, self.norm.bias], x_rows=rows)
             return out.view(P, 1, C)
-        # non-last layer: activations are an output, so they are materialised (forward only)
-        lib = _lib.load()
-        st = stream_ptr()
-        dev = rows.device
-        M = P * T
-        with torch.no_grad():
-            parts = lib.papc_mlp_gemm_parts(M)
-            y = torch.empty(M, C, device=dev, dtype=torch.float32)
-            stats = torch.empty(parts, 2, C, device=dev, dtype=torch.float32)
-            check(lib.papc_mlp_gemm_f32(0, ptr(rows), Cin, None, None, None, ptr(self.linear.weight), None, M, Cin, C, ptr(y),
-                                        ptr(stats), None, st), "papc_mlp_gemm_f32")
-            cst = torch.empty(4, C, device=dev, dtype=torch.float32)
-            check(lib.papc_bn_finalize_f32(ptr(stats), parts, M, C, ptr(self.norm.weight), ptr(self.norm.bias), self.norm.eps,
-                                           self.norm.momentum, cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
-                                           cst[3].data_ptr(), ptr(self.norm.running_mean), ptr(self.norm.running_var), st),
-                  "papc_bn_finalize_f32")
-            x = torch.empty(M, C, device=dev, dtype=torch.float32)
-            check(lib.papc_bn_relu_f32(ptr(y), cst[2].data_ptr(), cst[3].data_ptr(), M, C, ptr(x), st), "papc_bn_relu_f32")
-            x_max = torch.empty(P, C, device=dev, dtype=torch.float32)
-            check(lib.papc_bn_relu_max_f32(ptr(y), cst[2].data_ptr(), cst[3].data_ptr(), P, T, C, ptr(x_max), None, st),
-                  "papc_bn_relu_max_f32")
-            x = x.view(P, T, C)
-            return torch.cat([x, x_max.view(P, 1, C).expand(P, T, C)], dim=2)                  # :39-41
+        x = self.activations(rows)                                                             # [P*T, C]
+        x_max = _GroupMax.apply(x, P, T).view(P, 1, C)                                         # :34
+        if self.last_vfe:
+            return x_max                                                                       # :36-37
+        return torch.cat([x.view(P, T, C), x_max.expand(P, T, C)], dim=2)                      # :39-41
 
 
 class PillarFeatureNet(nn.Module):
@@ -130,11 +234,14 @@ class PillarFeatureNet(nn.Module):
         super().__init__()
         self.name = 'PillarFeatureNet'
         assert len(num_filters) > 0
-        if num_input_features != 4 or with_distance:
-            raise NotImplementedError("PillarFeatureNet is built for num_input_features=4, with_distance=False "
-                                      "(the shipped KITTI config)")
+        if num_input_features != 4:
+            raise NotImplementedError("PillarFeatureNet: the decoration kernel reads [x, y, z, r] points (num_input_features=4, the "
+                                      "only layout the reference's voxeliser produces, yaml NUM_POINT_FEATURES: 4)")
         num_input_features += 5                                                                # :55
+        if with_distance:
+            num_input_features += 1                                                            # :57-58
         self._with_distance = with_distance
+        self._use_norm = bool(use_norm)
         num_filters = [num_input_features] + list(num_filters)
         layers = []
         for i in range(len(num_filters) - 1):
@@ -149,14 +256,16 @@ class PillarFeatureNet(nn.Module):
         return (float(self.vx), float(self.vy), float(self.x_offset), float(self.y_offset))
 
     def decorate(self, features, num_voxels, coors):
-        """:82-102 only -> masked 9-channel rows [P,T,9]."""
+        """:82-102 only -> masked rows [P,T,9] (+ the point norm as a 10th channel with_distance, :92-94).  The inputs are data
+        (no gradient flows into the point cloud)."""
         lib = _lib.load()
         features = features.contiguous().float()
         P, T, _ = features.shape
-        out = torch.empty(P, T, 9, device=features.device, dtype=torch.float32)
+        nc = 10 if self._with_distance else 9
+        out = torch.empty(P, T, nc, device=features.device, dtype=torch.float32)
         vx, vy, xo, yo = self._geom()
         check(lib.papc_pfn_decorate_f32(ptr(features), ptr(num_voxels.int().contiguous()), ptr(coors.int().contiguous()), P, T,
-                                        vx, vy, xo, yo, ptr(out), stream_ptr()), "papc_pfn_decorate_f32")
+                                        vx, vy, xo, yo, int(self._with_distance), ptr(out), stream_ptr()), "papc_pfn_decorate_f32")
         return out
 
     def forward(self, features, num_voxels, coors):
@@ -166,12 +275,13 @@ class PillarFeatureNet(nn.Module):
         features = features.contiguous().float()
         num_voxels = num_voxels.int().contiguous()
         coors = coors.int().contiguous()
-        if len(self.pfn_layers) == 1:
-            pfn = self.pfn_layers[0]
+        pfn = self.pfn_layers[0]
+        if len(self.pfn_layers) == 1 and self._use_norm and not self._with_distance and pfn.units <= 64:
             out = _PFNFused.apply(self._geom(), features, num_voxels, coors, pfn.linear.weight, pfn.norm.weight, pfn.norm.bias,
-                                  pfn.norm.running_mean, pfn.norm.running_var, pfn.norm.eps, pfn.norm.momentum)
+                                  pfn.norm.running_mean, pfn.norm.running_var, pfn.norm.eps, pfn.norm.momentum, self.training)
             return out.squeeze()                                                               # :108
-        x = self.decorate(features, num_voxels, coors)
+        with torch.no_grad():
+            x = self.decorate(features, num_voxels, coors)
         for pfn in self.pfn_layers:                                                            # :105-106
             x = pfn(x)
         return x.squeeze()

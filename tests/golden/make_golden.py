@@ -77,11 +77,120 @@ def feature_propagation():
     np.savez_compressed(os.path.join(HERE, "fp_b2_n256.npz"), **out)
 
 
+def train_step():
+    """H row: one fwd + CrossEntropy + bwd + Adam(lr 1e-3, L2 1e-3) step of PointNet2_SSG_Clas
+    (PAPC/train.py:62-65, :106-116; classify/pointnet2/pointnet2.py:25-41) at B=8, N=1024, dropout p=0  (B=8, not 2: the
+    head's BatchNorm1D normalises over the batch, and over two samples it is a sign function that amplifies fp32 rounding
+    of its input by 1/sqrt(var + eps) -- a fixture at B=2 would test that amplification, not the kernels).
+    Sampling indices come from the f32 oracle (FPS / ball query are index-exact operators); the MLP stacks, the head, the
+    loss, the gradients and the Adam update are float64 torch on those indices (full gradient flow through the gathers, all
+    parameters trained: the build's default mode).  Stored: logits, loss and, per parameter tensor, a 48-element sample of
+    the gradient, of Adam's m / v and of the updated values, each tensor's max |grad|, and err32 = the error of PLAIN fp32
+    torch autograd on the same graph relative to max |grad| (weight gradients are cancelling sums over up to 131072 rows:
+    err32 says how much of a deviation is conditioning rather than kernel)."""
+    import torch
+    from papc_amd.models import PointNet2_SSG_Clas
+    from tests import torch_ref
+    from tests.util import seeded_model_state
+    B, N, seed = 8, 1024, 321
+    x = make_clouds(B, N, seed)
+    labels = np.array([3, 11, 0, 7, 15, 3, 9, 12], dtype=np.int64)
+    st1 = make_start_idx(B, N, seed)
+    st2 = make_start_idx(B, 512, seed + 1)
+    model = PointNet2_SSG_Clas(num_classes=16)
+    xyz = np.ascontiguousarray(x.transpose(0, 2, 1))
+    fps1 = R.farthest_point_sample(xyz, 512, st1)
+    nx1 = R.index_points(xyz, fps1)
+    idx1 = R.query_ball_point(0.2, 32, xyz, nx1)
+    fps2 = R.farthest_point_sample(nx1, 128, st2)
+    nx2 = R.index_points(nx1, fps2)
+    idx2 = R.query_ball_point(0.4, 64, nx1, nx2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+    margins = {}
+
+    def run(dt, state):
+        P = {k: torch.from_numpy(v).to(dt).requires_grad_(True) for k, v in state.items()}
+
+        def stack(prefix, rows, K):
+            x = rows
+            for l in range(3):
+                w = P["%s.mlp_convs.%d.weight" % (prefix, l)]
+                y = x @ w.reshape(w.shape[0], -1).t() + P["%s.mlp_convs.%d.bias" % (prefix, l)]
+                z = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * P["%s.mlp_bns.%d.weight" % (prefix, l)] \
+                    + P["%s.mlp_bns.%d.bias" % (prefix, l)]
+                x = torch.relu(z)
+            xg = x.reshape(-1, K, x.shape[1])
+            out = xg.max(dim=1).values
+            if dt == torch.float64:
+                # how far every pooled decision is from flipping: |z| of the winner (alive / dead) and the gap to the largest
+                # value that is not a copy of the winner (ball-query padding repeats rows exactly)
+                zg = z.detach().reshape(-1, K, x.shape[1])
+                zmax = zg.max(dim=1).values
+                runner = torch.where(zg < zmax.unsqueeze(1), zg, torch.full_like(zg, -1e30)).max(dim=1).values
+                gap = torch.where(zmax > 0, zmax - torch.clamp(runner, min=0.0), torch.full_like(zmax, 1e30))
+                scale = float(out.detach().abs().max())
+                margins[prefix] = (float(zmax.abs().min()) / scale, float(gap.min()) / scale)
+            return out
+
+        rows1 = torch_ref.group(t(xyz).to(dt), t(nx1).to(dt), None, t(idx1), True).reshape(B * 512 * 32, 3)
+        l1 = stack("sa1", rows1, 32).reshape(B, 512, 128)
+        rows2 = torch_ref.group(t(nx1).to(dt), t(nx2).to(dt), l1, t(idx2), True).reshape(B * 128 * 64, 131)
+        l2 = stack("sa2", rows2, 64).reshape(B, 128, 256)
+        rows3 = torch.cat([t(nx2).to(dt), l2], -1).reshape(B * 128, 259)          # sample_and_group_all: raw xyz first (:171-173)
+        l3 = stack("sa3", rows3, 128).reshape(B, 1024)
+
+        def bn1d(y, g, b):
+            return (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * g + b
+
+        h = torch.relu(bn1d(l3 @ P["fc1.weight"].t() + P["fc1.bias"], P["bn1.weight"], P["bn1.bias"]))
+        h = torch.relu(bn1d(h @ P["fc2.weight"].t() + P["fc2.bias"], P["bn2.weight"], P["bn2.bias"]))
+        logits = h @ P["fc3.weight"].t() + P["fc3.bias"]
+        loss = torch.nn.functional.cross_entropy(logits, t(labels))
+        loss.backward()
+        return P, l1, l3, logits, loss
+
+    # (margins: how close the ~400 000 pooled (group, channel) decisions -- is the winner alive, which row wins -- are to flipping.
+    # For every weight seed tried (99 .. 1210) some lie within 1e-7 of the activation scale: any fp32 evaluation re-routes a few of
+    # those max-pool gradients, ~1e-3 of a channel's gradient each.  The GPU test therefore allows 1e-2 on the set-abstraction
+    # gradients of this whole-model fixture; tests/test_gpu_mlp.py::test_backward_near_ties_explain_the_seed40_excess pins the
+    # routing and holds the same kernels to 2e-4.)
+    wseed = 99
+    state = seeded_model_state(model, wseed)
+    P, l1, l3, logits, loss = run(torch.float64, state)
+    print("pooled-decision margins (alive/dead, winner gap) relative to the activation scale:", margins)
+    P32 = run(torch.float32, state)[0]   # the same graph in plain fp32 autograd: how well conditioned each gradient is
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.999, 1e-8, 1e-3
+    out = dict(seed=seed, weight_seed=wseed, labels=labels, start1=st1, start2=st2, logits=logits.detach().numpy(), loss=float(loss),
+               l1_sample=l1.detach().numpy()[:, :4, :8], l3=l3.detach().numpy()[:, :64])
+    rng = np.random.default_rng(5)
+    for k, p in P.items():
+        g = p.grad.reshape(-1).numpy()
+        pv = p.detach().reshape(-1).numpy()
+        gd = g + wd * pv
+        m = (1 - b1) * gd
+        v = (1 - b2) * gd * gd
+        new = pv - lr * (m / (1 - b1)) / (np.sqrt(v / (1 - b2)) + eps)
+        sel = np.sort(rng.choice(g.size, size=min(48, g.size), replace=False))
+        out["sel/" + k] = sel
+        out["grad/" + k] = g[sel]
+        out["gmax/" + k] = np.abs(g).max()
+        out["err32/" + k] = np.abs(P32[k].grad.reshape(-1).double().numpy() - g).max() / max(np.abs(g).max(), 1e-300)
+        out["m/" + k] = m[sel]
+        out["v/" + k] = v[sel]
+        out["new/" + k] = new[sel]
+    np.savez_compressed(os.path.join(HERE, "step_b8_n1024.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "step":      # only the train-step fixture (the others are unchanged)
+        train_step()
+        sys.exit(0)
     sampling(2, 1024, 128, 1234, "sampling_b2_n1024.npz")
     sampling(1, 4096, 512, 4242, "sampling_b1_n4096.npz")
     sa_activations()
     pfn()
     feature_propagation()
+    train_step()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -240,3 +240,74 @@ def test_alternative_kernel_flavours(dev, env):
                         "-k", "sa_forward or group_all or msg_vs or stack_backward"], cwd=root, env=e,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_backward_near_ties_explain_the_seed40_excess(dev):
+    """The M = 32768 backward case uses weight seed 41 because seed 40 gives ~1e-3 .. 1e-2 on dW; the claimed cause is a
+    pooled (group, channel) decision within fp32 rounding of a tie, where the fp32 kernels and the float64 reference may
+    legitimately decide differently: WHICH row wins the max, and whether the winner is barely alive (z > 0) or dead.  Tested
+    here instead of asserted:
+    (i) the kernel's pooled output is within 1e-5 of the float64 max everywhere, and wherever its winner cannot be the float64
+        winner the two candidates differ by <= 1e-5 of the activation scale;
+    (ii) with the float64 reference routed through the kernel's decisions (winner row; alive iff the kernel's output is > 0),
+        every gradient agrees to the usual 2e-4 -- or, where the sum is ill conditioned (the first layer's weight gradient:
+        3 input channels, 32768 cancelling rows, ReLU decisions of the two layers above within rounding of 0), to three times
+        what PLAIN fp32 torch autograd loses on the same routed graph: the excess is a property of fp32, not of the kernels."""
+    B, N, S, K, mlp = 4, 1024, 256, 32, [64, 64, 128]
+    x = make_clouds(B, N, 31 + N)
+    xyz = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 1)).to(dev)
+    _, new_xyz = F._fps_raw(xyz, S, st)
+    idx = F._ball_query_raw([0.3], [K], xyz, new_xyz)[0]
+    ws = seeded_weights([3] + mlp, 40)
+    params = []
+    for (w, b, g, bt) in ws:
+        params += [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b, g, bt)]
+    spec = StackSpec(B, N, S, K, 0, True)
+    out = shared_mlp_max(spec, None, xyz, new_xyz, None, idx, params)
+    rng = np.random.default_rng(8)
+    gout = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+    kernel_argmax = out.grad_fn.saved_tensors[5].clone()                        # [B*S, C] int32: saved by the stack node for its backward
+    assert kernel_argmax.dtype == torch.int32 and tuple(kernel_argmax.shape) == (B * S, mlp[-1])
+    out.backward(gout)
+    o = out.detach().double()
+
+    def reference(dt):
+        """the stack in torch at precision dt, pooled through the KERNEL's decisions (winner row; alive iff its output > 0)"""
+        ps = [p.detach().to(dt).requires_grad_(True) for p in params]
+        act = torch_ref.group(xyz.to(dt), new_xyz.to(dt), None, idx, True).reshape(B * S * K, 3)
+        z = None
+        for l in range(3):
+            w, b, g, bt = ps[4 * l: 4 * l + 4]
+            y = act @ w.t() + b
+            z = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * g + bt
+            act = torch.relu(z)
+        z = z.reshape(B * S, K, mlp[-1])                                        # pre-ReLU values of the pooled layer
+        true_max = torch.relu(z).max(1).values.detach().double()
+        tol = 1e-5 * float(true_max.abs().max())
+        route = kernel_argmax.long().unsqueeze(1)                               # the row the kernel sent the gradient to
+        zr = z.gather(1, route).squeeze(1)
+        assert bool((torch.relu(zr.detach()).double() >= true_max - tol).all()), "a kernel winner is not within 1e-5 of the max"
+        alive = o > 0
+        routed = torch.where(alive, zr, torch.zeros_like(zr))
+        routed.backward(gout.to(dt))
+        return ps, z.detach(), zr.detach().double(), route, alive, true_max, tol
+
+    p64, z, zr, route, alive, true_max, tol = reference(torch.float64)
+    assert_close(out.detach().cpu().numpy(), true_max.cpu().numpy(), REL, "forward, seed 40")
+    assert bool((zr[alive] > -tol).all()) and bool((zr[~alive] < tol).all()), "a pooling decision outside the tie margin"
+    flips = int((alive != (zr > 0)).sum())
+    moved = int((route.squeeze(1) != torch.relu(z).argmax(1)).sum())
+    p32 = reference(torch.float32)[0]
+    bad = []
+    print("seed 40: %d alive/dead decisions and %d winner rows differ from float64 (of %d)" % (flips, moved, alive.numel()))
+    for l in range(3):
+        for j, nm in enumerate(["w", "b", "gamma", "beta"]):
+            if j == 1:
+                continue
+            want = p64[4 * l + j].grad
+            e32 = float((p32[4 * l + j].grad.double() - want).abs().max() / want.abs().max())
+            ours = float((params[4 * l + j].grad.double() - want).abs().max() / want.abs().max())
+            print("   d%s layer %d: kernels %.2e, plain fp32 torch autograd %.2e (of max|grad|)" % (nm, l, ours, e32))
+            bad.append((ours <= max(2e-4, 3.0 * e32), "seed 40 d%s layer %d: %.2e vs plain fp32 autograd %.2e" % (nm, l, ours, e32)))
+    assert all(ok for ok, _ in bad), [m for ok, m in bad if not ok]

@@ -119,3 +119,94 @@ def test_pfn_full_size_config5(dev):
     assert_close(out_p.cpu().detach().numpy(), out[perm].cpu().detach().numpy(), 1e-5, "pillar permutation equivariance")
     ref = R.pillar_feature_net(voxels, nump, coors, [(w, g, b)], (0.16, 0.16, 4), (0, -39.68, -3, 69.12, 39.68, 1), f64=True)
     assert_close(out.detach().cpu().numpy(), ref, 1e-5, "config-5 PFN vs f64 oracle")
+
+
+def _torch_pfn_layer(x, w, g, b, bias, last, use_norm, eps=1e-3, running=None):
+    """float64 torch restatement of PFNLayer.forward (pillars.py:29-41) on [P,T,Cin] rows"""
+    P, T, _ = x.shape
+    y = x.reshape(P * T, -1) @ w.t()
+    if bias is not None:
+        y = y + bias
+    if use_norm:
+        if running is None:
+            mean, var = y.mean(0), y.var(0, unbiased=False)
+        else:
+            mean, var = running
+        y = (y - mean) / torch.sqrt(var + eps) * g + b
+    z = torch.relu(y).reshape(P, T, -1)
+    zmax = z.max(1, keepdim=True).values
+    return zmax if last else torch.cat([z, zmax.expand(P, T, zmax.shape[2])], 2)
+
+
+@pytest.mark.parametrize("use_norm,with_distance", [(True, False), (False, False), (True, True), (False, True)])
+def test_pfn_default_ctor_trains_every_layer(dev, use_norm, with_distance):
+    """The source's DEFAULT PillarFeatureNet(num_filters=(64, 128)) (pillars.py:46): forward and the gradients of BOTH layers
+    (the non-last layer returns its activations concatenated with the tiled max, :39-41) against a float64 torch reference;
+    likewise use_norm=False (:25-27) and with_distance=True (:57-58, :92-94)."""
+    P, T = 150, 40
+    voxels, nump, coors = make_pillars(P=P, T=T, seed=8)
+    vs, pr = (0.16, 0.16, 4), (0, -39.68, -3, 69.12, 39.68, 1)
+    net = PillarFeatureNet(use_norm=use_norm, with_distance=with_distance, voxel_size=vs, pc_range=pr).to(dev)
+    cin = 10 if with_distance else 9
+    rng = np.random.default_rng(3)
+    ws = [_weights(32, cin, 1), _weights(128, 64, 2)]
+    bs = [(rng.normal(size=32) * 0.1).astype(np.float32), (rng.normal(size=128) * 0.1).astype(np.float32)]
+    with torch.no_grad():
+        for lay, (w, g, b), bias in zip(net.pfn_layers, ws, bs):
+            lay.linear.weight.copy_(torch.from_numpy(w))
+            if use_norm:
+                lay.norm.weight.copy_(torch.from_numpy(g)); lay.norm.bias.copy_(torch.from_numpy(b))
+            else:
+                lay.linear.bias.copy_(torch.from_numpy(bias))
+    out = net(torch.from_numpy(voxels).to(dev), torch.from_numpy(nump).to(dev), torch.from_numpy(coors).to(dev))
+    assert tuple(out.shape) == (P, 128)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    rows = torch.from_numpy(R.pillar_decorate(voxels, nump, coors, vs[0], vs[1], vs[0] / 2 + pr[0], vs[1] / 2 + pr[1],
+                                              with_distance=with_distance)).to(dev).double()
+    dec = net.decorate(torch.from_numpy(voxels).to(dev), torch.from_numpy(nump).to(dev), torch.from_numpy(coors).to(dev))
+    assert np.allclose(dec.cpu().numpy(), rows.cpu().numpy(), rtol=0, atol=2e-5)
+    if with_distance:
+        assert_close(dec.cpu().numpy()[..., 9], rows.cpu().numpy()[..., 9], 2e-7, "points_dist channel")
+    p64 = []
+    x = rows
+    for i, ((w, g, b), bias) in enumerate(zip(ws, bs)):
+        t = [torch.from_numpy(a).to(dev).double().requires_grad_(True) for a in (w, g, b, bias)]
+        p64.append(t)
+        x = _torch_pfn_layer(x, t[0], t[1], t[2], None if use_norm else t[3], i == 1, use_norm)
+    ref = x.squeeze()
+    assert_close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, "default-ctor PFN forward")
+    ref.backward(gout.double())
+    for i, lay in enumerate(net.pfn_layers):
+        assert_close(lay.linear.weight.grad.cpu().numpy(), p64[i][0].grad.cpu().numpy(), 2e-4, "dW layer %d" % i)
+        if use_norm:
+            assert_close(lay.norm.weight.grad.cpu().numpy(), p64[i][1].grad.cpu().numpy(), 2e-4, "dgamma layer %d" % i)
+            assert_close(lay.norm.bias.grad.cpu().numpy(), p64[i][2].grad.cpu().numpy(), 2e-4, "dbeta layer %d" % i)
+        else:
+            assert_close(lay.linear.bias.grad.cpu().numpy(), p64[i][3].grad.cpu().numpy(), 2e-4, "db layer %d" % i)
+
+
+@pytest.mark.parametrize("filters", [(64,), (64, 128)])
+def test_pfn_eval_uses_running_statistics(dev, filters):
+    """model.eval(): the norms are registered layers in the source (pillars.py:24), so inference normalises with the running
+    statistics, does not depend on the batch composition and leaves the statistics untouched."""
+    P, T = 120, 30
+    voxels, nump, coors = make_pillars(P=P, T=T, seed=4)
+    vs, pr = (0.16, 0.16, 4), (0, -39.68, -3, 69.12, 39.68, 1)
+    net = PillarFeatureNet(num_filters=filters, voxel_size=vs, pc_range=pr).to(dev)
+    tv, tn, tc = torch.from_numpy(voxels).to(dev), torch.from_numpy(nump).to(dev), torch.from_numpy(coors).to(dev)
+    net.train()
+    for _ in range(3):
+        net(tv, tn, tc)                                    # move the running statistics away from (0, 1)
+    net.eval()
+    before = [(l.norm.running_mean.clone(), l.norm.running_var.clone()) for l in net.pfn_layers]
+    out = net(tv, tn, tc)
+    half = net(tv[: P // 2].contiguous(), tn[: P // 2].contiguous(), tc[: P // 2].contiguous())
+    assert_close(half.detach().cpu().numpy(), out[: P // 2].detach().cpu().numpy(), 1e-6, "eval output independent of the batch")
+    for l, (m, v) in zip(net.pfn_layers, before):
+        assert torch.equal(l.norm.running_mean, m) and torch.equal(l.norm.running_var, v)
+    x = torch.from_numpy(R.pillar_decorate(voxels, nump, coors, vs[0], vs[1], vs[0] / 2 + pr[0], vs[1] / 2 + pr[1])).to(dev).double()
+    for i, l in enumerate(net.pfn_layers):
+        x = _torch_pfn_layer(x, l.linear.weight.double(), l.norm.weight.double(), l.norm.bias.double(), None, i == len(filters) - 1, True,
+                             running=(l.norm.running_mean.double(), l.norm.running_var.double()))
+    assert_close(out.detach().cpu().numpy(), x.squeeze().detach().cpu().numpy(), 1e-5, "eval PFN vs f64 torch")

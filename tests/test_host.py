@@ -90,3 +90,43 @@ def test_checkpoint_exchange_with_reference_layout(tmp_path):
     missing, unexpected = C.import_state(m3, C.load_pdparams(path))
     assert missing and all(k.startswith("sa") for k in missing) and not unexpected
     assert torch.equal(m3.fc2.weight, m.fc2.weight) and torch.equal(m3.bn1.running_var, m.bn1.running_var)
+
+
+def test_checkpoint_pointnet_basic_reference_names_and_restricted_pickle(tmp_path):
+    """A reference PointNet-Basic checkpoint names its conv stack mlp_1.{0,1,3,4} / mlp_2.{0,1,3,4,6,7} (pointnet_base.py:7-25):
+    the importer must fill the backbone, not only fc.*; and a pickle that names anything but numpy arrays is refused."""
+    import pickle
+    import numpy as np
+    import pytest
+    import torch
+    from papc_amd import checkpoint as C
+    from papc_amd.models import PointNet_Basic_Clas
+    torch.manual_seed(1)
+    m = PointNet_Basic_Clas(num_classes=16)
+    with torch.no_grad():
+        for bn in m.bns:
+            bn.running_mean.uniform_(-1, 1); bn.running_var.uniform_(0.5, 2)
+    st = C.export_state(m)
+    for k in ("mlp_1.0.weight", "mlp_1.1._mean", "mlp_1.3.bias", "mlp_1.4._variance", "mlp_2.0.weight", "mlp_2.1.weight", "mlp_2.3.weight",
+              "mlp_2.4.bias", "mlp_2.6.weight", "mlp_2.7._variance", "fc.0.weight", "fc.5.bias"):
+        assert k in st, k
+    assert st["mlp_2.6.weight"].shape[:2] == (1024, 128) and st["fc.0.weight"].shape == (1024, 512)
+    assert not any(k.startswith(("convs", "bns")) for k in st)
+    path = str(tmp_path / "basic.pdparams")
+    with open(path, "wb") as f:
+        pickle.dump(dict(st, **{"StructuredToParameterName@@": {}}), f, protocol=2)
+    m2 = PointNet_Basic_Clas(num_classes=16)
+    missing, unexpected = C.import_state(m2, C.load_pdparams(path), strict=True)
+    assert not missing and not unexpected
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(a, b), k
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("arbitrary code ran",))
+    bad = str(tmp_path / "bad.pdparams")
+    with open(bad, "wb") as f:
+        pickle.dump({"fc.0.weight": Evil()}, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError):
+        C.load_pdparams(bad)

@@ -26,3 +26,32 @@ def assert_close(got, ref, rel=1e-5, what=""):
     err = float(np.max(np.abs(got - ref))) / scale
     assert err <= rel, "%s: max rel err %.3e > %.1e" % (what, err, rel)
     return err
+
+
+def seeded_model_state(model, seed):
+    """Deterministic parameter values for a torch module from a numpy generator (independent of torch's RNG streams and of
+    the torch version): weights ~ N(0, 2/fan_in), biases ~ 0.1 N(0,1), norm weights in +-[0.5, 1.5], norm biases ~ 0.2 N(0,1).
+    Returns {name: float32 ndarray}; copy_into_model() loads it."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, p in model.named_parameters():
+        shape = tuple(p.shape)
+        if p.dim() >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            a = rng.normal(size=shape) * np.sqrt(2.0 / fan_in)
+        elif "bn" in name or "norm" in name:
+            if name.endswith("weight"):
+                a = rng.uniform(0.5, 1.5, size=shape) * rng.choice([1.0, 1.0, 1.0, -1.0], size=shape)
+            else:
+                a = rng.normal(size=shape) * 0.2
+        else:
+            a = rng.normal(size=shape) * 0.1
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def copy_into_model(model, state):
+    import torch
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(state[name]).to(p.device))
