@@ -150,23 +150,29 @@ def main():
         state["plan"], state["ev"] = plan, ev
 
     def step_eager():
-        if not args.overlap:
-            plan = None
-        else:
+        plan = None
+        if args.overlap:
             if state["plan"] is None:
                 launch_plan()
             plan, ev = state["plan"], state["ev"]
             main.wait_event(ev)
-        flat.zero_grad()
         # the next batch's pyramid is enqueued on the side stream beside this batch's MLP kernels (--fork sa2: only once the
         # main stream reaches SA3 -- the group_all layer, the FC head and their backward are small-grid kernels)
+        flat.zero_grad()
         if args.overlap and args.fork == "start":
             launch_plan()
-        logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap and args.fork == "sa2" else None))
+        tap = {} if use_dist else None
+        logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap and args.fork == "sa2" else None), tap=tap)
         loss = softmax_cross_entropy(logits, y)
-        loss.backward()
-        scale = flat.allreduce_grads()
-        opt.step(scale)
+        work = None
+        if use_dist:
+            l2 = tap["l2_points"]
+            (g_l2,) = torch.autograd.grad(loss, [l2])
+            _, work = flat.allreduce_grads(split, None, async_op=True)
+            torch.autograd.backward([l2], [g_l2])
+        else:
+            loss.backward()
+        finish(work)
         return loss
 
     # hipGraph of the launch-bound part of the step: ~125 kernels of 3-400 us each are otherwise issued one by one from
@@ -177,8 +183,21 @@ def main():
     # joined at the end): two graphs alternate, one reading the plan buffers the other one fills.
     use_graph = not args.no_graph
     graph_state = {"g": None, "loss": None, "i": 0}
+    if dist.is_initialized() and use_graph and args.overlap:
+        # RCCL's watchdog thread aborts the process when a capture involves a second stream while it polls the events of the
+        # collectives in flight ("operation not permitted on an event last recorded in a capturing stream", ROCm 7.0 / RCCL 2.26,
+        # seen with a forced 1-rank group): with N > 1 the graphs are captured on the main stream only and the sampling runs
+        # in-line.  Measured on one GPU: 2.70 ms (graph, in-line sampling) vs 2.79 ms (eager, overlapped sampling).
+        args.overlap = False
 
-    def fwd_bwd(plan_in=None, plan_out=None):
+    use_dist = dist.is_initialized()
+    # N > 1: the backward runs in two stages around l2_points (the tensor SA3 consumes).  Stage 1 = FC head + SA3, whose
+    # gradients are the tail [split, end) of the flat bucket (1 388 816 of 1 469 520 floats); their all-reduce is issued as soon
+    # as stage 1 is enqueued and runs over xGMI while stage 2 (SA2 + SA1 backward, ~1.4 ms) computes; only the 80 704-float head
+    # of the bucket is reduced after the last kernel.
+    split = flat.offset_of(model.sa3) if use_dist else 0
+
+    def stage1(plan_in=None, plan_out=None):
         flat.zero_grad()
 
         def fork():
@@ -189,36 +208,56 @@ def main():
                     for d, s_ in zip(dst_lvl, src_lvl):
                         d.copy_(s_)
 
-        if plan_out is not None and args.fork == "start":
+        # (N > 1: the two stages are two graphs and a fork must be joined inside the graph that opened it, so the sampling
+        # branch belongs to stage 2 -- the SA2 + SA1 backward, 1.4 ms -- there)
+        if plan_out is not None and args.fork == "start" and not use_dist:
             fork()
-        logits = model(x, (s1, s2), plan=plan_in, after_sa2=(fork if plan_out is not None and args.fork == "sa2" else None))
+        tap = {} if use_dist else None
+        logits = model(x, (s1, s2), plan=plan_in, tap=tap,
+                       after_sa2=(fork if plan_out is not None and args.fork == "sa2" and not use_dist else None))
         loss = softmax_cross_entropy(logits, y)
-        loss.backward()
-        if plan_out is not None:
-            main.wait_stream(side)                 # join: the branch is part of this step
-        return loss
+        if not use_dist:
+            loss.backward()
+            if plan_out is not None:
+                main.wait_stream(side)             # join: the branch is part of this step
+            return loss, None, None, None
+        l2 = tap["l2_points"]
+        (g_l2,) = torch.autograd.grad(loss, [l2])  # the kernels write the head's and SA3's gradients straight into the flat views
+        return loss, l2, g_l2, (fork if plan_out is not None else None)
+
+    def stage2(l2, g_l2, fork):
+        if fork is not None:
+            fork()
+        torch.autograd.backward([l2], [g_l2])      # SA2 + SA1
+        if fork is not None:
+            main.wait_stream(side)
+
 
     def capture():
         """Returns True when the graph(s) were captured; on any capture failure the bench falls back to eager launches."""
         torch.cuda.synchronize()
         try:
+            n_sets = 2 if args.overlap else 1
+            bufs = None
             if args.overlap:
                 p0 = model.plan_sampling(x, (s1, s2))
                 bufs = [tuple(tuple(t.clone() for t in lvl) for lvl in p0) for _ in range(2)]
                 torch.cuda.synchronize()
-                gs, losses = [], []
-                for i in range(2):
-                    g = torch.cuda.CUDAGraph()
-                    # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
-                    with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                        losses.append(fwd_bwd(bufs[i], bufs[1 - i]))
-                    gs.append(g)
-                graph_state["g"], graph_state["loss"] = gs, losses
-            else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                    loss = fwd_bwd()
-                graph_state["g"], graph_state["loss"] = [g], [loss]
+            gs, losses = [], []
+            for i in range(n_sets):
+                pin, pout = (bufs[i], bufs[1 - i]) if args.overlap else (None, None)
+                g1 = torch.cuda.CUDAGraph()
+                # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+                with torch.cuda.graph(g1, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                    loss, l2, g_l2, fork = stage1(pin, pout)
+                g2 = None
+                if use_dist:   # stage 2 is a second graph (same memory pool): the collective of the tail bucket goes between them
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, pool=g1.pool(), stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                        stage2(l2, g_l2, fork)
+                gs.append((g1, g2))
+                losses.append(loss)
+            graph_state["g"], graph_state["loss"] = gs, losses
         except Exception as e:   # noqa: BLE001
             print("[bench] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), file=sys.stderr)
             graph_state["g"], graph_state["loss"] = None, None
@@ -226,16 +265,30 @@ def main():
             return False
         return True
 
+    def finish(work):
+        """reduce what is left of the bucket, then the optimiser"""
+        if use_dist:
+            if work is not None:
+                work.wait()                        # the main stream waits for the tail bucket's collective (no host block)
+            scale = flat.allreduce_grads(0, split)
+        else:
+            scale = flat.allreduce_grads()
+        opt.step(scale)
+
     def step():
         if graph_state["g"] is None:
             return step_eager()
         i = graph_state["i"] % len(graph_state["g"])
         graph_state["i"] += 1
-        graph_state["g"][i].replay()
-        opt.step(flat.allreduce_grads())
+        g1, g2 = graph_state["g"][i]
+        g1.replay()
+        work = None
+        if g2 is not None:
+            _, work = flat.allreduce_grads(split, None, async_op=True)
+            g2.replay()
+        finish(work)
         return graph_state["loss"][i]
 
-    use_dist = dist.is_initialized()
 
     def sync():
         torch.cuda.synchronize()
@@ -357,7 +410,10 @@ def main():
                                     "batch i's step, fork at %s; every timed step computes one full pyramid" % args.fork) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
-                       "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager all-reduce + Adam" if use_graph else "eager"},
+                       "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager all-reduce + Adam" if use_graph else "eager",
+                       "collectives": ("two-stage backward: all-reduce of the [SA3 | FC head] tail of the flat bucket (%d floats) in flight "
+                                       "during the SA2 + SA1 backward, then the %d-float head of the bucket; RCCL over xGMI, per-GPU BatchNorm "
+                                       "statistics" % (flat.numel - split, split)) if use_dist else "none (one process)"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -26,7 +26,12 @@ class HeadSpec:
 
     def state(self, device):
         if self.rng_state is None or self.rng_state.device != device:
-            self.rng_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+            # every data-parallel rank seeds torch identically (same initial weights): mix the rank into the dropout stream so
+            # the ranks draw different masks
+            seed = torch.initial_seed()
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            self.rng_state = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
         return self.rng_state
 
 

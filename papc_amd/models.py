@@ -74,11 +74,13 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
             p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1])
         return p1, p2
 
-    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None):
+    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None):
         """inputs [B,3,N]; ``start_idx`` = optional (s1 [B], s2 [B]) FPS start indices (the source draws them at random);
         ``plan`` = optional result of :meth:`plan_sampling` for these inputs; ``after_sa2`` = optional callable invoked
         once SA2's kernels are enqueued -- from there to the end of SA3's backward only small-grid kernels run (group_all
-        layer, FC head), the window in which a side stream can sample the next batch on otherwise idle CUs."""
+        layer, FC head), the window in which a side stream can sample the next batch on otherwise idle CUs;
+        ``tap`` = optional dict that receives ``l2_points``, the tensor SA3 consumes: a data-parallel loop runs the backward in
+        two stages around it (head + SA3 first, their gradient bucket all-reducing while SA2 / SA1 follow; see bench.py)."""
         xyz = torch.as_tensor(inputs)
         B = xyz.shape[0]
         if self.normal_channel:
@@ -91,6 +93,8 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1], sampled=pl[1])
         if after_sa2 is not None:
             after_sa2()
+        if tap is not None:
+            tap["l2_points"] = l2_points
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
         x = l3_points.reshape(B, 1024)
         return self._head(x)

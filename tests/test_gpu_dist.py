@@ -1,0 +1,26 @@
+"""The N > 1 path of bench.py on the one GPU there is: the driver's exact launch line with a forced 1-rank RCCL group
+(PAPC_FORCE_DIST=1): init_from_env, broadcast, the two-stage backward with the tail bucket's all-reduce in flight, the
+all-reduce of the head of the bucket, barrier and the rank-0 JSON line all go through RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [[], ["--no-graph"]])
+def test_bench_forced_one_rank_rccl(dev, extra):
+    env = dict(os.environ, PAPC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
+    assert "two-stage" in out["config"]["collectives"]
