@@ -136,6 +136,7 @@ def main():
     # MFMA kernels own the rest of the chip.  Every step still computes exactly one pyramid (for the next batch).
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream()
+    ONE = torch.ones((), device=dev)            # d(loss)/d(loss), allocated once (loss.backward() would fill a fresh one every step)
     state = {"plan": None, "ev": None}
 
     def launch_plan():
@@ -167,11 +168,11 @@ def main():
         work = None
         if use_dist:
             l2 = tap["l2_points"]
-            (g_l2,) = torch.autograd.grad(loss, [l2])
+            (g_l2,) = torch.autograd.grad(loss, [l2], [ONE])
             _, work = flat.allreduce_grads(split, None, async_op=True)
             torch.autograd.backward([l2], [g_l2])
         else:
-            loss.backward()
+            loss.backward(ONE)
         finish(work)
         return loss
 
@@ -217,12 +218,12 @@ def main():
                        after_sa2=(fork if plan_out is not None and args.fork == "sa2" and not use_dist else None))
         loss = softmax_cross_entropy(logits, y)
         if not use_dist:
-            loss.backward()
+            loss.backward(ONE)
             if plan_out is not None:
                 main.wait_stream(side)             # join: the branch is part of this step
             return loss, None, None, None
         l2 = tap["l2_points"]
-        (g_l2,) = torch.autograd.grad(loss, [l2])  # the kernels write the head's and SA3's gradients straight into the flat views
+        (g_l2,) = torch.autograd.grad(loss, [l2], [ONE])  # the kernels write the head's and SA3's gradients straight into the flat views
         return loss, l2, g_l2, (fork if plan_out is not None else None)
 
     def stage2(l2, g_l2, fork):

@@ -394,6 +394,21 @@ int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, con
  * arrays are HOST arrays (read during the call); the matrices are device memory.  Used for the W^T operands of a stack's dX GEMMs. */
 int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream);
 
+/* Small data-movement entry points, so that a training step launches nothing but this library's kernels (the
+ * reference's layers interleave paddle.zeros / concat / slicing with the math, pointnet2_basic_layers.py:151,170-173):
+ *   papc_fill_f32                    p[0..n) = value
+ *   papc_copy2d_f32                  dst[r,c] = src[r,c] (transpose: dst[c,r]) for a [rows,cols] block, arbitrary row strides
+ *                                    (the feature / coordinate column blocks of a grouped layer's weight, and their transposes)
+ *   papc_reduce_partials_strided_f32 out[r*out_ld + c] (+)= sum_t partial[t*ld + r*cols + c]: partial weight gradients summed
+ *                                    straight into a column block of the [Cout, Cin] gradient (no concat, no add)
+ *   papc_scale_by_f32                out[i] = x[i] * scalar[0], scalar on the device (the upstream gradient of a scalar loss) */
+int papc_fill_f32(float *p, int64_t n, float value, papc_stream_t stream);
+int papc_copy2d_f32(const float *src, int64_t src_ld, float *dst, int64_t dst_ld, int rows, int cols, int transpose,
+                    papc_stream_t stream);
+int papc_reduce_partials_strided_f32(const float *partial, int n_chunks, int64_t ld, int rows, int cols, float *out,
+                                     int64_t out_ld, int accumulate, papc_stream_t stream);
+int papc_scale_by_f32(const float *x, const float *scalar, int64_t n, float *out, papc_stream_t stream);
+
 /* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params.  The betas are doubles:
  * 1 - beta and the bias corrections are formed in double on the host (as float, 1 - 0.999f is already 1.3e-5 off). */
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,

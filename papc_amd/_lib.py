@@ -98,6 +98,10 @@ SIGNATURES = {
     "papc_transpose_batch_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_rotate_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_rotate_iou_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "papc_fill_f32": (c_i, [c_p, c_l, c_f, c_p]),
+    "papc_copy2d_f32": (c_i, [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p]),
+    "papc_reduce_partials_strided_f32": (c_i, [c_p, c_i, c_l, c_i, c_i, c_p, c_l, c_i, c_p]),
+    "papc_scale_by_f32": (c_i, [c_p, c_p, c_l, c_p, c_p]),
     "papc_adam_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, ctypes.c_double, ctypes.c_double, c_f, c_f, c_i, c_f, c_p]),
     "papc_knob_set": (c_i, [ctypes.c_char_p, c_i]),
     "papc_knob_get": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
@@ -144,3 +148,35 @@ def stream_ptr():
 
 def ptr(t):
     return 0 if t is None else t.data_ptr()
+
+
+def zeros(shape, device):
+    """float32 zeros written by this library's fill kernel (torch.zeros would launch a library kernel)"""
+    import torch
+    t = torch.empty(shape, device=device, dtype=torch.float32)
+    if t.numel():
+        check(load().papc_fill_f32(t.data_ptr(), t.numel(), 0.0, stream_ptr()), "papc_fill_f32")
+    return t
+
+
+_CONSTS = {}
+
+
+def const_zeros(shape, device):
+    """cached read-only float32 zeros of a small fixed shape (e.g. the [B,1,3] centroid of sample_and_group_all)"""
+    import torch
+    key = ("z", tuple(shape), str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.zeros(tuple(shape), device=device, dtype=torch.float32)
+    return t
+
+
+def const_vec(value, n, device):
+    """cached read-only float32 vector of n copies of value (BN 'identity' constants and the like): filled once per device"""
+    import torch
+    key = (float(value), int(n), str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full((n,), float(value), device=device, dtype=torch.float32)
+    return t

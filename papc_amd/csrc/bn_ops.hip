@@ -356,6 +356,54 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     }
 }
 
+__global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ p, int64_t n, float v)
+{
+    const int64_t n4 = n >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(p);
+    const float4 v4 = make_float4(v, v, v, v);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) p4[i] = v4;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = v;
+}
+
+// dst[r, c] = src[r, c] (or dst[c, r] with transpose) for a [rows, cols] block of matrices with arbitrary row strides
+__global__ __launch_bounds__(256) void copy2d_kernel(const float *__restrict__ src, int64_t src_ld, float *__restrict__ dst, int64_t dst_ld,
+                                                     int rows, int cols, int transpose)
+{
+    const int64_t total = (int64_t)rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        // consecutive threads write consecutive destination elements (the small operand being re-laid-out is read through L2)
+        int r, c;
+        if (transpose) { c = (int)(e / rows); r = (int)(e - (int64_t)c * rows); dst[(int64_t)c * dst_ld + r] = src[(int64_t)r * src_ld + c]; }
+        else { r = (int)(e / cols); c = (int)(e - (int64_t)r * cols); dst[(int64_t)r * dst_ld + c] = src[(int64_t)r * src_ld + c]; }
+    }
+}
+
+// out[r * out_ld + c] (+)= sum_t part[t * ld + r * cols + c]   (chunks summed in order: deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float *__restrict__ part, int n_chunks, int64_t ld, int rows, int cols,
+                                                                      float *__restrict__ out, int64_t out_ld, int accumulate)
+{
+    const int64_t n = (int64_t)rows * cols;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int t0 = 0; t0 < n_chunks; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(t0 + j < n_chunks ? t0 + j : t0) * ld + e];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (t0 + j < n_chunks) s += v[j];
+    }
+    const int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+    float *o = out + (int64_t)r * out_ld + c;
+    *o = accumulate ? *o + s : s;
+}
+
+__global__ __launch_bounds__(256) void scale_by_kernel(const float *__restrict__ x, const float *__restrict__ scalar, int64_t n, float *__restrict__ out)
+{
+    const float g = scalar[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] * g;
+}
+
 static inline unsigned ew_grid(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 256 * 16)); }
 
 // ---------------------------------------------------------------------------------------------------
@@ -584,6 +632,48 @@ int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, floa
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, n, out, n, (float *)nullptr, accumulate);
     return check_launch("papc_reduce_partials_f32");
+}
+
+int papc_fill_f32(float *p, int64_t n, float value, papc_stream_t stream)
+{
+    PAPC_REQUIRE(p && n >= 1, PAPC_E_INVALID, "papc_fill_f32: null pointer or n < 1");
+    PAPC_REQUIRE(aligned16(p), PAPC_E_INVALID, "papc_fill_f32: p must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, st, p, n, value);
+    return check_launch("papc_fill_f32");
+}
+
+int papc_copy2d_f32(const float *src, int64_t src_ld, float *dst, int64_t dst_ld, int rows, int cols, int transpose, papc_stream_t stream)
+{
+    PAPC_REQUIRE(src && dst && rows >= 1 && cols >= 1, PAPC_E_INVALID, "papc_copy2d_f32: null pointer or empty block");
+    PAPC_REQUIRE(src_ld >= cols && dst_ld >= (transpose ? rows : cols), PAPC_E_INVALID, "papc_copy2d_f32: row stride shorter than a row");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid((int64_t)rows * cols)), dim3(256), 0, st, src, src_ld, dst, dst_ld, rows, cols, transpose);
+    return check_launch("papc_copy2d_f32");
+}
+
+int papc_reduce_partials_strided_f32(const float *partial, int n_chunks, int64_t ld, int rows, int cols, float *out, int64_t out_ld,
+                                     int accumulate, papc_stream_t stream)
+{
+    PAPC_REQUIRE(partial && out, PAPC_E_INVALID, "papc_reduce_partials_strided_f32: null pointer");
+    PAPC_REQUIRE(n_chunks >= 1 && rows >= 1 && cols >= 1 && ld >= (int64_t)rows * cols && out_ld >= cols, PAPC_E_INVALID,
+                 "papc_reduce_partials_strided_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0, st, partial, n_chunks, ld,
+                       rows, cols, out, out_ld, accumulate);
+    return check_launch("papc_reduce_partials_strided_f32");
+}
+
+int papc_scale_by_f32(const float *x, const float *scalar, int64_t n, float *out, papc_stream_t stream)
+{
+    PAPC_REQUIRE(x && scalar && out && n >= 1, PAPC_E_INVALID, "papc_scale_by_f32: null pointer or n < 1");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(scale_by_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, scalar, n, out);
+    return check_launch("papc_scale_by_f32");
 }
 
 int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scale, const float *shift, const float *mean,

@@ -66,7 +66,11 @@ class FlatParams:
         raise ValueError("module is not part of this FlatParams")
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            from . import _lib
+            _lib.check(_lib.load().papc_fill_f32(self.grad.data_ptr(), self.grad.numel(), 0.0, _lib.stream_ptr()), "papc_fill_f32")
+        else:
+            self.grad.zero_()
         for p in self.params:   # autograd accumulates in place into the existing views
             if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr():
                 raise RuntimeError("a parameter lost its flat .grad view (someone called zero_grad(set_to_none=True))")

@@ -138,7 +138,10 @@ class _SoftmaxXent(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
-        return dz * g, None
+        g = g.contiguous().float()                     # upstream gradient of the scalar loss, on the device
+        out = torch.empty_like(dz)
+        check(_lib.load().papc_scale_by_f32(ptr(dz), ptr(g), dz.numel(), ptr(out), stream_ptr()), "papc_scale_by_f32")
+        return out, None
 
 
 def softmax_cross_entropy(logits, labels):

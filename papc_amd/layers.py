@@ -15,6 +15,7 @@ Deliberate, flagged deviations from the source:
 import torch
 import torch.nn as nn
 
+from . import _lib
 from . import functional as F_
 from .mlp import StackSpec, shared_mlp_max
 
@@ -94,7 +95,7 @@ class PointNetSetAbstraction(nn.Module):
         D = 0 if feats is None else feats.shape[2]
         if self.group_all:                                                      # sample_and_group_all :160-176
             S, K = 1, N
-            new_xyz = torch.zeros(B, 1, 3, device=xyz.device, dtype=torch.float32)
+            new_xyz = _lib.const_zeros((B, 1, 3), xyz.device)                   # :170 (read-only: cached per device and batch size)
             idx = None
         else:                                                                   # sample_and_group :129-157
             S, K = self.npoint, self.nsample

@@ -126,9 +126,15 @@ class SharedMLPMax(torch.autograd.Function):
                 check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(x_rows), cin, None, None, None, ptr(w2), ptr(b), M, cin, cout,
                                             ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
             elif l == 0 and lin0:
-                # W_f feats_j depends on the source point only: one [B*N, D] x [D, cout] product, then a streaming gather-add
-                wf = (w2[:, 3:] if spec.xyz_first else w2[:, :spec.D]).contiguous()
-                P = torch.mm(feats.reshape(-1, spec.D), wf.t())
+                # W_f feats_j depends on the source point only: one [B*N, D] x [D, cout] product (the row GEMM kernel, plain input, no
+                # bias / statistics) on the feature block of the weight, then a streaming gather-add
+                fcol0 = 3 if spec.xyz_first else 0
+                wf = torch.empty(cout, spec.D, device=dev, dtype=torch.float32)
+                check(lib.papc_copy2d_f32(w2.data_ptr() + 4 * fcol0, cin, ptr(wf), spec.D, cout, spec.D, 0, st), "papc_copy2d_f32")
+                BN_ = spec.B * spec.N
+                P = torch.empty(BN_, cout, device=dev, dtype=torch.float32)
+                check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(feats), spec.D, None, None, None, ptr(wf), None, BN_, spec.D, cout, ptr(P), None,
+                                            None, st), "papc_mlp_gemm_f32")
                 parts_l = lib.papc_lingather_parts(M)
                 stats = torch.empty(parts_l, 2, cout, device=dev, dtype=torch.float32)
                 check(lib.papc_lingather_fwd_f32(ptr(P), ctypes.byref(grp), spec.B, ptr(w2), cin, 0 if spec.xyz_first else spec.D,
@@ -261,16 +267,21 @@ class SharedMLPMax(torch.autograd.Function):
                 BN_ = spec.B * spec.N
                 parts_l = lib.papc_lingather_parts(M)
                 dwx_part = torch.empty(parts_l, cout * 3, device=dev, dtype=torch.float32)
-                Gs = torch.zeros(BN_, cout, device=dev, dtype=torch.float32)
+                Gs = _lib.zeros((BN_, cout), dev)
                 check(lib.papc_lingather_bwd_f32(ctypes.byref(dy), ctypes.byref(grp), spec.B, cout, ptr(Gs), ptr(dwx_part), st),
                       "papc_lingather_bwd_f32")
-                dwx = torch.empty(cout, 3, device=dev, dtype=torch.float32)
-                check(lib.papc_reduce_partials_f32(ptr(dwx_part), parts_l, cout * 3, ptr(dwx), 0, st), "papc_reduce_partials_f32")
-                # dW_f = G^T feats on the library's own dW kernel (K = B*N rows: rocBLAS picks an unsplit 32x32 kernel, 108 us):
-                # G plays dY with BN constants that make dY = dz (scale 1, shift huge -> ReLU mask always on, c1 = c2 = 0)
-                one = torch.ones(cout, device=dev, dtype=torch.float32)
-                zero = torch.zeros(cout, device=dev, dtype=torch.float32)
-                big = torch.full((cout,), 1e30, device=dev, dtype=torch.float32)
+                # the gradient lands in ONE [cout, cin] tensor -- the parameter's .grad view (accumulate) or a fresh one: the
+                # coordinate block and the feature block are summed straight into their column ranges (no concat, no add)
+                fcol0, xcol0 = (3, 0) if spec.xyz_first else (0, spec.D)
+                if inplace:
+                    dw, acc = tgt[0].view(cout, cin), 1
+                else:
+                    dw, acc = torch.empty(cout, cin, device=dev, dtype=torch.float32), 0
+                check(lib.papc_reduce_partials_strided_f32(ptr(dwx_part), parts_l, cout * 3, cout, 3, dw.data_ptr() + 4 * xcol0, cin, acc, st),
+                      "papc_reduce_partials_strided_f32")
+                # dW_f = G^T feats on the library's own dW kernel: G plays dY with BN constants that make dY = dz (scale 1, shift huge
+                # -> ReLU mask always on, c1 = c2 = 0)
+                one, zero, big = _lib.const_vec(1.0, cout, dev), _lib.const_vec(0.0, cout, dev), _lib.const_vec(1e30, cout, dev)
                 dyg = BwdDy()
                 dyg.dz_mode, dyg.dz, dyg.gout, dyg.argmax, dyg.K = DZ_DENSE, Gs.data_ptr(), None, None, 1
                 dyg.y = Gs.data_ptr()
@@ -282,21 +293,20 @@ class SharedMLPMax(torch.autograd.Function):
                 part_g = torch.empty(n_chunks_g, pld_g, device=dev, dtype=torch.float32)
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dyg), A_PLAIN, ptr(feats), spec.D, None, None, None, BN_, spec.D, cout, rpc_g,
                                               part_g.data_ptr(), part_g.data_ptr() + 4 * cout * spec.D, pld_g, st), "papc_mlp_bwd_dw_f32")
-                dwf = torch.empty(cout, spec.D, device=dev, dtype=torch.float32)
-                dbf = torch.empty(cout, device=dev, dtype=torch.float32)
-                check(lib.papc_reduce_partials2_f32(ptr(part_g), n_chunks_g, pld_g, cout * spec.D, ptr(dwf), cout, ptr(dbf), 0, st),
-                      "papc_reduce_partials2_f32")
-                dw = torch.cat([dwx, dwf], 1) if spec.xyz_first else torch.cat([dwf, dwx], 1)
-                if inplace:
-                    tgt[0].add_(dw.reshape(tgt[0].shape))      # (db: a bias feeding a train-mode BN has gradient exactly 0)
-                else:
+                check(lib.papc_reduce_partials_strided_f32(ptr(part_g), n_chunks_g, pld_g, cout, spec.D, dw.data_ptr() + 4 * fcol0, cin, acc,
+                                                           st), "papc_reduce_partials_strided_f32")
+                if not inplace:           # (db: a bias feeding a train-mode BN has gradient exactly 0)
                     grads[0] = dw.reshape(w.shape)
-                    grads[1] = torch.zeros(cout, device=dev, dtype=torch.float32)
+                    grads[1] = _lib.zeros((cout,), dev)
                     grads[2] = dgb[0]
                     grads[3] = dgb[1]
                 if ctx.feats_needs_grad:
-                    wf = (w.reshape(cout, cin)[:, 3:] if spec.xyz_first else w.reshape(cout, cin)[:, :spec.D]).contiguous()
-                    grad_feats = torch.mm(Gs, wf).reshape(spec.B, spec.N, spec.D)
+                    # grad_feats = G W_f: the same row GEMM with the transposed feature block as its weight
+                    wft = torch.empty(spec.D, cout, device=dev, dtype=torch.float32)
+                    check(lib.papc_copy2d_f32(w.data_ptr() + 4 * fcol0, cin, ptr(wft), cout, cout, spec.D, 1, st), "papc_copy2d_f32")
+                    grad_feats = torch.empty(spec.B, spec.N, spec.D, device=dev, dtype=torch.float32)
+                    check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(Gs), cout, None, None, None, ptr(wft), None, BN_, cout, spec.D, ptr(grad_feats),
+                                                None, None, st), "papc_mlp_gemm_f32")
                 break
             # ---- dW, db
             rpc = _dw_rows_per_chunk(M, cout, cin)
@@ -367,7 +377,7 @@ class SharedMLPMax(torch.autograd.Function):
                 check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, ptr(grad_x), None, None, st), "papc_mlp_bwd_dx_f32")
             elif (not plain) and ctx.feats_needs_grad:
                 wt = wts[l]
-                grad_feats = torch.zeros(spec.B, spec.N, spec.D, device=dev, dtype=torch.float32)
+                grad_feats = _lib.zeros((spec.B, spec.N, spec.D), dev)
                 sc = ScatterDst()
                 sc.grad_feats, sc.idx = grad_feats.data_ptr(), ptr(idx)
                 sc.N, sc.S, sc.K, sc.D = spec.N, spec.S, spec.K, spec.D

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from .layers import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNetSetAbstractionMsg, _bn_buffers,
                      _stack_params)
+from . import _lib
 from . import head as _head
 from .mlp import StackSpec, shared_mlp_max
 
@@ -155,7 +156,7 @@ class PointNet_Basic_Clas(nn.Module):
         x = torch.as_tensor(inputs).float()                       # [B,3,N]
         B, _, N = x.shape
         xyz = x.transpose(1, 2)                                   # rows (b,n) read straight from the planar input
-        zero = torch.zeros(B, 1, 3, device=x.device, dtype=torch.float32)
+        zero = _lib.const_zeros((B, 1, 3), x.device)
         # the norms are registered layers in the source (nn.Sequential mlp_1 / mlp_2): model.eval() normalises with the running
         # statistics and leaves them untouched
         spec = StackSpec(B, N, 1, N, 0, xyz_first=True, eps=self.bns[0].eps, momentum=0.9, eval_bn=not self.training)
