@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (BASELINE config: 32)")
     ap.add_argument("--npoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=["ssg", "msg_seg", "pfn", "basic"], default="ssg",
+                    help="ssg (default) = the headline BASELINE configs[1]; the other single-GPU configs emit the same JSON (bench_configs.py)")
     ap.add_argument("--overlap", dest="overlap", action="store_true", default=True,
                     help="(default) software-pipelined sampling: batch i+1's pyramid (FPS + ball query: weight-independent, a serial "
                     "chain on 32 of the 256 CUs) runs on a side stream / graph branch beside batch i's MLP kernels")
@@ -100,6 +102,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
     args = ap.parse_args()
+    if args.config != "ssg":
+        import bench_configs
+        return bench_configs.run(args)
 
     from papc_amd import _lib
     from papc_amd.distributed import FlatAdam, FlatParams, init_from_env

@@ -1,0 +1,188 @@
+"""The other single-GPU BASELINE configs behind ``bench.py --config {msg_seg,pfn,basic}`` (BASELINE.json configs[2], [4], [0]).
+
+Same JSON contract as the headline line (bench.py): W untimed warm-up steps, K timed steps between synchronisations, value =
+units per second, ``roofline`` for the dominant kernel family from library-side HIP event pairs over the timed region,
+``cpu_baseline`` = the torch-CPU port of the same config (oracle/torch_cpu_reference.py) on this box's host cores.
+
+  msg_seg  PointNet2_MSG_Seg whole model (3-radius SA1, 2-radius SA2, group-all SA3, three feature-propagation levels, per-point
+           head), B=16, N=2048: fwd + CrossEntropy + bwd + Adam       /root/reference/PAPC/models/segment/pointnet2/pointnet2.py:53-98
+  pfn      PillarFeatureNet, one 12000 x 100 KITTI-shaped frame: fwd + bwd + Adam   .../pointpillars/models/bones/pillars.py:43-108
+  basic    PointNet_Basic_Clas, B=8, N=1024: fwd + CrossEntropy + bwd + Adam         .../classify/pointnet_base/pointnet_base.py:4-47
+"""
+import ctypes
+import json
+import os
+import time
+
+import torch
+
+PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_BF16_TFLOPS = 2500.0
+K_NAMES = ["fps", "ball_query", "group", "mlp_gemm_fwd", "bn_relu_max", "bwd_bn_reduce", "bwd_dx_gemm", "bwd_dw_gemm", "pfn", "misc"]
+
+
+def _stack_work(M, chans, gather_D=None, pool=True):
+    """algorithmic (flop, bytes) of one conv/BN/ReLU stack per family: fwd, dX, dW (same accounting as bench.algorithmic_work)"""
+    f_fwd = f_dx = b_fwd = b_dx = b_dw = 0.0
+    L = len(chans) - 1
+    for l in range(L):
+        cin, cout = chans[l], chans[l + 1]
+        dense = (l < L - 1) or not pool
+        f_fwd += 2.0 * M * cin * cout
+        b_fwd += 4.0 * M * (cin + cout)
+        dy = 4.0 * M * cout * (2 if dense else 1)
+        b_dw += dy + 4.0 * M * cin
+        if l > 0:
+            f_dx += 2.0 * M * cin * cout
+            b_dx += dy + 4.0 * M * cin * 2
+        elif gather_D:
+            f_dx += 2.0 * M * gather_D * cout
+            b_dx += dy + 4.0 * M * gather_D
+        elif gather_D is None:       # plain input rows that need a gradient (feature propagation / per-point head)
+            f_dx += 2.0 * M * cin * cout
+            b_dx += dy + 4.0 * M * cin
+    return {3: (f_fwd, b_fwd), 6: (f_dx, b_dx), 7: (f_fwd, b_dw)}
+
+
+def _sum_work(stacks):
+    tot = {}
+    for w in stacks:
+        for k, (f, b) in w.items():
+            F, Bt = tot.get(k, (0.0, 0.0))
+            tot[k] = (F + f, Bt + b)
+    return tot
+
+
+def _prof_read(lib):
+    out = {}
+    for k in range(len(K_NAMES)):
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        lib.papc_prof_read(k, ctypes.byref(ms), ctypes.byref(n))
+        out[k] = (ms.value, n.value)
+    return out
+
+
+def run(args):
+    from papc_amd import _lib
+    from papc_amd.distributed import FlatAdam, FlatParams
+    from papc_amd.synthetic import make_clouds, make_pillars, make_start_idx
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    assert args.gpus == 1, "--config %s is a single-GPU configuration" % args.config
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.cuda.set_stream(torch.cuda.Stream())
+    lib = _lib.load()
+    torch.manual_seed(1234)
+    one = torch.ones((), device=dev)
+    if args.config == "msg_seg":
+        from papc_amd.models import PointNet2_MSG_Seg
+        B, N = 16, 2048
+        model = PointNet2_MSG_Seg().to(dev).train()
+        x = torch.from_numpy(make_clouds(B, N, 3)).to(dev)
+        cls = (torch.arange(B).reshape(B, 1) % 16).numpy()
+        tgt = torch.randint(0, 50, (B * N,), device=dev)
+        st = (torch.from_numpy(make_start_idx(B, N, 3)).to(dev), torch.from_numpy(make_start_idx(B, 512, 4)).to(dev))
+        from papc_amd.head import softmax_cross_entropy
+        loss_fn = lambda: softmax_cross_entropy(model((x, cls), st).reshape(B * N, 50), tgt)
+        units, unit, metric = B, "point-clouds/s", "point-clouds/sec (fwd+bwd) PointNet++MSG segment B=16 N=2048"
+        workload = "PointNet++MSG part-segmentation whole model fwd+bwd+Adam, B=16, N=2048, 3-radius grouping (BASELINE configs[2])"
+        S1, S2 = B * 512, B * 128
+        work = _sum_work([_stack_work(S1 * 32, [6, 32, 32, 64], 3), _stack_work(S1 * 64, [6, 64, 64, 128], 3), _stack_work(S1 * 128, [6, 64, 96, 128], 3),
+                          _stack_work(S2 * 64, [323, 128, 128, 256], 320), _stack_work(S2 * 128, [323, 128, 196, 256], 320),
+                          _stack_work(B * 128, [515, 256, 512, 1024], 512),
+                          _stack_work(B * 128, [1536, 256, 256], None, False), _stack_work(B * 512, [576, 256, 128], None, False),
+                          _stack_work(B * N, [150, 128, 128], None, False), _stack_work(B * N, [128, 128], None, False)])
+    elif args.config == "basic":
+        from papc_amd.models import PointNet_Basic_Clas
+        B, N = 8, 1024
+        model = PointNet_Basic_Clas(num_classes=16).to(dev).train()
+        x = torch.from_numpy(make_clouds(B, N, 6)).to(dev)
+        tgt = torch.randint(0, 16, (B,), device=dev)
+        from papc_amd.head import softmax_cross_entropy
+        loss_fn = lambda: softmax_cross_entropy(model(x), tgt)
+        units, unit, metric = B, "point-clouds/s", "point-clouds/sec (fwd+bwd) PointNet-Basic B=8 N=1024"
+        workload = "PointNet-Basic classify fwd+bwd+Adam, B=8, N=1024 (BASELINE configs[0]: the reference's CPU-runnable plumbing case)"
+        work = _sum_work([_stack_work(B * N, [3, 64, 64, 64, 128, 1024], 0)])
+    else:
+        from papc_amd.pillars import PillarFeatureNet
+        v, n, c = make_pillars()
+        model = PillarFeatureNet(num_filters=(64,), voxel_size=(0.16, 0.16, 4), pc_range=(0, -39.68, -3, 69.12, 39.68, 1)).to(dev).train()
+        tv, tn, tc = torch.from_numpy(v).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev)
+        loss_fn = lambda: model(tv, tn, tc).square().mean()
+        units, unit, metric = 1, "frames/s", "pillar frames/sec (fwd+bwd) PillarFeatureNet 12000 pillars x 100 points"
+        workload = "PointPillars PillarFeatureNet fwd+bwd+Adam, 12000 pillars x 100 points, one KITTI-shaped frame (BASELINE configs[4])"
+        P, T = 12000, 100
+        feat = P * T * 4 * 4.0
+        # forward = statistics pass + apply pass (train-mode BN needs the batch statistics first; both recompute the 9 -> 64 layer
+        # instead of storing [P,T,64]) + the [P,64] output; backward = BN-backward reduce pass + dW pass over the same features
+        work = {8: (2.0 * P * T * 9 * 64 * 4, 4 * feat + P * 64 * 4.0 * 3)}
+    flat = FlatParams(model)
+    opt = FlatAdam(flat, lr=1e-3, weight_decay=1e-3)
+
+    def step():
+        flat.zero_grad()
+        loss = loss_fn()
+        loss.backward(one)
+        opt.step(flat.allreduce_grads())
+        return loss
+
+    for _ in range(max(1, args.warmup)):
+        loss = step()
+    torch.cuda.synchronize()
+    lib.papc_prof_enable(0x3FF)
+    lib.papc_prof_reset()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    fam = _prof_read(lib)
+    lib.papc_prof_enable(0)
+    cand = [k for k in fam if k in work and fam[k][0] > 0]
+    dominant = max(cand, key=lambda k: fam[k][0])
+    if args.profile_all:
+        import sys
+        for k, (ms, n) in sorted(fam.items(), key=lambda kv: -kv[1][0]):
+            print("  %-14s %8.3f ms/step  %4d launches/step" % (K_NAMES[k], ms / 3, n // 3), file=sys.stderr)
+    lib.papc_prof_enable(1 << dominant)
+    lib.papc_prof_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dom_ms, dom_n = _prof_read(lib)[dominant]
+    lib.papc_prof_enable(0)
+    final_loss = float(loss.item())
+    assert final_loss == final_loss, "loss is NaN"
+    flop, byts = work[dominant]
+    per_step_s = dom_ms / 1e3 / args.steps
+    mfma_peak = PEAK_MFMA_BF16_TFLOPS / 6.0
+    t_mfma, t_hbm = flop / (mfma_peak * 1e12), byts / (PEAK_HBM_GBS * 1e9)
+    if dominant != 8 and t_mfma >= t_hbm:
+        ach = flop / per_step_s / 1e12
+        roof = {"bound": "mfma", "kernel": K_NAMES[dominant], "achieved": round(ach, 2), "peak": round(mfma_peak, 1), "unit": "TFLOP/s",
+                "frac": round(ach / mfma_peak, 4), "traffic": None}
+    else:
+        ach = byts / per_step_s / 1e9
+        roof = {"bound": "hbm", "kernel": K_NAMES[dominant], "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+    roof["algorithmic"] = {"GFLOP_per_step": round(flop / 1e9, 2), "MB_per_step": round(byts / 1e6, 1), "mfma_floor_ms": round(t_mfma * 1e3, 4),
+                           "hbm_floor_ms": round(t_hbm * 1e3, 4)}
+    roof["launches_per_step"] = dom_n // args.steps
+    roof["ms_per_step"] = round(dom_ms / args.steps, 4)
+    roof["timing"] = "HIP event pairs around every launch of the family over the timed region (eager launches)"
+    roof["traffic_note"] = "PMC traffic of this configuration: profiles/r02_cfg_%s_pmc.txt where collected" % args.config
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import torch_cpu_reference as T
+        cores = min(len(os.sched_getaffinity(0)), 64)
+        t, u, sample = T.time_other_config(args.config, cores)
+        cpu = {"value": round(u / t, 3), "unit": unit, "cores": cores, "kind": "port",
+               "sample": "torch-CPU transliteration of the reference's op decomposition (oracle/torch_cpu_reference.py): " + sample}
+    out = {"metric": metric, "value": round(units * args.steps / elapsed, 2), "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": workload, "final_loss": round(final_loss, 4), "launch": "eager",
+                      "families_ms_per_step": {K_NAMES[k]: round(v[0] / 3, 4) for k, v in fam.items() if v[0] > 0}},
+           "roofline": roof, "cpu_baseline": cpu}
+    print(json.dumps(out))
