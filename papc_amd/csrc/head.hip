@@ -373,6 +373,40 @@ __global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restri
     if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
 }
 
+// the same for many rows (per-point segmentation logits: B*N = 32768 rows): one row per thread, any number of workgroups; the
+// per-workgroup partial sums of the loss are added with one float atomic each (the loss value may differ in its last bits from
+// run to run; the gradient does not)
+__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float *__restrict__ z, const int64_t *__restrict__ label, int B, int C,
+                                                                float *__restrict__ loss, float *__restrict__ dz)
+{
+    __shared__ float part[256];
+    float acc = 0.f;
+    const float invB = 1.0f / (float)B;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        const float *row = z + (int64_t)b * C;
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
+        const float lse = m + logf(s);
+        const int64_t y = label[b];
+        if (y >= 0 && y < C) acc += lse - row[y];
+        const float inv = invB / s;
+        for (int c = 0; c < C; ++c) {
+            float g = expf(row[c] - m) * inv;
+            if (c == y) g -= invB;
+            dz[(int64_t)b * C + c] = g;
+        }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss, part[0] * invB);
+}
+
 }  // namespace papc
 
 using namespace papc;
@@ -430,7 +464,13 @@ int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int
     PAPC_REQUIRE(B >= 1 && C >= 1, PAPC_E_INVALID, "papc_softmax_xent_f32: B=%d C=%d", B, C);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, st, logits, labels, B, C, loss, dlogits);
+    if (B <= 1024) {   // a classifier batch: one workgroup, fixed summation order (bit-reproducible loss)
+        hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, st, logits, labels, B, C, loss, dlogits);
+    } else {
+        if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("papc_softmax_xent_f32 (memset)");
+        hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3((unsigned)std::min(cdiv(B, 256), (int64_t)2048)), dim3(256), 0, st, logits, labels, B, C,
+                           loss, dlogits);
+    }
     return check_launch("papc_softmax_xent_f32");
 }
 

@@ -142,3 +142,19 @@ def test_model_uses_fused_head_and_trains():
     with torch.no_grad():
         out = model(x)
     assert out.shape == (4, 40) and int(model._head_spec.rng_state[1].item()) == 1
+
+
+def test_softmax_xent_many_rows_vs_torch(dev):
+    """per-point segmentation logits (B*N = 32768 rows, 50 parts): the multi-workgroup flavour of papc_softmax_xent_f32
+    (segment/pointnet2/pointnet2.py:96 -> PAPC/train.py:109 CrossEntropyLoss)"""
+    from papc_amd.head import softmax_cross_entropy
+    torch.manual_seed(3)
+    z = (torch.randn(32768, 50, device=dev) * 3).requires_grad_(True)
+    y = torch.randint(0, 50, (32768,), device=dev)
+    loss = softmax_cross_entropy(z, y)
+    loss.backward()
+    z64 = z.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(z64, y)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert float((z.grad.double() - z64.grad).abs().max()) <= 1e-6 * float(z64.grad.abs().max()) + 1e-12

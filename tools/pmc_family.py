@@ -15,9 +15,11 @@ def family(name):
         return "bwd_dw_gemm"
     if n.startswith("lingather_fwd_kernel"):
         return "mlp_gemm_fwd"
-    m = re.match(r"gemm_kernel<(\d+),", n)
+    m = re.match(r"(?:gemm|stream)_kernel<(\d+),", n)
     if m:
         return "mlp_gemm_fwd" if int(m.group(1)) <= 2 else "bwd_dx_gemm"
+    if n.startswith("pfn_kernel"):
+        return "pfn"
     if n.startswith("fps_kernel"):
         return "fps"
     if n.startswith("ball_query"):

@@ -10,6 +10,14 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stat
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_$c.log 2>&1
 done
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_sq.log 2>&1
-find $O -name "*.csv" | head -30
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_sq.log 2>&1
+# the other BASELINE configs (bench.py --config): bench line + kernel stats; PFN also its HBM traffic
+for c in msg_seg pfn basic; do
+  timeout 400 python bench.py --config $c > $O/bench_line_$c.json 2> $O/bench_line_$c.err
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_$c -o run -- python bench.py --config $c --no-cpu-baseline --steps 20 --warmup 5 > $O/prof_stats_$c.log 2>&1
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_pfn_$c -o run -- python bench.py --config pfn --no-cpu-baseline --steps 6 --warmup 2 > $O/pmc_pfn_$c.log 2>&1
+done
+find $O -name "*.csv" | head -40
 tail -c 300 $O/bench_line.json

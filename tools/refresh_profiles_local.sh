@@ -1,6 +1,6 @@
 #!/bin/bash
 # Turn gpurun_out/ of tools/refresh_profiles.sh into the committed summaries under profiles/ (round tag = $1, default r01).
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out
 P=profiles
 cp $O/prof_stats/run_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
@@ -9,7 +9,7 @@ grep "^{" $O/bench_line.json > $P/${R}_bench_line.json
   echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, with --kernel-trace only) of: python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2"
   echo "# values are KB per dispatch as reported; FETCH_SIZE must be DOUBLED on gfx950 (MI355X_MICROARCH.md, HBM section) -- calibrated in this repo on"
   echo "# bn_relu_max / bn_bwd_reduce-type streaming kernels whose traffic is known exactly (reported 131 MB vs 268 MB streamed)."
-  echo "# kernel names: gemm_kernel<AMODE, EPI, VEC, WGM, WGN, WM, WN, DEPTH, BF3, WS, TL>; dw_ws_kernel<XMODE, DYMODE, NTO, NTI>; dw_kernel<...> = f32-MFMA dW (gather layers)"
+  echo "# kernel names: stream_kernel<AMODE, EPI, K/16, CK, WN, ASM> (row-streaming GEMM, mlp_stream.hip); gemm_kernel<AMODE, EPI, VEC, WGM, WGN, WM, WN, DEPTH, BF3, WS, TL>; dw_ws_kernel<XMODE, DYMODE, NTO, NTI>; dw_kernel<...> = f32-MFMA dW (gather layers)"
   python tools/pmc_summary.py $O/pmc_FETCH_SIZE 24
   python tools/pmc_summary.py $O/pmc_WRITE_SIZE 24
 } > $P/${R}_bench_pmc_fetch_write.txt
@@ -21,4 +21,13 @@ grep "^{" $O/bench_line.json > $P/${R}_bench_line.json
   python tools/pmc_table.py $O/pmc_sq 30
 } > $P/${R}_bench_pmc_sq.txt
 python tools/pmc_family.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $P/${R}_bench_pmc_family.json
+for c in msg_seg pfn basic; do
+  cp $O/prof_stats_$c/run_kernel_stats.csv $P/${R}_cfg_${c}_kernel_stats.csv
+  grep "^{" $O/bench_line_$c.json > $P/${R}_cfg_${c}_bench_line.json
+done
+{
+  echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: python bench.py --config pfn --no-cpu-baseline --steps 6 --warmup 2  (KB per dispatch; FETCH_SIZE x2 on gfx950)"
+  python tools/pmc_summary.py $O/pmc_pfn_FETCH_SIZE 8
+  python tools/pmc_summary.py $O/pmc_pfn_WRITE_SIZE 8
+} > $P/${R}_cfg_pfn_pmc.txt
 wc -l $P/${R}_*
