@@ -378,24 +378,37 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float *__restrict__ s
     }
 }
 
-// out[r * out_ld + c] (+)= sum_t part[t * ld + r * cols + c]   (chunks summed in order: deterministic)
-__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float *__restrict__ part, int n_chunks, int64_t ld, int rows, int cols,
-                                                                      float *__restrict__ out, int64_t out_ld, int accumulate)
+// out[r * out_ld + c] (+)= sum_t part[t * ld + r * cols + c]   (fixed summation tree: deterministic)
+// A workgroup = 16 consecutive elements x 64 chunk slices: slice s sums chunks s, s+64, ... in order, then the 64 slice sums are folded
+// through LDS in a fixed binary tree.  (One thread per element walking all chunks took 80+ us for the 2048 x 192 gather-add partials.)
+__global__ __launch_bounds__(1024) void reduce_partials_strided_kernel(const float *__restrict__ part, int n_chunks, int64_t ld, int rows, int cols,
+                                                                       float *__restrict__ out, int64_t out_ld, int accumulate)
 {
+    __shared__ float red[64][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int64_t n = (int64_t)rows * cols;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    const int64_t e = (int64_t)blockIdx.x * 16 + el;
     float s = 0.f;
-    for (int t0 = 0; t0 < n_chunks; t0 += 8) {
-        float v[8];
+    if (e < n) {
+        for (int t0 = sl; t0 < n_chunks; t0 += 64 * 4) {
+            float v[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(t0 + j < n_chunks ? t0 + j : t0) * ld + e];
+            for (int j = 0; j < 4; ++j) v[j] = (t0 + 64 * j < n_chunks) ? part[(int64_t)(t0 + 64 * j) * ld + e] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (t0 + j < n_chunks) s += v[j];
+            for (int j = 0; j < 4; ++j) s += v[j];
+        }
     }
-    const int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
-    float *o = out + (int64_t)r * out_ld + c;
-    *o = accumulate ? *o + s : s;
+    red[sl][el] = s;
+    __syncthreads();
+    for (int h = 32; h >= 1; h >>= 1) {
+        if (sl < h) red[sl][el] += red[sl + h][el];
+        __syncthreads();
+    }
+    if (sl == 0 && e < n) {
+        const int r = (int)(e / cols), c = (int)(e - (int64_t)r * cols);
+        float *o = out + (int64_t)r * out_ld + c;
+        *o = accumulate ? *o + red[0][el] : red[0][el];
+    }
 }
 
 __global__ __launch_bounds__(256) void scale_by_kernel(const float *__restrict__ x, const float *__restrict__ scalar, int64_t n, float *__restrict__ out)
@@ -662,7 +675,7 @@ int papc_reduce_partials_strided_f32(const float *partial, int n_chunks, int64_t
                  "papc_reduce_partials_strided_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((unsigned)cdiv((int64_t)rows * cols, 256)), dim3(256), 0, st, partial, n_chunks, ld,
+    hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3((unsigned)cdiv((int64_t)rows * cols, 16)), dim3(1024), 0, st, partial, n_chunks, ld,
                        rows, cols, out, out_ld, accumulate);
     return check_launch("papc_reduce_partials_strided_f32");
 }

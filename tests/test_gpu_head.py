@@ -158,3 +158,27 @@ def test_softmax_xent_many_rows_vs_torch(dev):
     ref.backward()
     assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
     assert float((z.grad.double() - z64.grad).abs().max()) <= 1e-6 * float(z64.grad.abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("n_chunks,rows,cols,out_ld,acc", [(2048, 64, 3, 131, 0), (131, 128, 64, 67, 1), (1, 5, 7, 7, 0), (70, 1, 33, 40, 1)])
+def test_reduce_partials_strided_vs_float64(dev, n_chunks, rows, cols, out_ld, acc):
+    """papc_reduce_partials_strided_f32 (the gather-add and dW partials summed into a column block of the weight gradient): any chunk
+    count, ragged element counts, accumulate on/off; bit-identical when repeated."""
+    import ctypes
+    from papc_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(n_chunks + rows)
+    ld = rows * cols + 5
+    part = torch.randn(n_chunks, ld, device=dev)
+    base = torch.randn(rows, out_ld, device=dev)
+    outs = []
+    for _ in range(2):
+        out = base.clone()
+        _lib.check(lib.papc_reduce_partials_strided_f32(ctypes.c_void_p(part.data_ptr()), n_chunks, ld, rows, cols,
+                                                        ctypes.c_void_p(out.data_ptr()), out_ld, acc, None), "reduce")
+        outs.append(out)
+    ref = base.double().clone()
+    blk = part[:, :rows * cols].double().sum(0).view(rows, cols)
+    ref[:, :cols] = ref[:, :cols] + blk if acc else blk
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0].double() - ref).abs().max()) <= 1e-5 * float(blk.abs().max()) + 1e-6
