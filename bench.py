@@ -140,7 +140,10 @@ def main():
     # occupies B=32 of the 256 CUs, so the sampling pyramid of batch i+1 is computed on a side stream while batch i's
     # MFMA kernels own the rest of the chip.  Every step still computes exactly one pyramid (for the next batch).
     main = torch.cuda.current_stream()
-    side = torch.cuda.Stream()
+    # N > 1 (sampling enqueued eagerly beside the graph replays, see ext_sampling below): a high-priority stream gets its own hardware
+    # queue -- on a default-priority stream the sampling kernels queue up BEHIND the graphs already enqueued (2.81 ms vs 2.46 ms per step)
+    # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
+    side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else 0)
     ONE = torch.ones((), device=dev)            # d(loss)/d(loss), allocated once (loss.backward() would fill a fresh one every step)
     state = {"plan": None, "ev": None}
 
@@ -189,12 +192,12 @@ def main():
     # joined at the end): two graphs alternate, one reading the plan buffers the other one fills.
     use_graph = not args.no_graph
     graph_state = {"g": None, "loss": None, "i": 0}
-    if dist.is_initialized() and use_graph and args.overlap:
-        # RCCL's watchdog thread aborts the process when a capture involves a second stream while it polls the events of the
-        # collectives in flight ("operation not permitted on an event last recorded in a capturing stream", ROCm 7.0 / RCCL 2.26,
-        # seen with a forced 1-rank group): with N > 1 the graphs are captured on the main stream only and the sampling runs
-        # in-line.  Measured on one GPU: 2.70 ms (graph, in-line sampling) vs 2.79 ms (eager, overlapped sampling).
-        args.overlap = False
+    # N > 1: RCCL's watchdog thread aborts the process when a capture involves a second stream while it polls the events of the
+    # collectives in flight ("operation not permitted on an event last recorded in a capturing stream", ROCm 7.0 / RCCL 2.26, seen
+    # with a forced 1-rank group).  There the graphs are captured on the main stream only and the NEXT batch's sampling pyramid is
+    # enqueued EAGERLY on the side stream right after the graph replay (6 launches of CPU work beside a 2.4 ms graph), ordered with
+    # plain stream events outside any capture; the two graphs still alternate between the two plan buffers.
+    ext_sampling = dist.is_initialized() and use_graph and args.overlap
 
     use_dist = dist.is_initialized()
     # N > 1: the backward runs in two stages around l2_points (the tensor SA3 consumes).  Stage 1 = FC head + SA3, whose
@@ -203,7 +206,7 @@ def main():
     # of the bucket is reduced after the last kernel.
     split = flat.offset_of(model.sa3) if use_dist else 0
 
-    def stage1(plan_in=None, plan_out=None):
+    def stage1(plan_in=None, plan_out=None, cut=None):
         flat.zero_grad()
 
         def fork():
@@ -220,7 +223,7 @@ def main():
             fork()
         tap = {} if use_dist else None
         logits = model(x, (s1, s2), plan=plan_in, tap=tap,
-                       after_sa2=(fork if plan_out is not None and args.fork == "sa2" and not use_dist else None))
+                       after_sa2=cut if cut is not None else (fork if plan_out is not None and args.fork == "sa2" and not use_dist else None))
         loss = softmax_cross_entropy(logits, y)
         if not use_dist:
             loss.backward(ONE)
@@ -252,18 +255,47 @@ def main():
             gs, losses = [], []
             for i in range(n_sets):
                 pin, pout = (bufs[i], bufs[1 - i]) if args.overlap else (None, None)
+                if ext_sampling:
+                    pout = None                    # filled from outside the graph (step())
                 g1 = torch.cuda.CUDAGraph()
+                g1b = g2 = None
+                if ext_sampling:
+                    # three graphs per step (one memory pool): forward up to SA2 | SA3 + head + their backward | SA2 + SA1 backward.
+                    # The first cut is where the side stream's sampling is released (the SA3 / head kernels are small grids that
+                    # leave CUs free, as with the in-graph fork), the second is where the tail bucket's all-reduce is issued.
+                    g1b, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+
+                    def cut():
+                        g1.capture_end()
+                        g1b.capture_begin(pool=g1.pool(), capture_error_mode="thread_local")
+
+                    g1.capture_begin(capture_error_mode="thread_local")
+                    try:
+                        loss, l2, g_l2, fork = stage1(pin, None, cut)
+                        g1b.capture_end()
+                        g2.capture_begin(pool=g1.pool(), capture_error_mode="thread_local")
+                        stage2(l2, g_l2, None)
+                        g2.capture_end()
+                    except Exception:
+                        for g in (g1, g1b, g2):           # leave no capture open behind a failure
+                            try:
+                                g.capture_end()
+                            except Exception:     # noqa: BLE001
+                                pass
+                        raise
+                    gs.append((g1, g1b, g2))
+                    losses.append(loss)
+                    continue
                 # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
                 with torch.cuda.graph(g1, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
                     loss, l2, g_l2, fork = stage1(pin, pout)
-                g2 = None
                 if use_dist:   # stage 2 is a second graph (same memory pool): the collective of the tail bucket goes between them
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2, pool=g1.pool(), stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
                         stage2(l2, g_l2, fork)
-                gs.append((g1, g2))
+                gs.append((g1, None, g2))
                 losses.append(loss)
-            graph_state["g"], graph_state["loss"] = gs, losses
+            graph_state["g"], graph_state["loss"], graph_state["bufs"] = gs, losses, bufs
         except Exception as e:   # noqa: BLE001
             print("[bench] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), file=sys.stderr)
             graph_state["g"], graph_state["loss"] = None, None
@@ -281,13 +313,27 @@ def main():
             scale = flat.allreduce_grads()
         opt.step(scale)
 
+    def sample_into(plan_out):
+        """the next batch's pyramid, enqueued on the side stream beside the graph that is being replayed (N > 1)"""
+        with torch.cuda.stream(side):
+            p = model.plan_sampling(x, (s1, s2))
+            for dst_lvl, src_lvl in zip(plan_out, p):
+                for d, s_ in zip(dst_lvl, src_lvl):
+                    d.copy_(s_)
+
     def step():
         if graph_state["g"] is None:
             return step_eager()
         i = graph_state["i"] % len(graph_state["g"])
         graph_state["i"] += 1
-        g1, g2 = graph_state["g"][i]
+        g1, g1b, g2 = graph_state["g"][i]
+        if ext_sampling:
+            main.wait_stream(side)                 # this batch's plan (bufs[i]) was filled on the side stream during the last step
         g1.replay()
+        if ext_sampling:
+            side.wait_stream(main)                 # released when the main stream reaches SA3; bufs[1 - i]'s last reader is long done
+            sample_into(graph_state["bufs"][1 - i])
+            g1b.replay()
         work = None
         if g2 is not None:
             _, work = flat.allreduce_grads(split, None, async_op=True)
@@ -413,7 +459,8 @@ def main():
             "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
                        "sampling": ("software-pipelined: batch i+1's FPS + ball-query pyramid runs as a second branch (side stream) of "
-                                    "batch i's step, fork at %s; every timed step computes one full pyramid" % args.fork) if args.overlap else "in-line",
+                                    "batch i's step, %s; every timed step computes one full pyramid"
+                                    % ("enqueued on the side stream beside the graph replay" if ext_sampling else "fork at " + args.fork)) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
                        "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager all-reduce + Adam" if use_graph else "eager",
