@@ -293,6 +293,35 @@ int papc_pfn_bwd_dw_f32(const float *features, const int32_t *num_voxels, const 
                         const float *scale, const float *shift, const float *c1, const float *c2,
                         float *dw_partial, papc_stream_t stream);
 
+/* The Gram path of the same layer (what papc_amd.pillars.PillarFeatureNet calls; pillars.py:29-37, :79-108).  With 9 input
+ * channels the train-mode BatchNorm statistics and the weight gradient depend on the dense [P*T, C] activations only through the
+ * inputs' Gram matrix G = sum_rows [x | 1]^T [x | 1] (x = the decorated, masked row; y = x W^T, so sum y_c = W_c . colsum,
+ * sum y_c^2 = W_c G W_c^T, sum y_c x_k = (W G)_ck): no 64-channel pass is needed for either.
+ *   papc_pfn_gram_f32            one pass over the input: gram_partial [papc_pfn_gram_blocks(P)][256] float64 (16x16 tiles, row-major;
+ *                                rows/cols 0..8 = decorated channels, 9 = distance slot, 10 = the constant 1), accumulated in float64
+ *                                on the matrix pipe (the quadratic forms cancel: coordinates are O(70 m), a channel's spread O(1));
+ *   papc_pfn_gram_finalize_f32   partials -> gram [256] float64 and, when mean != NULL, the BN constants of the layer
+ *                                (as papc_bn_finalize_f32: biased variance, paddle momentum rule; M = P*T);
+ *   papc_pfn_bwd_sparse_f32      partial [papc_pfn_num_blocks(P)][11][C]: sum p, sum p*xhat and T[c][k] = sum p * x_k of the argmax
+ *                                rows (p = gout where the ReLU is alive) -- one row per (pillar, channel), nothing dense;
+ *                                reduce over the blocks with papc_reduce_partials_f32 (n = 11*C);
+ *   papc_pfn_bwd_finalize_f32    sums [11][C] + gram -> dgamma, dbeta and
+ *                                dW_ck = sc_c (T_ck - c1_c colsum_k - c2_c invstd_c ((W G)_ck - mean_c colsum_k)), c1 = sum p / M,
+ *                                c2 = sum p*xhat / M  (eval_bn != 0: running statistics, c1 = c2 = 0). */
+int papc_pfn_gram_blocks(int P);
+int papc_pfn_gram_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                      float vx, float vy, float x_offset, float y_offset, double *gram_partial, papc_stream_t stream);
+int papc_pfn_gram_finalize_f32(const double *gram_partial, int n_blocks, int64_t M, const float *w, int C, const float *gamma,
+                               const float *beta, float eps, float momentum, float *mean, float *invstd, float *scale, float *shift,
+                               float *running_mean, float *running_var, double *gram, papc_stream_t stream);
+int papc_pfn_bwd_sparse_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P,
+                            int T, float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                            const float *gout, const int32_t *argmax, const float *mean, const float *invstd,
+                            const float *scale, const float *shift, float *partial, papc_stream_t stream);
+int papc_pfn_bwd_finalize_f32(const float *sums, int64_t M, const float *w, int C, const double *gram, const float *mean,
+                              const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int eval_bn,
+                              papc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Harness helpers (the reference's Adam step, PAPC/train.py:62-65,113-116, on one flat buffer)
  * ---------------------------------------------------------------------------------------------- */

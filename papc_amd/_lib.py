@@ -80,6 +80,11 @@ SIGNATURES = {
     "papc_pfn_num_blocks": (c_i, [c_i]),
     "papc_pfn_bwd_reduce_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "papc_pfn_bwd_dw_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_pfn_gram_blocks": (c_i, [c_i]),
+    "papc_pfn_gram_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "papc_pfn_gram_finalize_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_pfn_bwd_sparse_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_pfn_bwd_finalize_f32": (c_i, [c_p, c_l, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_points_to_voxel_workspace": (ctypes.c_size_t, [c_i]),
     "papc_points_to_voxel_f32": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_pillar_scatter_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),

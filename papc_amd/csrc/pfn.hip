@@ -10,6 +10,17 @@
 // in VGPRs and walks the T rows with broadcast ds_read_b128 -- K = 9 is too short for MFMA to pay (it would pad to
 // 128 rows x 10), the kernel is VALU/HBM balanced.  Train-mode BN needs grid-wide statistics, so forward is two
 // passes (stats, then apply+ReLU+max) that both recompute the 9->C linear layer instead of storing [P,T,C].
+//
+// The Gram path (papc_pfn_gram_f32 & co, the one PillarFeatureNet uses): with K = 9 input channels everything the train-mode
+// BatchNorm and the weight gradient need from the DENSE [P*T, C] activations is a function of the inputs' 10x10 Gram matrix
+//   G = sum_rows [x | 1]^T [x | 1]        (x = the decorated, masked 9-channel row)
+// because y = x W^T:  sum y_c = W_c . colsum,  sum y_c^2 = W_c G W_c^T,  sum y_c x_k = (W G)_ck.  So
+//   forward statistics:  mean_c = W_c.colsum / M,  var_c = W_c G W_c^T / M - mean_c^2              (no 64-channel pass at all)
+//   backward:            dW_ck = sc_c ( T_ck - c1_c colsum_k - c2_c invstd_c ((W G)_ck - mean_c colsum_k) )
+// with T_ck = sum over (pillar, channel) of the max-pooled gradient times the argmax row's x_k -- sparse: one row per (pillar, c).
+// G is accumulated in float64 on the matrix pipe (v_mfma_f64_16x16x4_f64: products of fp32 values are exact in f64), since the
+// quadratic forms cancel: raw coordinates are O(70 m), a channel's spread O(1).  The only dense passes left are the Gram pass
+// (reads the 19 MB input once) and the apply pass.
 #include "common.h"
 
 namespace papc {
@@ -27,46 +38,66 @@ struct PfnArgs {
     // backward
     const float *gout; const int32_t *amax; const float *mean, *invstd, *c1, *c2;
     float *red; float *dwp;
+    double *gram;    // PFN_GRAM: [gridDim.x][256] partial Gram matrices
     int with_dist;   // PFN_DECORATE only: also write ||xyz|| as a 10th channel (pillars.py:92-94)
 };
 
-enum { PFN_STATS = 0, PFN_APPLY = 1, PFN_BWD_RED = 2, PFN_BWD_DW = 3, PFN_DECORATE = 4 };
+enum { PFN_STATS = 0, PFN_APPLY = 1, PFN_BWD_RED = 2, PFN_BWD_DW = 3, PFN_DECORATE = 4, PFN_GRAM = 5, PFN_BWD_SPARSE = 6 };
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int PFN_NACC = 11;   // accumulator slots per channel (BWD_SPARSE: sum p, sum p*xhat, 9 x sum p*x_k)
 
-// Phase A for one pillar: decorate + mask, rows -> LDS (this wave's slab)
-__device__ __forceinline__ void pfn_stage(const PfnArgs &a, int p, float *rows, int lane)
+// Phase A for one pillar: decorate + mask, rows -> LDS (this wave's slab).  Split into the loads (pfn_fetch) and the arithmetic
+// (pfn_stage_from) so that a mode whose per-pillar work is short can put the next pillar's loads in flight first.
+struct PfnRaw { float4 f[2]; int nv, cx, cy; };
+
+__device__ __forceinline__ PfnRaw pfn_fetch(const PfnArgs &a, int p, int lane)
 {
-    const int T = a.T;
-    const int nv = a.nvox[p];
-    float4 f[2];
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    PfnRaw r;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int t = lane + 64 * h;
-        f[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) f[h] = *reinterpret_cast<const float4 *>(a.feat + ((int64_t)p * T + t) * 4);
-        sx += f[h].x; sy += f[h].y; sz += f[h].z;
+        r.f[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < a.T) r.f[h] = *reinterpret_cast<const float4 *>(a.feat + ((int64_t)p * a.T + t) * 4);
     }
+    r.nv = a.nvox[p];
+    r.cx = a.coors[(int64_t)p * 4 + 3];
+    r.cy = a.coors[(int64_t)p * 4 + 2];
+    return r;
+}
+
+__device__ __forceinline__ void pfn_stage_from(const PfnArgs &a, const PfnRaw &raw, float *rows, int lane)
+{
+    const int T = a.T;
+    const int nv = raw.nv;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { sx += raw.f[h].x; sy += raw.f[h].y; sz += raw.f[h].z; }
     // features[:, :, :3].sum(axis=1) over ALL T rows (zero padding included) / num_voxels   (:82)
     sx = readlane63_f32(wave_sum_f32_to_lane63(sx));
     sy = readlane63_f32(wave_sum_f32_to_lane63(sy));
     sz = readlane63_f32(wave_sum_f32_to_lane63(sz));
     const float fn = (float)nv;
     const float mx = sx / fn, my = sy / fn, mz = sz / fn;
-    const float pcx = (float)a.coors[(int64_t)p * 4 + 3] * a.vx + a.xo;  // coors[:,3]*vx + x_offset  (:87)
-    const float pcy = (float)a.coors[(int64_t)p * 4 + 2] * a.vy + a.yo;  // coors[:,2]*vy + y_offset  (:88)
+    const float pcx = (float)raw.cx * a.vx + a.xo;  // coors[:,3]*vx + x_offset  (:87)
+    const float pcy = (float)raw.cy * a.vy + a.yo;  // coors[:,2]*vy + y_offset  (:88)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int t = lane + 64 * h;
         if (t < T) {
             const float mk = t < nv ? 1.f : 0.f;  // get_paddings_indicator: actual_num > t  (libs/tools/__init__.py:26-35)
             float *r = rows + t * PFN_LD;
-            const float4 v = f[h];
+            const float4 v = raw.f[h];
             *reinterpret_cast<float4 *>(r) = make_float4(v.x * mk, v.y * mk, v.z * mk, v.w * mk);
             *reinterpret_cast<float4 *>(r + 4) = make_float4((v.x - mx) * mk, (v.y - my) * mk, (v.z - mz) * mk, (v.x - pcx) * mk);
             // (slot 9: points_dist = paddle.norm(features[:, :, :3], 2, 2) of the with_distance variant, :92-94)
             *reinterpret_cast<float4 *>(r + 8) = make_float4((v.y - pcy) * mk, sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z) * mk, 0.f, 0.f);
         }
     }
+}
+
+__device__ __forceinline__ void pfn_stage(const PfnArgs &a, int p, float *rows, int lane)
+{
+    pfn_stage_from(a, pfn_fetch(a, p, lane), rows, lane);
 }
 
 __device__ __forceinline__ float pfn_dot(const float *r, const float (&w)[9])
@@ -81,30 +112,43 @@ __device__ __forceinline__ float pfn_dot(const float *r, const float (&w)[9])
     return y;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(64 * PFN_WAVES) void pfn_kernel(PfnArgs a)
+template <int MODE, int WAVES = PFN_WAVES>
+__global__ __launch_bounds__(64 * WAVES) void pfn_kernel(PfnArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float smem[PFN_WAVES * PFN_TMAX * PFN_LD + PFN_WAVES * 64 * 10];
+    constexpr int PFN_WAVES = WAVES;   // (shadows the default: the Gram pass runs 16-wave workgroups, fewer partial rows to fold)
+    __shared__ __attribute__((aligned(16))) float smem[PFN_WAVES * PFN_TMAX * PFN_LD + PFN_WAVES * 64 * PFN_NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *rows = smem + wave * PFN_TMAX * PFN_LD;
-    float *xred = smem + PFN_WAVES * PFN_TMAX * PFN_LD;  // [wave][10][64]
+    float *xred = smem + PFN_WAVES * PFN_TMAX * PFN_LD;  // [wave][PFN_NACC][64]
     const int c = lane;
     const bool cok = c < a.C;
 
     float w[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = (cok && MODE != PFN_DECORATE) ? a.w[c * 9 + k] : 0.f;
+    for (int k = 0; k < 9; ++k) w[k] = (cok && MODE != PFN_DECORATE && MODE != PFN_GRAM) ? a.w[c * 9 + k] : 0.f;
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, c1 = 0.f, c2 = 0.f;
-    if (MODE != PFN_STATS && MODE != PFN_DECORATE && cok) { sc = a.scale[c]; sh = a.shift[c]; }
-    if ((MODE == PFN_BWD_RED || MODE == PFN_BWD_DW) && cok) { mu = a.mean[c]; is = a.invstd[c]; }
+    if (MODE != PFN_STATS && MODE != PFN_DECORATE && MODE != PFN_GRAM && cok) { sc = a.scale[c]; sh = a.shift[c]; }
+    if ((MODE == PFN_BWD_RED || MODE == PFN_BWD_DW || MODE == PFN_BWD_SPARSE) && cok) { mu = a.mean[c]; is = a.invstd[c]; }
     if (MODE == PFN_BWD_DW && cok) { c1 = a.c1[c]; c2 = a.c2[c]; }
 
-    float acc[10];
+    float acc[PFN_NACC];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    for (int i = 0; i < PFN_NACC; ++i) acc[i] = 0.f;
+    double4_t gacc[4];                        // PFN_GRAM: this lane's 4 entries of the 16x16 f64 accumulator, x4 independent chains
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gacc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
 
+    PfnRaw nxt = {};
+    if (MODE == PFN_GRAM && (int)(blockIdx.x * PFN_WAVES + wave) < a.P) nxt = pfn_fetch(a, blockIdx.x * PFN_WAVES + wave, lane);
     for (int p = blockIdx.x * PFN_WAVES + wave; p < a.P; p += gridDim.x * PFN_WAVES) {
-        pfn_stage(a, p, rows, lane);
+        if (MODE == PFN_GRAM) {   // the next pillar's loads fly under this pillar's MFMAs
+            const PfnRaw cur = nxt;
+            const int pn = p + gridDim.x * PFN_WAVES;
+            if (pn < a.P) nxt = pfn_fetch(a, pn, lane);
+            pfn_stage_from(a, cur, rows, lane);
+        } else {
+            pfn_stage(a, p, rows, lane);
+        }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (MODE == PFN_DECORATE) {
@@ -112,6 +156,27 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_kernel(PfnArgs a)
             for (int e = lane; e < a.T * nc; e += 64) {
                 const int t = e / nc, k = e - t * nc;
                 a.out[((int64_t)p * a.T + t) * nc + k] = rows[t * PFN_LD + k];
+            }
+        } else if (MODE == PFN_GRAM) {
+            // G += X^T X over this pillar's T rows, 4 rows per v_mfma_f64_16x16x4_f64.  Lane (ch = lane & 15, kk = lane >> 4) holds
+            // X[4m + kk][ch] for BOTH operands (A[i][k] = X[k][i], B[k][j] = X[k][j]).  Channels 0..8 = the decorated row, 9 = the
+            // distance slot, 10 = the constant 1 (column sums), 11..15 = 0.
+            const int ch = lane & 15, kk = lane >> 4;
+            const int nm = (a.T + 3) >> 2;
+            const int chc = ch < PFN_LD ? ch : 0;
+            for (int m0 = 0; m0 < nm; m0 += 4) {   // 4 row quads per trip on 4 accumulators (a dependent f64 MFMA chain does not pipeline)
+                float x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int t = 4 * (m0 + q) + kk;
+                    x[q] = rows[(t < a.T ? t : 0) * PFN_LD + chc];
+                    x[q] = (t < a.T && ch < PFN_LD) ? (ch == 10 ? 1.f : x[q]) : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double xd = (double)x[q];
+                    gacc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xd, xd, gacc[q], 0, 0, 0);
+                }
             }
         } else if (MODE == PFN_STATS) {
             for (int t = 0; t < a.T; ++t) {
@@ -131,14 +196,22 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_kernel(PfnArgs a)
                 a.out[(int64_t)p * a.C + c] = best;
                 if (a.argmax) a.argmax[(int64_t)p * a.C + c] = bi;
             }
-        } else if (MODE == PFN_BWD_RED) {
+        } else if (MODE == PFN_BWD_RED || MODE == PFN_BWD_SPARSE) {
             if (cok) {
                 const int am = a.amax[(int64_t)p * a.C + c];
-                const float y = pfn_dot(rows + am * PFN_LD, w);
+                const float *r = rows + am * PFN_LD;
+                const float y = pfn_dot(r, w);
                 const float z = fmaf(sc, y, sh);
                 const float g = z > 0.f ? a.gout[(int64_t)p * a.C + c] : 0.f;
                 acc[0] += g;
                 acc[1] = fmaf(g, (y - mu) * is, acc[1]);
+                if (MODE == PFN_BWD_SPARSE) {   // T[c][k] += p * x_k of the argmax row
+                    const float4 x0 = *reinterpret_cast<const float4 *>(r);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(r + 4);
+                    acc[2] = fmaf(g, x0.x, acc[2]); acc[3] = fmaf(g, x0.y, acc[3]); acc[4] = fmaf(g, x0.z, acc[4]);
+                    acc[5] = fmaf(g, x0.w, acc[5]); acc[6] = fmaf(g, x1.x, acc[6]); acc[7] = fmaf(g, x1.y, acc[7]);
+                    acc[8] = fmaf(g, x1.z, acc[8]); acc[9] = fmaf(g, x1.w, acc[9]); acc[10] = fmaf(g, r[8], acc[10]);
+                }
             }
         } else {  // PFN_BWD_DW
             const int am = cok ? a.amax[(int64_t)p * a.C + c] : -1;
@@ -160,20 +233,133 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_kernel(PfnArgs a)
     }
 
     if (MODE == PFN_APPLY || MODE == PFN_DECORATE) return;
-    constexpr int NA = (MODE == PFN_BWD_DW) ? 9 : 2;
+    if (MODE == PFN_GRAM) {
+        // fold the 4 waves (fixed order) and store this workgroup's partial G as [i][j]: j = lane & 15, i = (lane >> 4) + 4 r
+        // (the accumulator layout of v_mfma_f64_16x16x4_f64, tools/probe/mfma_f64_layout.hip)
+        double *dred = reinterpret_cast<double *>(xred);   // [wave][4][64] doubles (2 KB of each wave's 2.75 KB slab)
 #pragma unroll
-    for (int i = 0; i < NA; ++i) xred[(wave * 10 + i) * 64 + lane] = acc[i];
+        for (int r = 0; r < 4; ++r) dred[(wave * 4 + r) * 64 + lane] = (gacc[0][r] + gacc[1][r]) + (gacc[2][r] + gacc[3][r]);
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double sum = 0.0;
+#pragma unroll
+                for (int g = 0; g < PFN_WAVES; ++g) sum += dred[(g * 4 + r) * 64 + lane];
+                a.gram[(int64_t)blockIdx.x * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = sum;
+            }
+        }
+        return;
+    }
+    constexpr int NA = (MODE == PFN_BWD_DW) ? 9 : (MODE == PFN_BWD_SPARSE ? PFN_NACC : 2);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) xred[(wave * PFN_NACC + i) * 64 + lane] = acc[i];
     __syncthreads();
     if (wave == 0 && cok) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             float s = 0.f;
 #pragma unroll
-            for (int g = 0; g < PFN_WAVES; ++g) s += xred[(g * 10 + i) * 64 + lane];
+            for (int g = 0; g < PFN_WAVES; ++g) s += xred[(g * PFN_NACC + i) * 64 + lane];
             if (MODE == PFN_BWD_DW) a.dwp[((int64_t)blockIdx.x * a.C + c) * 9 + i] = s;
+            else if (MODE == PFN_BWD_SPARSE) a.red[((int64_t)blockIdx.x * PFN_NACC + i) * a.C + c] = s;
             else if (MODE == PFN_STATS) a.stats[((int64_t)blockIdx.x * 2 + i) * a.C + c] = s;
             else a.red[((int64_t)blockIdx.x * 2 + i) * a.C + c] = s;
         }
+    }
+}
+
+// ---- Gram path, small kernels --------------------------------------------------------------------------------------
+constexpr int PFN_GRAM_WAVES = 16;
+constexpr int PFN_GRAM_BLOCKS = 256;   // workgroups (16 waves each) of the Gram pass = rows of its partial buffer
+constexpr int PFN_GN = 11;             // channels of G that are used: 9 decorated + distance slot + the constant 1
+
+// gram_partial [n_blocks][256] -> G [16][16] (f64, fixed summation tree), then the train-mode BatchNorm constants of the
+// 9 -> C linear layer straight from G (see the file header).  One workgroup of 1024 threads: 128 entry lanes x 8 block slices.
+__global__ __launch_bounds__(1024) void pfn_gram_finalize_kernel(const double *__restrict__ part, int n_blocks, double M, const float *__restrict__ w,
+                                                                int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                float eps, float momentum, float *mean, float *invstd, float *scale,
+                                                                float *shift, float *rmean, float *rvar, double *gram)
+{
+    __shared__ double red[8][128];
+    __shared__ double G[PFN_GN][PFN_GN];
+    const int e = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    const int gi = e / PFN_GN, gj = e - gi * PFN_GN;
+    double s = 0.0;
+    if (e < PFN_GN * PFN_GN) {
+        for (int b = sl; b < n_blocks; b += 8 * 16) {   // 16 loads in flight per thread: the kernel is a latency chain
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = (b + 8 * q < n_blocks) ? part[(int64_t)(b + 8 * q) * 256 + gi * 16 + gj] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += v[q];
+        }
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    for (int h = 4; h >= 1; h >>= 1) {
+        if (sl < h) red[sl][e] += red[sl + h][e];
+        __syncthreads();
+    }
+    if (sl == 0 && e < PFN_GN * PFN_GN) {
+        G[gi][gj] = red[0][e];
+        gram[gi * 16 + gj] = red[0][e];
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c < C && mean) {
+        double wc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wc[k] = (double)w[c * 9 + k];
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            s1 += wc[k] * G[k][10];
+            double t = 0.0;
+#pragma unroll
+            for (int l = 0; l < 9; ++l) t += wc[l] * G[k][l];
+            s2 += wc[k] * t;
+        }
+        const double mu = s1 / M;
+        double var = s2 / M - mu * mu;   // biased variance (paddle BatchNorm training), as bn_finalize_kernel
+        if (var < 0.0) var = 0.0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const double sc = (gamma ? (double)gamma[c] : 1.0) * is;
+        mean[c] = (float)mu;
+        invstd[c] = (float)is;
+        scale[c] = (float)sc;
+        shift[c] = (float)((beta ? (double)beta[c] : 0.0) - mu * sc);
+        if (rmean) rmean[c] = momentum * rmean[c] + (1.f - momentum) * (float)mu;
+        if (rvar) rvar[c] = momentum * rvar[c] + (1.f - momentum) * (float)var;
+    }
+}
+
+// sums [11][C] (sum p, sum p*xhat, T[c][0..8]; reduced over the workgroups by papc_reduce_partials_f32) + G -> dgamma, dbeta, dW [C][9]
+__global__ __launch_bounds__(64) void pfn_bwd_finalize_kernel(const float *__restrict__ sums, double M, const float *__restrict__ w, int C,
+                                                             const double *__restrict__ gram, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, const float *__restrict__ scale,
+                                                             float *dgamma, float *dbeta, float *dw, int eval_bn)
+{
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double s1 = (double)sums[0 * C + c], s2 = (double)sums[1 * C + c];
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    const double sc = (double)scale[c];
+    // eval-mode BatchNorm (running statistics): dy = sc * p, the batch-mean terms vanish
+    const double c1 = eval_bn ? 0.0 : s1 / M, c2 = eval_bn ? 0.0 : s2 / M;
+    const double mu = (double)mean[c], is = (double)invstd[c];
+    double wc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wc[k] = (double)w[c * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double wg = 0.0;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) wg += wc[l] * gram[l * 16 + k];
+        const double colsum = gram[k * 16 + 10];
+        const double t = (double)sums[(2 + k) * C + c];
+        dw[c * 9 + k] = (float)(sc * (t - c1 * colsum - c2 * is * (wg - mu * colsum)));
     }
 }
 
@@ -280,6 +466,70 @@ int papc_pfn_bwd_dw_f32(const float *features, const int32_t *num_voxels, const 
     a.w = w; a.C = C; a.gout = gout; a.amax = argmax; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift;
     a.c1 = c1; a.c2 = c2; a.dwp = dw_partial;
     return launch_pfn<PFN_BWD_DW>(a, as_stream(stream), "papc_pfn_bwd_dw_f32");
+}
+
+/* ---- Gram path (see the file header) ---- */
+int papc_pfn_gram_blocks(int P) { return P >= 1 ? (int)std::min<int64_t>(cdiv(P, PFN_GRAM_WAVES), PFN_GRAM_BLOCKS) : 0; }
+
+int papc_pfn_gram_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                      float vx, float vy, float x_offset, float y_offset, double *gram_partial, papc_stream_t stream)
+{
+    const float dummy = 0.f;
+    int rc = pfn_check("papc_pfn_gram_f32", features, num_voxels, coors, P, T, &dummy, 1);
+    if (rc) return rc;
+    PAPC_REQUIRE(gram_partial, PAPC_E_INVALID, "papc_pfn_gram_f32: null gram_partial");
+    PfnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
+    a.C = 1; a.gram = gram_partial;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_PFN, st);
+    hipLaunchKernelGGL((pfn_kernel<PFN_GRAM, PFN_GRAM_WAVES>), dim3(papc_pfn_gram_blocks(P)), dim3(64 * PFN_GRAM_WAVES), 0, st, a);
+    return check_launch("papc_pfn_gram_f32");
+}
+
+int papc_pfn_gram_finalize_f32(const double *gram_partial, int n_blocks, int64_t M, const float *w, int C, const float *gamma,
+                               const float *beta, float eps, float momentum, float *mean, float *invstd, float *scale, float *shift,
+                               float *running_mean, float *running_var, double *gram, papc_stream_t stream)
+{
+    PAPC_REQUIRE(gram_partial && gram, PAPC_E_INVALID, "papc_pfn_gram_finalize_f32: null pointer");
+    PAPC_REQUIRE(n_blocks >= 1 && M >= 1, PAPC_E_INVALID, "papc_pfn_gram_finalize_f32: bad sizes");
+    if (mean) {
+        PAPC_REQUIRE(w && invstd && scale && shift, PAPC_E_INVALID, "papc_pfn_gram_finalize_f32: null pointer");
+        PAPC_REQUIRE(C >= 1 && C <= 64, PAPC_E_UNSUPPORTED, "papc_pfn_gram_finalize_f32: C=%d not in [1,64]", C);
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_PFN, st);
+    hipLaunchKernelGGL(pfn_gram_finalize_kernel, dim3(1), dim3(1024), 0, st, gram_partial, n_blocks, (double)M, w, C, gamma, beta, eps, momentum,
+                       mean, invstd, scale, shift, running_mean, running_var, gram);
+    return check_launch("papc_pfn_gram_finalize_f32");
+}
+
+int papc_pfn_bwd_sparse_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P,
+                            int T, float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                            const float *gout, const int32_t *argmax, const float *mean, const float *invstd,
+                            const float *scale, const float *shift, float *partial, papc_stream_t stream)
+{
+    int rc = pfn_check("papc_pfn_bwd_sparse_f32", features, num_voxels, coors, P, T, w, C);
+    if (rc) return rc;
+    PAPC_REQUIRE(gout && argmax && mean && invstd && scale && shift && partial, PAPC_E_INVALID, "papc_pfn_bwd_sparse_f32: null pointer");
+    PfnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
+    a.w = w; a.C = C; a.gout = gout; a.amax = argmax; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.red = partial;
+    return launch_pfn<PFN_BWD_SPARSE>(a, as_stream(stream), "papc_pfn_bwd_sparse_f32");
+}
+
+int papc_pfn_bwd_finalize_f32(const float *sums, int64_t M, const float *w, int C, const double *gram, const float *mean,
+                              const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int eval_bn,
+                              papc_stream_t stream)
+{
+    PAPC_REQUIRE(sums && w && gram && mean && invstd && scale && dgamma && dbeta && dw, PAPC_E_INVALID, "papc_pfn_bwd_finalize_f32: null pointer");
+    PAPC_REQUIRE(C >= 1 && C <= 64 && M >= 1, PAPC_E_UNSUPPORTED, "papc_pfn_bwd_finalize_f32: C=%d not in [1,64]", C);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_PFN, st);
+    hipLaunchKernelGGL(pfn_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, sums, (double)M, w, C, gram, mean, invstd, scale, dgamma, dbeta, dw, eval_bn);
+    return check_launch("papc_pfn_bwd_finalize_f32");
 }
 
 }  // extern "C"

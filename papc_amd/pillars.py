@@ -31,15 +31,18 @@ class _PFNFused(torch.autograd.Function):
         C = w.shape[0]
         vx, vy, xo, yo = geom
         dev = features.device
-        nb = lib.papc_pfn_num_blocks(P)
         cst = torch.empty(4, C, device=dev, dtype=torch.float32)
+        gram = None
         if training:
-            stats = torch.empty(nb, 2, C, device=dev, dtype=torch.float32)
-            check(lib.papc_pfn_stats_f32(ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(w), C, ptr(stats),
-                                         None, st), "papc_pfn_stats_f32")
-            check(lib.papc_bn_finalize_f32(ptr(stats), nb, P * T, C, ptr(gamma), ptr(beta), eps, momentum, cst[0].data_ptr(),
-                                           cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), ptr(rmean), ptr(rvar), st),
-                  "papc_bn_finalize_f32")
+            # batch statistics from the inputs' Gram matrix (csrc/pfn.hip header): one float64-MFMA pass over the 19 MB of points
+            # instead of a 64-channel pass over [P*T, C]
+            ng = lib.papc_pfn_gram_blocks(P)
+            gpart = torch.empty(ng, 256, device=dev, dtype=torch.float64)
+            gram = torch.empty(256, device=dev, dtype=torch.float64)
+            check(lib.papc_pfn_gram_f32(ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(gpart), st), "papc_pfn_gram_f32")
+            check(lib.papc_pfn_gram_finalize_f32(ptr(gpart), ng, P * T, ptr(w), C, ptr(gamma), ptr(beta), eps, momentum, cst[0].data_ptr(),
+                                                 cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), ptr(rmean), ptr(rvar), ptr(gram), st),
+                  "papc_pfn_gram_finalize_f32")
         else:   # eval: running statistics, left untouched (self.norm is a registered BatchNorm1D in the source, :24)
             check(lib.papc_bn_eval_consts_f32(ptr(rmean), ptr(rvar), ptr(gamma), ptr(beta), eps, C, cst[0].data_ptr(),
                                               cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), st), "papc_bn_eval_consts_f32")
@@ -49,33 +52,34 @@ class _PFNFused(torch.autograd.Function):
                                      cst[2].data_ptr(), cst[3].data_ptr(), ptr(out), ptr(argmax), st), "papc_pfn_apply_f32")
         ctx.geom = geom
         ctx.training = bool(training)
-        ctx.save_for_backward(features, num_voxels, coors, w, cst, argmax)
+        ctx.save_for_backward(features, num_voxels, coors, w, cst, argmax, gram if gram is not None else cst.new_zeros(1))
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.load()
         st = stream_ptr()
-        features, num_voxels, coors, w, cst, argmax = ctx.saved_tensors
+        features, num_voxels, coors, w, cst, argmax, gram = ctx.saved_tensors
         vx, vy, xo, yo = ctx.geom
         P, T, _ = features.shape
         C = w.shape[0]
         dev = features.device
         gout = gout.contiguous().float()
         nb = lib.papc_pfn_num_blocks(P)
-        red = torch.empty(nb, 2, C, device=dev, dtype=torch.float32)
         geo = (ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(w), C)
         bn = (cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr())
-        check(lib.papc_pfn_bwd_reduce_f32(*geo, ptr(gout), ptr(argmax), *bn, ptr(red), st), "papc_pfn_bwd_reduce_f32")
+        if not ctx.training:       # eval-mode BN: only the sparse sums are needed, the Gram terms carry zero weight
+            gram = torch.zeros(256, device=dev, dtype=torch.float64)
+        # sparse pass (one argmax row per (pillar, channel)): sum p, sum p*xhat, sum p*x_k; the dense part of dW comes from G
+        part = torch.empty(nb, 11, C, device=dev, dtype=torch.float32)
+        check(lib.papc_pfn_bwd_sparse_f32(*geo, ptr(gout), ptr(argmax), *bn, ptr(part), st), "papc_pfn_bwd_sparse_f32")
+        sums = torch.empty(11, C, device=dev, dtype=torch.float32)
+        check(lib.papc_reduce_partials_f32(ptr(part), nb, 11 * C, ptr(sums), 0, st), "papc_reduce_partials_f32")
         dgb = torch.empty(2, C, device=dev, dtype=torch.float32)
-        c12 = torch.empty(2, C, device=dev, dtype=torch.float32)
-        check(lib.papc_bn_bwd_finalize_f32(ptr(red), nb, P * T, C, dgb[0].data_ptr(), dgb[1].data_ptr(), c12[0].data_ptr(),
-                                           c12[1].data_ptr(), 0 if ctx.training else 2, st), "papc_bn_bwd_finalize_f32")
-        dwp = torch.empty(nb, C, 9, device=dev, dtype=torch.float32)
-        check(lib.papc_pfn_bwd_dw_f32(*geo, ptr(gout), ptr(argmax), *bn, c12[0].data_ptr(), c12[1].data_ptr(), ptr(dwp), st),
-              "papc_pfn_bwd_dw_f32")
         dw = torch.empty(C, 9, device=dev, dtype=torch.float32)
-        check(lib.papc_reduce_partials_f32(ptr(dwp), nb, C * 9, ptr(dw), 0, st), "papc_reduce_partials_f32")
+        check(lib.papc_pfn_bwd_finalize_f32(ptr(sums), P * T, ptr(w), C, ptr(gram), cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
+                                            dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(dw), 0 if ctx.training else 1, st),
+              "papc_pfn_bwd_finalize_f32")
         return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None, None
 
 

@@ -210,3 +210,70 @@ def test_pfn_eval_uses_running_statistics(dev, filters):
         x = _torch_pfn_layer(x, l.linear.weight.double(), l.norm.weight.double(), l.norm.bias.double(), None, i == len(filters) - 1, True,
                              running=(l.norm.running_mean.double(), l.norm.running_var.double()))
     assert_close(out.detach().cpu().numpy(), x.squeeze().detach().cpu().numpy(), 1e-5, "eval PFN vs f64 torch")
+
+
+def test_pfn_gram_path_matches_two_pass_kernels(dev):
+    """The Gram path (BN statistics and dW from the inputs' 10x10 Gram matrix, float64 MFMA) against the dense two-pass entry points
+    (papc_pfn_stats_f32 + papc_bn_finalize_f32, papc_pfn_bwd_reduce_f32 + papc_bn_bwd_finalize_f32 + papc_pfn_bwd_dw_f32) on the full
+    config-5 frame (coordinates up to 70 m: the quadratic forms cancel), and the Gram matrix itself against float64 numpy."""
+    import ctypes
+    from papc_amd import _lib
+    lib = _lib.load()
+    P, T, C = 12000, 100, 64
+    voxels, nump, coors = make_pillars()
+    w, g, b = _weights(C, 9, 3)
+    vs, pr = (0.16, 0.16, 4), (0, -39.68, -3, 69.12, 39.68, 1)
+    geo = (vs[0], vs[1], vs[0] / 2 + pr[0], vs[1] / 2 + pr[1])
+    tv, tn, tc = torch.from_numpy(voxels).to(dev), torch.from_numpy(nump).to(dev), torch.from_numpy(coors).to(dev)
+    tw, tg, tb = torch.from_numpy(w).to(dev), torch.from_numpy(g).to(dev), torch.from_numpy(b).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    # dense two-pass statistics
+    nb = lib.papc_pfn_num_blocks(P)
+    stats = torch.empty(nb, 2, C, device=dev)
+    cst_a = torch.empty(4, C, device=dev)
+    _lib.check(lib.papc_pfn_stats_f32(p(tv), p(tn), p(tc), P, T, *geo, p(tw), C, p(stats), None, None), "stats")
+    _lib.check(lib.papc_bn_finalize_f32(p(stats), nb, P * T, C, p(tg), p(tb), 1e-3, 0.9, p(cst_a[0]), p(cst_a[1]), p(cst_a[2]), p(cst_a[3]),
+                                        None, None, None), "finalize")
+    # Gram path
+    ng = lib.papc_pfn_gram_blocks(P)
+    gpart = torch.empty(ng, 256, device=dev, dtype=torch.float64)
+    gram = torch.empty(256, device=dev, dtype=torch.float64)
+    cst_b = torch.empty(4, C, device=dev)
+    _lib.check(lib.papc_pfn_gram_f32(p(tv), p(tn), p(tc), P, T, *geo, p(gpart), None), "gram")
+    _lib.check(lib.papc_pfn_gram_finalize_f32(p(gpart), ng, P * T, p(tw), C, p(tg), p(tb), 1e-3, 0.9, p(cst_b[0]), p(cst_b[1]), p(cst_b[2]),
+                                              p(cst_b[3]), None, None, p(gram), None), "gram finalize")
+    rows = R.pillar_decorate(voxels, nump, coors, *geo).reshape(P * T, 9).astype(np.float64)
+    X = np.concatenate([rows, np.ones((P * T, 1))], axis=1)
+    G = gram.cpu().numpy().reshape(16, 16)
+    idx = list(range(9)) + [10]
+    Gref = X.T @ X
+    assert np.abs(G[np.ix_(idx, idx)] - Gref).max() <= 1e-5 * np.abs(Gref).max()   # (the cluster means differ in summation order: 2e-5 absolute on a row)
+    for i, name in enumerate(["mean", "invstd", "scale", "shift"]):
+        assert_close(cst_b[i].cpu().numpy(), cst_a[i].cpu().numpy(), 2e-5, "Gram vs dense " + name)
+    y64 = rows @ w.astype(np.float64).T
+    assert_close(cst_b[0].cpu().numpy(), y64.mean(0), 1e-5, "Gram mean vs f64")
+    assert_close(cst_b[1].cpu().numpy(), 1.0 / np.sqrt(y64.var(0) + 1e-3), 1e-5, "Gram invstd vs f64")
+    # backward: same gout / argmax through both
+    out = torch.empty(P, C, device=dev)
+    am = torch.empty(P, C, device=dev, dtype=torch.int32)
+    _lib.check(lib.papc_pfn_apply_f32(p(tv), p(tn), p(tc), P, T, *geo, p(tw), C, p(cst_a[2]), p(cst_a[3]), p(out), p(am), None), "apply")
+    torch.manual_seed(0)
+    gout = torch.randn(P, C, device=dev)
+    bn = (p(cst_a[0]), p(cst_a[1]), p(cst_a[2]), p(cst_a[3]))
+    red = torch.empty(nb, 2, C, device=dev)
+    dgb_a, c12 = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
+    _lib.check(lib.papc_pfn_bwd_reduce_f32(p(tv), p(tn), p(tc), P, T, *geo, p(tw), C, p(gout), p(am), *bn, p(red), None), "bwd reduce")
+    _lib.check(lib.papc_bn_bwd_finalize_f32(p(red), nb, P * T, C, p(dgb_a[0]), p(dgb_a[1]), p(c12[0]), p(c12[1]), 0, None), "bwd finalize")
+    dwp = torch.empty(nb, C, 9, device=dev)
+    dw_a = torch.empty(C, 9, device=dev)
+    _lib.check(lib.papc_pfn_bwd_dw_f32(p(tv), p(tn), p(tc), P, T, *geo, p(tw), C, p(gout), p(am), *bn, p(c12[0]), p(c12[1]), p(dwp), None), "dw")
+    _lib.check(lib.papc_reduce_partials_f32(p(dwp), nb, C * 9, p(dw_a), 0, None), "reduce")
+    part = torch.empty(nb, 11, C, device=dev)
+    sums = torch.empty(11, C, device=dev)
+    dgb_b, dw_b = torch.empty(2, C, device=dev), torch.empty(C, 9, device=dev)
+    _lib.check(lib.papc_pfn_bwd_sparse_f32(p(tv), p(tn), p(tc), P, T, *geo, p(tw), C, p(gout), p(am), *bn, p(part), None), "sparse")
+    _lib.check(lib.papc_reduce_partials_f32(p(part), nb, 11 * C, p(sums), 0, None), "reduce")
+    _lib.check(lib.papc_pfn_bwd_finalize_f32(p(sums), P * T, p(tw), C, p(gram), p(cst_a[0]), p(cst_a[1]), p(cst_a[2]), p(dgb_b[0]), p(dgb_b[1]),
+                                             p(dw_b), 0, None), "gram bwd finalize")
+    assert_close(dgb_b.cpu().numpy(), dgb_a.cpu().numpy(), 1e-5, "dgamma / dbeta")
+    assert_close(dw_b.cpu().numpy(), dw_a.cpu().numpy(), 2e-4, "Gram dW vs dense dW")
