@@ -74,6 +74,24 @@ struct StreamGeo {
 
 // AMODE: A_PLAIN, A_BNRELU, A_DY_DENSE, A_DY_MAX.  EPI: EPI_STORE, EPI_STORE_GMAX (forward), EPI_STORE_RED (dX).
 // KB16 = K / 16 k blocks, CK blocks per prefetch chunk, WN 32-column tiles per wave (N tile = 32 WN columns per workgroup).
+// ---- packed-f32 flavour of the operand transform + split (PAPC_STREAM_PK, default on).  A lane's 8 k values are 4 register pairs
+// (consecutive k, as the dwordx4 loads deliver them), so v_pk_fma_f32 / v_pk_add_f32 need no moves to form their 64-bit operands:
+// the BN fma, the BN-backward fmas and the two subtractions of the split each cost one instruction per PAIR.
+#ifndef PAPC_STREAM_PK
+#define PAPC_STREAM_PK 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// three bf16 planes of one pair: x = p0 + p1 + p2 exactly (see split3 in mlp_loaders.h)
+__device__ __forceinline__ void split3_pair(f32x2 x, unsigned &p0, unsigned &p1, unsigned &p2)
+{
+    p0 = pack_bf16x2(x.x, x.y);
+    x = x - f32x2{bf16_lo(p0), bf16_hi(p0)};
+    p1 = pack_bf16x2(x.x, x.y);
+    x = x - f32x2{bf16_lo(p1), bf16_hi(p1)};
+    p2 = pack_bf16x2(x.x, x.y);
+}
+
 template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM>
 __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo geo)
 {
@@ -219,6 +237,54 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             constexpr int blk = decltype(blk_)::value;
             constexpr int kb = ci * CK + blk;
             const f32x4 *r = &buf[bi][blk * NLD];
+            bf16x8 af[3];
+#if PAPC_STREAM_PK
+            {
+                f32x2 v2[4];   // pairs (k, k+1): r[0] = k 0..3, r[1] = k 4..7 of this lane's half block
+                if constexpr (AMODE == A_PLAIN) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v2[j] = f32x2{r[j >> 1][2 * (j & 1)], r[j >> 1][2 * (j & 1) + 1]};
+                } else if constexpr (AMODE == A_BNRELU) {
+                    const f32x4 s0 = *reinterpret_cast<const f32x4 *>(cl + kb * 64), s1 = *reinterpret_cast<const f32x4 *>(cl + kb * 64 + 16);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64), h1 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64 + 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int h = j >> 1, i = 2 * (j & 1);
+                        const f32x4 sc = h ? s1 : s0, sh = h ? h1 : h0;
+                        const f32x2 t = pk_fma(f32x2{sc[i], sc[i + 1]}, f32x2{r[h][i], r[h][i + 1]}, f32x2{sh[i], sh[i + 1]});
+                        v2[j] = f32x2{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f)};
+                    }
+                } else {
+                    f32x4 c[5][2];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        c[q][0] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64);
+                        c[q][1] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64 + 16);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int h = j >> 1, i = 2 * (j & 1);
+                        const f32x2 y = f32x2{r[h][i], r[h][i + 1]};
+                        f32x2 dz = f32x2{r[2 + h][i], r[2 + h][i + 1]};
+                        if constexpr (AMODE == A_DY_MAX) {
+                            dz.x = (__float_as_int(r[4 + h][i]) == kin) ? dz.x : 0.f;
+                            dz.y = (__float_as_int(r[4 + h][i + 1]) == kin) ? dz.y : 0.f;
+                        }
+                        const f32x2 c0 = f32x2{c[0][h][i], c[0][h][i + 1]};
+                        const f32x2 z = pk_fma(c0, y, f32x2{c[1][h][i], c[1][h][i + 1]});
+                        const f32x2 pp = f32x2{z.x > 0.f ? dz.x : 0.f, z.y > 0.f ? dz.y : 0.f};
+                        const f32x2 inner = pk_fma(c0, pp, -f32x2{c[3][h][i], c[3][h][i + 1]});
+                        v2[j] = pk_fma(-f32x2{c[4][h][i], c[4][h][i + 1]}, y - f32x2{c[2][h][i], c[2][h][i + 1]}, inner);
+                    }
+                }
+                unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split3_pair(v2[j], q0[j], q1[j], q2[j]);
+                af[0] = __builtin_bit_cast(bf16x8, make_uint4(q0[0], q0[1], q0[2], q0[3]));
+                af[1] = __builtin_bit_cast(bf16x8, make_uint4(q1[0], q1[1], q1[2], q1[3]));
+                af[2] = __builtin_bit_cast(bf16x8, make_uint4(q2[0], q2[1], q2[2], q2[3]));
+            }
+#else
             float v[8];
             if constexpr (AMODE == A_PLAIN) {
 #pragma unroll
@@ -253,10 +319,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             uint2 a0, a1, a2, b0, b1, b2;
             split3(make_float4(v[0], v[1], v[2], v[3]), a0, a1, a2);
             split3(make_float4(v[4], v[5], v[6], v[7]), b0, b1, b2);
-            bf16x8 af[3];
             af[0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
             af[1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
             af[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+#endif
             bf16x8 bq[WN][3];
 #pragma unroll
             for (int wn = 0; wn < WN; ++wn)
