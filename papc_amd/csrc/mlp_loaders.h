@@ -310,13 +310,25 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
 // planes p0 (leading), p1, p2 of four consecutive-k values, each as 4 packed bf16 (8 bytes)
+#ifndef PAPC_SPLIT_PK
+#define PAPC_SPLIT_PK 0   // 1: the two exact subtractions of a pair as one v_pk_add_f32 -- measured SLOWER in the LDS-staged kernels (dW family 0.85 -> 0.90 ms/step: the producers pay moves to form aligned register pairs); the row-streaming kernel, whose pairs are natural, uses its own split3_pair
+#endif
 __device__ __forceinline__ void split3(float4 v, uint2 &p0, uint2 &p1, uint2 &p2)
 {
+#if PAPC_SPLIT_PK
+    floatx2_t a = {v.x, v.y}, b = {v.z, v.w};
+    p0.x = pack_bf16x2(a.x, a.y); p0.y = pack_bf16x2(b.x, b.y);
+    a = a - floatx2_t{bf16_lo(p0.x), bf16_hi(p0.x)}; b = b - floatx2_t{bf16_lo(p0.y), bf16_hi(p0.y)};
+    p1.x = pack_bf16x2(a.x, a.y); p1.y = pack_bf16x2(b.x, b.y);
+    a = a - floatx2_t{bf16_lo(p1.x), bf16_hi(p1.x)}; b = b - floatx2_t{bf16_lo(p1.y), bf16_hi(p1.y)};
+    p2.x = pack_bf16x2(a.x, a.y); p2.y = pack_bf16x2(b.x, b.y);
+#else
     p0.x = pack_bf16x2(v.x, v.y); p0.y = pack_bf16x2(v.z, v.w);
     v.x -= bf16_lo(p0.x); v.y -= bf16_hi(p0.x); v.z -= bf16_lo(p0.y); v.w -= bf16_hi(p0.y);
     p1.x = pack_bf16x2(v.x, v.y); p1.y = pack_bf16x2(v.z, v.w);
     v.x -= bf16_lo(p1.x); v.y -= bf16_hi(p1.x); v.z -= bf16_lo(p1.y); v.w -= bf16_hi(p1.y);
     p2.x = pack_bf16x2(v.x, v.y); p2.y = pack_bf16x2(v.z, v.w);
+#endif
 }
 
 }  // namespace papc
