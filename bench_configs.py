@@ -79,7 +79,7 @@ def run(args):
         B, N = 16, 2048
         model = PointNet2_MSG_Seg().to(dev).train()
         x = torch.from_numpy(make_clouds(B, N, 3)).to(dev)
-        cls = (torch.arange(B).reshape(B, 1) % 16).numpy()
+        cls = (torch.arange(B).reshape(B, 1) % 16).to(dev)      # (resident like the points: a host array would be an H2D copy per step)
         tgt = torch.randint(0, 50, (B * N,), device=dev)
         st = (torch.from_numpy(make_start_idx(B, N, 3)).to(dev), torch.from_numpy(make_start_idx(B, 512, 4)).to(dev))
         from papc_amd.head import softmax_cross_entropy

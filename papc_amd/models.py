@@ -170,7 +170,8 @@ class PointNet_Basic_Clas(nn.Module):
 def Categorical(y, num_class=16):
     """pointnet2_basic_layers.py:7-14: class labels [B,1] (or [B]) -> one-hot float32 [B,num_class,1]."""
     y = torch.as_tensor(y).long().reshape(-1)
-    return F.one_hot(y, num_class).to(torch.float32).unsqueeze(2)
+    # (a comparison instead of F.one_hot: that one reads min / max back to the host, which a hipGraph capture cannot contain)
+    return (y.reshape(-1, 1) == torch.arange(num_class, device=y.device).reshape(1, -1)).to(torch.float32).unsqueeze(2)
 
 
 class _PartSegBase(nn.Module):
