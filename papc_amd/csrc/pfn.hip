@@ -65,6 +65,7 @@ __device__ __forceinline__ PfnRaw pfn_fetch(const PfnArgs &a, int p, int lane)
     return r;
 }
 
+template <bool DIST = true>
 __device__ __forceinline__ void pfn_stage_from(const PfnArgs &a, const PfnRaw &raw, float *rows, int lane)
 {
     const int T = a.T;
@@ -90,14 +91,16 @@ __device__ __forceinline__ void pfn_stage_from(const PfnArgs &a, const PfnRaw &r
             *reinterpret_cast<float4 *>(r) = make_float4(v.x * mk, v.y * mk, v.z * mk, v.w * mk);
             *reinterpret_cast<float4 *>(r + 4) = make_float4((v.x - mx) * mk, (v.y - my) * mk, (v.z - mz) * mk, (v.x - pcx) * mk);
             // (slot 9: points_dist = paddle.norm(features[:, :, :3], 2, 2) of the with_distance variant, :92-94)
-            *reinterpret_cast<float4 *>(r + 8) = make_float4((v.y - pcy) * mk, sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z) * mk, 0.f, 0.f);
+            // (DIST = false: the passes of the 9-channel layer never read the slot; a correctly rounded sqrt is ~30 instructions)
+            *reinterpret_cast<float4 *>(r + 8) = make_float4((v.y - pcy) * mk, DIST ? sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z) * mk : 0.f, 0.f, 0.f);
         }
     }
 }
 
+template <bool DIST = true>
 __device__ __forceinline__ void pfn_stage(const PfnArgs &a, int p, float *rows, int lane)
 {
-    pfn_stage_from(a, pfn_fetch(a, p, lane), rows, lane);
+    pfn_stage_from<DIST>(a, pfn_fetch(a, p, lane), rows, lane);
 }
 
 __device__ __forceinline__ float pfn_dot(const float *r, const float (&w)[9])
@@ -145,9 +148,9 @@ __global__ __launch_bounds__(64 * WAVES) void pfn_kernel(PfnArgs a)
             const PfnRaw cur = nxt;
             const int pn = p + gridDim.x * PFN_WAVES;
             if (pn < a.P) nxt = pfn_fetch(a, pn, lane);
-            pfn_stage_from(a, cur, rows, lane);
+            pfn_stage_from<false>(a, cur, rows, lane);
         } else {
-            pfn_stage(a, p, rows, lane);
+            pfn_stage<MODE == PFN_DECORATE>(a, p, rows, lane);
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -266,6 +269,137 @@ __global__ __launch_bounds__(64 * WAVES) void pfn_kernel(PfnArgs a)
             else if (MODE == PFN_STATS) a.stats[((int64_t)blockIdx.x * 2 + i) * a.C + c] = s;
             else a.red[((int64_t)blockIdx.x * 2 + i) * a.C + c] = s;
         }
+    }
+}
+
+// ---- apply pass on the bf16 matrix pipe -------------------------------------------------------------------------------
+// y [T, C] = X [T, 9] W^T for one pillar is 4 row tiles x 2 column tiles of v_mfma_f32_32x32x16_bf16 with the fp32 operands as
+// exact 3-way bf16 splits (6 products, fp32 accumulate: mlp_loaders.h).  K = 9 pads to ONE 16-wide k block: lane (row = lane & 31,
+// half = lane >> 5) feeds channels 0..7 / 8..15 of its row straight from the decorated LDS slab; W^T lives in registers for the
+// whole kernel.  The accumulator layout (lane = output channel, 16 rows per lane) is exactly what BN + ReLU + max over the T rows
+// want: z = fma(scale, y, shift) and a running (max, first row) per lane, one cross-half merge per pillar.  The lanes-are-channels
+// VALU form of this pass (pfn_kernel<PFN_APPLY>) spends 19 instructions per row and channel-wave; this one ~6.
+typedef __bf16 pfn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pfn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pfn_f32x2 __attribute__((ext_vector_type(2)));
+typedef float pfn_f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned pfn_pack2(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((pfn_f32x2){a, b}, pfn_bf16x2));
+}
+// three bf16 planes of 8 consecutive-k values: v = pl[0] + pl[1] + pl[2] exactly
+__device__ __forceinline__ void pfn_split8(const float (&vin)[8], pfn_bf16x8 (&pl)[3])
+{
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = vin[i];
+    unsigned q[3][4];
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned u = pfn_pack2(v[2 * j], v[2 * j + 1]);
+            q[lvl][j] = u;
+            v[2 * j] -= __uint_as_float(u << 16);
+            v[2 * j + 1] -= __uint_as_float(u & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < 3; ++lvl) pl[lvl] = __builtin_bit_cast(pfn_bf16x8, make_uint4(q[lvl][0], q[lvl][1], q[lvl][2], q[lvl][3]));
+}
+
+__global__ __launch_bounds__(64 * PFN_WAVES) void pfn_apply_mfma_kernel(PfnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[PFN_WAVES * PFN_TMAX * PFN_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    float *rows = smem + wave * PFN_TMAX * PFN_LD;
+
+    // B operand: lane (n = l31, half) holds W[32 wn + n][8 half .. 8 half + 7]  (k >= 9 and channels >= C are zero)
+    pfn_bf16x8 bq[2][3];
+    float sc[2], sh[2];
+#pragma unroll
+    for (int wn = 0; wn < 2; ++wn) {
+        const int c = wn * 32 + l31;
+        float wv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * hi + j;
+            wv[j] = (c < a.C && k < 9) ? a.w[c * 9 + k] : 0.f;
+        }
+        pfn_split8(wv, bq[wn]);
+        sc[wn] = c < a.C ? a.scale[c] : 0.f;
+        sh[wn] = c < a.C ? a.shift[c] : 0.f;
+    }
+    const int nt = (a.T + 31) >> 5;
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+
+    PfnRaw nxt = {};
+    if ((int)(blockIdx.x * PFN_WAVES + wave) < a.P) nxt = pfn_fetch(a, blockIdx.x * PFN_WAVES + wave, lane);
+    for (int p = blockIdx.x * PFN_WAVES + wave; p < a.P; p += gridDim.x * PFN_WAVES) {
+        const PfnRaw cur = nxt;
+        const int pn = p + gridDim.x * PFN_WAVES;
+        if (pn < a.P) nxt = pfn_fetch(a, pn, lane);      // the next pillar's points fly under this pillar's tiles
+        pfn_stage_from<false>(a, cur, rows, lane);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float best[2] = {0.f, 0.f};   // max_t relu(z_t): starts at relu's floor, row 0 (what a strict `>` scan from -1 over relu(z) ends with)
+        int bi[2] = {0, 0};
+        for (int t = 0; t < nt; ++t) {
+            // A operand of row 32 t + l31: channels 8 half .. 8 half + 7 (slab row = 12 floats: the upper half's second quad is past the row)
+            const float *r = rows + (32 * t + l31) * PFN_LD + 8 * hi;
+            const float4 x0 = *reinterpret_cast<const float4 *>(r);
+            float4 x1 = *reinterpret_cast<const float4 *>(rows + (32 * t + l31) * PFN_LD + 4);
+            if (hi) x1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            pfn_bf16x8 af[3];
+            pfn_split8(xv, af);
+            const bool full = 32 * (t + 1) <= a.T;
+#pragma unroll
+            for (int wn = 0; wn < 2; ++wn) {
+                pfn_f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[m]], bq[wn][PB[m]], acc, 0, 0, 0);
+                // C/D layout: column = l31, row = (q & 3) + 8 (q >> 2) + 4 half -- ascending in q
+                if (full) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = 32 * t + (q & 3) + 8 * (q >> 2) + 4 * hi;
+                        const float z = fmaf(sc[wn], acc[q], sh[wn]);
+                        const bool up = z > best[wn];
+                        best[wn] = up ? z : best[wn];
+                        bi[wn] = up ? row : bi[wn];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = 32 * t + (q & 3) + 8 * (q >> 2) + 4 * hi;
+                        const float z = fmaf(sc[wn], acc[q], sh[wn]);
+                        const bool up = row < a.T && z > best[wn];
+                        best[wn] = up ? z : best[wn];
+                        bi[wn] = up ? row : bi[wn];
+                    }
+                }
+            }
+        }
+        // the two halves of a lane pair hold disjoint rows of the same column: larger z wins, the earlier row on a tie
+#pragma unroll
+        for (int wn = 0; wn < 2; ++wn) {
+            const float ob = __shfl_xor(best[wn], 32);
+            const int oi = __shfl_xor(bi[wn], 32);
+            const bool take = ob > best[wn] || (ob == best[wn] && oi < bi[wn]);
+            const float fb = take ? ob : best[wn];
+            const int fi = take ? oi : bi[wn];
+            const int c = wn * 32 + l31;
+            if (hi == 0 && c < a.C) {
+                a.out[(int64_t)p * a.C + c] = fb;
+                if (a.argmax) a.argmax[(int64_t)p * a.C + c] = fi;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -433,6 +567,12 @@ int papc_pfn_apply_f32(const float *features, const int32_t *num_voxels, const i
     memset(&a, 0, sizeof(a));
     a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
     a.w = w; a.C = C; a.scale = scale; a.shift = shift; a.out = out; a.argmax = argmax;
+    if (knob(KNOB_PFN_MFMA)) {   // default: the matrix-pipe flavour (PAPC_PFN_MFMA=0: lanes-are-channels VALU flavour)
+        hipStream_t st = as_stream(stream);
+        ProfScope prof(PAPC_K_PFN, st);
+        hipLaunchKernelGGL(pfn_apply_mfma_kernel, dim3(pfn_blocks(P)), dim3(64 * PFN_WAVES), 0, st, a);
+        return check_launch("papc_pfn_apply_f32");
+    }
     return launch_pfn<PFN_APPLY>(a, as_stream(stream), "papc_pfn_apply_f32");
 }
 

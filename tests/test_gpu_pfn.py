@@ -277,3 +277,42 @@ def test_pfn_gram_path_matches_two_pass_kernels(dev):
                                              p(dw_b), 0, None), "gram bwd finalize")
     assert_close(dgb_b.cpu().numpy(), dgb_a.cpu().numpy(), 1e-5, "dgamma / dbeta")
     assert_close(dw_b.cpu().numpy(), dw_a.cpu().numpy(), 2e-4, "Gram dW vs dense dW")
+
+
+@pytest.mark.parametrize("P,T,C", [(12000, 100, 64), (37, 128, 64), (64, 33, 48), (5, 1, 64)])
+def test_pfn_apply_mfma_matches_valu_flavour(dev, P, T, C):
+    """papc_pfn_apply_f32 on the bf16 matrix pipe (exact 3-way split, PAPC_PFN_MFMA=1, the default) against the lanes-are-channels
+    fp32 fma-chain flavour: same max values to fp32 rounding, same argmax rows except where two rows tie to rounding, ragged T, C < 64,
+    negative BN scales."""
+    import ctypes
+    from papc_amd import _lib
+    lib = _lib.load()
+    voxels, nump, coors = make_pillars(P=P, T=T, seed=21)
+    w, g, b = _weights(C, 9, 5)
+    geo = (0.16, 0.16, 0.08, -39.6)
+    tv, tn, tc = torch.from_numpy(voxels).to(dev), torch.from_numpy(nump).to(dev), torch.from_numpy(coors).to(dev)
+    tw = torch.from_numpy(w).to(dev)
+    sc, sh = torch.from_numpy(g).to(dev) * 0.7, torch.from_numpy(b).to(dev) - 0.2
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    res = {}
+    try:
+        for flav in (0, 1):
+            _lib.check(lib.papc_knob_set(b"PAPC_PFN_MFMA", flav), "knob")
+            out = torch.full((P, C), -7.0, device=dev)
+            am = torch.full((P, C), -7, device=dev, dtype=torch.int32)
+            _lib.check(lib.papc_pfn_apply_f32(p(tv), p(tn), p(tc), P, T, *geo, p(tw), C, p(sc), p(sh), p(out), p(am), None), "apply")
+            res[flav] = (out.cpu().numpy(), am.cpu().numpy())
+    finally:
+        _lib.check(lib.papc_knob_set(b"PAPC_PFN_MFMA", 1), "knob")
+    (o0, a0), (o1, a1) = res[0], res[1]
+    assert (o1 >= 0).all() and (a1 >= 0).all() and (a1 < T).all()
+    assert_close(o1, o0, 2e-6, "MFMA apply vs VALU apply")
+    differ = a0 != a1
+    assert differ.mean() <= 2e-3, differ.mean()          # argmax rows: equal except at rounding-level ties
+    if differ.any():                                     # ... and where they differ the two rows' values tie to rounding
+        rows = R.pillar_decorate(voxels, nump, coors, *geo).astype(np.float64)
+        pi, ci = np.nonzero(differ)
+        y0 = np.einsum("nk,nk->n", rows[pi, a0[pi, ci]], w[ci].astype(np.float64))
+        y1 = np.einsum("nk,nk->n", rows[pi, a1[pi, ci]], w[ci].astype(np.float64))
+        z0, z1 = y0 * sc.cpu().numpy()[ci] + sh.cpu().numpy()[ci], y1 * sc.cpu().numpy()[ci] + sh.cpu().numpy()[ci]
+        assert np.all(np.abs(z0 - z1) <= 1e-5 * (1 + np.abs(z0)) + (np.maximum(z0, z1) <= 1e-6))   # (both dead -> row 0 either way)
