@@ -180,10 +180,11 @@ __global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
             const float invstd = 1.0f / sqrtf(var + a.eps);
             a.mean[c] = mean;
             a.invstd[c] = invstd;
-            if (a.running_mean) {     // nn.BatchNorm1D train step: unbiased variance into the running estimate
-                const float unb = a.B > 1 ? v / (float)(a.B - 1) : var;
+            if (a.running_mean) {     // paddle.nn.BatchNorm1D train step (classify/pointnet2/pointnet2.py:18,21): the BIASED batch variance goes
+                                      // into the running estimate (torch would use the unbiased one) -- the convention of every other
+                                      // BatchNorm in this library, and what a .pdparams exchanged with the reference carries
                 a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * var;
             }
             s_mean[tid] = mean;
             s_scale[tid] = invstd * a.gamma[c];

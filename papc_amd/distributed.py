@@ -52,6 +52,10 @@ class FlatParams:
                 self.data[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.data[off:off + k].view(p.shape)
                 p.grad = self.grad[off:off + k].view(p.shape)
+                # opt in to the kernels' in-place gradient accumulation (mlp.grad_targets_of): this container owns the gradient
+                # reduction itself (allreduce_grads); do NOT wrap such a module in torch's DistributedDataParallel or hang
+                # post-accumulate-grad hooks on its parameters
+                p._papc_inplace_grad = True
                 off += k
 
     def offset_of(self, module):

@@ -387,12 +387,18 @@ class SharedMLPMax(torch.autograd.Function):
 
 
 def grad_targets_of(params):
-    """The parameters' existing contiguous fp32 .grad tensors (e.g. views of distributed.FlatParams.grad), or None
-    if any is missing.  With targets the backward adds each gradient in place (one fused accumulate in the reduce
+    """The .grad tensors of parameters that opted in to in-place accumulation (views of distributed.FlatParams.grad), or None
+    if any parameter has not.  With targets the backward adds each gradient in place (one fused accumulate in the reduce
     kernels) and hands autograd ``None``: no per-parameter AccumulateGrad add kernels."""
     tg = []
     for p in params:
         if not isinstance(p, torch.nn.Parameter):   # e.g. a zero-padded view of a weight: gradients go back through autograd
+            return None
+        # explicit opt-in (distributed.FlatParams marks its parameters): writing .grad behind autograd's back skips AccumulateGrad
+        # hooks, so torch's DistributedDataParallel, post-accumulate hooks, torch.autograd.grad() and checkpoint recomputation would
+        # miss or double-count these gradients -- a parameter that merely HAS a .grad (second step of any plain optimizer loop) does
+        # not qualify
+        if not getattr(p, "_papc_inplace_grad", False):
             return None
         g = p.grad
         if not (p.requires_grad and g is not None and g.is_contiguous()

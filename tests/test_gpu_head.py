@@ -30,7 +30,7 @@ def _ref64(x0, mods, keeps, glogits):
     for (w, b, g, be), keep, p in ((prm[0:4], keeps[0], d1.p), (prm[4:8], keeps[1], d2.p)):
         y = h @ w.t() + b
         mean, var = y.mean(0), y.var(0, unbiased=False)
-        stats.append((mean.detach(), y.var(0, unbiased=True).detach()))
+        stats.append((mean.detach(), var.detach()))   # paddle's running estimate takes the BIASED batch variance
         h = torch.relu((y - mean) / torch.sqrt(var + 1e-5) * g + be) * keep.double().cpu() / (1.0 - p)
     logits = h @ prm[8].t() + prm[9]
     logits.backward(glogits.double().cpu())
@@ -83,9 +83,9 @@ def test_head_matches_float64(B, c3, accumulate, dims):
         else:
             close(got, w, 5e-5 if accumulate else 2e-5)
     m = 0.1
-    for (mean, unb), (rm, rv), bn in zip(stats, ((rm0[0], rm0[1]), (rm0[2], rm0[3])), (bn1, bn2)):
+    for (mean, bvar), (rm, rv), bn in zip(stats, ((rm0[0], rm0[1]), (rm0[2], rm0[3])), (bn1, bn2)):
         close(bn.running_mean, (1 - m) * rm.double().cpu() + m * mean)
-        close(bn.running_var, (1 - m) * rv.double().cpu() + m * unb)
+        close(bn.running_var, (1 - m) * rv.double().cpu() + m * bvar)
         assert int(bn.num_batches_tracked.item()) == 1
 
 
