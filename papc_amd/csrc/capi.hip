@@ -55,6 +55,7 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_STREAM_CK", 0, 0, 8},           // k blocks per prefetch chunk (0 = per shape)
     {"PAPC_STREAM_ASM", 1, 0, 1},          // operand loads hidden from hipcc's waitcnt pass (hand-counted vmcnt)
     {"PAPC_PFN_MFMA", 1, 0, 1},            // PillarFeatureNet apply pass on the bf16 matrix pipe (0: lanes-are-channels VALU flavour)
+    {"PAPC_DW_RS64", 1, 0, 1},             // dW of 64 x 64 layers: 64-row stages (all producer threads busy)
 };
 static int g_knobs[KNOB_COUNT];
 static int knob_parse(int id, const char *e)

@@ -248,13 +248,18 @@ __global__ __launch_bounds__(256, 2) void dw_kernel(DwArgs p)
 // in: a producer thread owns a 4-row x 4-channel block, builds per channel the 4 consecutive-row values, splits them and
 // writes 8 bytes per plane.  Lane l of a consumer reads its operand (channel tile*32 + (l&31), rows 8*(l>>5)..+7) with
 // one ds_read_b128 per plane.
-template <int XMODE, int DYMODE, int NTO, int NTI>
+template <int XMODE, int DYMODE, int NTO, int NTI, int RS = 32>
 __global__ __launch_bounds__(768, 3) void dw_ws_kernel(DwArgs p)
 {
     constexpr int TO = NTO * 64, TI = NTI * 64;   // padded tile widths handled by this instantiation
-    // a stage is 32 rows = two k blocks; BOTH producer groups work in every slot (group g on rows 16g..16g+15 of the stage):
-    // a SIMD needs two active waves to keep its VALU busy, a lone producer wave issues only every ~8-10 cycles
-    constexpr int RS = 32, G = 2, ROWB = 3 * RS * 2 + 16;
+    // a stage is RS = 32 rows = two k blocks; BOTH producer groups work in every slot (group g on rows 16g..16g+15 of the stage):
+    // a SIMD needs two active waves to keep its VALU busy, a lone producer wave issues only every ~8-10 cycles.
+    // RS = 64 (64 x 64 tiles only): with 128 operand channels a 32-row stage has work for HALF of the 512 producer threads, so the
+    // narrow layers take 64-row stages (each group 32 rows: all producers busy, half as many barriers)
+    static_assert(RS == 32 || (RS == 64 && TO == 64 && TI == 64), "64-row stages: 64 x 64 tiles");
+    constexpr int G = 2, ROWB = 3 * RS * 2 + 16;
+    constexpr int HG = RS / G;          // rows of a stage handled by one producer group
+    constexpr int RQ = HG / 4;          // row quads per group (4 or 8)
     constexpr int STAGE_B = (TO + TI) * ROWB;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_B];
 
@@ -273,12 +278,14 @@ __global__ __launch_bounds__(768, 3) void dw_ws_kernel(DwArgs p)
         // A block = 4 consecutive rows x 4 consecutive channels; the channel quad is fixed for the whole kernel, so the BN
         // constants are loaded (and pre-folded) once.
         // (TO and TI are multiples of 64, so the role is the same for a whole wave: make that visible to the compiler)
-        const bool isy = __builtin_amdgcn_readfirstlane((int)(lt < TO)) != 0;
-        const bool isx = !isy && __builtin_amdgcn_readfirstlane((int)(lt < TO + TI)) != 0;
-        const int lb = isy ? lt : lt - TO;
+        constexpr int NTY = TO * RQ / 4, NTX = TI * RQ / 4;   // threads carrying dY / X blocks (multiples of 64)
+        static_assert(NTY + NTX <= 256, "a producer group has 256 threads");
+        const bool isy = __builtin_amdgcn_readfirstlane((int)(lt < NTY)) != 0;
+        const bool isx = !isy && __builtin_amdgcn_readfirstlane((int)(lt < NTY + NTX)) != 0;
+        const int lb = isy ? lt : lt - NTY;
         // a wave covers 16 channel quads x all 4 row quads: its 8-byte LDS writes then spread over 32 of the 64 banks
         // (the 112-byte channel stride maps channel quads to only 4 distinct bank offsets; the row quads supply the rest)
-        const int cq = (lb & 15) + 16 * (lb >> 6), rq = (lb >> 4) & 3;   // channel quad, row quad (0..3)
+        const int cq = (lb & 15) + 16 * (lb / (16 * RQ)), rq = (lb >> 4) & (RQ - 1);   // channel quad, row quad (0..RQ-1)
         const int ch = (isy ? o0 : i0) + cq * 4;           // first global channel of the block
         const int C = isy ? p.Cout : p.Cin;
         const bool chok = ch < C;                          // VEC shapes: C % 4 == 0, so a quad is all in or all out
@@ -297,14 +304,14 @@ __global__ __launch_bounds__(768, 3) void dw_ws_kernel(DwArgs p)
             ksc = ld4(p.x.sc + chc); ksh = ld4(p.x.sh + chc);
         }
         if (!chok) { ksc = ksh = kmu = kA = kB = make_float4(0.f, 0.f, 0.f, 0.f); }
-        char *const wbase = smem + ((isy ? 0 : TO) + cq * 4) * ROWB + pgrp * 32 + rq * 8;   // plane-relative: row 16*pgrp + 4*rq
+        char *const wbase = smem + ((isy ? 0 : TO) + cq * 4) * ROWB + pgrp * (HG * 2) + rq * 8;   // plane-relative: row HG*pgrp + 4*rq
 
         // addressing: workgroup-uniform chunk bases + 32-bit per-thread byte offsets (the host guarantees rows_per_chunk * ld * 4 < 2^31)
         const int64_t ld = isy ? (int64_t)p.Cout : p.x.ldx;
         const char *const b0 = reinterpret_cast<const char *>(isy ? p.dy.d.y + mbeg * p.Cout : p.x.x + mbeg * p.x.ldx);
         const char *const b1 = reinterpret_cast<const char *>(p.dy.d.dz ? p.dy.d.dz + mbeg * p.Cout : p.dy.d.y);   // DENSE only
         const uint32_t ldb = (uint32_t)ld * 4u;
-        uint32_t off = (uint32_t)(pgrp * 16 + rq * 4) * ldb + (uint32_t)chc * 4u;   // row 0 of this thread's block in its next stage
+        uint32_t off = (uint32_t)(pgrp * HG + rq * 4) * ldb + (uint32_t)chc * 4u;   // row 0 of this thread's block in its next stage
         const uint32_t adv = (uint32_t)RS * ldb;
 
         float4 ry[4], rz[4];   // raw rows: x | y, and dz (DENSE)
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(768, 3) void dw_ws_kernel(DwArgs p)
         int nvalid = 4;      // rows of the block that exist (ragged last stage only)
         auto issue = [&]() {
             if (s_next < n_stages && (isy || isx)) {
-                const int64_t m0 = mbeg + (int64_t)s_next * RS + pgrp * 16 + rq * 4;
+                const int64_t m0 = mbeg + (int64_t)s_next * RS + pgrp * HG + rq * 4;
                 const int64_t left = mend - m0;
                 nvalid = left >= 4 ? 4 : (left > 0 ? (int)left : 0);
 #pragma unroll
@@ -587,6 +594,7 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
         if (to > 2 && ti > 2) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 2, 2>), grid, dim3(768), 0, st, p);
         else if (to > 2) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 2, 1>), grid, dim3(768), 0, st, p);
         else if (ti > 2) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 1, 2>), grid, dim3(768), 0, st, p);
+        else if (knob(KNOB_DW_RS64)) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 1, 1, 64>), grid, dim3(768), 0, st, p);   // 64 x 64 tiles: 64-row stages
         else hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 1, 1>), grid, dim3(768), 0, st, p);
         if (dbg_on) dw_dbg_report(p, XMODE, DYMODE);
         return check_launch("papc_mlp_bwd_dw_f32");
