@@ -56,11 +56,17 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restri
     const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
-    r1[tl][cl] = s1; r2[tl][cl] = s2;
+    // fixed-shape reduction over the 64 part-lanes (deterministic): the 4 part-lanes of a wave by two shuffles, the 16 waves through
+    // LDS and ONE barrier (a 6-level LDS tree cost seven barriers: ~2 us of a ~6 us, launch-latency-sized kernel that runs 18x per step)
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if ((threadIdx.x & 63) < 16) { r1[threadIdx.x >> 6][cl] = s1; r2[threadIdx.x >> 6][cl] = s2; }
     __syncthreads();
-    for (int h = 32; h >= 1; h >>= 1) {  // fixed-shape tree over the 64 part-lanes (deterministic)
-        if (tl < h) { r1[tl][cl] += r1[tl + h][cl]; r2[tl][cl] += r2[tl + h][cl]; }
-        __syncthreads();
+    if (tl == 0) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { t1 += r1[w][cl]; t2 += r2[w][cl]; }
+        r1[0][cl] = t1; r2[0][cl] = t2;   // (only this thread reads them back)
     }
     if (tl == 0 && c < C) {
         s1 = r1[0][cl]; s2 = r2[0][cl];
@@ -232,11 +238,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__re
     const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
-    r1[tl][cl] = s1; r2[tl][cl] = s2;
+    // fixed-shape reduction over the 64 part-lanes (deterministic): the 4 part-lanes of a wave by two shuffles, the 16 waves through
+    // LDS and ONE barrier (a 6-level LDS tree cost seven barriers: ~2 us of a ~6 us, launch-latency-sized kernel that runs 18x per step)
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if ((threadIdx.x & 63) < 16) { r1[threadIdx.x >> 6][cl] = s1; r2[threadIdx.x >> 6][cl] = s2; }
     __syncthreads();
-    for (int h = 32; h >= 1; h >>= 1) {  // fixed-shape tree over the 64 part-lanes (deterministic)
-        if (tl < h) { r1[tl][cl] += r1[tl + h][cl]; r2[tl][cl] += r2[tl + h][cl]; }
-        __syncthreads();
+    if (tl == 0) {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { t1 += r1[w][cl]; t2 += r2[w][cl]; }
+        r1[0][cl] = t1; r2[0][cl] = t2;   // (only this thread reads them back)
     }
     if (tl == 0 && c < C) {
         s1 = r1[0][cl]; s2 = r2[0][cl];
