@@ -254,6 +254,16 @@ int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, floa
                              papc_stream_t stream);
 /* two outputs from ONE partial buffer whose chunk rows are [n1 | n2] floats with row stride ld (the dW and db
  * partials of papc_mlp_bwd_dw_f32 laid out back to back): out1[i] (+)= sum_t partial[t*ld + i], out2[j] likewise */
+/* count <= 8 reductions of the papc_reduce_partials2_f32 kind in ONE launch (`jobs` is a HOST array read during the call): the dW / db
+ * partials of every layer of a stack folded at the end of its backward instead of one launch-latency-sized kernel per layer */
+typedef struct papc_reduce_job {
+    const float *partial;   /* [n_chunks][ld] */
+    int32_t n_chunks;
+    int32_t accumulate;     /* != 0: add into out1 / out2 */
+    int64_t ld, n1, n2;     /* row stride; elements [0,n1) -> out1, [n1,n1+n2) -> out2 */
+    float *out1, *out2;     /* out2 may be NULL when n2 == 0 */
+} papc_reduce_job;
+int papc_reduce_partials_batch_f32(const papc_reduce_job *jobs, int count, papc_stream_t stream);
 int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, int64_t n1, float *out1, int64_t n2,
                               float *out2, int accumulate, papc_stream_t stream);
 

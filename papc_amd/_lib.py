@@ -41,6 +41,12 @@ class BwdRed(ctypes.Structure):
     _fields_ = [("y", c_p), ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("red_partial", c_p)]
 
 
+class ReduceJob(ctypes.Structure):
+    """papc_reduce_job"""
+    _fields_ = [("partial", c_p), ("n_chunks", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("ld", c_l), ("n1", c_l), ("n2", c_l),
+                ("out1", c_p), ("out2", c_p)]
+
+
 class ScatterDst(ctypes.Structure):
     """papc_scatter_dst"""
     _fields_ = [("grad_feats", c_p), ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("col0", c_i)]
@@ -73,6 +79,7 @@ SIGNATURES = {
     "papc_mlp_bwd_dx_f32": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_mlp_bwd_dw_f32": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "papc_reduce_partials2_f32": (c_i, [c_p, c_i, c_l, c_l, c_p, c_l, c_p, c_i, c_p]),
+    "papc_reduce_partials_batch_f32": (c_i, [c_p, c_i, c_p]),
     "papc_reduce_partials_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p]),
     "papc_pfn_decorate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_p, c_p]),
     "papc_pfn_stats_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p]),

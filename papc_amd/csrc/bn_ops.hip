@@ -518,6 +518,46 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch t)
     }
 }
 
+// up to 8 partial reductions in one launch (blockIdx.y = job): the dW partials of all layers of a stack are folded together at the end
+// of its backward instead of one launch-latency-sized kernel per layer
+struct ReduceBatch {
+    const float *part[8]; float *out1[8], *out2[8];
+    int64_t ld[8], n1[8], n[8];
+    int n_chunks[8], accumulate[8];
+};
+__global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(ReduceBatch b)
+{
+    __shared__ float red[16][64];
+    const int job = blockIdx.y;
+    const float *__restrict__ part = b.part[job];
+    const int64_t n = b.n[job], ld = b.ld[job];
+    const int n_chunks = b.n_chunks[job];
+    if ((int64_t)blockIdx.x * 64 >= n) return;               // (uniform per workgroup: this job is narrower than the widest one)
+    const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
+    const int64_t i = (int64_t)blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (i < n) {
+        for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {     // 8 loads in flight per lane; summed in chunk order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + 16 * j;
+                v[j] = part[(int64_t)(t < n_chunks ? t : t0) * ld + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (t0 + 16 * j < n_chunks) ? v[j] : 0.f;
+        }
+    }
+    red[cl][el] = s;
+    __syncthreads();
+    if (cl == 0 && i < n) {
+#pragma unroll
+        for (int g = 1; g < 16; ++g) s += red[g][el];
+        float *o = i < b.n1[job] ? b.out1[job] + i : b.out2[job] + (i - b.n1[job]);
+        *o = b.accumulate[job] ? *o + s : s;
+    }
+}
+
 }  // namespace papc
 
 
@@ -647,6 +687,27 @@ int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, in
     else
         hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, ld, out1, n1, out2, accumulate);
     return check_launch("papc_reduce_partials2_f32");
+}
+
+int papc_reduce_partials_batch_f32(const papc_reduce_job *jobs, int count, papc_stream_t stream)
+{
+    PAPC_REQUIRE(jobs, PAPC_E_INVALID, "papc_reduce_partials_batch_f32: null jobs");
+    PAPC_REQUIRE(count >= 1 && count <= 8, PAPC_E_INVALID, "papc_reduce_partials_batch_f32: count=%d not in [1, 8]", count);
+    ReduceBatch b;
+    memset(&b, 0, sizeof(b));
+    int64_t nmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const papc_reduce_job &j = jobs[i];
+        PAPC_REQUIRE(j.partial && j.out1 && (j.n2 == 0 || j.out2), PAPC_E_INVALID, "papc_reduce_partials_batch_f32: null pointer in job %d", i);
+        PAPC_REQUIRE(j.n_chunks >= 1 && j.n1 >= 1 && j.n2 >= 0 && j.ld >= j.n1 + j.n2, PAPC_E_INVALID, "papc_reduce_partials_batch_f32: bad sizes in job %d", i);
+        b.part[i] = j.partial; b.out1[i] = j.out1; b.out2[i] = j.out2; b.ld[i] = j.ld; b.n1[i] = j.n1; b.n[i] = j.n1 + j.n2;
+        b.n_chunks[i] = j.n_chunks; b.accumulate[i] = j.accumulate;
+        nmax = std::max(nmax, j.n1 + j.n2);
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3((unsigned)cdiv(nmax, 64), (unsigned)count), dim3(1024), 0, st, b);
+    return check_launch("papc_reduce_partials_batch_f32");
 }
 
 int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, int accumulate, papc_stream_t stream)

@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import BwdDy, BwdRed, GroupMax, GroupSrc, ScatterDst, check, ptr, stream_ptr
+from ._lib import BwdDy, BwdRed, GroupMax, GroupSrc, ReduceJob, ScatterDst, check, ptr, stream_ptr
 
 A_PLAIN, A_BNRELU, A_GROUP = 0, 1, 2
 DZ_DENSE, DZ_MAX = 0, 1
@@ -201,6 +201,7 @@ class SharedMLPMax(torch.autograd.Function):
         grp = None if plain else _group_src(spec, xyz, new_xyz, feats, idx)
         n_parts = min(_RESIDENT_WGS, (M + 127) // 128)
         grads = [None] * (4 * L)
+        reduce_jobs = []   # (partial tensor, n_chunks, ld, n1, out1 ptr, n2, out2 ptr, accumulate): see the dW section
         grad_feats = None
         grad_x = None
         dz = None
@@ -324,16 +325,18 @@ class SharedMLPMax(torch.autograd.Function):
                 pc = consts[l - 1]
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_BNRELU, ys[l - 1].data_ptr(), cin, None, pc[2].data_ptr(),
                                               pc[3].data_ptr(), M, cin, cout, rpc, dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
+            # the partials of all layers are folded in ONE launch once the stack's last dW kernel is enqueued (papc_reduce_partials_batch_f32)
             if inplace:
-                check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, tgt[0].data_ptr(), cout,
-                                                    tgt[1].data_ptr(), 1, st), "papc_reduce_partials2_f32")
+                reduce_jobs.append((part, n_chunks, pld, cout * cin, tgt[0].data_ptr(), cout, tgt[1].data_ptr(), 1))
             else:
                 dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
                 db = torch.empty(cout, device=dev, dtype=torch.float32)
-                check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, ptr(dw), cout, ptr(db), 0, st),
-                      "papc_reduce_partials2_f32")
                 if spec.eval_bn:      # no batch-mean term removes the bias direction: db = sum_m dy = scale * sum_m p (tiny [C] op)
+                    check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, ptr(dw), cout, ptr(db), 0, st),
+                          "papc_reduce_partials2_f32")
                     db = cst[2] * dgb[1]
+                else:
+                    reduce_jobs.append((part, n_chunks, pld, cout * cin, dw.data_ptr(), cout, db.data_ptr(), 0))
                 grads[4 * l + 0] = dw.reshape(w.shape)
                 grads[4 * l + 1] = db
                 grads[4 * l + 2] = dgb[0]
@@ -383,6 +386,12 @@ class SharedMLPMax(torch.autograd.Function):
                 sc.N, sc.S, sc.K, sc.D = spec.N, spec.S, spec.K, spec.D
                 sc.col0 = 3 if spec.xyz_first else 0
                 check(lib.papc_mlp_bwd_dx_f32(ctypes.byref(dy), ptr(wt), M, cin, cout, None, ctypes.byref(sc), None, st), "papc_mlp_bwd_dx_f32")
+        for k0 in range(0, len(reduce_jobs), 8):       # (at most 8 jobs per launch)
+            chunk = reduce_jobs[k0:k0 + 8]
+            jobs = (ReduceJob * len(chunk))()
+            for j, (part_t, nch, ld_, n1_, o1, n2_, o2, acc_) in zip(jobs, chunk):
+                j.partial, j.n_chunks, j.accumulate, j.ld, j.n1, j.n2, j.out1, j.out2 = part_t.data_ptr(), nch, acc_, ld_, n1_, n2_, o1, o2
+            check(lib.papc_reduce_partials_batch_f32(jobs, len(chunk), st), "papc_reduce_partials_batch_f32")
         return (None, None, None, None, grad_feats, None, grad_x) + tuple(grads)
 
 

@@ -182,3 +182,36 @@ def test_reduce_partials_strided_vs_float64(dev, n_chunks, rows, cols, out_ld, a
     ref[:, :cols] = ref[:, :cols] + blk if acc else blk
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0].double() - ref).abs().max()) <= 1e-5 * float(blk.abs().max()) + 1e-6
+
+
+def test_reduce_partials_batch_vs_float64(dev):
+    """papc_reduce_partials_batch_f32: several (dW | db) partial buffers of different widths and chunk counts folded in one launch,
+    accumulate on / off per job, bit-identical when repeated."""
+    import ctypes
+    from papc_amd import _lib
+    from papc_amd._lib import ReduceJob
+    lib = _lib.load()
+    torch.manual_seed(5)
+    shapes = [(256, 128 * 64, 128, 1), (16, 1024 * 512, 1024, 0), (3, 7, 0, 0), (130, 64 * 3, 64, 1)]
+    parts, outs, refs = [], [], []
+    for nch, n1, n2, acc in shapes:
+        ld = n1 + n2 + 3
+        part = torch.randn(nch, ld, device=dev)
+        o1, o2 = torch.randn(n1, device=dev), torch.randn(max(n2, 1), device=dev)
+        s = part.double().sum(0)
+        refs.append(((o1.double() if acc else 0) + s[:n1], (o2.double()[:n2] if acc else 0) + s[n1:n1 + n2]))
+        parts.append(part); outs.append((o1, o2))
+    res = []
+    for _ in range(2):
+        cur = [(a.clone(), b.clone()) for a, b in outs]
+        jobs = (ReduceJob * len(shapes))()
+        for j, (nch, n1, n2, acc), part, (o1, o2) in zip(jobs, shapes, parts, cur):
+            j.partial, j.n_chunks, j.accumulate, j.ld, j.n1, j.n2 = part.data_ptr(), nch, acc, part.shape[1], n1, n2
+            j.out1, j.out2 = o1.data_ptr(), (o2.data_ptr() if n2 else None)
+        _lib.check(lib.papc_reduce_partials_batch_f32(jobs, len(shapes), None), "batch")
+        res.append(cur)
+    for (a0, b0), (a1, b1), (r1, r2), (nch, n1, n2, acc) in zip(res[0], res[1], refs, shapes):
+        assert torch.equal(a0, a1) and torch.equal(b0, b1)
+        assert float((a0.double() - r1).abs().max()) <= 2e-5 * float(r1.abs().max()) + 1e-6
+        if n2:
+            assert float((b0.double()[:n2] - r2).abs().max()) <= 2e-5 * float(r2.abs().max()) + 1e-6
