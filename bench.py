@@ -245,6 +245,12 @@ def main():
     def capture():
         """Returns True when the graph(s) were captured; on any capture failure the bench falls back to eager launches."""
         torch.cuda.synchronize()
+        if use_dist:
+            # RCCL's watchdog thread polls the end events of the collectives it still lists; the synchronous ones run on THIS stream,
+            # and HIP refuses an event query once that stream is capturing (hipErrorCapturedEvent: the capture is invalidated and the
+            # watchdog aborts the process -- seen in 1 of 14 runs).  Everything is complete after the synchronize: give the watchdog
+            # (100 ms poll period) time to retire its list before the capture begins.
+            time.sleep(1.0)
         try:
             n_sets = 2 if args.overlap else 1
             bufs = None

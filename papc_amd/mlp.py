@@ -73,6 +73,36 @@ def _dw_rows_per_chunk(M, cout, cin):
     return rpc
 
 
+# ---- W^T operands of the dX GEMMs, precomputed for several stacks in one launch -------------------------------------------------
+# A stack's backward needs the transposes of its layers' weights (one papc_transpose_batch_f32 per stack).  A model that runs several
+# stacks per step can hand ALL of them over before its forward (precompute_wt): one launch instead of one per stack.  The table is
+# replaced by every call and a stack only uses it when it was recorded by the SAME forward pass (ctx.wt_id), so a stale transpose
+# (weights updated in between) can never be picked up; anything missing is transposed locally as before.
+_WT = {"id": 0, "map": {}}
+
+
+def precompute_wt(weights):
+    """weights: conv / linear weights [Cout, Cin(, 1...)] whose [Cin, Cout] transposes the coming backward passes will need."""
+    lib = _lib.load()
+    st = stream_ptr()
+    _WT["id"] += 1
+    table = {}
+    ws = [w for w in weights if w.is_cuda and w.is_contiguous() and w.dtype == torch.float32]
+    for g0 in range(0, len(ws), 8):
+        grp_w = ws[g0:g0 + 8]
+        n = len(grp_w)
+        srcs, dsts, rws, cls = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        for i, w in enumerate(grp_w):
+            cout = w.shape[0]
+            cin = w.numel() // cout
+            t = torch.empty(cin, cout, device=w.device, dtype=torch.float32)
+            table[w.data_ptr()] = t
+            srcs[i], dsts[i], rws[i], cls[i] = w.data_ptr(), t.data_ptr(), cout, cin
+        check(lib.papc_transpose_batch_f32(srcs, dsts, rws, cls, n, st), "papc_transpose_batch_f32")
+    _WT["map"] = table
+    return _WT["id"]
+
+
 class SharedMLPMax(torch.autograd.Function):
     """out[g, :] = max_{k<K} relu(bn_L(conv_L(... relu(bn_1(conv_1(rows)))...)))   with rows gathered on the fly.
 
@@ -176,6 +206,7 @@ class SharedMLPMax(torch.autograd.Function):
                   "papc_bn_relu_max_f32")
         ctx.spec = spec
         ctx.L = L
+        ctx.wt_id = _WT["id"]
         ctx.feats_needs_grad = feats is not None and feats.requires_grad and not spec.cut_gather_grad
         ctx.x_needs_grad = plain and x_rows.requires_grad
         ctx.cin0 = cin0
@@ -218,6 +249,13 @@ class SharedMLPMax(torch.autograd.Function):
         if ctx.lin0 and 0 in need_wt:
             need_wt.remove(0)
         wts = {}
+        if ctx.wt_id == _WT["id"]:         # transposes handed over for this very forward pass (precompute_wt)
+            for l in list(need_wt):
+                t = _WT["map"].get(params[4 * l].data_ptr())
+                cin_l = ctx.cin0 if l == 0 else params[4 * (l - 1)].shape[0]
+                if t is not None and tuple(t.shape) == (cin_l, params[4 * l].shape[0]):
+                    wts[l] = t
+                    need_wt.remove(l)
         for g0 in range(0, len(need_wt), 8):
             grp_l = need_wt[g0:g0 + 8]
             n = len(grp_l)
