@@ -341,8 +341,12 @@ class SharedMLPMax(torch.autograd.Function):
                     grads[3] = dgb[1]
                 if ctx.feats_needs_grad:
                     # grad_feats = G W_f: the same row GEMM with the transposed feature block as its weight
-                    wft = torch.empty(spec.D, cout, device=dev, dtype=torch.float32)
-                    check(lib.papc_copy2d_f32(w.data_ptr() + 4 * fcol0, cin, ptr(wft), cout, cout, spec.D, 1, st), "papc_copy2d_f32")
+                    wt_full = _WT["map"].get(w.data_ptr()) if ctx.wt_id == _WT["id"] else None
+                    if wt_full is not None and tuple(wt_full.shape) == (cin, cout):
+                        wft = wt_full[fcol0:fcol0 + spec.D]     # rows of the precomputed W^T [cin, cout]: the feature block, contiguous
+                    else:
+                        wft = torch.empty(spec.D, cout, device=dev, dtype=torch.float32)
+                        check(lib.papc_copy2d_f32(w.data_ptr() + 4 * fcol0, cin, ptr(wft), cout, cout, spec.D, 1, st), "papc_copy2d_f32")
                     grad_feats = torch.empty(spec.B, spec.N, spec.D, device=dev, dtype=torch.float32)
                     check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(Gs), cout, None, None, None, ptr(wft), None, BN_, cout, spec.D, ptr(grad_feats),
                                                 None, None, st), "papc_mlp_gemm_f32")
