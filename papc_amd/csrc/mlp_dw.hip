@@ -563,6 +563,174 @@ static bool dw_f32_exact()
     return knob(KNOB_DW_F32) == 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-streaming dW for narrow inputs (Cin = 64; PAPC_DW_ROWS): no LDS staging, no producer / consumer split, no barrier
+// in the main loop.  The MFMA contracts over ROWS, and lane (channel = lane & 31, half = lane >> 5) wants 8 CONSECUTIVE ROWS of its
+// channel: with row-major data that is 8 dword loads whose 32 lanes read 32 consecutive floats of one row -- coalesced 128-byte
+// segments straight into the operand layout (a dwordx4 load would deliver 4 channels of one row: the transpose dw_ws_kernel does
+// through LDS).  A lane's channel is fixed per tile, so the BN / BN-backward constants sit in registers.  A workgroup owns a row
+// chunk and a 64-channel block of Cout; its 8 waves take the chunk's 16-row blocks round-robin, each accumulating the whole
+// 64 x 64 tile (4 accumulators), and fold them in a fixed 3-level tree through LDS at the end (one partial row per workgroup, as
+// the staged kernels write).  What this buys: every thread loads, transforms and multiplies -- no idle consumers, no barrier skew.
+template <int DYMODE>
+__global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
+{
+    constexpr int NTO = 2, NTI = 2;
+    __shared__ float slab[4][NTO * NTI * 16][64];   // 64 KB: the upper half of the waves parks its accumulators here
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int o0 = blockIdx.y * 64;
+    const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
+    const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
+    const int n_kb = mbeg < mend ? (int)((mend - mbeg + 15) >> 4) : 0;
+    const DySrc &d = p.dy.d;
+    const int Cout = p.Cout, ldx = (int)p.x.ldx;
+
+    float ksc[NTO], ksh[NTO], kmu[NTO], kA[NTO], kB[NTO], xs[NTI], xh[NTI];
+#pragma unroll
+    for (int a = 0; a < NTO; ++a) {
+        const int c = o0 + 32 * a + l31;
+        ksc[a] = d.scale[c]; ksh[a] = d.shift[c]; kmu[a] = d.mean[c];
+        kA[a] = ksc[a] * d.c1[c];
+        kB[a] = ksc[a] * d.c2[c] * d.invstd[c];
+    }
+#pragma unroll
+    for (int b = 0; b < NTI; ++b) { xs[b] = p.x.sc[32 * b + l31]; xh[b] = p.x.sh[32 * b + l31]; }
+
+    floatx16 acc[NTO][NTI];
+#pragma unroll
+    for (int a = 0; a < NTO; ++a)
+#pragma unroll
+        for (int b = 0; b < NTI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    struct Raw { float y[NTO][8], z[NTO][8], x[NTI][8]; int am[NTO]; };
+    auto fetch = [&](int kb, Raw &w) {
+        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int64_t row = r0 + j;
+            row = row < mend ? row : mend - 1;    // (ragged last block: re-read a valid row, zeroed below)
+#pragma unroll
+            for (int a = 0; a < NTO; ++a) {
+                w.y[a][j] = d.y[row * Cout + o0 + 32 * a + l31];
+                if (DYMODE == A_DY_DENSE) w.z[a][j] = d.dz[row * Cout + o0 + 32 * a + l31];
+            }
+#pragma unroll
+            for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x.x[row * ldx + 32 * b + l31];
+        }
+        if (DYMODE == A_DY_MAX) {   // K % 16 == 0 (host-checked): the block's 16 rows share one group
+            const int64_t g = (mbeg + 16 * (int64_t)kb) / d.K;
+#pragma unroll
+            for (int a = 0; a < NTO; ++a) {
+                w.z[a][0] = d.gout[g * Cout + o0 + 32 * a + l31];
+                w.am[a] = d.argmax[g * Cout + o0 + 32 * a + l31];
+            }
+        }
+    };
+    auto split8 = [&](const float (&vin)[8], bf16x8 (&pl)[3]) {
+        uint2 a0, a1, a2, b0, b1, b2;
+        split3(make_float4(vin[0], vin[1], vin[2], vin[3]), a0, a1, a2);
+        split3(make_float4(vin[4], vin[5], vin[6], vin[7]), b0, b1, b2);
+        pl[0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+        pl[1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+        pl[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+    };
+    auto compute = [&](int kb, const Raw &w) {
+        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
+        const bool tail = mbeg + 16 * (int64_t)kb + 16 > mend;
+        int kin0 = 0;
+        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - ((mbeg + 16 * (int64_t)kb) / d.K) * d.K);
+        bf16x8 pa[NTO][3], pb[NTI][3];
+#pragma unroll
+        for (int a = 0; a < NTO; ++a) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = w.y[a][j];
+                float dz;
+                if (DYMODE == A_DY_DENSE) dz = w.z[a][j];
+                else dz = (w.am[a] == kin0 + j) ? w.z[a][0] : 0.f;
+                const float z = fmaf(ksc[a], y, ksh[a]);
+                const float pp = z > 0.f ? dz : 0.f;
+                v[j] = fmaf(ksc[a], pp, -fmaf(kB[a], y - kmu[a], kA[a]));
+                if (tail && r0 + j >= mend) v[j] = 0.f;
+            }
+            split8(v, pa[a]);
+        }
+#pragma unroll
+        for (int b = 0; b < NTI; ++b) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = fmaxf(fmaf(xs[b], w.x[b][j], xh[b]), 0.f);
+                if (tail && r0 + j >= mend) v[j] = 0.f;
+            }
+            split8(v, pb[b]);
+        }
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int a = 0; a < NTO; ++a)
+#pragma unroll
+                for (int b = 0; b < NTI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][PA[t]], pb[b][PB[t]], acc[a][b], 0, 0, 0);
+    };
+
+    // this wave's blocks: wave, wave + 8, ...; the next block's loads are in flight while the current one is computed
+    Raw ra, rb;
+    int kb = wave;
+    if (kb < n_kb) fetch(kb, ra);
+    while (kb < n_kb) {
+        if (kb + 8 < n_kb) fetch(kb + 8, rb);
+        compute(kb, ra);
+        kb += 8;
+        if (kb >= n_kb) break;
+        if (kb + 8 < n_kb) fetch(kb + 8, ra);
+        compute(kb, rb);
+        kb += 8;
+    }
+
+    // ---- fold the 8 waves' tiles: 4 -> LDS, +4; 2 -> LDS, +2; 1 -> LDS, +1 (fixed order); slab[w][reg][lane]: conflict-free
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int a = 0; a < NTO; ++a)
+#pragma unroll
+                for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[wave - half][(a * NTI + b) * 16 + r][lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int a = 0; a < NTO; ++a)
+#pragma unroll
+                for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += slab[wave][(a * NTI + b) * 16 + r][lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {   // C/D layout: row (cout) = (r & 3) + 8 (r >> 2) + 4 half, col (cin) = lane & 31
+        float *out = p.dw_partial + (int64_t)blockIdx.x * p.part_ld;
+#pragma unroll
+        for (int a = 0; a < NTO; ++a)
+#pragma unroll
+            for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    out[(int64_t)co * p.Cin + 32 * b + l31] = acc[a][b][r];
+                }
+    }
+    // (bias gradient: exactly 0 under a train-mode BN, see dw_ws_kernel)
+    if (p.db_partial && tid < 64) p.db_partial[(int64_t)blockIdx.x * p.part_ld + o0 + tid] = 0.f;
+}
+
 static unsigned long long *g_dw_dbg = nullptr;
 static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 {
@@ -589,6 +757,17 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     const int to = p.TOp / 32, ti = p.TIp / 32;  // 32-wide tiles per workgroup (upper bound)
     const bool off32 = (int64_t)p.rows_per_chunk * std::max<int64_t>(p.Cout, XMODE == A_GROUP ? 1 : p.x.ldx) * 4 < (1ll << 31);
     const bool k4 = DYMODE != A_DY_MAX || p.dy.d.K % 4 == 0;
+    // measured (config 2, SA1): 64 -> 64 dense 99.5 -> 94 us, 64 -> 128 under the max 119 -> 132 us (two 64-channel blocks of Cout
+    // transform the input twice): PAPC_DW_ROWS=1 (default) takes the first kind only, =2 every eligible layer, =0 none
+    const int rows_knob = knob(KNOB_DW_ROWS);
+    const bool rows_ok = rows_knob == 2 || (rows_knob == 1 && DYMODE == A_DY_DENSE && p.Cout == 64);
+    if (VEC && XMODE == A_BNRELU && rows_ok && p.Cin == 64 && p.Cout % 64 == 0 && p.x.ldx == 64 && p.rows_per_chunk % 16 == 0 &&
+        !dw_f32_exact() && (DYMODE != A_DY_MAX || p.dy.d.K % 16 == 0) && (int64_t)p.M * std::max(p.Cout, 64) < (1ll << 40)) {
+        // narrow input (64 channels): row-streaming kernel, every thread loads + transforms + multiplies
+        dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 64));
+        hipLaunchKernelGGL((dw_rows_kernel<DYMODE>), g2, dim3(512), 0, st, p);
+        return check_launch("papc_mlp_bwd_dw_f32");
+    }
     if (VEC && XMODE != A_GROUP && !wide && to >= 2 && ti >= 2 && off32 && k4 && !dw_f32_exact()) {
         // dense layers with >= 64-wide tiles: wave-specialised bf16x3 kernel
         if (to > 2 && ti > 2) hipLaunchKernelGGL((dw_ws_kernel<XMODE, DYMODE, 2, 2>), grid, dim3(768), 0, st, p);

@@ -91,3 +91,35 @@ def test_stream_is_taken_and_deterministic_at_config2_size(dev, stream_knobs):
     _, _, _, o3 = _run(dev, G, K, chans, 11, False)
     assert torch.isfinite(o1).all()
     assert_close(o1.detach().cpu().numpy(), o3.detach().cpu().numpy(), 2e-6, "full-size stream vs tiled")
+
+
+@pytest.mark.parametrize("chans,K", [([64, 64, 128], 32), ([64, 64, 64], 16)])
+def test_dw_row_streaming_matches_staged_kernels(dev, chans, K):
+    """dW of layers with a 64-channel input on the row-streaming kernel (PAPC_DW_ROWS=2: dense AND max-pooled layers) against the
+    LDS-staged kernels (=0): the same exact-split products in another summation order, ragged last chunk included."""
+    import ctypes
+    from papc_amd import _lib
+    from papc_amd.mlp import StackSpec, shared_mlp_max
+    lib = _lib.load()
+    G = 1000                      # M = G*K rows: not a multiple of the chunk size
+    M = G * K
+    torch.manual_seed(11)
+    x = torch.randn(M, chans[0], device=dev)
+    ps = []
+    for cin, cout in zip(chans[:-1], chans[1:]):
+        ps += [torch.randn(cout, cin, device=dev) * (2.0 / cin) ** 0.5, torch.zeros(cout, device=dev), torch.rand(cout, device=dev) + 0.5,
+               torch.randn(cout, device=dev) * 0.1]
+    z = torch.zeros(1, 1, 3, device=dev)
+    gout = torch.randn(G, chans[-1], device=dev)
+    grads = {}
+    try:
+        for flav in (0, 2):
+            _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWS", flav), "knob")
+            prm = [p.clone().requires_grad_(True) for p in ps]
+            out = shared_mlp_max(StackSpec(1, M, G, K, chans[0] - 3, True), None, z, z, None, None, prm, x_rows=x)
+            out.backward(gout)
+            grads[flav] = [p.grad.clone() for p in prm]
+    finally:
+        _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWS", 1), "knob")
+    for a, b in zip(grads[0], grads[2]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7
