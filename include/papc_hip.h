@@ -248,6 +248,10 @@ int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const float *x, int64
                         int Cin, int Cout, int rows_per_chunk, float *dw_partial, float *db_partial,
                         int64_t part_ld, papc_stream_t stream);
 
+/* rows_per_chunk papc_mlp_bwd_dw_f32 would like for this layer (a multiple of 64), or 0 for "any": the row-streaming flavour it runs on
+ * layers with a 64-channel BN+ReLU input wants exactly one residency wave of workgroups.  K: rows per group (PAPC_DZ_MAX), else 0. */
+int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mode, int dz_mode, int K);
+
 /* out[i] (+)= sum_t partial[t, i]  (fixed order -> deterministic); n = elements per chunk; accumulate != 0 adds
  * into out (gradient accumulation straight into a parameter's .grad) */
 int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, int accumulate,

@@ -742,6 +742,14 @@ static void dw_dbg_report(const DwArgs &p, int xm, int dm)
             xm, dm, (long long)p.M, p.Cout, p.Cin, n, h[0] / n, h[1] / n, h[8] / n, h[9] / n, h[10] / n, h[11] / n);
 }
 
+// row-streaming kernel (dw_rows_kernel): which layers take it (PAPC_DW_ROWS=0: none).  Measured on config 2's SA1 with one workgroup
+// per CU (papc_mlp_bwd_dw_chunk_hint): 64 -> 64 dense 99.5 -> 81 us; 64 -> 128 under the max 119 -> ~110 us although its two 64-channel
+// blocks of Cout transform the input twice; dW family 0.85 -> 0.82 ms/step.
+static bool dw_rows_eligible(int Cin, int Cout, bool dense, int K)
+{
+    return knob(KNOB_DW_ROWS) != 0 && Cin == 64 && Cout % 64 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));
+}
+
 template <int XMODE, int DYMODE, bool VEC>
 static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
 {
@@ -757,12 +765,7 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     const int to = p.TOp / 32, ti = p.TIp / 32;  // 32-wide tiles per workgroup (upper bound)
     const bool off32 = (int64_t)p.rows_per_chunk * std::max<int64_t>(p.Cout, XMODE == A_GROUP ? 1 : p.x.ldx) * 4 < (1ll << 31);
     const bool k4 = DYMODE != A_DY_MAX || p.dy.d.K % 4 == 0;
-    // measured (config 2, SA1): 64 -> 64 dense 99.5 -> 94 us, 64 -> 128 under the max 119 -> 132 us (two 64-channel blocks of Cout
-    // transform the input twice): PAPC_DW_ROWS=1 (default) takes the first kind only, =2 every eligible layer, =0 none
-    const int rows_knob = knob(KNOB_DW_ROWS);
-    const bool rows_ok = rows_knob == 2 || (rows_knob == 1 && DYMODE == A_DY_DENSE && p.Cout == 64);
-    if (VEC && XMODE == A_BNRELU && rows_ok && p.Cin == 64 && p.Cout % 64 == 0 && p.x.ldx == 64 && p.rows_per_chunk % 16 == 0 &&
-        !dw_f32_exact() && (DYMODE != A_DY_MAX || p.dy.d.K % 16 == 0) && (int64_t)p.M * std::max(p.Cout, 64) < (1ll << 40)) {
+    if (VEC && XMODE == A_BNRELU && dw_rows_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == 64 && p.rows_per_chunk % 16 == 0) {
         // narrow input (64 channels): row-streaming kernel, every thread loads + transforms + multiplies
         dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 64));
         hipLaunchKernelGGL((dw_rows_kernel<DYMODE>), g2, dim3(512), 0, st, p);
@@ -800,6 +803,21 @@ static int pad_tile(int c) { return c <= 32 ? 32 : (c <= 64 ? 64 : 128); }
 }  // namespace papc
 
 using namespace papc;
+
+/* rows_per_chunk the dW entry point would like for this layer, or 0 for "the caller's own rule": the row-streaming kernel keeps a whole
+ * 64 x 64 tile per wave (241 registers: one workgroup per CU), so it wants ONE residency wave of workgroups -- ncu row chunks in all */
+extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mode, int dz_mode, int K)
+{
+    if (a_mode != PAPC_A_BNRELU || M < 1 || !dw_rows_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K)) return 0;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    static int ncu = 0;
+    if (!ncu) { ncu = 256; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+    const int64_t want = std::max<int64_t>(1, ncu / (Cout / 64));
+    int64_t rpc = cdiv(M, want);
+    rpc = std::max<int64_t>(64, cdiv(rpc, 64) * 64);
+    return (int)std::min<int64_t>(rpc, 1 << 24);
+}
 
 extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const float *x, int64_t ldx,
                                    const papc_group_src *grp, const float *bn_scale, const float *bn_shift, int64_t M,

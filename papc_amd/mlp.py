@@ -352,7 +352,11 @@ class SharedMLPMax(torch.autograd.Function):
                                                 None, None, st), "papc_mlp_gemm_f32")
                 break
             # ---- dW, db
-            rpc = _dw_rows_per_chunk(M, cout, cin)
+            rpc = 0
+            if l > 0:                        # (the kernel's own preference where it has one: papc_mlp_bwd_dw_chunk_hint)
+                rpc = lib.papc_mlp_bwd_dw_chunk_hint(M, cin, cout, A_BNRELU, dy.dz_mode, spec.K if dy.dz_mode == DZ_MAX else 0)
+            if rpc <= 0:
+                rpc = _dw_rows_per_chunk(M, cout, cin)
             n_chunks = (M + rpc - 1) // rpc
             pld = cout * cin + cout          # one partial buffer: chunk rows are [dW (cout*cin) | db (cout)]
             part = torch.empty(n_chunks, pld, device=dev, dtype=torch.float32)
