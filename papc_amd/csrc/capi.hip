@@ -57,6 +57,7 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_PFN_MFMA", 1, 0, 1},            // PillarFeatureNet apply pass on the bf16 matrix pipe (0: lanes-are-channels VALU flavour)
     {"PAPC_DW_RS64", 1, 0, 1},             // dW of 64 x 64 layers: 64-row stages (all producer threads busy)
     {"PAPC_DW_ROWS", 1, 0, 1},             // dW of layers with a 64-channel BN+ReLU input on the row-streaming kernel (dw_rows_kernel)
+    {"PAPC_DW_ROWS_BLOCKS", 4, 1, 16},     // ... for layers of at most this many 64 x 64 output blocks (8: slower, each block transforms its operands again)
 };
 static int g_knobs[KNOB_COUNT];
 static int knob_parse(int id, const char *e)

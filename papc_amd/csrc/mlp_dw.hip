@@ -579,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
     __shared__ float slab[4][NTO * NTI * 16][64];   // 64 KB: the upper half of the waves parks its accumulators here
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int o0 = blockIdx.y * 64;
+    const int o0 = blockIdx.y * 64, i0 = blockIdx.z * 64;
     const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
     const int n_kb = mbeg < mend ? (int)((mend - mbeg + 15) >> 4) : 0;
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
         kB[a] = ksc[a] * d.c2[c] * d.invstd[c];
     }
 #pragma unroll
-    for (int b = 0; b < NTI; ++b) { xs[b] = p.x.sc[32 * b + l31]; xh[b] = p.x.sh[32 * b + l31]; }
+    for (int b = 0; b < NTI; ++b) { xs[b] = p.x.sc[i0 + 32 * b + l31]; xh[b] = p.x.sh[i0 + 32 * b + l31]; }
 
     floatx16 acc[NTO][NTI];
 #pragma unroll
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
                 if (DYMODE == A_DY_DENSE) w.z[a][j] = d.dz[row * Cout + o0 + 32 * a + l31];
             }
 #pragma unroll
-            for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x.x[row * ldx + 32 * b + l31];
+            for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x.x[row * ldx + i0 + 32 * b + l31];
         }
         if (DYMODE == A_DY_MAX) {   // K % 16 == 0 (host-checked): the block's 16 rows share one group
             const int64_t g = (mbeg + 16 * (int64_t)kb) / d.K;
@@ -724,11 +724,11 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = o0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    out[(int64_t)co * p.Cin + 32 * b + l31] = acc[a][b][r];
+                    out[(int64_t)co * p.Cin + i0 + 32 * b + l31] = acc[a][b][r];
                 }
     }
     // (bias gradient: exactly 0 under a train-mode BN, see dw_ws_kernel)
-    if (p.db_partial && tid < 64) p.db_partial[(int64_t)blockIdx.x * p.part_ld + o0 + tid] = 0.f;
+    if (p.db_partial && blockIdx.z == 0 && tid < 64) p.db_partial[(int64_t)blockIdx.x * p.part_ld + o0 + tid] = 0.f;
 }
 
 static unsigned long long *g_dw_dbg = nullptr;
@@ -747,7 +747,8 @@ static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 // blocks of Cout transform the input twice; dW family 0.85 -> 0.82 ms/step.
 static bool dw_rows_eligible(int Cin, int Cout, bool dense, int K)
 {
-    return knob(KNOB_DW_ROWS) != 0 && Cin == 64 && Cout % 64 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));
+    // (64 x 64 blocks of the output: every block transforms its operands again, so at most four of them)
+    return knob(KNOB_DW_ROWS) != 0 && Cin % 64 == 0 && Cout % 64 == 0 && (Cin / 64) * (Cout / 64) <= knob(KNOB_DW_ROWS_BLOCKS) && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));
 }
 
 template <int XMODE, int DYMODE, bool VEC>
@@ -765,9 +766,9 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     const int to = p.TOp / 32, ti = p.TIp / 32;  // 32-wide tiles per workgroup (upper bound)
     const bool off32 = (int64_t)p.rows_per_chunk * std::max<int64_t>(p.Cout, XMODE == A_GROUP ? 1 : p.x.ldx) * 4 < (1ll << 31);
     const bool k4 = DYMODE != A_DY_MAX || p.dy.d.K % 4 == 0;
-    if (VEC && XMODE == A_BNRELU && dw_rows_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == 64 && p.rows_per_chunk % 16 == 0) {
+    if (VEC && XMODE == A_BNRELU && dw_rows_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
         // narrow input (64 channels): row-streaming kernel, every thread loads + transforms + multiplies
-        dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 64));
+        dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 64), (unsigned)(p.Cin / 64));
         hipLaunchKernelGGL((dw_rows_kernel<DYMODE>), g2, dim3(512), 0, st, p);
         return check_launch("papc_mlp_bwd_dw_f32");
     }
@@ -813,7 +814,7 @@ extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mo
     int dev = 0;
     static int ncu = 0;
     if (!ncu) { ncu = 256; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    const int64_t want = std::max<int64_t>(1, ncu / (Cout / 64));
+    const int64_t want = std::max<int64_t>(1, ncu / ((Cout / 64) * (Cin / 64)));
     int64_t rpc = cdiv(M, want);
     rpc = std::max<int64_t>(64, cdiv(rpc, 64) * 64);
     return (int)std::min<int64_t>(rpc, 1 << 24);

@@ -93,7 +93,7 @@ def test_stream_is_taken_and_deterministic_at_config2_size(dev, stream_knobs):
     assert_close(o1.detach().cpu().numpy(), o3.detach().cpu().numpy(), 2e-6, "full-size stream vs tiled")
 
 
-@pytest.mark.parametrize("chans,K", [([64, 64, 128], 32), ([64, 64, 64], 16)])
+@pytest.mark.parametrize("chans,K", [([64, 64, 128], 32), ([64, 64, 64], 16), ([64, 128, 128], 64)])
 def test_dw_row_streaming_matches_staged_kernels(dev, chans, K):
     """dW of layers with a 64-channel input on the row-streaming kernel (PAPC_DW_ROWS=1: dense and max-pooled layers) against the
     LDS-staged kernels (=0): the same exact-split products in another summation order, ragged last chunk included."""
