@@ -58,6 +58,7 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_DW_RS64", 1, 0, 1},             // dW of 64 x 64 layers: 64-row stages (all producer threads busy)
     {"PAPC_DW_ROWS", 1, 0, 1},             // dW of layers with a 64-channel BN+ReLU input on the row-streaming kernel (dw_rows_kernel)
     {"PAPC_DW_ROWS_BLOCKS", 4, 1, 16},     // ... for layers of at most this many 64 x 64 output blocks (8: slower, each block transforms its operands again)
+    {"PAPC_DW_ROWSX", 0, 0, 1},            // experiment, off: dW of 128 -> 256k layers with dY streamed per wave and x staged once per workgroup (dw_rowsx_kernel: 161 vs 138 us)
 };
 static int g_knobs[KNOB_COUNT];
 static int knob_parse(int id, const char *e)

@@ -731,6 +731,162 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
     if (p.db_partial && blockIdx.z == 0 && tid < 64) p.db_partial[(int64_t)blockIdx.x * p.part_ld + o0 + tid] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-streaming dW for 128-channel inputs and 256-channel blocks of Cout (PAPC_DW_ROWSX): the hybrid of dw_rows_kernel and the staged
+// kernels.  Each of the 8 waves owns 32 channels of Cout and streams ITS dY operand straight into the MFMA layout (coalesced dword
+// loads, constants in registers: nothing is transformed twice, nothing of dY touches LDS).  The input operand x is common to all
+// waves: the workgroup transforms each 16-row block of it once (4 values per thread), splits it and parks the three bf16 planes in
+// LDS ([plane][channel][16 rows], 48-byte channel stride: conflict-free ds_read_b128), double-buffered, ONE barrier per block --
+// and since all waves do identical work the barrier costs little skew.  A wave accumulates 32 x 128 of dW (4 accumulators) and
+// stores its rows of the partial itself: no cross-wave fold.
+template <int DYMODE>
+__global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
+{
+    constexpr int NTI = 4, CI = 128, CHS = 48, PLB = CI * CHS, STG = 3 * PLB;   // bytes: channel stride, plane, stage
+    __shared__ __attribute__((aligned(16))) char xs_lds[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int co = blockIdx.y * 256 + wave * 32 + l31;       // this lane's dY channel
+    const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
+    const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
+    const int n_kb = mbeg < mend ? (int)((mend - mbeg + 15) >> 4) : 0;
+    const DySrc &d = p.dy.d;
+    const int Cout = p.Cout;
+
+    const float ksc = d.scale[co], ksh = d.shift[co], kmu = d.mean[co];
+    const float kA = ksc * d.c1[co], kB = ksc * d.c2[co] * d.invstd[co];
+    // x producer role: channel xc, rows 4 xq .. 4 xq + 3 of the block
+    const int xc = tid & 127, xq = tid >> 7;
+    const float xsc = p.x.sc[xc], xsh = p.x.sh[xc];
+
+    floatx16 acc[NTI];
+#pragma unroll
+    for (int b = 0; b < NTI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+
+    struct Raw { float y[8], z[8]; int am; };
+    struct RawX { float x[4]; };
+    auto fetch = [&](int kb, Raw &w) {
+        const int64_t b0 = mbeg + 16 * (int64_t)kb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int64_t row = b0 + 8 * hi + j;
+            row = row < mend ? row : mend - 1;
+            w.y[j] = d.y[row * Cout + co];
+            if (DYMODE == A_DY_DENSE) w.z[j] = d.dz[row * Cout + co];
+        }
+        if (DYMODE == A_DY_MAX) {
+            const int64_t g = b0 / d.K;
+            w.z[0] = d.gout[g * Cout + co];
+            w.am = d.argmax[g * Cout + co];
+        }
+    };
+    auto fetch_x = [&](int kb, RawX &w) {
+        const int64_t b0 = mbeg + 16 * (int64_t)kb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t row = b0 + 4 * xq + j;
+            row = row < mend ? row : mend - 1;
+            w.x[j] = p.x.x[row * CI + xc];
+        }
+    };
+    auto stage_x = [&](int kb, const RawX &w, char *stg) {   // this thread's 4 rows of channel xc -> three 8-byte plane pieces
+        const int64_t b0 = mbeg + 16 * (int64_t)kb + 4 * xq;
+        float4 v;
+        v.x = fmaxf(fmaf(xsc, w.x[0], xsh), 0.f); v.y = fmaxf(fmaf(xsc, w.x[1], xsh), 0.f);
+        v.z = fmaxf(fmaf(xsc, w.x[2], xsh), 0.f); v.w = fmaxf(fmaf(xsc, w.x[3], xsh), 0.f);
+        if (b0 + 3 >= mend) {
+            if (b0 + 0 >= mend) v.x = 0.f;
+            if (b0 + 1 >= mend) v.y = 0.f;
+            if (b0 + 2 >= mend) v.z = 0.f;
+            v.w = 0.f;
+        }
+        uint2 q0, q1, q2;
+        split3(v, q0, q1, q2);
+        char *dst = stg + xc * CHS + xq * 8;
+        *reinterpret_cast<uint2 *>(dst) = q0;
+        *reinterpret_cast<uint2 *>(dst + PLB) = q1;
+        *reinterpret_cast<uint2 *>(dst + 2 * PLB) = q2;
+    };
+    auto compute = [&](int kb, const Raw &w, const char *stg) {
+        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
+        const bool tail = mbeg + 16 * (int64_t)kb + 16 > mend;
+        int kin0 = 0;
+        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - ((mbeg + 16 * (int64_t)kb) / d.K) * d.K);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = w.y[j];
+            float dz;
+            if (DYMODE == A_DY_DENSE) dz = w.z[j];
+            else dz = (w.am == kin0 + j) ? w.z[0] : 0.f;
+            const float z = fmaf(ksc, y, ksh);
+            const float pp = z > 0.f ? dz : 0.f;
+            v[j] = fmaf(ksc, pp, -fmaf(kB, y - kmu, kA));
+            if (tail && r0 + j >= mend) v[j] = 0.f;
+        }
+        uint2 a0, a1, a2, b0, b1, b2;
+        split3(make_float4(v[0], v[1], v[2], v[3]), a0, a1, a2);
+        split3(make_float4(v[4], v[5], v[6], v[7]), b0, b1, b2);
+        bf16x8 pa[3];
+        pa[0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+        pa[1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+        pa[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+        bf16x8 pb[NTI][3];
+#pragma unroll
+        for (int b = 0; b < NTI; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                pb[b][pl] = *reinterpret_cast<const bf16x8 *>(stg + pl * PLB + (32 * b + l31) * CHS + hi * 16);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int b = 0; b < NTI; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[PA[t]], pb[b][PB[t]], acc[b], 0, 0, 0);
+    };
+
+    // every wave walks ALL blocks of the chunk (it owns channels, not rows).  Iteration kb: put dY of block kb + 1 and x of block kb + 2 in
+    // flight, stage x of block kb + 1 (fetched one iteration ago) into the other LDS stage, compute block kb, one barrier.
+    Raw da, db;
+    RawX xa, xb;
+    if (n_kb > 0) {
+        fetch(0, da);
+        fetch_x(0, xa);
+        if (n_kb > 1) fetch_x(1, xb);
+        stage_x(0, xa, xs_lds);
+        lds_barrier();
+    }
+    for (int kb = 0; kb < n_kb; kb += 2) {
+        // even block kb: dY in da, LDS stage 0; x of kb + 1 waits in xb
+        if (kb + 1 < n_kb) fetch(kb + 1, db);
+        if (kb + 2 < n_kb) fetch_x(kb + 2, xa);
+        if (kb + 1 < n_kb) stage_x(kb + 1, xb, xs_lds + STG);
+        compute(kb, da, xs_lds);
+        lds_barrier();
+        if (kb + 1 >= n_kb) break;
+        // odd block kb + 1: dY in db, LDS stage 1; x of kb + 2 waits in xa
+        if (kb + 2 < n_kb) fetch(kb + 2, da);
+        if (kb + 3 < n_kb) fetch_x(kb + 3, xb);
+        if (kb + 2 < n_kb) stage_x(kb + 2, xa, xs_lds);
+        compute(kb + 1, db, xs_lds + STG);
+        lds_barrier();
+    }
+
+    // ---- this wave's 32 rows of the partial: row (cout) = (r & 3) + 8 (r >> 2) + 4 half, col (cin) = lane & 31
+    float *out = p.dw_partial + (int64_t)blockIdx.x * p.part_ld;
+    const int cbase = blockIdx.y * 256 + wave * 32;
+#pragma unroll
+    for (int b = 0; b < NTI; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = cbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            out[(int64_t)c * CI + 32 * b + l31] = acc[b][r];
+        }
+    if (p.db_partial && tid < 256) p.db_partial[(int64_t)blockIdx.x * p.part_ld + blockIdx.y * 256 + tid] = 0.f;
+}
+
 static unsigned long long *g_dw_dbg = nullptr;
 static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 {
@@ -745,6 +901,10 @@ static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 // row-streaming kernel (dw_rows_kernel): which layers take it (PAPC_DW_ROWS=0: none).  Measured on config 2's SA1 with one workgroup
 // per CU (papc_mlp_bwd_dw_chunk_hint): 64 -> 64 dense 99.5 -> 81 us; 64 -> 128 under the max 119 -> ~110 us although its two 64-channel
 // blocks of Cout transform the input twice; dW family 0.85 -> 0.82 ms/step.
+static bool dw_rowsx_eligible(int Cin, int Cout, bool dense, int K)   // dw_rowsx_kernel: 128-channel input, 256-channel blocks of Cout
+{
+    return knob(KNOB_DW_ROWSX) != 0 && Cin == 128 && Cout % 256 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));
+}
 static bool dw_rows_eligible(int Cin, int Cout, bool dense, int K)
 {
     // (64 x 64 blocks of the output: every block transforms its operands again, so at most four of them)
@@ -766,6 +926,11 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     const int to = p.TOp / 32, ti = p.TIp / 32;  // 32-wide tiles per workgroup (upper bound)
     const bool off32 = (int64_t)p.rows_per_chunk * std::max<int64_t>(p.Cout, XMODE == A_GROUP ? 1 : p.x.ldx) * 4 < (1ll << 31);
     const bool k4 = DYMODE != A_DY_MAX || p.dy.d.K % 4 == 0;
+    if (VEC && XMODE == A_BNRELU && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
+        dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 256));
+        hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE>), g2, dim3(512), 0, st, p);
+        return check_launch("papc_mlp_bwd_dw_f32");
+    }
     if (VEC && XMODE == A_BNRELU && dw_rows_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
         // narrow input (64 channels): row-streaming kernel, every thread loads + transforms + multiplies
         dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 64), (unsigned)(p.Cin / 64));
@@ -809,12 +974,14 @@ using namespace papc;
  * 64 x 64 tile per wave (241 registers: one workgroup per CU), so it wants ONE residency wave of workgroups -- ncu row chunks in all */
 extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mode, int dz_mode, int K)
 {
-    if (a_mode != PAPC_A_BNRELU || M < 1 || !dw_rows_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K)) return 0;
+    if (a_mode != PAPC_A_BNRELU || M < 1) return 0;
+    const bool xk = dw_rowsx_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K);
+    if (!xk && !dw_rows_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K)) return 0;
     hipDeviceProp_t prop;
     int dev = 0;
     static int ncu = 0;
     if (!ncu) { ncu = 256; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    const int64_t want = std::max<int64_t>(1, ncu / ((Cout / 64) * (Cin / 64)));
+    const int64_t want = xk ? std::max<int64_t>(1, ncu / (Cout / 256)) : std::max<int64_t>(1, ncu / ((Cout / 64) * (Cin / 64)));
     int64_t rpc = cdiv(M, want);
     rpc = std::max<int64_t>(64, cdiv(rpc, 64) * 64);
     return (int)std::min<int64_t>(rpc, 1 << 24);

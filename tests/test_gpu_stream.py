@@ -93,7 +93,7 @@ def test_stream_is_taken_and_deterministic_at_config2_size(dev, stream_knobs):
     assert_close(o1.detach().cpu().numpy(), o3.detach().cpu().numpy(), 2e-6, "full-size stream vs tiled")
 
 
-@pytest.mark.parametrize("chans,K", [([64, 64, 128], 32), ([64, 64, 64], 16), ([64, 128, 128], 64)])
+@pytest.mark.parametrize("chans,K", [([64, 64, 128], 32), ([64, 64, 64], 16), ([64, 128, 128], 64), ([64, 128, 256], 64), ([128, 128, 256, 512], 16)])
 def test_dw_row_streaming_matches_staged_kernels(dev, chans, K):
     """dW of layers with a 64-channel input on the row-streaming kernel (PAPC_DW_ROWS=1: dense and max-pooled layers) against the
     LDS-staged kernels (=0): the same exact-split products in another summation order, ragged last chunk included."""
@@ -115,11 +115,13 @@ def test_dw_row_streaming_matches_staged_kernels(dev, chans, K):
     try:
         for flav in (0, 1):
             _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWS", flav), "knob")
+            _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWSX", flav), "knob")
             prm = [p.clone().requires_grad_(True) for p in ps]
             out = shared_mlp_max(StackSpec(1, M, G, K, chans[0] - 3, True), None, z, z, None, None, prm, x_rows=x)
             out.backward(gout)
             grads[flav] = [p.grad.clone() for p in prm]
     finally:
         _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWS", 1), "knob")
+        _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWSX", 0), "knob")   # (the hybrid kernel is an opt-in experiment)
     for a, b in zip(grads[0], grads[1]):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7
