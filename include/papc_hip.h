@@ -321,7 +321,7 @@ int papc_pfn_bwd_dw_f32(const float *features, const int32_t *num_voxels, const 
  *                                reduce over the blocks with papc_reduce_partials_f32 (n = 11*C);
  *   papc_pfn_bwd_finalize_f32    sums [11][C] + gram -> dgamma, dbeta and
  *                                dW_ck = sc_c (T_ck - c1_c colsum_k - c2_c invstd_c ((W G)_ck - mean_c colsum_k)), c1 = sum p / M,
- *                                c2 = sum p*xhat / M  (eval_bn != 0: running statistics, c1 = c2 = 0). */
+ *                                c2 = sum p*xhat / M.  flags bit 0: eval-mode BN (running statistics, c1 = c2 = 0); bit 1: ADD into dgamma / dbeta / dw. */
 int papc_pfn_gram_blocks(int P);
 int papc_pfn_gram_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
                       float vx, float vy, float x_offset, float y_offset, double *gram_partial, papc_stream_t stream);
@@ -333,7 +333,7 @@ int papc_pfn_bwd_sparse_f32(const float *features, const int32_t *num_voxels, co
                             const float *gout, const int32_t *argmax, const float *mean, const float *invstd,
                             const float *scale, const float *shift, float *partial, papc_stream_t stream);
 int papc_pfn_bwd_finalize_f32(const float *sums, int64_t M, const float *w, int C, const double *gram, const float *mean,
-                              const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int eval_bn,
+                              const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int flags,
                               papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -472,13 +472,14 @@ __global__ __launch_bounds__(1024) void pfn_gram_finalize_kernel(const double *_
 __global__ __launch_bounds__(64) void pfn_bwd_finalize_kernel(const float *__restrict__ sums, double M, const float *__restrict__ w, int C,
                                                              const double *__restrict__ gram, const float *__restrict__ mean,
                                                              const float *__restrict__ invstd, const float *__restrict__ scale,
-                                                             float *dgamma, float *dbeta, float *dw, int eval_bn)
+                                                             float *dgamma, float *dbeta, float *dw, int flags)
 {
+    const int eval_bn = flags & 1, accumulate = flags & 2;   // bit 1: add into dgamma / dbeta / dw (a parameter's .grad)
     const int c = threadIdx.x;
     if (c >= C) return;
     const double s1 = (double)sums[0 * C + c], s2 = (double)sums[1 * C + c];
-    dbeta[c] = (float)s1;
-    dgamma[c] = (float)s2;
+    dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     const double sc = (double)scale[c];
     // eval-mode BatchNorm (running statistics): dy = sc * p, the batch-mean terms vanish
     const double c1 = eval_bn ? 0.0 : s1 / M, c2 = eval_bn ? 0.0 : s2 / M;
@@ -493,7 +494,8 @@ __global__ __launch_bounds__(64) void pfn_bwd_finalize_kernel(const float *__res
         for (int l = 0; l < 9; ++l) wg += wc[l] * gram[l * 16 + k];
         const double colsum = gram[k * 16 + 10];
         const double t = (double)sums[(2 + k) * C + c];
-        dw[c * 9 + k] = (float)(sc * (t - c1 * colsum - c2 * is * (wg - mu * colsum)));
+        const float g = (float)(sc * (t - c1 * colsum - c2 * is * (wg - mu * colsum)));
+        dw[c * 9 + k] = accumulate ? dw[c * 9 + k] + g : g;
     }
 }
 

@@ -52,6 +52,8 @@ class _PFNFused(torch.autograd.Function):
                                      cst[2].data_ptr(), cst[3].data_ptr(), ptr(out), ptr(argmax), st), "papc_pfn_apply_f32")
         ctx.geom = geom
         ctx.training = bool(training)
+        from .mlp import grad_targets_of
+        ctx.grad_targets = grad_targets_of([w, gamma, beta]) if torch.is_grad_enabled() or w.requires_grad else None
         ctx.save_for_backward(features, num_voxels, coors, w, cst, argmax, gram if gram is not None else cst.new_zeros(1))
         return out
 
@@ -75,10 +77,16 @@ class _PFNFused(torch.autograd.Function):
         check(lib.papc_pfn_bwd_sparse_f32(*geo, ptr(gout), ptr(argmax), *bn, ptr(part), st), "papc_pfn_bwd_sparse_f32")
         sums = torch.empty(11, C, device=dev, dtype=torch.float32)
         check(lib.papc_reduce_partials_f32(ptr(part), nb, 11 * C, ptr(sums), 0, st), "papc_reduce_partials_f32")
+        flags = 0 if ctx.training else 1
+        tg = ctx.grad_targets            # (w.grad, gamma.grad, beta.grad) of parameters that opted in to in-place accumulation, or None
+        if tg is not None:
+            check(lib.papc_pfn_bwd_finalize_f32(ptr(sums), P * T, ptr(w), C, ptr(gram), cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
+                                                tg[1].data_ptr(), tg[2].data_ptr(), tg[0].data_ptr(), flags | 2, st), "papc_pfn_bwd_finalize_f32")
+            return (None,) * 12
         dgb = torch.empty(2, C, device=dev, dtype=torch.float32)
         dw = torch.empty(C, 9, device=dev, dtype=torch.float32)
         check(lib.papc_pfn_bwd_finalize_f32(ptr(sums), P * T, ptr(w), C, ptr(gram), cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
-                                            dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(dw), 0 if ctx.training else 1, st),
+                                            dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(dw), flags, st),
               "papc_pfn_bwd_finalize_f32")
         return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None, None
 

@@ -316,3 +316,27 @@ def test_pfn_apply_mfma_matches_valu_flavour(dev, P, T, C):
         y1 = np.einsum("nk,nk->n", rows[pi, a1[pi, ci]], w[ci].astype(np.float64))
         z0, z1 = y0 * sc.cpu().numpy()[ci] + sh.cpu().numpy()[ci], y1 * sc.cpu().numpy()[ci] + sh.cpu().numpy()[ci]
         assert np.all(np.abs(z0 - z1) <= 1e-5 * (1 + np.abs(z0)) + (np.maximum(z0, z1) <= 1e-6))   # (both dead -> row 0 either way)
+
+
+def test_pfn_inplace_gradients_match_autograd(dev):
+    """FlatParams opts the parameters in to in-place accumulation: the fused PFN backward then ADDS dW / dgamma / dbeta straight into the
+    flat gradient buffer (no AccumulateGrad kernels).  Same values as the autograd path, and a second backward accumulates."""
+    from papc_amd.distributed import FlatParams
+    P, T = 300, 50
+    voxels, nump, coors = make_pillars(P=P, T=T, seed=9)
+    w, g, b = _weights(64, 9, 2)
+    vs, pr = (0.16, 0.16, 4), (0, -39.68, -3, 69.12, 39.68, 1)
+    tv, tn, tc = torch.from_numpy(voxels).to(dev), torch.from_numpy(nump).to(dev), torch.from_numpy(coors).to(dev)
+    gout = torch.randn(P, 64, device=dev)
+    nets = []
+    for flat_mode in (False, True):
+        net = PillarFeatureNet(num_filters=(64,), voxel_size=vs, pc_range=pr).to(dev)
+        _load(net.pfn_layers[0], w, g, b)
+        flat = FlatParams(net) if flat_mode else None
+        for _ in range(2):
+            net(tv, tn, tc).backward(gout)
+        nets.append((net, flat))
+    (ref, _), (got, flat) = nets
+    for pr_, pg in zip(ref.parameters(), got.parameters()):
+        assert pg.grad.data_ptr() >= flat.grad.data_ptr() and pg.grad.data_ptr() < flat.grad.data_ptr() + 4 * flat.grad.numel()
+        assert_close(pg.grad.cpu().numpy(), pr_.grad.cpu().numpy(), 1e-6, "in-place PFN gradient")
