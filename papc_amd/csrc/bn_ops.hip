@@ -431,6 +431,57 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const float *__restrict__
 
 static inline unsigned ew_grid(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 256 * 16)); }
 
+// The same reduction for FEW, LONG groups (PointNet-Basic: 8 clouds x 1024 points x 1024 channels): one thread per (group, channel quad)
+// walking K rows is 2048 threads on the whole chip (300 us for 33 MB).  Here a workgroup owns (group, 256 channels) and its 16 row slices
+// walk K / 16 consecutive rows each; the slices are folded through LDS in row order with a strict >, i.e. the first row attaining the max
+// wins, as in the serial scan.
+static __device__ __forceinline__ float4 ld4f(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__global__ __launch_bounds__(1024) void bn_relu_max_split_kernel(const float *__restrict__ y, const float *__restrict__ scale,
+                                                                const float *__restrict__ shift, int64_t G, int K, int C,
+                                                                float *__restrict__ out, int32_t *__restrict__ argmax)
+{
+    __shared__ float sv[16][64][4];
+    __shared__ int si[16][64][4];
+    const int cq = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int64_t g = blockIdx.x;
+    const int c = (blockIdx.y * 64 + cq) * 4;
+    const bool cok = c < C;       // C % 4 == 0
+    const int per = (K + 15) / 16;
+    const int k0 = sl * per, k1 = min(K, k0 + per);
+    float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);
+    int4 bi = make_int4(0, 0, 0, 0);
+    if (cok) {
+        const float4 sc = ld4f(scale + c), sh = ld4f(shift + c);
+        const float *yp = y + (g * K) * (int64_t)C + c;
+        for (int k = k0; k < k1; ++k) {
+            const float4 v = ld4f(yp + (int64_t)k * C);
+            float z;
+            z = fmaxf(fmaf(sc.x, v.x, sh.x), 0.f); if (z > best.x) { best.x = z; bi.x = k; }
+            z = fmaxf(fmaf(sc.y, v.y, sh.y), 0.f); if (z > best.y) { best.y = z; bi.y = k; }
+            z = fmaxf(fmaf(sc.z, v.z, sh.z), 0.f); if (z > best.z) { best.z = z; bi.z = k; }
+            z = fmaxf(fmaf(sc.w, v.w, sh.w), 0.f); if (z > best.w) { best.w = z; bi.w = k; }
+        }
+    }
+    sv[sl][cq][0] = best.x; sv[sl][cq][1] = best.y; sv[sl][cq][2] = best.z; sv[sl][cq][3] = best.w;
+    si[sl][cq][0] = bi.x; si[sl][cq][1] = bi.y; si[sl][cq][2] = bi.z; si[sl][cq][3] = bi.w;
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int q = threadIdx.x >> 2, i = threadIdx.x & 3;
+        const int cc = (blockIdx.y * 64 + q) * 4 + i;
+        float b = -1.f;
+        int bk = 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {       // slices in row order, strict >: the first row attaining the max wins
+            const float v = sv[s2][q][i];
+            if (v > b) { b = v; bk = si[s2][q][i]; }
+        }
+        if (cc < C) {
+            out[g * C + cc] = b;
+            if (argmax) argmax[g * C + cc] = bk;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Max-pooled last layer, backward without its dense output y (papc_mlp_bwd_dx_max_f32):
 //   dy = s*p - e*y + f            with s = scale, e = s*c2*invstd, f = e*mean - s*c1   (the BN+ReLU backward, expanded)
@@ -587,6 +638,10 @@ int papc_bn_relu_max_f32(const float *y, const float *scale, const float *shift,
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BN_RELU_MAX, st);
     const bool v4 = (C % 4 == 0) && aligned16(y) && aligned16(scale) && aligned16(shift) && aligned16(out);
+    if (v4 && K >= 256 && G * (C / 4) < 65536 && G <= 65535) {   // few, long groups: split the rows over the workgroup
+        hipLaunchKernelGGL(bn_relu_max_split_kernel, dim3((unsigned)G, (unsigned)cdiv(C, 256)), dim3(1024), 0, st, y, scale, shift, G, K, C, out, argmax);
+        return check_launch("papc_bn_relu_max_f32");
+    }
     if (v4) hipLaunchKernelGGL(bn_relu_max_kernel<4>, dim3(ew_grid(G * (C / 4))), dim3(256), 0, st, y, scale, shift, G, K, C, out, argmax);
     else hipLaunchKernelGGL(bn_relu_max_kernel<1>, dim3(ew_grid(G * C)), dim3(256), 0, st, y, scale, shift, G, K, C, out, argmax);
     return check_launch("papc_bn_relu_max_f32");

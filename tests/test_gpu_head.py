@@ -215,3 +215,33 @@ def test_reduce_partials_batch_vs_float64(dev):
         assert float((a0.double() - r1).abs().max()) <= 2e-5 * float(r1.abs().max()) + 1e-6
         if n2:
             assert float((b0.double()[:n2] - r2).abs().max()) <= 2e-5 * float(r2.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("G,K,C", [(8, 1024, 1024), (3, 300, 260), (1, 256, 4)])
+def test_bn_relu_max_few_long_groups(dev, G, K, C):
+    """papc_bn_relu_max_f32 on few, long groups (PointNet-Basic's max over the 1024 points of a cloud, pointnet_base.py:44): the row-split
+    flavour must return the same max and the FIRST row attaining it, ties (many exact zeros after the ReLU) included."""
+    import ctypes
+    from papc_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(G + K)
+    y = torch.randn(G * K, C, device=dev)
+    n7 = y[3::7].shape[0]
+    y[::7][:n7] = y[3::7]                                     # exact duplicates: ties between rows
+    sc = torch.randn(C, device=dev)
+    sh = torch.randn(C, device=dev) * 0.3 - 0.5               # plenty of channels whose max is the ReLU floor
+    out = torch.empty(G, C, device=dev)
+    am = torch.empty(G, C, device=dev, dtype=torch.int32)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.papc_bn_relu_max_f32(p(y), p(sc), p(sh), G, K, C, p(out), p(am), None), "bn_relu_max")
+    z = torch.relu(torch.addcmul(sh, y, sc)).reshape(G, K, C)   # (fma vs mul+add: compare with a tolerance, indices through the values)
+    ref, _ = z.max(1)
+    assert float((out - ref).abs().max()) <= 1e-6 * (1 + float(ref.abs().max()))
+    got_at = torch.gather(z, 1, am.long().unsqueeze(1)).squeeze(1)
+    assert float((got_at - ref).abs().max()) <= 1e-6 * (1 + float(ref.abs().max()))
+    # first occurrence: no earlier row is strictly larger-or-equal beyond rounding
+    ks = torch.arange(K, device=dev).reshape(1, K, 1)
+    earlier = (ks < am.long().unsqueeze(1)) & (z > ref.unsqueeze(1) + 1e-6)
+    assert not bool(earlier.any())
+    dead = ref == 0
+    assert bool((am[dead] == 0).all())                        # all-dead channels: row 0, as the serial scan returns
