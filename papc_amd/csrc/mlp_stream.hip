@@ -493,7 +493,8 @@ template <int AMODE, int EPI, int KB16, int WN>
 static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
-    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || (AMODE == A_DY_DENSE && WN == 4) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : 2;
+    constexpr int CK2 = (KB16 == 6) ? 1 : 2;   // (six k blocks: an even chunk count needs 1 or 3 per chunk, and 3 spills the asm-loaded ring)
+    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || (AMODE == A_DY_DENSE && WN == 4) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : CK2;
     const int ncb = p.Nout / (32 * WN);
     // one workgroup per CU in total (weights + 8 waves of up to 256 registers fill it); column blocks of the same rows are
     // gridDim.x apart in the flat id, i.e. on the same XCD when gridDim.x % 8 == 0: the second reader of a row finds it in L2
@@ -513,12 +514,17 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     const int kb = p.Kin / 16;
     // N tile: as many columns as the weights' LDS image allows (6 K + 16 bytes per column, <= ~100 KB), at most 128
     const int nt = p.Kin > 128 ? 64 : 128;
-    const int wn = std::min(p.Nout, nt) / 32;
-    if (p.Nout % (32 * wn) != 0) return 0;
+    int wn = std::min(p.Nout, nt) / 32;
+    if (p.Nout % (32 * wn) != 0) {       // 96 = 3 column tiles (the MSG branches' 96-channel layers); otherwise whole 64- or 128-wide blocks only
+        if (p.Nout == 96 && nt >= 96) wn = 3;
+        else return 0;
+    }
 #define STREAM_CASE(KB, WNN) if (kb == KB && wn == WNN) return stream_go<AMODE, EPI, KB, WNN>(p, geo, st)
     STREAM_CASE(2, 2); STREAM_CASE(2, 4);
     STREAM_CASE(4, 2); STREAM_CASE(4, 4);
     STREAM_CASE(8, 2); STREAM_CASE(8, 4);
+    STREAM_CASE(4, 3); STREAM_CASE(8, 3);          // 96 output channels
+    STREAM_CASE(6, 2); STREAM_CASE(6, 4);          // 96 input channels
     if constexpr (AMODE == A_DY_DENSE || AMODE == A_DY_MAX || AMODE == A_BNRELU) { STREAM_CASE(16, 2); }
 #undef STREAM_CASE
     return 0;
@@ -535,7 +541,7 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
 {
     if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !vec) return 0;
     if (p.M % 32 != 0 || p.M / 32 < knob(KNOB_STREAM_MINTILES)) return 0;
-    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > 256 || p.Nout % 64 != 0) return 0;
+    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > 256 || p.Nout % 32 != 0 || p.Nout < 64) return 0;
     if (p.wmap || p.nmap || p.ldy != p.Nout) return 0;
     if (!(p.stats || epi == EPI_STORE)) return 0;
     StreamGeo geo;

@@ -52,6 +52,7 @@ def _run(dev, G, K, chans, seed, stream, need_x_grad=False):
     (64, 64, [128, 128, 128, 256]),    # SA2-shaped: K = 128 operands, two column blocks, group = two tiles; dX MAX with K = 256
     (24, 128, [32, 64, 128]),          # group = four tiles, 32-wide first layer, ragged number of units per wave
     (100, 32, [64, 128, 64]),          # unit count not a multiple of the wave count
+    (96, 64, [64, 64, 96, 128]),       # the MSG branches' 96-channel layers: three column tiles (64 -> 96), six k blocks (96 -> 128)
 ])
 @pytest.mark.parametrize("asm", [1, 0])
 def test_stream_matches_tiled_and_f64(dev, stream_knobs, G, K, chans, asm):
