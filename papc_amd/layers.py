@@ -82,9 +82,10 @@ class PointNetSetAbstraction(nn.Module):
         idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz)[0]
         return new_xyz, idx
 
-    def forward(self, xyz, points, start_idx=None, sampled=None):
+    def forward(self, xyz, points, start_idx=None, sampled=None, wt_table=None):
         """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S].
-        ``sampled`` = optional (new_xyz, idx) from :meth:`sample` (skips FPS / ball query here)."""
+        ``sampled`` = optional (new_xyz, idx) from :meth:`sample` (skips FPS / ball query here);
+        ``wt_table`` = optional result of ``mlp.precompute_wt`` covering this layer's weights, made for THIS forward pass."""
         xyz = xyz.transpose(1, 2)                                               # :203  [B,N,3] view
         if xyz.dtype != torch.float32:
             xyz = xyz.float()
@@ -109,6 +110,7 @@ class PointNetSetAbstraction(nn.Module):
             feats, params, D = _pad_features(feats, params, True)
         spec = StackSpec(B, N, S, K, D, xyz_first=True, eps=self.mlp_bns[0].eps, momentum=0.9,
                          cut_gather_grad=self.reference_quirks)
+        spec.wt_table = wt_table
         out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx, params)   # :214-219
         new_points = out.view(B, S, -1).transpose(1, 2)                         # [B,D',S]
         return new_xyz.transpose(1, 2), new_points                              # :220-221

@@ -39,6 +39,8 @@ class StackSpec:
         # optional: per-parameter gradient buffers (contiguous, same shape as the parameter) that the backward
         # accumulates into directly instead of returning gradients to autograd (see grad_targets_of)
         self.grad_targets = None
+        # optional: W^T operands precomputed for THIS forward pass by the caller (precompute_wt); None = transpose in the backward
+        self.wt_table = None
 
 
 def _group_src(spec, xyz, new_xyz, feats, idx):
@@ -75,17 +77,17 @@ def _dw_rows_per_chunk(M, cout, cin):
 
 # ---- W^T operands of the dX GEMMs, precomputed for several stacks in one launch -------------------------------------------------
 # A stack's backward needs the transposes of its layers' weights (one papc_transpose_batch_f32 per stack).  A model that runs several
-# stacks per step can hand ALL of them over before its forward (precompute_wt): one launch instead of one per stack.  The table is
-# replaced by every call and a stack only uses it when it was recorded by the SAME forward pass (ctx.wt_id), so a stale transpose
-# (weights updated in between) can never be picked up; anything missing is transposed locally as before.
-_WT = {"id": 0, "map": {}}
+# stacks per step can transpose ALL of them in one launch before its forward (precompute_wt) and hand the resulting table to exactly
+# the stack invocations of THAT forward pass (StackSpec.wt_table, kept on the autograd node).  There is no module-level state: a stack
+# called without a table (a layer used on its own, a later forward after the optimiser moved the weights) transposes locally, so a
+# stale transpose can never be picked up.
 
 
 def precompute_wt(weights):
-    """weights: conv / linear weights [Cout, Cin(, 1...)] whose [Cin, Cout] transposes the coming backward passes will need."""
+    """weights: conv / linear weights [Cout, Cin(, 1...)] whose [Cin, Cout] transposes the coming backward passes will need.
+    Returns the table {weight.data_ptr(): W^T tensor} to pass on as ``StackSpec.wt_table`` for this forward pass only."""
     lib = _lib.load()
     st = stream_ptr()
-    _WT["id"] += 1
     table = {}
     ws = [w for w in weights if w.is_cuda and w.is_contiguous() and w.dtype == torch.float32]
     for g0 in range(0, len(ws), 8):
@@ -99,8 +101,7 @@ def precompute_wt(weights):
             table[w.data_ptr()] = t
             srcs[i], dsts[i], rws[i], cls[i] = w.data_ptr(), t.data_ptr(), cout, cin
         check(lib.papc_transpose_batch_f32(srcs, dsts, rws, cls, n, st), "papc_transpose_batch_f32")
-    _WT["map"] = table
-    return _WT["id"]
+    return table
 
 
 class SharedMLPMax(torch.autograd.Function):
@@ -206,7 +207,7 @@ class SharedMLPMax(torch.autograd.Function):
                   "papc_bn_relu_max_f32")
         ctx.spec = spec
         ctx.L = L
-        ctx.wt_id = _WT["id"]
+        ctx.wt_table = spec.wt_table
         ctx.feats_needs_grad = feats is not None and feats.requires_grad and not spec.cut_gather_grad
         ctx.x_needs_grad = plain and x_rows.requires_grad
         ctx.cin0 = cin0
@@ -249,9 +250,9 @@ class SharedMLPMax(torch.autograd.Function):
         if ctx.lin0 and 0 in need_wt:
             need_wt.remove(0)
         wts = {}
-        if ctx.wt_id == _WT["id"]:         # transposes handed over for this very forward pass (precompute_wt)
+        if ctx.wt_table is not None:       # transposes handed over for this very forward pass (precompute_wt)
             for l in list(need_wt):
-                t = _WT["map"].get(params[4 * l].data_ptr())
+                t = ctx.wt_table.get(params[4 * l].data_ptr())
                 cin_l = ctx.cin0 if l == 0 else params[4 * (l - 1)].shape[0]
                 if t is not None and tuple(t.shape) == (cin_l, params[4 * l].shape[0]):
                     wts[l] = t
@@ -341,7 +342,7 @@ class SharedMLPMax(torch.autograd.Function):
                     grads[3] = dgb[1]
                 if ctx.feats_needs_grad:
                     # grad_feats = G W_f: the same row GEMM with the transposed feature block as its weight
-                    wt_full = _WT["map"].get(w.data_ptr()) if ctx.wt_id == _WT["id"] else None
+                    wt_full = ctx.wt_table.get(w.data_ptr()) if ctx.wt_table is not None else None
                     if wt_full is not None and tuple(wt_full.shape) == (cin, cout):
                         wft = wt_full[fcol0:fcol0 + spec.D]     # rows of the precomputed W^T [cin, cout]: the feature block, contiguous
                     else:

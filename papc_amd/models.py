@@ -90,19 +90,20 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
             norm = None
         s = _starts(start_idx, 2)
         pl = plan if plan is not None else (None, None)
+        wt = None
         if torch.is_grad_enabled() and xyz.is_cuda:
             # the W^T operands of the three stacks' dX GEMMs in one launch (SA1 / SA2: layers 2, 3; SA3 also its first layer, whose
             # input features carry a gradient)
             from .mlp import precompute_wt
-            precompute_wt([c.weight for c in list(self.sa1.mlp_convs)[1:]] + [c.weight for c in self.sa2.mlp_convs]
+            wt = precompute_wt([c.weight for c in list(self.sa1.mlp_convs)[1:]] + [c.weight for c in self.sa2.mlp_convs]
                           + [c.weight for c in self.sa3.mlp_convs])     # (SA2's first layer: the feature block of its W^T, gather-add backward)
-        l1_xyz, l1_points = self.sa1(xyz, norm, s[0], sampled=pl[0])
-        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1], sampled=pl[1])
+        l1_xyz, l1_points = self.sa1(xyz, norm, s[0], sampled=pl[0], wt_table=wt)
+        l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1], sampled=pl[1], wt_table=wt)
         if after_sa2 is not None:
             after_sa2()
         if tap is not None:
             tap["l2_points"] = l2_points
-        l3_xyz, l3_points = self.sa3(l2_xyz, l2_points)
+        l3_xyz, l3_points = self.sa3(l2_xyz, l2_points, wt_table=wt)
         x = l3_points.reshape(B, 1024)
         return self._head(x)
 
