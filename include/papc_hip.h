@@ -21,6 +21,7 @@
 #ifndef PAPC_HIP_H
 #define PAPC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -432,6 +433,93 @@ int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scal
 int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, int64_t ldx, const float *bn_scale,
                             const float *bn_shift, const float *wcat, const float *hbias, int64_t M, int Cin, int Cout, float *dx,
                             const papc_bwd_red *next_red, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stacks with FEW rows (the group_all set-abstraction layer: sample_and_group_all + conv/BN/ReLU x L + max,
+ * pointnet2_basic_layers.py:160-176, :215-219; PointNet2_SSG_Clas.sa3, classify/pointnet2/pointnet2.py:16 -- M = B*128 rows,
+ * up to 1024 channels).  The operand transforms are taken out of the GEMMs (csrc/smallm.hip): prep kernels write every operand
+ * once as the three bf16 PLANES of the exact fp32 product (x = p0 + p1 + p2, six MFMA products per fp32 product) in MFMA fragment
+ * order, and one matrix kernel multiplies two plane sets:  C[i, j] = sum_k A[i, k] * B[j, k].
+ *
+ * planes of an [R x K] matrix (K = the contraction): R padded to 128, K to 32; papc_pg_planes_bytes(R, K) bytes, 16-byte aligned.
+ *   forward  y[M, Co]   : A = planes of the layer input [M x Ci],  B = planes of W [Co x Ci]
+ *   dX       dz[M, Ci]  : A = planes of dY [M x Co],               B = planes of W^T [Ci x Co]
+ *   dW       dW[Co, Ci] : A = planes of dY^T [Co x M],             B = planes of input^T [Ci x M]   (split over the M contraction)
+ * ---------------------------------------------------------------------------------------------- */
+size_t papc_pg_planes_bytes(int64_t R, int64_t K);
+
+/* count <= 8 strided fp32 matrices -> planes in one launch: element (r, k) = src[r*row_stride + k*col_stride], r < R, k < K
+ * (W: row_stride = Ci, col_stride = 1; W^T: row_stride = 1, col_stride = Ci).  jobs is a HOST array. */
+typedef struct papc_pg_wjob {
+    const float *src;
+    int64_t row_stride, col_stride;
+    int R, K;
+    void *planes;
+} papc_pg_wjob;
+int papc_pg_prep_weights_f32(const papc_pg_wjob *jobs, int count, papc_stream_t stream);
+
+/* Rows [M x C] -> planes (contraction over the C channels) and / or planes_t (the transpose: rows = channels, contraction over M;
+ * needs M % 32 == 0), with the elementwise part of the layer applied on the way: */
+#define PAPC_PG_PLAIN 0    /* x[m, k]                                   (x [M, ldx])                                          */
+#define PAPC_PG_CONCAT 1   /* sample_and_group_all rows [xyz | feats] (xyz_first) or [feats | xyz]: xyz strided [B, N, 3], feats [M, D], C = D + 3 */
+#define PAPC_PG_BNRELU 2   /* relu(bn(x)): x = the previous layer's pre-BN output; the train-mode batch statistics are folded here from
+                            * stats [parts, 2, C] (papc_pg_gemm_f32 FWD epilogue) -- mean / invstd / scale / shift and the running
+                            * statistics are WRITTEN (what papc_bn_finalize_f32 does as a separate launch)                      */
+#define PAPC_PG_DY_DENSE 3 /* dY of papc_bwd_dy (DENSE): x = this layer's y, dz [M, C]; c1 / c2 are folded here from red [red_parts, 2, C]
+                            * (papc_pg_gemm_f32 RED epilogue) and dgamma / dbeta written or accumulated (papc_bn_bwd_finalize_f32)  */
+#define PAPC_PG_DY_MAX 4   /* the same under the max over groups of K rows: gout / argmax [M/K, C]; red may be NULL, then the sums
+                            * are taken from gout and ysel [M/K, C] (the raw y at the argmax, papc_pg_final_f32)                 */
+typedef struct papc_pg_prep {
+    int mode;
+    int64_t M; int C;
+    const float *x; int64_t ldx;
+    const float *xyz; int64_t sb, sn, sc; const float *feats; int N, D, xyz_first;
+    const float *dz;
+    const float *gout, *ysel; const int32_t *argmax; int K;
+    const float *stats; int parts;
+    const float *gamma, *beta; float eps, momentum; float *running_mean, *running_var;
+    float *mean, *invstd, *scale, *shift;
+    const float *red; int red_parts;
+    float *dgamma, *dbeta; int accumulate;
+    void *planes, *planes_t;
+} papc_pg_prep;
+int papc_pg_prep_rows_f32(const papc_pg_prep *args, papc_stream_t stream);
+
+/* C[i, j] (+ bias[j]) = sum_k A[i, k] B[j, k], i < R1, j < R2, K = contraction length (both plane sets padded alike).
+ * Epilogues: */
+#define PAPC_PG_STORE 0     /* c [R1, ldc]; split > 1: split-K partials c + z*split_stride (fold with papc_pg_fold_f32)          */
+#define PAPC_PG_FWD 1       /* + bias, + stats [ceil(R1/128), 2, R2]: column sums / sums of squares per 128-row tile             */
+#define PAPC_PG_FWD_GMAX 2  /* + per 128-row tile (= one group: nsample = 128) max / min of the column and the first row offset  *
+                             * attaining each: gmax / gmin / amax / amin [R1/128, R2] (papc_group_max with K = 128)               */
+#define PAPC_PG_RED 3       /* dX: + the BN-backward sums of the layer BELOW over the dz just produced (papc_bwd_red): y_prev    *
+                             * [R1, R2] and its constants; stats [ceil(R1/128), 2, R2] = sums of p and p*xhat                     */
+typedef struct papc_pg_gemm {
+    int epi;
+    const void *a, *b;
+    int R1, R2, K;
+    float *c; int64_t ldc;
+    int split; int64_t split_stride;
+    const float *bias;
+    float *stats;
+    float *gmax, *gmin; int32_t *amax, *amin;
+    const float *y_prev, *mean, *invstd, *scale, *shift;
+    int family;             /* PAPC_K_* family the launch is timed under (event profiler) */
+} papc_pg_gemm;
+int papc_pg_gemm_f32(const papc_pg_gemm *args, papc_stream_t stream);
+
+/* Last forward layer of such a stack: stats [parts, 2, C] -> mean / invstd / scale / shift (+ running statistics), then
+ * out[g, c] = relu(scale*(scale >= 0 ? gmax : gmin) + shift), argmax = the matching row offset, and gmax is left holding the
+ * selected raw value ysel (papc_bn_finalize_f32 + papc_bn_select_max_f32 in one launch). */
+int papc_pg_final_f32(const float *stats, int parts, int64_t M, int C, const float *gamma, const float *beta, float eps, float momentum,
+                      float *mean, float *invstd, float *scale, float *shift, float *running_mean, float *running_var, float *gmax,
+                      const float *gmin, const int32_t *amax, const int32_t *amin, int64_t G, float *out, int32_t *argmax, papc_stream_t stream);
+
+/* count <= 8 split-K partial sets folded in one launch, fixed order: out[e] (+)= sum_t partial[t*stride + e], e < n.  HOST array. */
+typedef struct papc_pg_fold_job {
+    const float *partial; int nsplit; int64_t stride, n;
+    float *out; int accumulate;
+} papc_pg_fold_job;
+int papc_pg_fold_f32(const papc_pg_fold_job *jobs, int count, papc_stream_t stream);
 
 /* count <= 8 row-major fp32 matrices transposed in one launch: dst[i] [cols[i], rows[i]] = src[i] [rows[i], cols[i]]^T.  The four
  * arrays are HOST arrays (read during the call); the matrices are device memory.  Used for the W^T operands of a stack's dX GEMMs. */

@@ -24,7 +24,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-fast-mat
 # per-file extra flags
 NOSLP = ["-fno-slp-vectorize"]
 RES = ["-Rpass-analysis=kernel-resource-usage"]
-EXTRA = {"mlp_stream.hip": NOSLP + RES, "mlp_gemm.hip": NOSLP, "mlp_dw.hip": NOSLP, "sampling.hip": NOSLP, "bn_ops.hip": NOSLP, "pfn.hip": NOSLP, "interp.hip": NOSLP, "nms.hip": NOSLP, "head.hip": NOSLP, "lingather.hip": NOSLP}  # packed f32 VALU (v_pk_add_f32 ...) is slower than scalar beside MFMAs
+EXTRA = {"mlp_stream.hip": NOSLP + RES, "mlp_gemm.hip": NOSLP, "mlp_dw.hip": NOSLP, "sampling.hip": NOSLP, "bn_ops.hip": NOSLP, "pfn.hip": NOSLP, "interp.hip": NOSLP, "nms.hip": NOSLP, "head.hip": NOSLP, "lingather.hip": NOSLP, "smallm.hip": NOSLP + RES}  # packed f32 VALU (v_pk_add_f32 ...) is slower than scalar beside MFMAs
 
 
 def _hipcc():
