@@ -212,10 +212,7 @@ def main():
         def fork():
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                p = model.plan_sampling(x, (s1, s2))
-                for dst_lvl, src_lvl in zip(plan_out, p):
-                    for d, s_ in zip(dst_lvl, src_lvl):
-                        d.copy_(s_)
+                model.plan_sampling(x, (s1, s2), out=plan_out)     # the kernels write the other graph's plan buffers in place
 
         # (N > 1: the two stages are two graphs and a fork must be joined inside the graph that opened it, so the sampling
         # branch belongs to stage 2 -- the SA2 + SA1 backward, 1.4 ms -- there)
@@ -322,10 +319,7 @@ def main():
     def sample_into(plan_out):
         """the next batch's pyramid, enqueued on the side stream beside the graph that is being replayed (N > 1)"""
         with torch.cuda.stream(side):
-            p = model.plan_sampling(x, (s1, s2))
-            for dst_lvl, src_lvl in zip(plan_out, p):
-                for d, s_ in zip(dst_lvl, src_lvl):
-                    d.copy_(s_)
+            model.plan_sampling(x, (s1, s2), out=plan_out)
 
     def step():
         if graph_state["g"] is None:

@@ -248,6 +248,8 @@ struct PgArgs {
     float *stats;                     // FWD: [gridDim.x][2][R2] column sums / sums of squares; RED: sums of p, p * xhat
     float *gmax, *gmin; int32_t *amax, *amin;   // FWD_GMAX: [gridDim.x][R2]
     const float *y_prev, *mean, *invstd, *scale, *shift;   // RED: the layer below ([R1, R2] and its BN constants)
+    int dbg;                          // PAPC_PG_DBG phase-removal bits (timing experiments only)
+    int g1, g2;                       // row / column tiles (the grid is 1-D: g1 * g2 * splits workgroups)
 };
 
 // one 1 KiB fragment global -> LDS: the LDS address is M0 + lane * 16 (wave-uniform base), the global address per lane
@@ -270,7 +272,7 @@ __device__ __forceinline__ void pg_wait_barrier()
 // Epilogue from the accumulator layout: lane = column (lane & 31) of a 32-column block, register r = row (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3)
 // of a 32-row block.  FULL: the tile lies inside C (no masks).
 template <int EPI, int NB, bool FULL>
-__device__ __forceinline__ void pg_epilogue(const PgArgs &p, floatx16 (&acc)[2][NB], char *smem, int lane, int wr, int wc, int bi, int bj)
+__device__ __forceinline__ void pg_epilogue(const PgArgs &p, floatx16 (&acc)[2][NB], char *smem, int lane, int wr, int wc, int bi, int bj, int bz)
 {
     const int cl = lane & 31, h = lane >> 5;
     constexpr bool FWD = (EPI == PG_EPI_FWD || EPI == PG_EPI_FWD_GMAX);
@@ -285,7 +287,7 @@ __device__ __forceinline__ void pg_epilogue(const PgArgs &p, floatx16 (&acc)[2][
         const int j = bj * (NB * 64) + jt;
         const bool jok = FULL || j < p.R2;
         const int jj = jok ? j : 0;
-        float *cp = p.c + (int64_t)blockIdx.z * p.zstride + (int64_t)(bi * 128 + it0) * p.ldc + jj;
+        float *cp = p.c + (int64_t)bz * p.zstride + (int64_t)(bi * 128 + it0) * p.ldc + jj;
         float bias = 0.f, sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
         if (FWD && p.bias) bias = p.bias[jj];
         if (EPI == PG_EPI_RED) { sc = p.scale[jj]; sh = p.shift[jj]; mu = p.mean[jj]; is = p.invstd[jj]; }
@@ -366,19 +368,30 @@ __device__ __forceinline__ void pg_epilogue(const PgArgs &p, floatx16 (&acc)[2][
     }
 }
 
-template <int EPI, int NB>
+// NS = stages in the LDS ring (NS - 1 of them in flight): 3 stages x 48 KiB is one workgroup per CU; (NB = 1, NS = 2) is 72 KiB, two
+// workgroups per CU whose waves fill each other's LDS-read and barrier gaps.
+template <int EPI, int NB, int NS>
 __global__ __launch_bounds__(256, 1) void pg_gemm_kernel(PgArgs p)
 {
     constexpr int NRB = 4 + 2 * NB;              // 32-row blocks per stage: 4 of A, then 2 NB of B
     constexpr int STAGE = NRB * 6 * 1024;        // a (row block, k32) piece is 6 KiB: [2 k16][3 planes][1 KiB]
     constexpr int NLW = NRB * 6 / 4;             // fragment loads per wave and stage
-    __shared__ __attribute__((aligned(1024))) char smem[3 * STAGE];
+    __shared__ __attribute__((aligned(1024))) char smem[NS * STAGE];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = w >> 1, wc = w & 1;
-    const int bi = blockIdx.x, bj = blockIdx.y;
+    // workgroup -> (split z, row tile bi, column tile bj).  Consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each): give
+    // every XCD a CONTIGUOUS range of the (z, bi, bj) order, so that it streams one k range of few row tiles against all column tiles
+    // (forward / dX) or all tiles of one k range (dW) through its own L2 instead of every XCD pulling every operand from the fabric.
+    int t = blockIdx.x;
+    const int nwg = gridDim.x;
+    if ((nwg & 7) == 0) t = (t & 7) * (nwg >> 3) + (t >> 3);
+    const int tiles = p.g1 * p.g2;
+    const int bz = t / tiles;
+    t -= bz * tiles;
+    const int bi = t / p.g2, bj = t - bi * p.g2;
     const int nst = p.nst;
-    const int64_t st0 = (int64_t)blockIdx.z * nst;
+    const int64_t st0 = (int64_t)bz * nst;
     const unsigned lds0 = (unsigned)(uintptr_t)smem;
 
     // this wave's share of a stage: A row block w (6 fragments) and, of B, row block w (NB = 2) or half of row block w >> 1 (NB = 1)
@@ -409,16 +422,20 @@ __global__ __launch_bounds__(256, 1) void pg_gemm_kernel(PgArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ia][ib][r] = 0.f;
 
-    issue(0, 0);
-    if (nst > 1) issue(1, 1);
+    if (!(p.dbg & 2)) {
+        issue(0, 0);
+        if (NS == 3 && nst > 1) issue(1, 1);
+    }
     int buf = 0;
     for (int s = 0; s < nst; ++s) {
-        if (s + 1 < nst) pg_wait_barrier<NLW>();
+        if (NS == 3 && s + 1 < nst) pg_wait_barrier<NLW>();
         else pg_wait_barrier<0>();
-        if (s + 2 < nst) issue(s + 2, buf == 0 ? 2 : buf - 1);      // the buffer every wave finished reading before this barrier
+        // refill the buffer every wave finished reading before this barrier
+        if (s + NS - 1 < nst && !(p.dbg & 2)) issue(s + NS - 1, buf == 0 ? NS - 1 : buf - 1);
         const char *sb = smem + buf * STAGE + lane * 16;
 #pragma unroll
         for (int kbl = 0; kbl < 2; ++kbl) {
+            if (p.dbg & 4) continue;
             bf16x8 af[2][3], bq[NB][3];
 #pragma unroll
             for (int ia = 0; ia < 2; ++ia)
@@ -430,6 +447,17 @@ __global__ __launch_bounds__(256, 1) void pg_gemm_kernel(PgArgs p)
                 for (int pl = 0; pl < 3; ++pl) bq[ib][pl] = *reinterpret_cast<const bf16x8 *>(sb + ((4 + wc * NB + ib) * 6 + kbl * 3 + pl) * 1024);
             // a*b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0), smallest terms first
             constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+            if (p.dbg & 1) {   // keep the LDS reads alive without the matrix work
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(af[ia][pl]));
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) asm volatile("" ::"v"(bq[ib][pl]));
+                continue;
+            }
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -438,14 +466,15 @@ __global__ __launch_bounds__(256, 1) void pg_gemm_kernel(PgArgs p)
                     for (int ib = 0; ib < NB; ++ib)
                         acc[ia][ib] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ia][PA[t]], bq[ib][PB[t]], acc[ia][ib], 0, 0, 0);
         }
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == NS - 1 ? 0 : buf + 1;
     }
 
     // ---- epilogue (full tiles take the straight-line flavour: a per-element predicate puts every store in its own basic block
     // behind an s_waitcnt vmcnt(0))
+    if (p.dbg & 8) return;
     const bool full = bi * 128 + 128 <= p.R1 && (bj + 1) * (NB * 64) <= p.R2;
-    if (full) pg_epilogue<EPI, NB, true>(p, acc, smem, lane, wr, wc, bi, bj);
-    else pg_epilogue<EPI, NB, false>(p, acc, smem, lane, wr, wc, bi, bj);
+    if (full) pg_epilogue<EPI, NB, true>(p, acc, smem, lane, wr, wc, bi, bj, bz);
+    else pg_epilogue<EPI, NB, false>(p, acc, smem, lane, wr, wc, bi, bj, bz);
 }
 
 // ---- last forward layer: batch statistics -> BN constants, then BN + ReLU on the selected extreme of every (group, channel) ------
@@ -625,7 +654,7 @@ int papc_pg_gemm_f32(const papc_pg_gemm *g, papc_stream_t stream)
     memset(&p, 0, sizeof(p));
     p.a = reinterpret_cast<const char *>(g->a); p.b = reinterpret_cast<const char *>(g->b); p.KB = nst_all * 2; p.nst = nst_all / split;
     p.R1 = g->R1; p.R2 = g->R2; p.c = g->c; p.ldc = g->ldc; p.zstride = g->split_stride;
-    p.bias = g->bias; p.stats = g->stats;
+    p.bias = g->bias; p.stats = g->stats; p.dbg = knob(KNOB_PG_DBG);
     const int epi = g->epi;
     if (epi == PG_EPI_FWD || epi == PG_EPI_FWD_GMAX || epi == PG_EPI_RED) PAPC_REQUIRE(g->stats, PAPC_E_INVALID, "papc_pg_gemm_f32: this epilogue needs stats");
     if (epi == PG_EPI_FWD_GMAX) {
@@ -638,14 +667,22 @@ int papc_pg_gemm_f32(const papc_pg_gemm *g, papc_stream_t stream)
     }
     hipStream_t st = as_stream(stream);
     ProfScope prof(g->family >= 0 && g->family < PAPC_K_COUNT ? g->family : PAPC_K_MISC, st);
-    // column tiles of 128 when that already fills the chip, else of 64 (twice the workgroups)
+    // Tile flavours.  (NB = 2, NS = 3): 128 x 128 tiles, 144 KiB of LDS, one workgroup (one wave per SIMD) per CU -- the least operand
+    // traffic, but every LDS-read wait of its lone wave is exposed.  (NB = 1, NS = 2): 128 x 64 tiles, 72 KiB, two workgroups per CU.
+    // PAPC_PG_NB / PAPC_PG_NS force one (experiments).
     const int64_t t1 = cdiv(g->R1, 128);
-    const bool nb2 = g->R2 > 64 && t1 * cdiv(g->R2, 128) * split >= 160;
-    const dim3 grid((unsigned)t1, (unsigned)cdiv(g->R2, nb2 ? 128 : 64), (unsigned)split);
-#define PG_GO(E)                                                                                   \
-    do {                                                                                           \
-        if (nb2) hipLaunchKernelGGL((pg_gemm_kernel<E, 2>), grid, dim3(256), 0, st, p);            \
-        else hipLaunchKernelGGL((pg_gemm_kernel<E, 1>), grid, dim3(256), 0, st, p);                \
+    int nb = knob(KNOB_PG_NB), ns = knob(KNOB_PG_NS);
+    if (nb == 0) nb = (g->R2 > 64 && t1 * cdiv(g->R2, 128) * split >= 200) ? 2 : 1;
+    if (g->R2 <= 64) nb = 1;
+    if (ns == 0) ns = 2;   // (96 / 72 KiB: the workgroup also fits beside a 49 KiB farthest-point-sampling workgroup of the sampling branch)
+    p.g1 = (int)t1; p.g2 = (int)cdiv(g->R2, nb == 2 ? 128 : 64);
+    const dim3 grid((unsigned)(p.g1 * p.g2 * split));
+#define PG_GO(E)                                                                                      \
+    do {                                                                                              \
+        if (nb == 2 && ns == 3) hipLaunchKernelGGL((pg_gemm_kernel<E, 2, 3>), grid, dim3(256), 0, st, p);      \
+        else if (nb == 2) hipLaunchKernelGGL((pg_gemm_kernel<E, 2, 2>), grid, dim3(256), 0, st, p);            \
+        else if (ns == 3) hipLaunchKernelGGL((pg_gemm_kernel<E, 1, 3>), grid, dim3(256), 0, st, p);            \
+        else hipLaunchKernelGGL((pg_gemm_kernel<E, 1, 2>), grid, dim3(256), 0, st, p);                         \
     } while (0)
     switch (epi) {
     case PG_EPI_STORE: PG_GO(PG_EPI_STORE); break;

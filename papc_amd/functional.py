@@ -75,8 +75,10 @@ class _IndexPoints(torch.autograd.Function):
         return gp, None
 
 
-def _fps_raw(xyz, npoint, start_idx, init_dist=1.0, want_new_xyz=True):
-    """xyz [B,N,3] (any strides, e.g. a transposed [B,3,N]) -> (idx int32 [B,npoint], new_xyz [B,npoint,3])."""
+def _fps_raw(xyz, npoint, start_idx, init_dist=1.0, want_new_xyz=True, new_xyz_out=None):
+    """xyz [B,N,3] (any strides, e.g. a transposed [B,3,N]) -> (idx int32 [B,npoint], new_xyz [B,npoint,3]).
+    ``new_xyz_out``: optional preallocated contiguous float32 [B,npoint,3] the centroids are written to (a static buffer of a
+    captured training step)."""
     _need_cuda(xyz)
     if xyz.dtype != torch.float32:
         xyz = xyz.float()
@@ -87,6 +89,9 @@ def _fps_raw(xyz, npoint, start_idx, init_dist=1.0, want_new_xyz=True):
     start_idx = start_idx.to(device=xyz.device, dtype=torch.int64).contiguous()
     idx = torch.empty(B, npoint, device=xyz.device, dtype=torch.int32)
     new_xyz = torch.empty(B, npoint, 3, device=xyz.device, dtype=torch.float32) if want_new_xyz else None
+    if new_xyz_out is not None:
+        assert tuple(new_xyz_out.shape) == (B, npoint, 3) and new_xyz_out.is_contiguous() and new_xyz_out.dtype == torch.float32
+        new_xyz = new_xyz_out
     check(_lib.load().papc_fps_f32(ptr(xyz), xyz.stride(0), xyz.stride(1), xyz.stride(2), B, N, npoint,
                                    ptr(start_idx), float(init_dist), ptr(idx), ptr(new_xyz), stream_ptr()), "papc_fps_f32")
     return idx, new_xyz
@@ -103,8 +108,9 @@ def farthest_point_sample(xyz, npoint, start_idx=None, init_dist=1.0, as_float=F
     return idx.float() if as_float else idx.long()
 
 
-def _ball_query_raw(radii, nsamples, xyz, new_xyz, idx64=False):
-    """All radii in one scan.  xyz [B,N,3] strided, new_xyz [B,S,3] -> list of [B,S,K_r] (int32 / int64)."""
+def _ball_query_raw(radii, nsamples, xyz, new_xyz, idx64=False, outs=None):
+    """All radii in one scan.  xyz [B,N,3] strided, new_xyz [B,S,3] -> list of [B,S,K_r] (int32 / int64).
+    ``outs``: optional preallocated contiguous index tensors, one per radius."""
     _need_cuda(xyz, new_xyz)
     if xyz.dtype != torch.float32:
         xyz = xyz.float()
@@ -113,7 +119,10 @@ def _ball_query_raw(radii, nsamples, xyz, new_xyz, idx64=False):
     S = new_xyz.shape[1]
     n = len(radii)
     dt = torch.int64 if idx64 else torch.int32
-    outs = [torch.empty(B, S, int(k), device=xyz.device, dtype=dt) for k in nsamples]
+    if outs is None:
+        outs = [torch.empty(B, S, int(k), device=xyz.device, dtype=dt) for k in nsamples]
+    else:
+        assert len(outs) == n and all(tuple(o.shape) == (B, S, int(k)) and o.dtype == dt and o.is_contiguous() for o, k in zip(outs, nsamples))
     thr = (ctypes.c_float * n)(*[radius_threshold(r) for r in radii])
     ns = (ctypes.c_int * n)(*[int(k) for k in nsamples])
     op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])

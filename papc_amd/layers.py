@@ -69,17 +69,18 @@ class PointNetSetAbstraction(nn.Module):
             for p in self.parameters():
                 p.requires_grad_(False)
 
-    def sample(self, xyz, start_idx=None):
+    def sample(self, xyz, start_idx=None, out=None):
         """The weight-independent half of the layer (FPS + ball query, :143-145) on its own: xyz [B,3,N] ->
         (new_xyz [B,S,3], idx [B,S,K] int32).  Lets a training loop run batch i+1's sampling on a side stream while
-        batch i's MLP kernels own the other CUs (FPS is a serial chain that occupies only B of the 256 CUs)."""
+        batch i's MLP kernels own the other CUs (FPS is a serial chain that occupies only B of the 256 CUs).
+        ``out`` = optional preallocated (new_xyz, idx) the kernels write straight into (no copies in a captured step)."""
         if self.group_all:
             return None
         xyz = xyz.transpose(1, 2)
         if xyz.dtype != torch.float32:
             xyz = xyz.float()
-        _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist)
-        idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz)[0]
+        _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=None if out is None else out[0])
+        idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz, outs=None if out is None else [out[1]])[0]
         return new_xyz, idx
 
     def forward(self, xyz, points, start_idx=None, sampled=None, wt_table=None):

@@ -62,17 +62,19 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
         self.drop2 = nn.Dropout(0.4)
         self.fc3 = nn.Linear(256, num_classes)
 
-    def plan_sampling(self, inputs, start_idx=None):
+    def plan_sampling(self, inputs, start_idx=None, out=None):
         """The whole weight-independent sampling pyramid of one batch (FPS1, ball query 1, FPS2, ball query 2): returns
         ((new_xyz1, idx1), (new_xyz2, idx2)).  Pass it to forward(plan=...); a training loop can compute it for batch
-        i+1 on a side stream while batch i trains (see bench.py)."""
+        i+1 on a side stream while batch i trains (see bench.py).  ``out`` = optional preallocated plan (same structure) that the
+        kernels fill in place."""
         xyz = torch.as_tensor(inputs)
         if self.normal_channel:
             xyz = xyz[:, :3, :]
         s = _starts(start_idx, 2)
         with torch.no_grad():
-            p1 = self.sa1.sample(xyz, s[0])
-            p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1])
+            o = out if out is not None else (None, None)
+            p1 = self.sa1.sample(xyz, s[0], out=o[0])
+            p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1], out=o[1])
         return p1, p2
 
     def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None):
