@@ -101,6 +101,14 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
+    ap.add_argument("--lr", type=float, default=1e-3, help="Adam learning rate (train.py:62-65: 1e-3).  (tests) A training step is a "
+                    "discontinuous function of the weights -- which row wins a neighbourhood max, which side of 0 a pre-activation falls -- "
+                    "so the last-bit noise of the gather-add backward's float atomics grows ~30x per step at lr = 1e-3: two runs of the SAME "
+                    "launch structure differ by percents after ten steps (tools/probe/repro.py).  The launch-structure test compares "
+                    "trajectories at a small lr, where the weights still move every step but the noise stays at rounding level")
+    ap.add_argument("--dump-trajectory", default=None, metavar="FILE.npz", help="(tests) save the loss of every timed step and the flat "
+                    "parameter buffer after the last one: tests/test_gpu_bench.py holds the graph-replayed, sampling-forked step "
+                    "structure to the eager in-line one")
     args = ap.parse_args()
     if args.config != "ssg":
         import bench_configs
@@ -128,7 +136,8 @@ def main():
     model.train()
     flat = FlatParams(model)
     flat.broadcast(0)
-    opt = FlatAdam(flat, lr=1e-3, weight_decay=1e-3)
+    params0 = flat.data.detach().cpu().numpy() if args.dump_trajectory else None
+    opt = FlatAdam(flat, lr=args.lr, weight_decay=1e-3)
 
     seed = 1234 + rank                            # each rank owns its own shard of clouds
     x = torch.from_numpy(make_clouds(B, N, seed)).to(dev)
@@ -370,18 +379,21 @@ def main():
     if use_graph:
         loss = None                               # drop the last eager autograd graph before capturing
         use_graph = capture()                     # event profiler off: nothing but kernels, memsets and copies in the graph
-        for _ in range(2):
-            loss = step()
-        torch.cuda.synchronize()
+    for _ in range(2):                            # (also without a graph: every launch structure runs the same number of optimiser steps)
+        loss = step()
+    torch.cuda.synchronize()
     if not use_graph:
         lib.papc_prof_enable(1 << dominant)       # eager timed region: event pairs only around the dominant family
         lib.papc_prof_reset()
 
     # ---- timed region
+    traj = []
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+        if args.dump_trajectory:
+            traj.append(loss.detach().clone())    # (the replayed graphs overwrite their loss tensor)
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -389,6 +401,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    if args.dump_trajectory and rank == 0:
+        import numpy as np
+        np.savez(args.dump_trajectory, loss=torch.stack(traj).cpu().numpy(), params=flat.data.detach().cpu().numpy(), params0=params0, grad=flat.grad.detach().cpu().numpy(),
+                 graph=np.array(int(use_graph)), overlap=np.array(int(args.overlap)))
     n_roof = args.steps
     if use_graph:
         # kernels inside a replayed graph cannot carry host-visible event pairs: the dominant family's launch durations are

@@ -1,0 +1,101 @@
+"""What the driver times: bench.py's N = 1 launch structure (two alternating hipGraphs, the next batch's FPS + ball-query pyramid as a
+forked branch of the step's graph, B = 32, N = 4096) held to the same steps launched eagerly with in-line sampling -- loss trajectory
+and the flat parameter buffer after the last step -- and the row-streaming GEMM's STORE_RED flavour repeated bit-identically while a
+second stream runs the sampling kernels beside it (the hazard that flavour's LATE1 ordering closes)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(tmp_path, name, lr, *flags):
+    out = str(tmp_path / (name + ".npz"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline",
+                        "--lr", lr, "--dump-trajectory", out, *flags], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return np.load(out), line
+
+
+def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
+    """(a) lr = 0: the weights stay put, so all 17 steps of both structures run the same forward (fresh dropout masks every step) --
+    the loss trajectories must be BIT-identical (the forward has no atomics) and the last step's gradients equal up to the order of
+    the float atomics of the gather-add backward.  (b) lr = 1e-5: the graphs must read LIVE weights; trajectories are compared
+    against the run-to-run noise of the eager structure itself.  (A train step is a discontinuous function of the weights -- max
+    routing, ReLU sides -- so at the reference's lr = 1e-3 that atomics noise grows ~30x per step and two eager runs already differ
+    by 2 % after ten steps: tools/probe/repro.py.)"""
+    g, line = _bench(tmp_path, "graph0", "0")
+    assert int(g["graph"]) == 1 and int(g["overlap"]) == 1, "the default bench must replay captured graphs with the sampling fork: " + line
+    assert '"launch": "hipGraph replay' in line and "fork at sa2" in line
+    e, _ = _bench(tmp_path, "eager0", "0", "--no-graph", "--no-overlap")
+    assert int(e["graph"]) == 0 and int(e["overlap"]) == 0
+    assert g["loss"].shape == e["loss"].shape == (10,) and np.all(np.isfinite(g["loss"]))
+    assert np.array_equal(g["loss"], e["loss"]), (g["loss"], e["loss"])
+    assert len(set(g["loss"].tolist())) == 10                                     # a new dropout mask per replay
+    assert np.array_equal(g["params"], g["params0"]) and np.array_equal(e["params"], e["params0"])
+    gs = float(np.max(np.abs(e["grad"])))
+    dg = float(np.max(np.abs(g["grad"] - e["grad"]))) / gs
+    print("lr 0: losses bit-identical, gradient diff %.2e of max |g|" % dg)
+    assert dg <= 1e-5, dg
+    # (b)
+    g1, _ = _bench(tmp_path, "graph1", "1e-5")
+    e1, _ = _bench(tmp_path, "eager1", "1e-5", "--no-graph", "--no-overlap")
+    e2, _ = _bench(tmp_path, "eager2", "1e-5", "--no-graph", "--no-overlap")
+    rel = lambda a, b: float(np.max(np.abs(a["loss"] - b["loss"]) / np.abs(b["loss"])))
+    pd = lambda a, b: float(np.max(np.abs(a["params"] - b["params"])))
+    noise_l, noise_p = rel(e2, e1), pd(e2, e1)
+    dl, dp = rel(g1, e1), pd(g1, e1)
+    moved = float(np.max(np.abs(e1["params"] - e1["params0"])))
+    print("lr 1e-5: graph vs eager loss %.2e params %.2e | eager vs eager loss %.2e params %.2e | weights moved %.2e" % (dl, dp, noise_l, noise_p, moved))
+    assert moved >= 5e-5, moved
+    assert dl <= max(3 * noise_l, 5e-4), (dl, noise_l)
+    assert dp <= max(3 * noise_p, 1e-4), (dp, noise_p)
+
+
+def test_store_red_stream_kernel_bit_identical_beside_sampling_stream(dev):
+    """200 repeats of the dX launches that carry the BN-backward sums (stream_kernel<DY_*, STORE_RED>: asm prefetch ring + the
+    epilogue's own y loads) while FPS / ball query run on a second stream: every repeat equals the first, bit for bit."""
+    from papc_amd import functional as F
+    from papc_amd.mlp import StackSpec, shared_mlp_max
+    from papc_amd.synthetic import make_clouds, make_start_idx
+    G, K, chans = 2048, 64, [128, 128, 256]            # SA2-shaped: DY_MAX 256 -> 128 and DY_DENSE 128 -> 128, both STORE_RED
+    M = G * K
+    torch.manual_seed(5)
+    x = torch.randn(M, chans[0], device=dev)
+    ps = []
+    for cin, cout in zip(chans[:-1], chans[1:]):
+        ps += [torch.randn(cout, cin, device=dev) * (2.0 / cin) ** 0.5, torch.zeros(cout, device=dev), torch.rand(cout, device=dev) + 0.5,
+               torch.randn(cout, device=dev) * 0.1]
+    z = torch.zeros(1, 1, 3, device=dev)
+    gout = torch.randn(G, chans[-1], device=dev)
+    B, N = 32, 4096
+    cloud = torch.from_numpy(np.ascontiguousarray(make_clouds(B, N, 3).transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 3)).to(dev)
+    side = torch.cuda.Stream()
+    first = None
+    x.requires_grad_(True)
+    for rep in range(200):
+        if rep % 8 == 0:                                # keep the side stream busy: ~0.4 ms of FPS + ball query per launch group
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _, nx = F._fps_raw(cloud, 512, st)
+                F._ball_query_raw([0.2], [32], cloud, nx)
+        prm = [p.clone().requires_grad_(True) for p in ps]
+        x.grad = None
+        out = shared_mlp_max(StackSpec(1, M, G, K, chans[0] - 3, True), None, z, z, None, None, prm, x_rows=x)
+        out.backward(gout)
+        res = [x.grad] + [p.grad for p in prm]
+        if first is None:
+            first = [r.clone() for r in res]
+        else:
+            for a, b in zip(first, res):
+                assert torch.equal(a, b), "repeat %d differs" % rep
+    torch.cuda.synchronize()
