@@ -144,8 +144,9 @@ __global__ __launch_bounds__(64 * WAVES) void pfn_kernel(PfnArgs a)
     PfnRaw nxt = {};
     if (MODE == PFN_GRAM && (int)(blockIdx.x * PFN_WAVES + wave) < a.P) nxt = pfn_fetch(a, blockIdx.x * PFN_WAVES + wave, lane);
     for (int p = blockIdx.x * PFN_WAVES + wave; p < a.P; p += gridDim.x * PFN_WAVES) {
+        PfnRaw cur = {};
         if (MODE == PFN_GRAM) {   // the next pillar's loads fly under this pillar's MFMAs
-            const PfnRaw cur = nxt;
+            cur = nxt;
             const int pn = p + gridDim.x * PFN_WAVES;
             if (pn < a.P) nxt = pfn_fetch(a, pn, lane);
             pfn_stage_from<false>(a, cur, rows, lane);
@@ -164,16 +165,20 @@ __global__ __launch_bounds__(64 * WAVES) void pfn_kernel(PfnArgs a)
             // G += X^T X over this pillar's T rows, 4 rows per v_mfma_f64_16x16x4_f64.  Lane (ch = lane & 15, kk = lane >> 4) holds
             // X[4m + kk][ch] for BOTH operands (A[i][k] = X[k][i], B[k][j] = X[k][j]).  Channels 0..8 = the decorated row, 9 = the
             // distance slot, 10 = the constant 1 (column sums), 11..15 = 0.
+            // Rows t >= num_voxels are all-zero after the mask (:99-102): they add nothing to G except their count to G[10][10], so the
+            // MFMAs run over the real rows only (a KITTI pillar holds ~12 of its 100 slots) and the padded rows are counted once.
             const int ch = lane & 15, kk = lane >> 4;
-            const int nm = (a.T + 3) >> 2;
+            const int nvc = cur.nv < 0 ? 0 : (cur.nv < a.T ? cur.nv : a.T);
+            const int nm = (nvc + 3) >> 2;
             const int chc = ch < PFN_LD ? ch : 0;
+            if (lane == 42) gacc[0][2] += (double)(a.T - nvc);     // G[10][10]: accumulator entry i = (lane >> 4) + 4 r, j = lane & 15
             for (int m0 = 0; m0 < nm; m0 += 4) {   // 4 row quads per trip on 4 accumulators (a dependent f64 MFMA chain does not pipeline)
                 float x[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int t = 4 * (m0 + q) + kk;
-                    x[q] = rows[(t < a.T ? t : 0) * PFN_LD + chc];
-                    x[q] = (t < a.T && ch < PFN_LD) ? (ch == 10 ? 1.f : x[q]) : 0.f;
+                    x[q] = rows[(t < nvc ? t : 0) * PFN_LD + chc];
+                    x[q] = (t < nvc && ch < PFN_LD) ? (ch == 10 ? 1.f : x[q]) : 0.f;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -332,7 +337,6 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_apply_mfma_kernel(PfnArgs 
         sc[wn] = c < a.C ? a.scale[c] : 0.f;
         sh[wn] = c < a.C ? a.shift[c] : 0.f;
     }
-    const int nt = (a.T + 31) >> 5;
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
 
     PfnRaw nxt = {};
@@ -346,7 +350,12 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_apply_mfma_kernel(PfnArgs 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         float best[2] = {0.f, 0.f};   // max_t relu(z_t): starts at relu's floor, row 0 (what a strict `>` scan from -1 over relu(z) ends with)
         int bi[2] = {0, 0};
-        for (int t = 0; t < nt; ++t) {
+        // Rows t >= num_voxels are zero after the mask (:99-102) and the Linear has no bias (:23): y = 0, z = shift for every one of
+        // them.  Only the tiles that hold real rows go through the matrix pipe; the padded rows enter the max as ONE candidate,
+        // z = shift at row num_voxels (the first of them: the first-maximum rule), below.
+        const int nvc = cur.nv < 0 ? 0 : (cur.nv < a.T ? cur.nv : a.T);
+        const int ntr = (nvc + 31) >> 5;
+        for (int t = 0; t < ntr; ++t) {
             // A operand of row 32 t + l31: channels 8 half .. 8 half + 7 (slab row = 12 floats: the upper half's second quad is past the row)
             const float *r = rows + (32 * t + l31) * PFN_LD + 8 * hi;
             const float4 x0 = *reinterpret_cast<const float4 *>(r);
@@ -391,8 +400,11 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_apply_mfma_kernel(PfnArgs 
             const float ob = __shfl_xor(best[wn], 32);
             const int oi = __shfl_xor(bi[wn], 32);
             const bool take = ob > best[wn] || (ob == best[wn] && oi < bi[wn]);
-            const float fb = take ? ob : best[wn];
-            const int fi = take ? oi : bi[wn];
+            float fb = take ? ob : best[wn];
+            int fi = take ? oi : bi[wn];
+            // the padded rows (all after the real ones: only a strictly larger value moves the argmax; the zero rows inside the last
+            // processed tile have already offered the same value at the same first row)
+            if (nvc < a.T && sh[wn] > fb) { fb = sh[wn]; fi = nvc; }
             const int c = wn * 32 + l31;
             if (hi == 0 && c < a.C) {
                 a.out[(int64_t)p * a.C + c] = fb;
@@ -572,7 +584,7 @@ int papc_pfn_apply_f32(const float *features, const int32_t *num_voxels, const i
     if (knob(KNOB_PFN_MFMA)) {   // default: the matrix-pipe flavour (PAPC_PFN_MFMA=0: lanes-are-channels VALU flavour)
         hipStream_t st = as_stream(stream);
         ProfScope prof(PAPC_K_PFN, st);
-        hipLaunchKernelGGL(pfn_apply_mfma_kernel, dim3(pfn_blocks(P)), dim3(64 * PFN_WAVES), 0, st, a);
+        hipLaunchKernelGGL(pfn_apply_mfma_kernel, dim3(pfn_blocks(P)), dim3(64 * PFN_WAVES), 0, st, a);   // (512 .. 3000 workgroups: same time)
         return check_launch("papc_pfn_apply_f32");
     }
     return launch_pfn<PFN_APPLY>(a, as_stream(stream), "papc_pfn_apply_f32");
