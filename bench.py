@@ -97,7 +97,7 @@ def main():
                     help="(default) software-pipelined sampling: batch i+1's pyramid (FPS + ball query: weight-independent, a serial "
                     "chain on 32 of the 256 CUs) runs on a side stream / graph branch beside batch i's MLP kernels")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="sample in-line at the head of every step")
-    ap.add_argument("--fork", choices=["start", "sa2"], default="sa2", help="where the step forks the next batch's sampling branch")
+    ap.add_argument("--fork", choices=["start", "sa2", "sa3", "loss"], default="sa2", help="where the step forks the next batch's sampling branch")
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
@@ -229,9 +229,12 @@ def main():
             fork()
         tap = {} if use_dist else None
         logits = model(x, (s1, s2), plan=plan_in, tap=tap,
-                       after_sa2=cut if cut is not None else (fork if plan_out is not None and args.fork == "sa2" and not use_dist else None))
+                       after_sa2=cut if cut is not None else (fork if plan_out is not None and args.fork == "sa2" and not use_dist else None),
+                       after_sa3=(fork if plan_out is not None and args.fork == "sa3" and not use_dist else None))
         loss = softmax_cross_entropy(logits, y)
         if not use_dist:
+            if plan_out is not None and args.fork == "loss":
+                fork()
             loss.backward(ONE)
             if plan_out is not None:
                 main.wait_stream(side)             # join: the branch is part of this step

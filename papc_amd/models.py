@@ -77,7 +77,7 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
             p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1], out=o[1])
         return p1, p2
 
-    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None):
+    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None, after_sa3=None):
         """inputs [B,3,N]; ``start_idx`` = optional (s1 [B], s2 [B]) FPS start indices (the source draws them at random);
         ``plan`` = optional result of :meth:`plan_sampling` for these inputs; ``after_sa2`` = optional callable invoked
         once SA2's kernels are enqueued -- from there to the end of SA3's backward only small-grid kernels run (group_all
@@ -106,6 +106,8 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
         if tap is not None:
             tap["l2_points"] = l2_points
         l3_xyz, l3_points = self.sa3(l2_xyz, l2_points, wt_table=wt)
+        if after_sa3 is not None:
+            after_sa3()
         x = l3_points.reshape(B, 1024)
         return self._head(x)
 

@@ -8,10 +8,10 @@ import torch.nn.functional as TF
 
 from oracle import reference_np as R
 from papc_amd.distributed import FlatAdam, FlatParams
-from papc_amd.layers import PointNetSetAbstraction
+from papc_amd.layers import PointNetSetAbstraction, PointNetSetAbstractionMsg
 from papc_amd.models import PointNet2_MSG_Clas, PointNet2_SSG_Clas, PointNet_Basic_Clas
 from papc_amd.synthetic import make_clouds, make_labels, make_start_idx
-from tests.util import assert_close, seeded_weights
+from tests.util import assert_close, copy_into_model, seeded_model_state, seeded_weights
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -218,3 +218,86 @@ def test_grad_targets_follow_the_optimizer():
             if n.endswith("weight") and ("conv" in n or "fc" in n or "mlp" in n.lower()):
                 assert float(p.grad.abs().max()) > 0, (n, mode)
         opt.step()
+
+
+def _np_stack(convs, bns):
+    return [(c.weight.detach().cpu().numpy().reshape(c.weight.shape[0], -1), c.bias.detach().cpu().numpy(),
+             bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy()) for c, bn in zip(convs, bns)]
+
+
+def test_msg_clas_model_forward_vs_oracle_layers(dev):
+    """PointNet2_MSG_Clas (/root/reference/PAPC/models/classify/pointnet2/pointnet2.py:43-75; nsample lists [16, 32, 128] and
+    [32, 64, 128]: the K = 16 branch runs without the fused group-max epilogue, the K = 128 / group_all stacks on the planes kernels):
+    every set-abstraction level against the f64 oracle on the oracle's own inputs (1e-5), centroids exact."""
+    B, N = 2, 1024
+    x = make_clouds(B, N, 21)
+    s1, s2 = make_start_idx(B, N, 21), make_start_idx(B, 512, 22)
+    torch.manual_seed(3)
+    m = PointNet2_MSG_Clas(num_classes=16).to(dev)
+    copy_into_model(m, seeded_model_state(m, 17))        # non-trivial norm weights, including negative gammas
+    m.eval()
+    o1 = R.PointNetSetAbstractionMsg(512, [0.1, 0.2, 0.4], [16, 32, 128], 0, [[32, 32, 64], [64, 64, 128], [64, 96, 128]],
+                                     [_np_stack(m.sa1.conv_blocks[i], m.sa1.bn_blocks[i]) for i in range(3)])
+    o2 = R.PointNetSetAbstractionMsg(128, [0.2, 0.4, 0.8], [32, 64, 128], 320, [[64, 64, 128], [128, 128, 256], [128, 128, 256]],
+                                     [_np_stack(m.sa2.conv_blocks[i], m.sa2.bn_blocks[i]) for i in range(3)])
+    o3 = R.PointNetSetAbstraction(None, None, None, 643, [256, 512, 1024], True, _np_stack(m.sa3.mlp_convs, m.sa3.mlp_bns))
+    r1_xyz, r1 = o1.forward(x, None, s1, f64=True)
+    r2_xyz, r2 = o2.forward(r1_xyz, r1.astype(np.float32), s2, f64=True)
+    _, r3 = o3.forward(r2_xyz, r2.astype(np.float32), f64=True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with torch.no_grad():
+        l1_xyz, l1 = m.sa1(t(x), None, t(s1))
+        l2_xyz, l2 = m.sa2(t(r1_xyz), t(r1.astype(np.float32)), t(s2))          # each level on the ORACLE's input
+        _, l3 = m.sa3(t(r2_xyz), t(r2.astype(np.float32)))
+        logits = m(t(x), (t(s1), t(s2)))
+    assert np.array_equal(l1_xyz.cpu().numpy(), r1_xyz) and np.array_equal(l2_xyz.cpu().numpy(), r2_xyz)
+    e1 = assert_close(l1.cpu().numpy(), r1, 1e-5, "MSG clas SA1 (K = 16 / 32 / 128) vs f64 oracle")
+    e2 = assert_close(l2.cpu().numpy(), r2, 1e-5, "MSG clas SA2 vs f64 oracle")
+    e3 = assert_close(l3.cpu().numpy(), r3, 1e-5, "MSG clas SA3 (group_all, 643 channels) vs f64 oracle")
+    print("MSG clas rel err: SA1 %.1e SA2 %.1e SA3 %.1e" % (e1, e2, e3))
+    assert tuple(logits.shape) == (B, 16) and torch.isfinite(logits).all()
+
+
+def test_msg_clas_sa1_backward_vs_f64(dev):
+    """one backward through the MSG classifier's first level (branches K = 16, 32, 128, feats-first rows :266-267) against float64
+    torch autograd on the same neighbour lists: every parameter gradient and the gradient of the input features, 2e-4"""
+    from papc_amd import functional as F_
+    from tests import torch_ref
+    B, N, S, D = 2, 1024, 128, 6
+    x = make_clouds(B, N, 33)
+    rng = np.random.default_rng(5)
+    pts = torch.from_numpy(rng.normal(size=(B, D, N)).astype(np.float32)).to(dev).requires_grad_(True)
+    radii, ks, mlps = [0.1, 0.2, 0.4], [16, 32, 128], [[32, 32, 64], [64, 64, 128], [64, 96, 128]]
+    layer = PointNetSetAbstractionMsg(S, radii, ks, D, mlps).to(dev)
+    copy_into_model(layer, seeded_model_state(layer, 41))
+    xt = torch.from_numpy(x).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 33)).to(dev)
+    _, out = layer(xt, pts, st)
+    gout = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+    out.backward(gout)
+    # float64 reference on the kernels' own (index-exact, tests/test_gpu_sampling.py) neighbour lists
+    xyz = xt.transpose(1, 2).contiguous()
+    _, new_xyz = F_._fps_raw(xyz, S, st)
+    idxs = F_._ball_query_raw(radii, ks, xyz, new_xyz)
+    f64 = pts.detach().double().requires_grad_(True)
+    outs, p64s = [], []
+    for i, K in enumerate(ks):
+        p64 = []
+        for c, bn in zip(layer.conv_blocks[i], layer.bn_blocks[i]):
+            p64 += [c.weight.detach().double().reshape(c.weight.shape[0], -1).requires_grad_(True), c.bias.detach().double().requires_grad_(True),
+                    bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)]
+        rows = torch_ref.group(xyz.double(), new_xyz.double(), f64.transpose(1, 2), idxs[i], False).reshape(B * S * K, D + 3)
+        outs.append(torch_ref.stack_max(rows, [tuple(p64[4 * l:4 * l + 4]) for l in range(3)], K, 1e-5).reshape(B, S, -1))
+        p64s.append(p64)
+    ref = torch.cat(outs, 2).transpose(1, 2)
+    assert_close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, "MSG SA1 forward vs f64")
+    ref.backward(gout.double())
+    for i in range(3):
+        got = []
+        for c, bn in zip(layer.conv_blocks[i], layer.bn_blocks[i]):
+            got += [c.weight.grad.reshape(c.weight.shape[0], -1), c.bias.grad, bn.weight.grad, bn.bias.grad]
+        for j, (g, w) in enumerate(zip(got, p64s[i])):
+            if j % 4 == 1:
+                continue                                   # conv bias under a train-mode BN: true gradient 0
+            assert_close(g.cpu().numpy(), w.grad.cpu().numpy(), 2e-4, "MSG SA1 branch %d (K = %d) param %d" % (i, ks[i], j))
+    assert_close(pts.grad.cpu().numpy(), f64.grad.cpu().numpy(), 2e-4, "MSG SA1 d(points)")

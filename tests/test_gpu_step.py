@@ -115,3 +115,106 @@ def test_adam_kernel_vs_float64(dev):
     assert np.allclose(m.cpu().numpy(), M, rtol=1e-5, atol=2e-7 * np.abs(M).max())
     assert np.allclose(v.cpu().numpy(), V, rtol=2e-5, atol=1e-30)
     assert np.abs(p.cpu().numpy() - P).max() <= 1e-6
+
+
+def _stack_node(t):
+    """the autograd node of the MLP stack behind a set-abstraction output [B, D', S] (transpose <- view <- stack)"""
+    fn = t.grad_fn
+    for _ in range(4):
+        if "MLPMax" in type(fn).__name__:
+            return fn
+        fn = fn.next_functions[0][0]
+    raise AssertionError("no stack node behind " + type(t.grad_fn).__name__)
+
+
+def test_whole_model_gradients_with_pinned_routing(dev):
+    """Every parameter gradient of one PointNet2_SSG_Clas step (sampling -> SA1 -> SA2 -> SA3 -> FC head -> cross-entropy,
+    classify/pointnet2/pointnet2.py:33-39, train.py:106-109) against float64 torch autograd of the same graph at 2e-4 of max |grad|.
+    A max-pooled gradient is a discontinuous function of the activations, so the float64 reference is routed through the kernels' own
+    decisions (winner row of every (group, channel); alive iff the kernel's pooled output is > 0) -- with routing equal a missing or
+    mis-scaled term anywhere in the SA2 / SA1 backward shows up at its full size instead of hiding under the golden fixture's 3e-2
+    near-tie allowance.  Where plain fp32 torch autograd on the same routed graph is itself worse than 2e-4 / 3 (ill-conditioned
+    first-layer sums), the bar is 3x that.  Reports how many decisions differ from float64's own."""
+    from tests import torch_ref
+    B, N = 4, 1024
+    model = PointNet2_SSG_Clas(num_classes=16)
+    copy_into_model(model, seeded_model_state(model, 99))
+    model.drop1.p = model.drop2.p = 0.0
+    model = model.to(dev).train()
+    x = torch.from_numpy(make_clouds(B, N, 7)).to(dev)
+    from papc_amd.synthetic import make_labels, make_start_idx
+    s1, s2 = torch.from_numpy(make_start_idx(B, N, 7)).to(dev), torch.from_numpy(make_start_idx(B, 512, 8)).to(dev)
+    labels = torch.from_numpy(make_labels(B, 16, 7)).reshape(-1).to(dev)
+    plan = model.plan_sampling(x, (s1, s2))
+    l1_xyz, l1 = model.sa1(x, None, s1, sampled=plan[0])
+    l2_xyz, l2 = model.sa2(l1_xyz, l1, s2, sampled=plan[1])
+    l3_xyz, l3 = model.sa3(l2_xyz, l2)
+    logits = model._head(l3.reshape(B, 1024))
+    loss = softmax_cross_entropy(logits, labels)
+    nodes = [_stack_node(t) for t in (l1, l2, l3)]
+    assert "Planes" in type(nodes[2]).__name__                      # the group_all layer runs on the planes kernels
+    argmaxes = [(n.saved_tensors[0] if "Planes" in type(n).__name__ else n.saved_tensors[5]).clone() for n in nodes]
+    pooled = [l1.detach().transpose(1, 2).reshape(-1, l1.shape[1]), l2.detach().transpose(1, 2).reshape(-1, l2.shape[1]),
+              l3.detach().transpose(1, 2).reshape(-1, l3.shape[1])]
+    loss.backward()
+    stats = {}
+
+    def reference(dt):
+        ps = {n: p.detach().to(dt).requires_grad_(True) for n, p in model.named_parameters()}
+        xyz = x.transpose(1, 2).to(dt)
+        feats = None
+        cur_xyz = xyz
+        levels = [("sa1", plan[0], 32, True), ("sa2", plan[1], 64, True), ("sa3", None, 128, True)]
+        for li, (nm, pl, K, xyz_first) in enumerate(levels):
+            if pl is not None:
+                new_xyz, idx = pl[0].to(dt), pl[1]
+                S = new_xyz.shape[1]
+            else:
+                S = 1
+                new_xyz = torch.zeros(B, 1, 3, device=dev, dtype=dt)
+                idx = torch.arange(cur_xyz.shape[1], device=dev).view(1, 1, -1).expand(B, 1, -1)
+            act = torch_ref.group(cur_xyz, new_xyz, feats, idx, xyz_first).reshape(B * S * K, -1)
+            z = None
+            for l in range(3):
+                w = ps["%s.mlp_convs.%d.weight" % (nm, l)].reshape(-1, act.shape[1])
+                y = act @ w.t() + ps["%s.mlp_convs.%d.bias" % (nm, l)]
+                z = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * ps["%s.mlp_bns.%d.weight" % (nm, l)] + ps["%s.mlp_bns.%d.bias" % (nm, l)]
+                act = torch.relu(z)
+            C = z.shape[1]
+            z = z.reshape(B * S, K, C)
+            route = argmaxes[li].long().unsqueeze(1)
+            zr = z.gather(1, route).squeeze(1)
+            alive = pooled[li] > 0
+            if dt == torch.float64:
+                tm = torch.relu(z).max(1).values.detach()
+                tol = 1e-5 * float(tm.abs().max())
+                assert bool((torch.relu(zr.detach()) >= tm - tol).all()), "%s: a kernel winner is not within 1e-5 of the max" % nm
+                stats[nm] = (int((route.squeeze(1) != torch.relu(z).argmax(1)).sum()), int((alive != (zr > 0)).sum()), alive.numel())
+            feats = torch.where(alive, zr, torch.zeros_like(zr)).reshape(B, S, C)
+            cur_xyz = new_xyz
+        h = feats.reshape(B, 1024)
+        for i, (fc, bn) in enumerate((("fc1", "bn1"), ("fc2", "bn2"))):
+            y = h @ ps[fc + ".weight"].t() + ps[fc + ".bias"]
+            h = torch.relu((y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-5) * ps[bn + ".weight"] + ps[bn + ".bias"])
+        lg = h @ ps["fc3.weight"].t() + ps["fc3.bias"]
+        ls = torch.nn.functional.cross_entropy(lg, labels)
+        ls.backward()
+        return ps, lg.detach(), float(ls.detach())
+
+    p64, lg64, ls64 = reference(torch.float64)
+    p32, _, _ = reference(torch.float32)
+    assert_close(logits.detach().cpu().numpy(), lg64.cpu().numpy(), 2e-4, "logits vs routed f64 chain")
+    assert abs(float(loss) - ls64) <= 2e-4 * abs(ls64)
+    for nm, (moved, flips, n) in stats.items():
+        print("%s: %d winner rows and %d alive/dead decisions differ from float64's own (of %d)" % (nm, moved, flips, n))
+    bad = []
+    for n, p in model.named_parameters():
+        want = p64[n].grad
+        if _bn_fed_bias(n):
+            continue
+        scale = float(want.abs().max())
+        ours = float((p.grad.double() - want).abs().max()) / scale
+        e32 = float((p32[n].grad.double() - want).abs().max()) / scale
+        if ours > max(2e-4, 3.0 * e32):
+            bad.append("%s: %.2e of max|grad| (plain fp32 autograd %.2e)" % (n, ours, e32))
+    assert not bad, bad

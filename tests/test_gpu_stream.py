@@ -126,3 +126,31 @@ def test_dw_row_streaming_matches_staged_kernels(dev, chans, K):
         _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWSX", 0), "knob")   # (the hybrid kernel is an opt-in experiment)
     for a, b in zip(grads[0], grads[1]):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("chans,K", [([64, 64, 128], 32), ([64, 128, 128], 64), ([64, 64, 64], 16)])
+def test_dw_row_streaming_vs_f64(dev, chans, K):
+    """dw_rows_kernel on its own shapes (64-channel BN+ReLU input; dense layer and the max-pooled last layer) straight against float64
+    torch autograd -- not through the staged kernels: every weight / norm gradient at 2e-4 of max |grad|."""
+    lib = _lib.load()
+    v = _lib.ctypes.c_int(0)
+    _lib.check(lib.papc_knob_get(b"PAPC_DW_ROWS", _lib.ctypes.byref(v)), "papc_knob_get")
+    assert v.value == 1, "the row-streaming dW must be the default path"
+    G = 1000
+    M = G * K
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.normal(size=(M, chans[0])).astype(np.float32)).to(dev)
+    ws = seeded_weights(chans, 41)
+    ps = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+    z = torch.zeros(1, 1, 3, device=dev)
+    gout = torch.from_numpy(rng.normal(size=(G, chans[-1])).astype(np.float32)).to(dev)
+    out = shared_mlp_max(StackSpec(1, M, G, K, chans[0] - 3, True), None, z, z, None, None, ps, x_rows=x)
+    out.backward(gout)
+    p64 = [p.detach().double().requires_grad_(True) for p in ps]
+    ref = torch_ref.stack_max(x.double(), [tuple(p64[4 * l:4 * l + 4]) for l in range(len(chans) - 1)], K, 1e-5)
+    assert_close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, "forward")
+    ref.backward(gout.double())
+    for l in range(len(chans) - 1):
+        for j, nm in enumerate(["w", "b", "gamma", "beta"]):
+            if j != 1:
+                assert_close(ps[4 * l + j].grad.cpu().numpy(), p64[4 * l + j].grad.cpu().numpy(), 2e-4, "dw_rows d%s layer %d vs f64" % (nm, l))

@@ -24,7 +24,12 @@ def assert_close(got, ref, rel=1e-5, what=""):
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = max(float(np.max(np.abs(ref))), 1e-30)
     err = float(np.max(np.abs(got - ref))) / scale
-    assert err <= rel, "%s: max rel err %.3e > %.1e" % (what, err, rel)
+    # second figure, reported next to the max-norm one: the worst ELEMENTWISE relative error among the entries that are not tiny
+    # (|ref| >= 1e-3 of the largest) -- a wrong small entry hides under a max-norm bar
+    big = np.abs(ref) >= 1e-3 * scale
+    elem = float(np.max(np.abs(got - ref)[big] / np.abs(ref)[big])) if big.any() else 0.0
+    print("[assert_close] %s: %.2e of max|ref|, elementwise %.2e (entries >= 1e-3 max)" % (what, err, elem))
+    assert err <= rel, "%s: max rel err %.3e > %.1e (elementwise %.3e)" % (what, err, rel, elem)
     return err
 
 
