@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
+    ap.add_argument("--require-graph", action="store_true", help="fail instead of falling back to eager launches when the hipGraph capture "
+                    "does not succeed (a multi-GPU run must not quietly measure the slow path)")
+    ap.add_argument("--dry-run", action="store_true", help="capture, run the warm-up steps, print the launch structure as JSON and exit")
     ap.add_argument("--lr", type=float, default=1e-3, help="Adam learning rate (train.py:62-65: 1e-3).  (tests) A training step is a "
                     "discontinuous function of the weights -- which row wins a neighbourhood max, which side of 0 a pre-activation falls -- "
                     "so the last-bit noise of the gather-add backward's float atomics grows ~30x per step at lr = 1e-3: two runs of the SAME "
@@ -135,7 +138,16 @@ def main():
     model = PointNet2_SSG_Clas(num_classes=16).to(dev)
     model.train()
     flat = FlatParams(model)
-    flat.broadcast(0)
+    if dist.is_initialized():
+        # the only collective before the graphs are captured runs on its OWN stream: RCCL's watchdog thread polls the end events of the
+        # collectives it still lists, and HIP refuses an event query on a stream that is being captured (the capture is invalidated and
+        # the watchdog aborts the process).  No collective ever touches the capturing stream before the capture below -- the eager
+        # passes ahead of it run without gradient exchange -- so there is nothing for the watchdog to poll there: no settle-sleep.
+        comm = torch.cuda.Stream()
+        comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(comm):
+            flat.broadcast(0)
+        comm.synchronize()
     params0 = flat.data.detach().cpu().numpy() if args.dump_trajectory else None
     opt = FlatAdam(flat, lr=args.lr, weight_decay=1e-3)
 
@@ -167,7 +179,9 @@ def main():
                 t.record_stream(main)              # consumed by main-stream kernels: keep the blocks alive for them
         state["plan"], state["ev"] = plan, ev
 
-    def step_eager():
+    def step_eager(exchange=True):
+        """exchange=False (N > 1, ahead of the graph capture): forward + backward only -- no collective, no optimiser step, so the
+        replicas stay identical and no collective runs on the stream about to be captured"""
         plan = None
         if args.overlap:
             if state["plan"] is None:
@@ -183,14 +197,15 @@ def main():
         logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap and args.fork == "sa2" else None), tap=tap)
         loss = softmax_cross_entropy(logits, y)
         work = None
-        if use_dist:
+        if use_dist and exchange:
             l2 = tap["l2_points"]
             (g_l2,) = torch.autograd.grad(loss, [l2], [ONE])
             _, work = flat.allreduce_grads(split, None, async_op=True)
             torch.autograd.backward([l2], [g_l2])
         else:
             loss.backward(ONE)
-        finish(work)
+        if exchange:
+            finish(work)
         return loss
 
     # hipGraph of the launch-bound part of the step: ~125 kernels of 3-400 us each are otherwise issued one by one from
@@ -200,7 +215,7 @@ def main():
     # With --overlap the sampling of the NEXT batch is a second branch of the same graph (forked from the capturing stream,
     # joined at the end): two graphs alternate, one reading the plan buffers the other one fills.
     use_graph = not args.no_graph
-    graph_state = {"g": None, "loss": None, "i": 0}
+    graph_state = {"g": None, "loss": None, "i": 0, "why": None}
     # N > 1: RCCL's watchdog thread aborts the process when a capture involves a second stream while it polls the events of the
     # collectives in flight ("operation not permitted on an event last recorded in a capturing stream", ROCm 7.0 / RCCL 2.26, seen
     # with a forced 1-rank group).  There the graphs are captured on the main stream only and the NEXT batch's sampling pyramid is
@@ -214,6 +229,11 @@ def main():
     # as stage 1 is enqueued and runs over xGMI while stage 2 (SA2 + SA1 backward, ~1.4 ms) computes; only the 80 704-float head
     # of the bucket is reduced after the last kernel.
     split = flat.offset_of(model.sa3) if use_dist else 0
+    if use_dist:
+        # the two-stage backward takes stage 1's parameter gradients from the kernels' in-place accumulation into the flat bucket
+        # (torch.autograd.grad returns only d loss / d l2_points): every parameter must have opted in, and the fused head must be usable
+        assert all(getattr(p, "_papc_inplace_grad", False) for p in model.parameters()), "two-stage backward needs FlatParams-owned parameters"
+        assert 2 <= B <= 256, "two-stage backward needs the fused classifier head (2 <= B <= 256)"
 
     def stage1(plan_in=None, plan_out=None, cut=None):
         flat.zero_grad()
@@ -254,12 +274,6 @@ def main():
     def capture():
         """Returns True when the graph(s) were captured; on any capture failure the bench falls back to eager launches."""
         torch.cuda.synchronize()
-        if use_dist:
-            # RCCL's watchdog thread polls the end events of the collectives it still lists; the synchronous ones run on THIS stream,
-            # and HIP refuses an event query once that stream is capturing (hipErrorCapturedEvent: the capture is invalidated and the
-            # watchdog aborts the process -- seen in 1 of 14 runs).  Everything is complete after the synchronize: give the watchdog
-            # (100 ms poll period) time to retire its list before the capture begins.
-            time.sleep(1.0)
         try:
             n_sets = 2 if args.overlap else 1
             bufs = None
@@ -312,7 +326,10 @@ def main():
                 losses.append(loss)
             graph_state["g"], graph_state["loss"], graph_state["bufs"] = gs, losses, bufs
         except Exception as e:   # noqa: BLE001
-            print("[bench] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), file=sys.stderr)
+            graph_state["why"] = "%s: %s" % (type(e).__name__, e)
+            if args.require_graph:
+                raise SystemExit("[bench] hipGraph capture failed (%s) and --require-graph is set" % graph_state["why"])
+            print("[bench] WARNING: hipGraph capture failed (%s); the timed steps launch EAGERLY -- the slow path" % graph_state["why"], file=sys.stderr)
             graph_state["g"], graph_state["loss"] = None, None
             torch.cuda.synchronize()
             return False
@@ -361,15 +378,19 @@ def main():
             torch.cuda.synchronize()
 
     # ---- warmup, then an untimed 3-step pass with the event profiler on every family to find the dominant one
+    # N = 1: the W warm-up steps, then the family pass, run eagerly ahead of the capture.  N > 1: the passes ahead of the capture are
+    # forward + backward only (no collective on the stream about to be captured, see above); the W warm-up steps proper -- gradient
+    # exchange + Adam -- follow the capture, on the launch structure that is timed.
     loss = None
-    for _ in range(max(1, args.warmup)):
-        loss = step()
+    pre = (lambda: step_eager(exchange=False)) if use_dist else step
+    for _ in range(max(1, args.warmup) if not use_dist else 2):
+        loss = pre()
     torch.cuda.synchronize()
     lib.papc_prof_enable(0x3FF)
     lib.papc_prof_reset()
     NPROF = 3
     for _ in range(NPROF):
-        loss = step()
+        loss = pre()
     torch.cuda.synchronize()
     fam = prof_read(lib)
     lib.papc_prof_enable(0)
@@ -382,9 +403,19 @@ def main():
     if use_graph:
         loss = None                               # drop the last eager autograd graph before capturing
         use_graph = capture()                     # event profiler off: nothing but kernels, memsets and copies in the graph
-    for _ in range(2):                            # (also without a graph: every launch structure runs the same number of optimiser steps)
+    for _ in range(2 + (max(1, args.warmup) if use_dist else 0)):   # (also without a graph: every launch structure runs the same number of optimiser steps)
         loss = step()
     torch.cuda.synchronize()
+    if args.dry_run:                              # launch-structure check only (no timing): what got captured, on how many ranks
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "graphs_per_step": (len([g for g in graph_state["g"][0] if g is not None]) if use_graph else 0),
+                              "graph_sets": len(graph_state["g"]) if use_graph else 0, "capture_error": graph_state["why"],
+                              "sampling": "side stream beside the graph replays" if ext_sampling else ("in-graph fork" if (use_graph and args.overlap) else "in-line"),
+                              "loss": float(loss.item())}))
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if not use_graph:
         lib.papc_prof_enable(1 << dominant)       # eager timed region: event pairs only around the dominant family
         lib.papc_prof_reset()
@@ -482,10 +513,14 @@ def main():
                                     % ("enqueued on the side stream beside the graph replay" if ext_sampling else "fork at " + args.fork)) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
-                       "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager all-reduce + Adam" if use_graph else "eager",
-                       "collectives": ("two-stage backward: all-reduce of the [SA3 | FC head] tail of the flat bucket (%d floats) in flight "
-                                       "during the SA2 + SA1 backward, then the %d-float head of the bucket; RCCL over xGMI, per-GPU BatchNorm "
-                                       "statistics" % (flat.numel - split, split)) if use_dist else "none (one process)"},
+                       "launch": ("hipGraph replay of zero_grad+fwd+loss+bwd (%d graph(s) per step, two alternating sets), eager all-reduce + Adam"
+                                  % len([g for g in graph_state["g"][0] if g is not None])) if use_graph
+                                 else ("eager" + (" (hipGraph capture FAILED: %s)" % graph_state["why"] if graph_state["why"] else "")),
+                       "collectives": ("world %d, backend %s (RCCL %s); two-stage backward: all-reduce of the [SA3 | FC head] tail of the flat bucket "
+                                       "(%d floats) in flight during the SA2 + SA1 backward, then the %d-float head of the bucket; RCCL over xGMI, "
+                                       "per-GPU BatchNorm statistics"
+                                       % (world, dist.get_backend(), ".".join(str(v) for v in torch.cuda.nccl.version()), flat.numel - split, split))
+                                      if use_dist else "none (one process)"},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
