@@ -91,6 +91,8 @@ class _Head(torch.autograd.Function):
         st = stream_ptr()
         glogits = glogits.contiguous().float()
         tg = spec.grad_targets
+        if tg is not None and any(t is None for t in tg):    # (all of the head's parameters or none: a partial set goes through autograd)
+            tg = None
         acc = 1 if tg is not None else 0
         if tg is None:
             shapes = [w1.shape, (w1.shape[0],), (w1.shape[0],), (w1.shape[0],), w2.shape, (w2.shape[0],), (w2.shape[0],),

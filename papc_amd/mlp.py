@@ -277,7 +277,9 @@ class SharedMLPMax(torch.autograd.Function):
             c12 = torch.empty(2, cout, device=dev, dtype=torch.float32)
             tgt = spec.grad_targets[4 * l: 4 * l + 4] if spec.grad_targets is not None else None
             inplace = tgt is not None and all(t is not None for t in tgt)
-            if inplace:   # accumulate straight into the parameters' .grad (flat-bucket views): no autograd add kernels
+            # the norm's two vectors can go in place on their own (a layer whose conv weight is a padded view keeps them off autograd)
+            gb_inplace = tgt is not None and tgt[2] is not None and tgt[3] is not None and not spec.eval_bn
+            if gb_inplace:   # accumulate straight into the parameters' .grad (flat-bucket views): no autograd add kernels
                 dgamma_p, dbeta_p = tgt[2].data_ptr(), tgt[3].data_ptr()
             else:
                 dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)  # dgamma, dbeta
@@ -300,7 +302,7 @@ class SharedMLPMax(torch.autograd.Function):
             else:
                 red, red_parts = fused_red, gemm_parts
             check(lib.papc_bn_bwd_finalize_f32(ptr(red), red_parts, M, cout, dgamma_p, dbeta_p,
-                                               c12[0].data_ptr(), c12[1].data_ptr(), int(inplace) | (2 if spec.eval_bn else 0), st),
+                                               c12[0].data_ptr(), c12[1].data_ptr(), int(gb_inplace) | (2 if spec.eval_bn else 0), st),
                   "papc_bn_bwd_finalize_f32")
             if l == 0 and ctx.lin0:
                 # G[j] = sum of the dY rows that gathered point j (+ the xyz columns of dW, streamed); the D-wide products run on B*N rows
@@ -337,9 +339,10 @@ class SharedMLPMax(torch.autograd.Function):
                                                            st), "papc_reduce_partials_strided_f32")
                 if not inplace:           # (db: a bias feeding a train-mode BN has gradient exactly 0)
                     grads[0] = dw.reshape(w.shape)
-                    grads[1] = _lib.zeros((cout,), dev)
-                    grads[2] = dgb[0]
-                    grads[3] = dgb[1]
+                    grads[1] = None if (tgt is not None and tgt[1] is not None) else _lib.zeros((cout,), dev)   # (exact 0: nothing to add in place)
+                    if not gb_inplace:
+                        grads[2] = dgb[0]
+                        grads[3] = dgb[1]
                 if ctx.feats_needs_grad:
                     # grad_feats = G W_f: the same row GEMM with the transposed feature block as its weight
                     wt_full = ctx.wt_table.get(w.data_ptr()) if ctx.wt_table is not None else None
@@ -385,9 +388,10 @@ class SharedMLPMax(torch.autograd.Function):
                 else:
                     reduce_jobs.append((part, n_chunks, pld, cout * cin, dw.data_ptr(), cout, db.data_ptr(), 0))
                 grads[4 * l + 0] = dw.reshape(w.shape)
-                grads[4 * l + 1] = db
-                grads[4 * l + 2] = dgb[0]
-                grads[4 * l + 3] = dgb[1]
+                grads[4 * l + 1] = None if (tgt is not None and tgt[1] is not None and not spec.eval_bn) else db
+                if not gb_inplace:
+                    grads[4 * l + 2] = dgb[0]
+                    grads[4 * l + 3] = dgb[1]
             # ---- dX
             fused_red = None
             if l > 0:
@@ -443,25 +447,23 @@ class SharedMLPMax(torch.autograd.Function):
 
 
 def grad_targets_of(params):
-    """The .grad tensors of parameters that opted in to in-place accumulation (views of distributed.FlatParams.grad), or None
-    if any parameter has not.  With targets the backward adds each gradient in place (one fused accumulate in the reduce
-    kernels) and hands autograd ``None``: no per-parameter AccumulateGrad add kernels."""
+    """Per parameter: its .grad tensor when the parameter opted in to in-place accumulation (a view of distributed.FlatParams.grad),
+    else None -- or None altogether when no parameter did.  With a target the backward adds the gradient in place (one fused accumulate
+    in the reduce kernels) and hands autograd ``None`` for it: no per-parameter AccumulateGrad add kernels.  Entries that are not
+    opted-in leaf Parameters (e.g. the zero-padded view of a first conv weight, layers._pad_features) go back through autograd as usual."""
     tg = []
     for p in params:
-        if not isinstance(p, torch.nn.Parameter):   # e.g. a zero-padded view of a weight: gradients go back through autograd
-            return None
+        g = None
         # explicit opt-in (distributed.FlatParams marks its parameters): writing .grad behind autograd's back skips AccumulateGrad
         # hooks, so torch's DistributedDataParallel, post-accumulate hooks, torch.autograd.grad() and checkpoint recomputation would
         # miss or double-count these gradients -- a parameter that merely HAS a .grad (second step of any plain optimizer loop) does
         # not qualify
-        if not getattr(p, "_papc_inplace_grad", False):
-            return None
-        g = p.grad
-        if not (p.requires_grad and g is not None and g.is_contiguous()
-                and g.dtype == torch.float32 and g.shape == p.shape):
-            return None
+        if isinstance(p, torch.nn.Parameter) and getattr(p, "_papc_inplace_grad", False):
+            g = p.grad
+            if not (p.requires_grad and g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape):
+                g = None
         tg.append(g)
-    return tg
+    return tg if any(t is not None for t in tg) else None
 
 
 def shared_mlp_max(spec, bn_buffers, xyz, new_xyz, feats, idx, params, x_rows=None):

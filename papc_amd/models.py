@@ -226,7 +226,11 @@ class _PartSegBase(nn.Module):
             feat = F.relu(F.batch_norm(y, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight, self.bn1.bias,
                                        False, 0.0, self.bn1.eps))
         x = self.drop1(feat)                                                                        # :48
-        x = F.linear(x, self.conv2.weight.reshape(self.conv2.out_channels, 128), self.conv2.bias)   # :49
+        if x.is_cuda:
+            from .linear import linear_rows
+            x = linear_rows(x, self.conv2.weight, self.conv2.bias)                                   # :49 (own row kernels, no library GEMM)
+        else:
+            x = F.linear(x, self.conv2.weight.reshape(self.conv2.out_channels, 128), self.conv2.bias)
         return x.view(B, N, -1)                                                                     # :50 [B,N,num_parts]
 
 

@@ -79,6 +79,8 @@ class _PFNFused(torch.autograd.Function):
         check(lib.papc_reduce_partials_f32(ptr(part), nb, 11 * C, ptr(sums), 0, st), "papc_reduce_partials_f32")
         flags = 0 if ctx.training else 1
         tg = ctx.grad_targets            # (w.grad, gamma.grad, beta.grad) of parameters that opted in to in-place accumulation, or None
+        if tg is not None and any(t is None for t in tg):
+            tg = None
         if tg is not None:
             check(lib.papc_pfn_bwd_finalize_f32(ptr(sums), P * T, ptr(w), C, ptr(gram), cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
                                                 tg[1].data_ptr(), tg[2].data_ptr(), tg[0].data_ptr(), flags | 2, st), "papc_pfn_bwd_finalize_f32")

@@ -223,7 +223,8 @@ class PlanesMLPMax(torch.autograd.Function):
             cst = consts[l]
             tgt = spec.grad_targets[4 * l: 4 * l + 4] if spec.grad_targets is not None else None
             inplace = tgt is not None and all(t is not None for t in tgt)
-            if inplace:
+            gb_inplace = tgt is not None and tgt[2] is not None and tgt[3] is not None
+            if gb_inplace:
                 dgamma_p, dbeta_p = tgt[2].data_ptr(), tgt[3].data_ptr()
             else:
                 dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)
@@ -233,7 +234,7 @@ class PlanesMLPMax(torch.autograd.Function):
             dyp = _planes(lib, M, cout, dev) if need_dx else None
             dypt = _planes(lib, cout, M, dev)
             common = dict(M=M, C=cout, x=ys[l].data_ptr(), ldx=cout, mean=cst[0].data_ptr(), invstd=cst[1].data_ptr(), scale=cst[2].data_ptr(),
-                          shift=cst[3].data_ptr(), dgamma=dgamma_p, dbeta=dbeta_p, accumulate=int(inplace), planes=ptr(dyp), planes_t=dypt.data_ptr())
+                          shift=cst[3].data_ptr(), dgamma=dgamma_p, dbeta=dbeta_p, accumulate=int(gb_inplace), planes=ptr(dyp), planes_t=dypt.data_ptr())
             if l == L - 1:
                 prep(mode=DY_MAX, gout=gout.data_ptr(), ysel=ysel.data_ptr(), argmax=argmax.data_ptr(), K=GROUP, **common)
             else:
@@ -269,9 +270,11 @@ class PlanesMLPMax(torch.autograd.Function):
                 dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
                 fold.append((part.data_ptr(), split, cout * cin, cout * cin, dw.data_ptr(), 0))
                 grads[4 * l + 0] = dw.reshape(params[4 * l].shape)
-                grads[4 * l + 1] = _lib.zeros((cout,), dev)     # a bias feeding a train-mode BN has gradient exactly 0
-                grads[4 * l + 2] = dgb[0]
-                grads[4 * l + 3] = dgb[1]
+                # a bias feeding a train-mode BN has gradient exactly 0
+                grads[4 * l + 1] = None if (tgt is not None and tgt[1] is not None) else _lib.zeros((cout,), dev)
+                if not gb_inplace:
+                    grads[4 * l + 2] = dgb[0]
+                    grads[4 * l + 3] = dgb[1]
             if l > 0:
                 dz, red = dz_prev, red_prev
         for j0 in range(0, len(fold), 8):

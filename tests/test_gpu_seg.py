@@ -135,3 +135,32 @@ def test_full_size_config3_msg_seg(dev):
     kth = full.topk(3, dim=2, largest=False).values
     assert (kth - d.double()).abs().max() < 1e-5
     assert (w.sum(-1) - 1).abs().max() < 1e-5
+
+
+def test_linear_rows_vs_f64(dev):
+    """the segmentation heads' last layer (conv2, segment/pointnet2/pointnet2.py:49: 128 -> 50 part logits per point) on the row
+    kernels: forward 1e-5, dW / db / dX 2e-4 against float64 torch, with and without in-place gradient targets"""
+    import numpy as np
+    from papc_amd.linear import linear_rows
+    rng = np.random.default_rng(2)
+    M, cin, cout = 4096 + 37, 128, 50
+    x = torch.from_numpy(rng.normal(size=(M, cin)).astype(np.float32)).to(dev).requires_grad_(True)
+    w = torch.nn.Parameter(torch.from_numpy((rng.normal(size=(cout, cin, 1)) * 0.1).astype(np.float32)).to(dev))
+    b = torch.nn.Parameter(torch.from_numpy(rng.normal(size=cout).astype(np.float32)).to(dev))
+    g = torch.from_numpy(rng.normal(size=(M, cout)).astype(np.float32)).to(dev)
+    y = linear_rows(x, w, b)
+    y.backward(g)
+    x64, w64, b64 = x.detach().double().requires_grad_(True), w.detach().double().reshape(cout, cin).requires_grad_(True), b.detach().double().requires_grad_(True)
+    r = x64 @ w64.t() + b64
+    r.backward(g.double())
+    assert_close(y.detach().cpu().numpy(), r.detach().cpu().numpy(), 1e-5, "linear_rows forward")
+    assert_close(w.grad.reshape(cout, cin).cpu().numpy(), w64.grad.cpu().numpy(), 2e-4, "linear_rows dW")
+    assert_close(b.grad.cpu().numpy(), b64.grad.cpu().numpy(), 2e-4, "linear_rows db")
+    assert_close(x.grad.cpu().numpy(), x64.grad.cpu().numpy(), 2e-4, "linear_rows dX")
+    # in-place targets: the gradients are ADDED to what the buffers hold
+    for p in (w, b):
+        p._papc_inplace_grad = True
+        p.grad = torch.ones_like(p)
+    linear_rows(x.detach(), w, b).backward(g)
+    assert_close((w.grad - 1).reshape(cout, cin).cpu().numpy(), w64.grad.cpu().numpy(), 2e-4, "linear_rows dW in place")
+    assert_close((b.grad - 1).cpu().numpy(), b64.grad.cpu().numpy(), 2e-4, "linear_rows db in place")
