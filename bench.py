@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
+    ap.add_argument("--diag-fixed-plan", action="store_true", help="DIAGNOSTIC ONLY (the printed value is NOT the benchmark): reuse one "
+                    "precomputed sampling plan in every step, i.e. time the MLP branch alone, to measure what the sampling overlap costs")
     ap.add_argument("--require-graph", action="store_true", help="fail instead of falling back to eager launches when the hipGraph capture "
                     "does not succeed (a multi-GPU run must not quietly measure the slow path)")
     ap.add_argument("--dry-run", action="store_true", help="capture, run the warm-up steps, print the launch structure as JSON and exit")
@@ -248,6 +250,8 @@ def main():
         if plan_out is not None and args.fork == "start" and not use_dist:
             fork()
         tap = {} if use_dist else None
+        if args.diag_fixed_plan:
+            plan_in, plan_out = graph_state["fixed_plan"], None
         logits = model(x, (s1, s2), plan=plan_in, tap=tap,
                        after_sa2=cut if cut is not None else (fork if plan_out is not None and args.fork == "sa2" and not use_dist else None),
                        after_sa3=(fork if plan_out is not None and args.fork == "sa3" and not use_dist else None))
@@ -275,6 +279,9 @@ def main():
         """Returns True when the graph(s) were captured; on any capture failure the bench falls back to eager launches."""
         torch.cuda.synchronize()
         try:
+            if args.diag_fixed_plan:
+                graph_state["fixed_plan"] = model.plan_sampling(x, (s1, s2))
+                torch.cuda.synchronize()
             n_sets = 2 if args.overlap else 1
             bufs = None
             if args.overlap:
@@ -502,7 +509,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(N)
         out = {
-            "metric": "point-clouds/sec (fwd+bwd) PointNet++SSG B=32 N=4096",
+            "metric": "point-clouds/sec (fwd+bwd) PointNet++SSG B=32 N=4096" + (" -- DIAGNOSTIC, sampling excluded: not a benchmark value" if args.diag_fixed_plan else ""),
             "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

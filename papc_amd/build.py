@@ -39,13 +39,28 @@ def _check_no_spills(remarks):
     (or scratch-backed) register of such a kernel would be copied before its load has landed.  Refuse to build one."""
     import re
     name = None
+    seen = set()
     for line in remarks.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = m.group(1)
         m = re.search(r"(VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]): (\d+)", line)
-        if m and name and "stream_kernel" in name and "Lb1E" in name and int(m.group(2)) != 0 and "SGPRs Spill" not in m.group(1):
-            raise RuntimeError("mlp_stream.hip: %s has %s = %s (asm-loaded registers must not spill)" % (name, m.group(1), m.group(2)))
+        if m and name and "stream_kernel" in name and "Lb1E" in name:
+            seen.add(name)
+            if int(m.group(2)) != 0 and "SGPRs Spill" not in m.group(1):
+                raise RuntimeError("mlp_stream.hip: %s has %s = %s (asm-loaded registers must not spill)" % (name, m.group(1), m.group(2)))
+    if not seen:     # fail closed: a toolchain that words its remarks or mangles the names differently must not pass unchecked
+        raise RuntimeError("mlp_stream.hip: no kernel-resource-usage remark of an asm-ring stream_kernel was found; the spill guard cannot vouch for this build")
+
+
+def _audit_asm_ring(asm_path):
+    """Static audit of mlp_stream.hip's hidden operand ring (tools/probe/late1_isa.py): between an inline-asm global_load_dwordx4 and
+    the hand-placed s_waitcnt that covers it no compiler instruction may touch the destination registers (a v_mov / AGPR copy of a
+    register whose load is in flight copies stale data and the late data lands in a register that was given away).  Fails closed."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "late1_isa.py"), asm_path, "stream_kernel"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0 or "clean" not in r.stdout or "scanned 0 " in r.stdout:
+        raise RuntimeError("mlp_stream.hip: the asm-ring audit failed\n" + r.stdout[-2000:])
 
 
 def _newest(paths):
@@ -72,11 +87,21 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         return s, r.returncode, r.stdout
 
+    jobs_by_src = {s_: c_ for s_, c_ in jobs}
     if jobs:
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for s, rc, out in ex.map(run, jobs):
-                if os.path.basename(s) == "mlp_stream.hip":
+                if os.path.basename(s) == "mlp_stream.hip" and rc == 0:
                     _check_no_spills(out)
+                    asm = os.path.join(OBJ, "mlp_stream.s")
+                    cmd_s = [c for c in jobs_by_src[s] if c not in RES]
+                    cmd_s[cmd_s.index("-c")] = "-S"
+                    cmd_s[cmd_s.index("-o") + 1] = asm
+                    r2 = subprocess.run(cmd_s + ["--cuda-device-only"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                    if r2.returncode != 0:
+                        raise RuntimeError("hipcc -S failed on mlp_stream.hip\n" + r2.stdout[-2000:])
+                    _audit_asm_ring(asm)
+                    os.remove(asm)
                     out = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l)
                 if verbose and out.strip():
                     print(out)

@@ -425,7 +425,11 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             // them proved unsound on hardware while asm loads it cannot see are in flight (late data landed in registers it had
             // already reused: wrong rows, timing dependent), so for that epilogue nothing hidden is outstanding: chunk 1 of the next
             // tile is issued AFTER the epilogue instead of before it (it still has chunk 0's whole compute phase to land).
+#ifdef PAPC_STREAM_NO_LATE1
+            constexpr bool LATE1 = false;    // (diagnostic build: reproduces the hazard described above; tools/probe/late1_isa.py)
+#else
             constexpr bool LATE1 = (EPI == EPI_STORE_RED);
+#endif
             sfor<0, NCH>([&](auto c_) {
                 constexpr int c = decltype(c_)::value;
                 constexpr int bi = c & 1;
