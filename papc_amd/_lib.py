@@ -181,12 +181,19 @@ def zeros(shape, device):
 _CONSTS = {}
 
 
+def _capturing():
+    import torch
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def const_zeros(shape, device):
     """cached read-only float32 zeros of a small fixed shape (e.g. the [B,1,3] centroid of sample_and_group_all)"""
     import torch
     key = ("z", tuple(shape), str(device))
     t = _CONSTS.get(key)
     if t is None:
+        if _capturing():     # a tensor born inside a hipGraph capture lives in that graph's pool and is only filled on replay: never cache it
+            return torch.zeros(tuple(shape), device=device, dtype=torch.float32)
         t = _CONSTS[key] = torch.zeros(tuple(shape), device=device, dtype=torch.float32)
     return t
 
@@ -197,5 +204,7 @@ def const_vec(value, n, device):
     key = (float(value), int(n), str(device))
     t = _CONSTS.get(key)
     if t is None:
+        if _capturing():
+            return torch.full((n,), float(value), device=device, dtype=torch.float32)
         t = _CONSTS[key] = torch.full((n,), float(value), device=device, dtype=torch.float32)
     return t

@@ -114,6 +114,8 @@ class PointNetSetAbstraction(nn.Module):
         spec.wt_table = wt_table
         out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx, params)   # :214-219
         new_points = out.view(B, S, -1).transpose(1, 2)                         # [B,D',S]
+        # (group_all: new_xyz is the cached READ-ONLY zero centre of sample_and_group_all, :170 -- a clone here would put a copy kernel
+        # into every training step; callers must not edit the returned coordinates in place)
         return new_xyz.transpose(1, 2), new_points                              # :220-221
 
 

@@ -28,6 +28,24 @@ def _starts(start_idx, n):
     return list(start_idx)
 
 
+def _bn1d(bn, y):
+    """BatchNorm1d of the fallback head path with the convention of the fused kernels (and of paddle.nn.BatchNorm1D, which the
+    reference uses: classify/pointnet2/pointnet2.py:18,21): in training the BIASED batch variance goes into the running estimate --
+    torch's module would store the unbiased one, so the running statistics (and an exported .pdparams) would depend on which path a
+    batch size selects."""
+    if not (bn.training and bn.track_running_stats and y.shape[0] > 1):
+        return bn(y)
+    mean = y.mean(0)
+    var = y.var(0, unbiased=False)
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    with torch.no_grad():
+        bn.running_mean.mul_(1.0 - mom).add_(mean.detach(), alpha=mom)
+        bn.running_var.mul_(1.0 - mom).add_(var.detach(), alpha=mom)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    return (y - mean) / torch.sqrt(var + bn.eps) * bn.weight + bn.bias
+
+
 class _ClasHead:
     """fc1/bn1/drop1/fc2/bn2/drop2/fc3 (pointnet2.py:37-39): fused launches in train mode on the GPU (head.py), the modules otherwise."""
 
@@ -37,8 +55,8 @@ class _ClasHead:
             spec = self.__dict__["_head_spec"] = _head.HeadSpec()
         if _FUSED_HEAD and _head.usable(x, self.fc1, self.fc2, self.fc3, self.training):
             return _head.classifier_head(spec, x, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3)
-        x = self.drop1(F.relu(self.bn1(self.fc1(x))))
-        x = self.drop2(F.relu(self.bn2(self.fc2(x))))
+        x = self.drop1(F.relu(_bn1d(self.bn1, self.fc1(x))))
+        x = self.drop2(F.relu(_bn1d(self.bn2, self.fc2(x))))
         return self.fc3(x)
 
 
