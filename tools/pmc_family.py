@@ -11,8 +11,12 @@ from collections import defaultdict
 
 def family(name):
     n = re.sub(r"^void ", "", name).replace("papc::", "")
-    if n.startswith(("dw_ws_kernel", "dw_kernel", "dw_xyz_kernel", "lingather_bwd_kernel")):
+    if n.startswith(("dw_ws_kernel", "dw_kernel", "dw_xyz_kernel", "dw_rows_kernel", "dw_rowsx_kernel", "lingather_bwd_kernel", "pg_fold_kernel",
+                     "xyz_l1_bwd_kernel")):
         return "bwd_dw_gemm"
+    m = re.match(r"pg_gemm_kernel<(\d+),", n)      # planes GEMM (smallm.hip): epilogue 1 / 2 = forward, 3 = dX (+ BN-backward sums), 0 = dW partials (and the last dX)
+    if m:
+        return {1: "mlp_gemm_fwd", 2: "mlp_gemm_fwd", 3: "bwd_dx_gemm"}.get(int(m.group(1)), "bwd_dw_gemm")
     if n.startswith("lingather_fwd_kernel"):
         return "mlp_gemm_fwd"
     m = re.match(r"(?:gemm|stream)_kernel<(\d+),", n)
