@@ -114,6 +114,9 @@ int papc_three_interpolate_bwd_f32(const float *grad_out, const int32_t *idx3, c
 #define PAPC_A_PLAIN 0   /* x[m,k]                                                       */
 #define PAPC_A_BNRELU 1  /* relu(scale[k]*x[m,k] + shift[k])   (previous layer's BN+ReLU folded into the load) */
 #define PAPC_A_GROUP 2   /* rows gathered on the fly: [xyz[idx]-new_xyz, feats[idx]] (see papc_group_points_f32) */
+#define PAPC_A_XYZ 6     /* the activation of a coordinates-only FIRST layer, recomputed: relu(wf[k][0] x + wf[k][1] y + wf[k][2] z + wf[k][3])
+                          * with (x, y, z) = xc[m]; x = xc [M, 4] (ldx = 4, papc_xyz_group_f32), bn_scale = wf [Cin, 4] (papc_xyz_l1_finalize_f32).
+                          * Forward (no group max) and dW only, where papc_mlp_xyz_ok(M, Cin, Cout) != 0 */
 
 typedef struct papc_group_src {
     const float *xyz;      /* strided cloud */
@@ -433,6 +436,32 @@ int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scal
 int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, int64_t ldx, const float *bn_scale,
                             const float *bn_shift, const float *wcat, const float *hbias, int64_t M, int Cin, int Cout, float *dx,
                             const papc_bwd_red *next_red, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * First layer of a stack fed by coordinates only (sample_and_group with points = None, pointnet2_basic_layers.py:152-153; SA1 of the
+ * classifiers, classify/pointnet2/pointnet2.py:11,33): y[m, c] = W[c] . x[m] + b[c], x[m] = xyz[idx[m]] - new_xyz[m / K], 3 channels in.
+ * The [M, C] output is never materialised (csrc/xyz1.hip): train-mode BatchNorm statistics and the whole backward of the layer are
+ * closed forms of the inputs' second moments, and the layer folds into the next one's operand (PAPC_A_XYZ).
+ *   papc_xyz_group_f32            xc [M, 4] = (x, y, z, 0) rows, M = B*S*K (grp: xyz / new_xyz / idx / N / S / K), and the float64
+ *                                 partial moments gram_partial [papc_xyz_parts(M), 16] (sum x, y, z, xx, xy, xz, yy, yz, zz, count)
+ *   papc_xyz_l1_finalize_f32      moments -> gram [16]; per channel mean / invstd / scale / shift (+ running statistics, paddle momentum)
+ *                                 and the folded layer wf [C, 4]: relu(scale (W x + b) + shift) = relu(wf[c][0..2] . x + wf[c][3]);
+ *                                 w [C, ldw] with the coordinate columns at xcol0..xcol0+2
+ *   papc_xyz_l1_bwd_f32           one pass over dz [M, C] (the gradient w.r.t. the layer's activation): partial [papc_xyz_bwd_parts(M), C, 4]
+ *                                 = sums of p x, p y, p z, p with p = dz [activation > 0]
+ *   papc_xyz_l1_bwd_finalize_f32  partials + gram -> dgamma, dbeta, dW (coordinate columns of dw [C, ldw]); accumulate != 0 adds in place
+ * ---------------------------------------------------------------------------------------------- */
+int papc_mlp_xyz_ok(int64_t M, int C1, int C2);
+int papc_xyz_parts(int64_t M);
+int papc_xyz_bwd_parts(int64_t M);
+int papc_xyz_group_f32(const papc_group_src *grp, int B, float *xc, double *gram_partial, papc_stream_t stream);
+int papc_xyz_l1_finalize_f32(const double *gram_partial, int parts, int64_t M, const float *w, int ldw, int xcol0, const float *bias,
+                             const float *gamma, const float *beta, float eps, float momentum, int C, float *mean, float *invstd, float *scale,
+                             float *shift, float *running_mean, float *running_var, float *wf, double *gram, papc_stream_t stream);
+int papc_xyz_l1_bwd_f32(const float *dz, const float *xc, const float *wf, int64_t M, int C, float *partial, papc_stream_t stream);
+int papc_xyz_l1_bwd_finalize_f32(const float *partial, int parts, int64_t M, int C, const double *gram, const float *w, int ldw, int xcol0,
+                                 const float *bias, const float *mean, const float *invstd, const float *scale, float *dgamma, float *dbeta,
+                                 float *dw, int accumulate, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stacks with FEW rows (the group_all set-abstraction layer: sample_and_group_all + conv/BN/ReLU x L + max,

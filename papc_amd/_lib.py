@@ -108,6 +108,13 @@ SIGNATURES = {
     "papc_lingather_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "papc_bn_max_prep_f32": (c_i, [c_p] * 10 + [c_l, c_i, c_i] + [c_p] * 6),
     "papc_mlp_bwd_dx_max_f32": (c_i, [c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
+    "papc_mlp_xyz_ok": (c_i, [c_l, c_i, c_i]),
+    "papc_xyz_parts": (c_i, [c_l]),
+    "papc_xyz_bwd_parts": (c_i, [c_l]),
+    "papc_xyz_group_f32": (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    "papc_xyz_l1_finalize_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_f, c_i] + [c_p] * 9),
+    "papc_xyz_l1_bwd_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_p]),
+    "papc_xyz_l1_bwd_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_i, c_i] + [c_p] * 7 + [c_i, c_p]),
     "papc_pg_planes_bytes": (ctypes.c_size_t, [c_l, c_l]),
     "papc_pg_prep_weights_f32": (c_i, [c_p, c_i, c_p]),
     "papc_pg_prep_rows_f32": (c_i, [c_p, c_p]),

@@ -572,7 +572,9 @@ static bool dw_f32_exact()
 // chunk and a 64-channel block of Cout; its 8 waves take the chunk's 16-row blocks round-robin, each accumulating the whole
 // 64 x 64 tile (4 accumulators), and fold them in a fixed 3-level tree through LDS at the end (one partial row per workgroup, as
 // the staged kernels write).  What this buys: every thread loads, transforms and multiplies -- no idle consumers, no barrier skew.
-template <int DYMODE>
+// XYZ: the x operand is the activation of a coordinates-only first layer, recomputed from the row's centred coordinates (xyz1.hip):
+// relu(wf_c . x[m] + t_c) with xc [M, 4] = p.x.x and the folded layer wf [Cin, 4] = p.x.sc -- 12 bytes per row instead of 4 per element.
+template <int DYMODE, bool XYZ = false>
 __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
 {
     constexpr int NTO = 2, NTI = 2;
@@ -595,7 +597,13 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
         kB[a] = ksc[a] * d.c2[c] * d.invstd[c];
     }
 #pragma unroll
-    for (int b = 0; b < NTI; ++b) { xs[b] = p.x.sc[i0 + 32 * b + l31]; xh[b] = p.x.sh[i0 + 32 * b + l31]; }
+    for (int b = 0; b < NTI; ++b) {
+        if (XYZ) { xs[b] = 0.f; xh[b] = 0.f; }
+        else { xs[b] = p.x.sc[i0 + 32 * b + l31]; xh[b] = p.x.sh[i0 + 32 * b + l31]; }
+    }
+    float4 wfk[NTI];
+#pragma unroll
+    for (int b = 0; b < NTI; ++b) wfk[b] = XYZ ? ld4(p.x.sc + 4 * (i0 + 32 * b + l31)) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     floatx16 acc[NTO][NTI];
 #pragma unroll
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    struct Raw { float y[NTO][8], z[NTO][8], x[NTI][8]; int am[NTO]; };
+    struct Raw { float y[NTO][8], z[NTO][8], x[XYZ ? 3 : NTI][8]; int am[NTO]; };
     auto fetch = [&](int kb, Raw &w) {
         const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
 #pragma unroll
@@ -617,8 +625,13 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
                 w.y[a][j] = d.y[row * Cout + o0 + 32 * a + l31];
                 if (DYMODE == A_DY_DENSE) w.z[a][j] = d.dz[row * Cout + o0 + 32 * a + l31];
             }
+            if (XYZ) {
+                const float *q = p.x.x + row * 4;            // (the same 12 bytes for the 32 lanes of a half: one broadcast line)
+                w.x[0][j] = q[0]; w.x[1][j] = q[1]; w.x[2][j] = q[2];
+            } else {
 #pragma unroll
-            for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x.x[row * ldx + i0 + 32 * b + l31];
+                for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x.x[row * ldx + i0 + 32 * b + l31];
+            }
         }
         if (DYMODE == A_DY_MAX) {   // K % 16 == 0 (host-checked): the block's 16 rows share one group
             const int64_t g = (mbeg + 16 * (int64_t)kb) / d.K;
@@ -664,7 +677,8 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                v[j] = fmaxf(fmaf(xs[b], w.x[b][j], xh[b]), 0.f);
+                if (XYZ) v[j] = fmaxf(fmaf(wfk[b].z, w.x[2][j], fmaf(wfk[b].y, w.x[1][j], fmaf(wfk[b].x, w.x[0][j], wfk[b].w))), 0.f);
+                else v[j] = fmaxf(fmaf(xs[b], w.x[b][j], xh[b]), 0.f);
                 if (tail && r0 + j >= mend) v[j] = 0.f;
             }
             split8(v, pb[b]);
@@ -974,7 +988,7 @@ using namespace papc;
  * 64 x 64 tile per wave (241 registers: one workgroup per CU), so it wants ONE residency wave of workgroups -- ncu row chunks in all */
 extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mode, int dz_mode, int K)
 {
-    if (a_mode != PAPC_A_BNRELU || M < 1) return 0;
+    if ((a_mode != PAPC_A_BNRELU && a_mode != PAPC_A_XYZ) || M < 1) return 0;
     const bool xk = dw_rowsx_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K);
     if (!xk && !dw_rows_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K)) return 0;
     hipDeviceProp_t prop;
@@ -1005,6 +1019,20 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     memset(&p, 0, sizeof(p));
     rc = fill_asrc(p.x, a_mode, x, ldx, grp, bn_scale, bn_shift, Cin, "papc_mlp_bwd_dw_f32");
     if (rc) return rc;
+    if (a_mode == A_XYZ) {   // recomputed first-layer activations: only the row-streaming kernel has the flavour
+        const bool dense_ = dy->dz_mode == PAPC_DZ_DENSE;
+        PAPC_REQUIRE(vdy && p.x.vec && dw_rows_eligible(Cin, Cout, dense_, dy->K) && rows_per_chunk % 16 == 0, PAPC_E_UNSUPPORTED,
+                     "papc_mlp_bwd_dw_f32: PAPC_A_XYZ is not built for Cin=%d Cout=%d (see papc_mlp_xyz_ok)", Cin, Cout);
+        fill_dy(p.dy.d, dy);
+        p.dy.d.C = Cout;
+        p.M = M; p.Cin = Cin; p.Cout = Cout; p.rows_per_chunk = rows_per_chunk; p.dw_partial = dw_partial; p.db_partial = db_partial; p.part_ld = part_ld;
+        hipStream_t st2 = as_stream(stream);
+        ProfScope prof2(PAPC_K_BWD_DW, st2);
+        dim3 g2((unsigned)cdiv(M, rows_per_chunk), (unsigned)(Cout / 64), (unsigned)(Cin / 64));
+        if (dense_) hipLaunchKernelGGL((dw_rows_kernel<A_DY_DENSE, true>), g2, dim3(512), 0, st2, p);
+        else hipLaunchKernelGGL((dw_rows_kernel<A_DY_MAX, true>), g2, dim3(512), 0, st2, p);
+        return check_launch("papc_mlp_bwd_dw_f32");
+    }
     fill_dy(p.dy.d, dy);
     p.dy.d.C = Cout;
     const bool vec = vdy && p.x.vec;

@@ -958,6 +958,10 @@ int fill_asrc(ASrc &a, int a_mode, const float *x, int64_t ldx, const papc_group
         PAPC_REQUIRE(a_mode == A_PLAIN || (sc && sh), PAPC_E_INVALID, "%s: BNRELU needs bn_scale/bn_shift", who);
         a.x = x; a.ldx = ldx; a.sc = sc; a.sh = sh;
         a.vec = aligned16(x) && (ldx % 4 == 0) && (Cin % 4 == 0) && (a_mode == A_PLAIN || (aligned16(sc) && aligned16(sh)));
+    } else if (a_mode == A_XYZ) {
+        PAPC_REQUIRE(x && ldx == 4 && sc, PAPC_E_INVALID, "%s: XYZ needs xc [M, 4] (ldx = 4) and the folded first layer wf [Cin, 4] as bn_scale", who);
+        a.x = x; a.ldx = 4; a.sc = sc; a.sh = nullptr;
+        a.vec = aligned16(x) && aligned16(sc) && Cin % 4 == 0;
     } else if (a_mode == A_GROUP) {
         PAPC_REQUIRE(grp && grp->xyz && grp->new_xyz, PAPC_E_INVALID, "%s: GROUP needs grp->xyz/new_xyz", who);
         PAPC_REQUIRE(grp->D == 0 || grp->feats, PAPC_E_INVALID, "%s: GROUP D=%d but feats null", who, grp->D);
@@ -1008,6 +1012,7 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
     const bool vec = p.a.vec && (p.wmap || (aligned16(w) && Cin % 4 == 0));
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MLP_GEMM, st);
+    PAPC_REQUIRE(!(gmax && a_mode == A_XYZ), PAPC_E_UNSUPPORTED, "papc_mlp_gemm_f32: PAPC_A_XYZ has no fused group-max flavour");
     if (gmax) {
         PAPC_REQUIRE(gmax->gmax && gmax->gmin && gmax->amax && gmax->amin, PAPC_E_INVALID, "papc_mlp_gemm_f32: null pointer in gmax");
         PAPC_REQUIRE(papc_mlp_gemm_gmax_ok(M, Cout, gmax->K), PAPC_E_UNSUPPORTED,
@@ -1020,11 +1025,29 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
         default: return launch_gemm<A_GROUP, EPI_STORE_GMAX>(p, vec, st);
         }
     }
+    if (a_mode == A_XYZ) {   // only the row-streaming kernel computes this operand (papc_mlp_xyz_ok says where it applies)
+        GemmArgs q = p;
+        q.parts = gemm_parts(p.M);
+        const int rc2 = stream_gemm_try(q, A_XYZ, EPI_STORE, vec, st);
+        if (rc2 == 0) { set_error("papc_mlp_gemm_f32: PAPC_A_XYZ is not built for M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout); return PAPC_E_UNSUPPORTED; }
+        return rc2 < 0 ? rc2 : PAPC_OK;
+    }
     switch (a_mode) {
     case A_PLAIN: return launch_gemm<A_PLAIN, EPI_STORE>(p, vec, st);
     case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE>(p, vec, st);
     default: return launch_gemm<A_GROUP, EPI_STORE>(p, vec, st);
     }
+}
+
+/* 1 when a stack whose first layer is fed by coordinates only (D = 0) can run that layer through its input moments (xyz1.hip): the
+ * second layer's forward and dW must both have their A_XYZ flavours (row-streaming kernels: M >= 65 536 rows, 64- or 128-channel widths) */
+int papc_mlp_xyz_ok(int64_t M, int C1, int C2)
+{
+    if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !knob(KNOB_DW_ROWS) || knob(KNOB_DW_F32)) return 0;
+    if (M % 64 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES)) return 0;
+    if (C1 != 64 || !(C2 == 64 || C2 == 128)) return 0;
+    if ((C1 / 64) * (C2 / 64) > knob(KNOB_DW_ROWS_BLOCKS)) return 0;
+    return 1;
 }
 
 int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, float *dx,

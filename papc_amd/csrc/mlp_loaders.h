@@ -19,7 +19,9 @@
 
 namespace papc {
 
-enum { A_PLAIN = PAPC_A_PLAIN, A_BNRELU = PAPC_A_BNRELU, A_GROUP = PAPC_A_GROUP, A_DY_DENSE = 3, A_DY_MAX = 4, A_MAXCAT = 5 };
+enum { A_PLAIN = PAPC_A_PLAIN, A_BNRELU = PAPC_A_BNRELU, A_GROUP = PAPC_A_GROUP, A_DY_DENSE = 3, A_DY_MAX = 4, A_MAXCAT = 5, A_XYZ = PAPC_A_XYZ };
+// A_XYZ (xyz1.hip): the operand is the activation of a coordinates-only first layer, recomputed from the grouped centred coordinates:
+// a[m, k] = relu(wf[k][0] x + wf[k][1] y + wf[k][2] z + wf[k][3]) with (x, y, z) = xc[m] (float4 rows, a.x / a.ldx = 4) and wf = a.sc [Kin][4].
 // A_MAXCAT (dX of a max-pooled last layer without reading its output y, see papc_mlp_bwd_dx_max_f32): the operand row is the
 // concatenation [ P (d.C columns) | relu(bn(x)) (Kin - d.C columns) ] where P[m, c] = (m % K == argmax[m / K, c]) ? psel[m / K, c] : 0
 // is the sparse max-backward gradient (psel = d.gout, already masked and scaled) and x / sc / sh are the layer's BN+ReLU input.

@@ -101,11 +101,12 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     constexpr int NCH = KB16 / CK;
     static_assert(KB16 % CK == 0 && NCH >= 2 && NCH % 2 == 0, "an even number of chunks per tile");
     constexpr bool DY = (AMODE == A_DY_DENSE || AMODE == A_DY_MAX);
+    constexpr bool XYZ = (AMODE == A_XYZ);   // operand computed from the row's centred coordinates: no streamed operand, no asm ring
     constexpr int NLD = (AMODE == A_DY_MAX) ? 6 : (AMODE == A_DY_DENSE ? 4 : 2);   // 16-byte loads per lane and k block
     constexpr int CL = CK * NLD;                                                      // ... per chunk
     static_assert(CL <= 60, "vmcnt is a 6-bit field");
     constexpr int ROWB = 6 * K + 16;          // LDS bytes of one weight row: [plane 0 | plane 1 | plane 2] bf16 + 16 (odd number of 16-B slots)
-    constexpr int NCST = (AMODE == A_BNRELU) ? 2 : (DY ? 5 : 0);
+    constexpr int NCST = (AMODE == A_BNRELU) ? 2 : (DY ? 5 : (XYZ ? 4 : 0));
     constexpr int W_BYTES = NT * ROWB;
     constexpr int CST_BYTES = NCST * K * 4;
     constexpr int RED_BYTES = 2 * NW * NT * 4;
@@ -147,6 +148,9 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         for (int k = tid; k < K; k += NW * 64) {
             if (AMODE == A_BNRELU) {
                 cf[k] = p.a.sc[k]; cf[K + k] = p.a.sh[k];
+            } else if (XYZ) {        // folded first layer wf [K][4] -> four per-channel arrays
+                const float4 q = ld4(p.a.sc + 4 * k);
+                cf[k] = q.x; cf[K + k] = q.y; cf[2 * K + k] = q.z; cf[3 * K + k] = q.w;
             } else if (DY) {
                 // dy = sc (p - c1 - xhat c2), p = dz [sc y + sh > 0], xhat = (y - mean) invstd   ==   sc p - (A + Bp (y - mean))
                 const float sc = p.a.d.scale[k];
@@ -229,6 +233,45 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     const char *wl = smem + l31 * ROWB + hi * 16;        // this lane's weight-fragment row (tile 0, plane 0, k block 0)
     const char *cl = cstb + hi * 32;                     // this lane's constants (k block 0)
     int kin = 0;                                         // DY_MAX: this lane's row offset inside its group
+
+    // k block kb of a tile whose operand comes from the lane's centred coordinates (A_XYZ): relu(wf . x + t) for the lane's 8 channels
+    auto compute_xyz = [&](auto kb_, const float4 &xv) {
+        constexpr int kb = decltype(kb_)::value;
+        f32x4 c[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            c[q][0] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64);
+            c[q][1] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64 + 16);
+        }
+        unsigned q0[4], q1[4], q2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int h = j >> 1, i = 2 * (j & 1);
+// (plain fmas: the packed form needs the row's coordinate broadcast into both halves -- hipcc encodes that as v_pk_fma_f32 with
+            // op_sel / op_sel_hi on the (x, y) register pair, and that instruction returned wrong values for a varying ~15 % of the rows
+            // on gfx950, ROCm 7.2: tools/probe/dbg_xyz2.py; the natural-pair pk_fma of the other operand flavours is unaffected)
+            f32x2 t;
+            t.x = fmaf(c[2][h][i], xv.z, fmaf(c[1][h][i], xv.y, fmaf(c[0][h][i], xv.x, c[3][h][i])));
+            t.y = fmaf(c[2][h][i + 1], xv.z, fmaf(c[1][h][i + 1], xv.y, fmaf(c[0][h][i + 1], xv.x, c[3][h][i + 1])));
+            split3_pair(f32x2{fmaxf(t.x, 0.f), fmaxf(t.y, 0.f)}, q0[j], q1[j], q2[j]);
+        }
+        bf16x8 af[3];
+        af[0] = __builtin_bit_cast(bf16x8, make_uint4(q0[0], q0[1], q0[2], q0[3]));
+        af[1] = __builtin_bit_cast(bf16x8, make_uint4(q1[0], q1[1], q1[2], q1[3]));
+        af[2] = __builtin_bit_cast(bf16x8, make_uint4(q2[0], q2[1], q2[2], q2[3]));
+        bf16x8 bq[WN][3];
+#pragma unroll
+        for (int wn = 0; wn < WN; ++wn)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                bq[wn][pl] = *reinterpret_cast<const bf16x8 *>(wl + wn * 32 * ROWB + pl * 2 * K + kb * 32);
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int wn = 0; wn < WN; ++wn)
+                acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]], bq[wn][PB[t]], acc[wn], 0, 0, 0);
+    };
 
     // MFMAs of chunk `ci` from buffer `bi`
     auto compute = [&](auto bi_, auto ci_) {
@@ -409,8 +452,26 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         }
     };
 
+    // ---- A_XYZ: the operand is 12 bytes per row; one float4 load per lane and tile, prefetched one tile ahead (a compiler-visible load:
+    // this flavour issues no hidden ones)
+    if constexpr (XYZ) {
+        if (my_tiles > 0) {
+            const float4 *xc = reinterpret_cast<const float4 *>(p.a.x);
+            int row0 = tile_row0(0);
+            float4 xn = xc[row0 + l31];
+            for (int j = 0; j < my_tiles; ++j) {
+                const float4 xv = xn;
+                const int row0n = tile_row0(j + 1);
+                xn = xc[row0n + l31];
+                asm volatile("" ::: "memory");   // (keeps the weight / constant LDS reads inside the tile loop: hoisted, they are 250+ registers)
+                sfor<0, KB16>([&](auto kb_) { compute_xyz(kb_, xv); });
+                epilogue(row0, j & (U - 1));
+                row0 = row0n;
+            }
+        }
+    }
     // ---- main loop.  Chunk c of the flat (tile, chunk) sequence lives in buffer c & 1 and is prefetched two chunks ahead.
-    if (my_tiles > 0) {
+    if (!XYZ && my_tiles > 0) {
         int row0 = tile_row0(0);
         SB sa = bases(row0);
         issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sa);
@@ -506,7 +567,8 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     gx = std::min(gx, std::max(1, (geo.n_units + 7) / 8));
     if (gx > p.parts) gx = p.parts;
     dim3 grid((unsigned)gx, (unsigned)ncb);
-    if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true>), grid, dim3(512), 0, st, p, geo);
+    if constexpr (AMODE == A_XYZ) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);   // (no streamed operand: no asm ring)
+    else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true>), grid, dim3(512), 0, st, p, geo);
     else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);
     const int rc = check_launch("mlp stream gemm");
     return rc ? rc : 1;
@@ -524,12 +586,19 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
         else return 0;
     }
 #define STREAM_CASE(KB, WNN) if (kb == KB && wn == WNN) return stream_go<AMODE, EPI, KB, WNN>(p, geo, st)
-    STREAM_CASE(2, 2); STREAM_CASE(2, 4);
-    STREAM_CASE(4, 2); STREAM_CASE(4, 4);
-    STREAM_CASE(8, 2); STREAM_CASE(8, 4);
-    STREAM_CASE(4, 3); STREAM_CASE(8, 3);          // 96 output channels
-    STREAM_CASE(6, 2); STREAM_CASE(6, 4);          // 96 input channels
-    if constexpr (AMODE == A_DY_DENSE || AMODE == A_DY_MAX || AMODE == A_BNRELU) { STREAM_CASE(16, 2); }
+    if constexpr (AMODE == A_XYZ) {
+        // the layer above a coordinates-only first layer (xyz1.hip, papc_mlp_xyz_ok): 64 channels below, 64 or 128 above
+        STREAM_CASE(4, 2); STREAM_CASE(4, 4);
+    } else if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE) {
+        STREAM_CASE(4, 2); STREAM_CASE(8, 2);
+    } else {
+        STREAM_CASE(2, 2); STREAM_CASE(2, 4);
+        STREAM_CASE(4, 2); STREAM_CASE(4, 4);
+        STREAM_CASE(8, 2); STREAM_CASE(8, 4);
+        STREAM_CASE(4, 3); STREAM_CASE(8, 3);          // 96 output channels
+        STREAM_CASE(6, 2); STREAM_CASE(6, 4);          // 96 input channels
+        if constexpr (AMODE == A_DY_DENSE || AMODE == A_DY_MAX || AMODE == A_BNRELU) { STREAM_CASE(16, 2); }
+    }
 #undef STREAM_CASE
     return 0;
 }
@@ -565,6 +634,8 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
     if (amode == A_BNRELU && epi == EPI_STORE_GMAX) return stream_pick<A_BNRELU, EPI_STORE_GMAX>(p, geo, st);
     if (amode == A_PLAIN && epi == EPI_STORE) return stream_pick<A_PLAIN, EPI_STORE>(p, geo, st);
     if (amode == A_DY_DENSE && epi == EPI_STORE_RED) return stream_pick<A_DY_DENSE, EPI_STORE_RED>(p, geo, st);
+    if (amode == A_DY_DENSE && epi == EPI_STORE) return stream_pick<A_DY_DENSE, EPI_STORE>(p, geo, st);   // (layer above a Gram-path first layer: no BN-backward sums)
+    if (amode == A_XYZ && epi == EPI_STORE) return stream_pick<A_XYZ, EPI_STORE>(p, geo, st);
     if (amode == A_DY_MAX && epi == EPI_STORE_RED) return stream_pick<A_DY_MAX, EPI_STORE_RED>(p, geo, st);
     return 0;
 }

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import BwdDy, BwdRed, GroupMax, GroupSrc, ReduceJob, ScatterDst, check, ptr, stream_ptr
 
-A_PLAIN, A_BNRELU, A_GROUP = 0, 1, 2
+A_PLAIN, A_BNRELU, A_GROUP, A_XYZ = 0, 1, 2, 6
 DZ_DENSE, DZ_MAX = 0, 1
 
 
@@ -62,6 +62,7 @@ _RESIDENT_WGS = int(os.environ.get("PAPC_PARTS", "512"))   # persistent-grid siz
 _LIN_GATHER = os.environ.get("PAPC_LIN_GATHER", "1") == "1"    # first grouped layer: linear map per source point, then gather-add (lingather.hip)
 _SPARSE_MAX = os.environ.get("PAPC_SPARSE_MAX", "0") == "1"   # dX of the max-pooled last layer without reading its output y (papc_mlp_bwd_dx_max_f32)
 _DW_WGS = int(os.environ.get("PAPC_DW_WGS", "512"))         # workgroups of one dW launch (row chunks x output tiles)
+_XYZ1 = os.environ.get("PAPC_XYZ1", "1") == "1"             # coordinates-only first layer through its input moments, never materialised (xyz1.hip)
 
 
 def _dw_rows_per_chunk(M, cout, cin):
@@ -134,6 +135,11 @@ class SharedMLPMax(torch.autograd.Function):
         assert not ev or bn_buffers is not None, "eval_bn needs the running statistics"
         lin0 = (_LIN_GATHER and not ev and not plain and idx is not None and feats is not None and L >= 2 and spec.D % 4 == 0 and spec.D >= 16
                 and params[0].shape[0] % 4 == 0 and params[0].shape[0] <= 256 and feats.is_contiguous())
+        # coordinates-only first layer (D = 0): its [M, C1] output is never stored -- BN statistics from the inputs' second moments, the
+        # layer folded into the second layer's operand (xyz1.hip)
+        xyz1 = (_XYZ1 and not ev and not plain and idx is not None and feats is None and spec.D == 0 and L >= 3
+                and bool(lib.papc_mlp_xyz_ok(M, params[0].shape[0], params[4].shape[0])))
+        xc = wf = gram = None
         for l in range(L):
             w, b, gamma, beta = params[4 * l: 4 * l + 4]
             cout = w.shape[0]
@@ -153,7 +159,28 @@ class SharedMLPMax(torch.autograd.Function):
                 gm.amax, gm.amin = gbuf_i[0].data_ptr(), gbuf_i[1].data_ptr()
                 gm.K = spec.K
                 gm_ref = ctypes.byref(gm)
-            if l == 0 and plain:
+            if l == 0 and xyz1:
+                y = stats = None
+                xc = torch.empty(M, 4, device=dev, dtype=torch.float32)
+                nparts = lib.papc_xyz_parts(M)
+                gpart = torch.empty(nparts, 16, device=dev, dtype=torch.float64)
+                check(lib.papc_xyz_group_f32(ctypes.byref(grp), spec.B, ptr(xc), ptr(gpart), st), "papc_xyz_group_f32")
+                cst = torch.empty(4, cout, device=dev, dtype=torch.float32)
+                wf = torch.empty(cout, 4, device=dev, dtype=torch.float32)
+                gram = torch.empty(16, device=dev, dtype=torch.float64)
+                rm, rv = (bn_buffers[l] if bn_buffers is not None else (None, None))
+                check(lib.papc_xyz_l1_finalize_f32(ptr(gpart), nparts, M, ptr(w2), cin, 0, ptr(b), ptr(gamma), ptr(beta), spec.eps, spec.momentum,
+                                                   cout, cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), ptr(rm), ptr(rv),
+                                                   ptr(wf), ptr(gram), st), "papc_xyz_l1_finalize_f32")
+                ys.append(None)
+                consts.append(cst)
+                prev_y, prev_sc, prev_sh = None, cst[2], cst[3]
+                cin = cout
+                continue
+            if l == 1 and xyz1:
+                check(lib.papc_mlp_gemm_f32(A_XYZ, ptr(xc), 4, None, ptr(wf), None, ptr(w2), ptr(b), M, cin, cout,
+                                            ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
+            elif l == 0 and plain:
                 check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(x_rows), cin, None, None, None, ptr(w2), ptr(b), M, cin, cout,
                                             ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
             elif l == 0 and lin0:
@@ -212,7 +239,11 @@ class SharedMLPMax(torch.autograd.Function):
         ctx.x_needs_grad = plain and x_rows.requires_grad
         ctx.cin0 = cin0
         ctx.lin0 = lin0
+        ctx.xyz1 = xyz1
         ysel = gbuf_f[0] if (spec.pool and gm_ref is not None) else None   # raw y at the argmax (left in gmax by select_max)
+        if xyz1:
+            ys[0] = xc                 # (slot of the first layer's output, which does not exist: the grouped coordinates instead)
+            consts = consts + [wf, gram]
         ctx.save_for_backward(xyz, new_xyz, feats, idx, x_rows, argmax, ysel, *params, *ys, *consts)
         return out
 
@@ -226,6 +257,10 @@ class SharedMLPMax(torch.autograd.Function):
         params = saved[7:7 + 4 * L]
         ys = saved[7 + 4 * L: 7 + 5 * L]
         consts = saved[7 + 5 * L: 7 + 6 * L]
+        xyz1 = ctx.xyz1
+        xc = wf = gram = None
+        if xyz1:
+            xc, (wf, gram) = ys[0], saved[7 + 6 * L: 7 + 6 * L + 2]
         plain = x_rows is not None
         dev = gout.device
         M = spec.M
@@ -291,6 +326,31 @@ class SharedMLPMax(torch.autograd.Function):
                 dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_MAX, None, gout.data_ptr(), argmax.data_ptr(), spec.K
             else:
                 dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_DENSE, dz.data_ptr(), None, None, 1
+            if l == 0 and xyz1:
+                # the whole backward of the coordinates-only layer from one pass over dz and the inputs' moments: p = dz [a > 0] summed
+                # against the coordinates, then closed forms for dgamma / dbeta / dW (no y, no BN-backward sums from the layer above)
+                nbp = lib.papc_xyz_bwd_parts(M)
+                bpart = torch.empty(nbp, cout, 4, device=dev, dtype=torch.float32)
+                check(lib.papc_xyz_l1_bwd_f32(ptr(dz), ptr(xc), ptr(wf), M, cout, ptr(bpart), st), "papc_xyz_l1_bwd_f32")
+                if inplace:
+                    dw0, acc0 = tgt[0].view(cout, cin), 1
+                else:
+                    dw0, acc0 = torch.empty(cout, cin, device=dev, dtype=torch.float32), 0
+                if gb_inplace != bool(acc0):       # (one accumulate flag for the three outputs: fall back to fresh gamma / beta buffers)
+                    dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)
+                    dgamma_p, dbeta_p = dgb[0].data_ptr(), dgb[1].data_ptr()
+                    gb_fresh = True
+                else:
+                    gb_fresh = not gb_inplace
+                check(lib.papc_xyz_l1_bwd_finalize_f32(ptr(bpart), nbp, M, cout, ptr(gram), ptr(w), cin, 0, ptr(params[1]), cst[0].data_ptr(),
+                                                       cst[1].data_ptr(), cst[2].data_ptr(), dgamma_p, dbeta_p, ptr(dw0), acc0, st),
+                      "papc_xyz_l1_bwd_finalize_f32")
+                if not inplace:
+                    grads[0] = dw0.reshape(w.shape)
+                    grads[1] = None if (tgt is not None and tgt[1] is not None) else _lib.zeros((cout,), dev)
+                if gb_fresh:
+                    grads[2], grads[3] = dgb[0], dgb[1]
+                break
             dy.y = ys[l].data_ptr()
             dy.mean, dy.invstd, dy.scale, dy.shift = (cst[i].data_ptr() for i in range(4))
             dy.c1, dy.c2 = c12[0].data_ptr(), c12[1].data_ptr()
@@ -357,8 +417,9 @@ class SharedMLPMax(torch.autograd.Function):
                 break
             # ---- dW, db
             rpc = 0
+            x1 = xyz1 and l == 1             # the input of this layer is the recomputed activation of the coordinates-only first layer
             if l > 0:                        # (the kernel's own preference where it has one: papc_mlp_bwd_dw_chunk_hint)
-                rpc = lib.papc_mlp_bwd_dw_chunk_hint(M, cin, cout, A_BNRELU, dy.dz_mode, spec.K if dy.dz_mode == DZ_MAX else 0)
+                rpc = lib.papc_mlp_bwd_dw_chunk_hint(M, cin, cout, A_XYZ if x1 else A_BNRELU, dy.dz_mode, spec.K if dy.dz_mode == DZ_MAX else 0)
             if rpc <= 0:
                 rpc = _dw_rows_per_chunk(M, cout, cin)
             n_chunks = (M + rpc - 1) // rpc
@@ -371,6 +432,9 @@ class SharedMLPMax(torch.autograd.Function):
             elif l == 0:
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_GROUP, None, 0, ctypes.byref(grp), None, None, M, cin, cout, rpc,
                                               dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
+            elif x1:
+                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_XYZ, ptr(xc), 4, None, ptr(wf), None, M, cin, cout, rpc, dwp_p, dbp_p, pld, st),
+                      "papc_mlp_bwd_dw_f32")
             else:
                 pc = consts[l - 1]
                 check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_BNRELU, ys[l - 1].data_ptr(), cin, None, pc[2].data_ptr(),
@@ -399,7 +463,7 @@ class SharedMLPMax(torch.autograd.Function):
                 dz_prev = torch.empty(M, cin, device=dev, dtype=torch.float32)
                 # the dX kernel also accumulates layer l-1's BN-backward reductions over the dz it produces
                 nr_ref = None
-                if _FUSE_RED:
+                if _FUSE_RED and not x1:     # (x1: the layer below takes its BN-backward sums from its own pass over dz, xyz1.hip)
                     pc = consts[l - 1]
                     fused_red = torch.empty(gemm_parts, 2, cin, device=dev, dtype=torch.float32)
                     nr = BwdRed()

@@ -311,3 +311,67 @@ def test_backward_near_ties_explain_the_seed40_excess(dev):
             print("   d%s layer %d: kernels %.2e, plain fp32 torch autograd %.2e (of max|grad|)" % (nm, l, ours, e32))
             bad.append((ours <= max(2e-4, 3.0 * e32), "seed 40 d%s layer %d: %.2e vs plain fp32 autograd %.2e" % (nm, l, ours, e32)))
     assert all(ok for ok, _ in bad), [m for ok, m in bad if not ok]
+
+
+@pytest.mark.parametrize("mlp", [[64, 64, 128], [64, 128, 128]])
+def test_xyz_first_layer_gram_path_vs_rows_and_f64(dev, mlp):
+    """SA1 of the classifiers (coordinates only, pointnet2_basic_layers.py:152-153): the first layer run through its input moments
+    (csrc/xyz1.hip -- no [M, 64] output, BN statistics and the layer's whole backward in closed form, the layer folded into the
+    second one's operand) against (a) the row kernels that materialise it and (b) float64 torch: forward 1e-5, every gradient
+    2e-4, running statistics equal, in-place gradient targets honoured."""
+    from papc_amd import mlp as M_
+    B, N, S, K = 8, 1024, 256, 32                       # M = 65536 rows: the smallest problem the streaming kernels take
+    x = make_clouds(B, N, 77)
+    xyz = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 5)).to(dev)
+    _, new_xyz = F._fps_raw(xyz, S, st)
+    idx = F._ball_query_raw([0.25], [K], xyz, new_xyz)[0]
+    ws = seeded_weights([3] + mlp, 43)
+    rng = np.random.default_rng(3)
+    res = {}
+    for flag in (True, False):
+        params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+        bufs = [(torch.zeros(c, device=dev), torch.ones(c, device=dev)) for c in mlp]
+        old = M_._XYZ1
+        M_._XYZ1 = flag
+        try:
+            out = shared_mlp_max(StackSpec(B, N, S, K, 0, True), bufs, xyz, new_xyz, None, idx, params)
+        finally:
+            M_._XYZ1 = old
+        assert out.grad_fn.xyz1 == flag, "the Gram path must be taken exactly when enabled"
+        gout = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        res[flag] = (out.detach(), [p.grad for p in params], bufs, params, gout)
+    out, grads, bufs, params, gout = res[True]
+    out_r, grads_r, bufs_r, _, _ = res[False]
+    assert_close(out.cpu().numpy(), out_r.cpu().numpy(), 2e-6, "gram path vs rows forward")
+    for (rm, rv), (rm_r, rv_r) in zip(bufs, bufs_r):
+        assert_close(rm.cpu().numpy(), rm_r.cpu().numpy(), 1e-5, "running mean")
+        assert_close(rv.cpu().numpy(), rv_r.cpu().numpy(), 1e-5, "running var")
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    rows = torch_ref.group(xyz.double(), new_xyz.double(), None, idx, True).reshape(B * S * K, 3)
+    ref = torch_ref.stack_max(rows, [tuple(p64[4 * l:4 * l + 4]) for l in range(3)], K, 1e-5)
+    assert_close(out.cpu().numpy(), ref.detach().cpu().numpy(), REL, "gram path forward vs f64")
+    ref.backward(gout.double())
+    for l in range(3):
+        for j, nm in enumerate(["w", "b", "gamma", "beta"]):
+            if j == 1:
+                assert grads[4 * l + j] is None or float(grads[4 * l + j].abs().max()) <= 1e-4 * float(p64[4 * l].grad.abs().max())
+                continue
+            assert_close(grads[4 * l + j].cpu().numpy(), p64[4 * l + j].grad.cpu().numpy(), 2e-4, "gram path d%s layer %d vs f64" % (nm, l))
+            # (sanity only: the row kernels take their ReLU / max decisions from MFMA-computed activations, the Gram path from fma chains --
+            # decisions within rounding of a tie differ, which moves a max-pooled gradient by up to ~1e-2, tests/test_gpu_step.py)
+            assert_close(grads[4 * l + j].cpu().numpy(), grads_r[4 * l + j].cpu().numpy(), 3e-2, "gram path d%s layer %d vs rows" % (nm, l))
+    # in-place targets: added on top of what the buffers hold
+    tg = [torch.ones_like(p) for p in params]
+    spec = StackSpec(B, N, S, K, 0, True)
+    spec.grad_targets = tg
+    from papc_amd.mlp import SharedMLPMax
+    o3 = SharedMLPMax.apply(spec, None, xyz, new_xyz, None, idx, None, *params)
+    for p in params:
+        p.grad = None
+    o3.backward(gout)
+    for l in range(3):
+        for j in (0, 2, 3):
+            assert params[4 * l + j].grad is None
+            assert torch.allclose(tg[4 * l + j] - 1.0, grads[4 * l + j].reshape(tg[4 * l + j].shape), rtol=1e-4, atol=3e-6), (l, j)
