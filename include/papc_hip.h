@@ -455,6 +455,8 @@ int papc_mlp_xyz_ok(int64_t M, int C1, int C2);
 int papc_xyz_parts(int64_t M);
 int papc_xyz_bwd_parts(int64_t M);
 int papc_xyz_group_f32(const papc_group_src *grp, int B, float *xc, double *gram_partial, papc_stream_t stream);
+/* gram_partial [parts, 16] -> gram [16] in fixed order; papc_xyz_l1_finalize_f32 accepts the result as a one-row partial buffer (parts = 1) */
+int papc_xyz_gram_fold_f32(const double *gram_partial, int parts, double *gram, papc_stream_t stream);
 int papc_xyz_l1_finalize_f32(const double *gram_partial, int parts, int64_t M, const float *w, int ldw, int xcol0, const float *bias,
                              const float *gamma, const float *beta, float eps, float momentum, int C, float *mean, float *invstd, float *scale,
                              float *shift, float *running_mean, float *running_var, float *wf, double *gram, papc_stream_t stream);

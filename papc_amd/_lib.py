@@ -112,6 +112,7 @@ SIGNATURES = {
     "papc_xyz_parts": (c_i, [c_l]),
     "papc_xyz_bwd_parts": (c_i, [c_l]),
     "papc_xyz_group_f32": (c_i, [c_p, c_i, c_p, c_p, c_p]),
+    "papc_xyz_gram_fold_f32": (c_i, [c_p, c_i, c_p, c_p]),
     "papc_xyz_l1_finalize_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_i, c_p, c_p, c_p, c_f, c_f, c_i] + [c_p] * 9),
     "papc_xyz_l1_bwd_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_p]),
     "papc_xyz_l1_bwd_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_i, c_i] + [c_p] * 7 + [c_i, c_p]),

@@ -67,6 +67,23 @@ __global__ __launch_bounds__(XYZ_T) void xyz_group_kernel(GroupSrc g, int64_t M,
     }
 }
 
+// moments [parts][16] -> [16], fixed order (weight-independent: runs with the grouping pass, off the critical path)
+__global__ __launch_bounds__(256) void xyz_gram_fold_kernel(const double *__restrict__ partial, int parts, double *__restrict__ gram)
+{
+    __shared__ double red[16][16];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    double s = 0.0;
+    if (e < 10) for (int t = sl; t < parts; t += 16) s += partial[(int64_t)t * 16 + e];
+    red[sl][e] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][threadIdx.x];
+        gram[threadIdx.x] = threadIdx.x < 10 ? v : 0.0;
+    }
+}
+
 // moments [parts][16] -> gram[16] (fixed order), then per channel the BatchNorm constants and the folded first layer
 __global__ __launch_bounds__(256) void xyz_l1_finalize_kernel(const double *__restrict__ partial, int parts, double M, const float *__restrict__ w, int ldw,
                                                               int xcol0, const float *__restrict__ bias, const float *__restrict__ gamma,
@@ -172,43 +189,55 @@ __global__ __launch_bounds__(XYZ_T) void xyz_l1_bwd_kernel(const float *__restri
     }
 }
 
-// partial [parts][C][4] (T0, T1, T2, S) + the input moments -> dgamma, dbeta, dW [C][3]  (closed form, float64)
+// partial [parts][C][4] (T0, T1, T2, S) + the input moments -> dgamma, dbeta, dW [C][3]  (closed form, float64).
+// A workgroup owns 16 channels: 64 entries x 16 slices of the partial rows, summed in fixed order.
 __global__ __launch_bounds__(1024) void xyz_l1_bwd_finalize_kernel(const float *__restrict__ partial, int parts, double M, int C, const double *__restrict__ gram,
                                                                    const float *__restrict__ w, int ldw, int xcol0, const float *__restrict__ bias,
                                                                    const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                    const float *__restrict__ scale, float *dgamma, float *dbeta, float *dw, int accumulate)
 {
-    __shared__ double red[4][256];
-    const int e = threadIdx.x & 255, sl = threadIdx.x >> 8;     // 256 entries (C * 4 <= 256 per pass) x 4 slices
-    for (int e0 = 0; e0 < C * 4; e0 += 256) {
-        double s = 0.0;
-        if (e0 + e < C * 4) for (int t = sl; t < parts; t += 4) s += (double)partial[(int64_t)t * C * 4 + e0 + e];
-        red[sl][e] = s;
-        __syncthreads();
-        if (sl == 0) red[0][e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        __syncthreads();
-        const int c = (e0 >> 2) + threadIdx.x;
-        if (threadIdx.x < 64 && c < C && c * 4 < e0 + 256) {
-            const double T0 = red[0][threadIdx.x * 4 + 0], T1 = red[0][threadIdx.x * 4 + 1], T2 = red[0][threadIdx.x * 4 + 2], S = red[0][threadIdx.x * 4 + 3];
-            const double w0 = w[(int64_t)c * ldw + xcol0], w1 = w[(int64_t)c * ldw + xcol0 + 1], w2 = w[(int64_t)c * ldw + xcol0 + 2];
-            const double b = bias ? (double)bias[c] : 0.0;
-            const double mu = mean[c], is = invstd[c], sc = scale[c];
-            const double dg = is * (w0 * T0 + w1 * T1 + w2 * T2 + (b - mu) * S);     // sum p xhat
-            dbeta[c] = accumulate ? dbeta[c] + (float)S : (float)S;
-            dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
-            const double c1 = S / M, c2 = dg / M;
-            const double Sx[3] = {gram[0], gram[1], gram[2]};
-            const double Sxx[3][3] = {{gram[3], gram[4], gram[5]}, {gram[4], gram[6], gram[7]}, {gram[5], gram[7], gram[8]}};
-            const double T[3] = {T0, T1, T2};
+    __shared__ double red[16][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e0 = blockIdx.x * 64;                  // first entry (channel * 4 + slot) of this workgroup
+    double s = 0.0;
+    if (e0 + e < C * 4) {
+        for (int t0 = sl; t0 < parts; t0 += 16 * 8) {   // 8 loads in flight per thread
+            float v[8];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double yx = w0 * Sxx[0][k] + w1 * Sxx[1][k] + w2 * Sxx[2][k] + (b - mu) * Sx[k];      // sum_m (y - mean) x_k
-                const float gk_ = (float)(sc * (T[k] - c1 * Sx[k] - c2 * is * yx));
-                float *o = dw + (int64_t)c * ldw + xcol0 + k;
-                *o = accumulate ? *o + gk_ : gk_;
-            }
+            for (int q = 0; q < 8; ++q) v[q] = (t0 + 16 * q < parts) ? partial[(int64_t)(t0 + 16 * q) * C * 4 + e0 + e] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += (double)v[q];
         }
-        __syncthreads();
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][e];
+        red[0][e] = t;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x < 16 && c < C) {
+        const double T0 = red[0][threadIdx.x * 4 + 0], T1 = red[0][threadIdx.x * 4 + 1], T2 = red[0][threadIdx.x * 4 + 2], S = red[0][threadIdx.x * 4 + 3];
+        const double w0 = w[(int64_t)c * ldw + xcol0], w1 = w[(int64_t)c * ldw + xcol0 + 1], w2 = w[(int64_t)c * ldw + xcol0 + 2];
+        const double b = bias ? (double)bias[c] : 0.0;
+        const double mu = mean[c], is = invstd[c], sc = scale[c];
+        const double dg = is * (w0 * T0 + w1 * T1 + w2 * T2 + (b - mu) * S);     // sum p xhat
+        dbeta[c] = accumulate ? dbeta[c] + (float)S : (float)S;
+        dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
+        const double c1 = S / M, c2 = dg / M;
+        const double Sx[3] = {gram[0], gram[1], gram[2]};
+        const double Sxx[3][3] = {{gram[3], gram[4], gram[5]}, {gram[4], gram[6], gram[7]}, {gram[5], gram[7], gram[8]}};
+        const double T[3] = {T0, T1, T2};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double yx = w0 * Sxx[0][k] + w1 * Sxx[1][k] + w2 * Sxx[2][k] + (b - mu) * Sx[k];      // sum_m (y - mean) x_k
+            const float gk_ = (float)(sc * (T[k] - c1 * Sx[k] - c2 * is * yx));
+            float *o = dw + (int64_t)c * ldw + xcol0 + k;
+            *o = accumulate ? *o + gk_ : gk_;
+        }
     }
 }
 
@@ -237,6 +266,15 @@ int papc_xyz_group_f32(const papc_group_src *grp, int B, float *xc, double *gram
     ProfScope prof(PAPC_K_GROUP, st);
     hipLaunchKernelGGL(xyz_group_kernel, dim3((unsigned)papc_xyz_parts(M)), dim3(XYZ_T), 0, st, g, M, reinterpret_cast<float4 *>(xc), gram_partial);
     return check_launch("papc_xyz_group_f32");
+}
+
+int papc_xyz_gram_fold_f32(const double *gram_partial, int parts, double *gram, papc_stream_t stream)
+{
+    PAPC_REQUIRE(gram_partial && gram && parts >= 1, PAPC_E_INVALID, "papc_xyz_gram_fold_f32: bad arguments");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_GROUP, st);
+    hipLaunchKernelGGL(xyz_gram_fold_kernel, dim3(1), dim3(256), 0, st, gram_partial, parts, gram);
+    return check_launch("papc_xyz_gram_fold_f32");
 }
 
 int papc_xyz_l1_finalize_f32(const double *gram_partial, int parts, int64_t M, const float *w, int ldw, int xcol0, const float *bias,
@@ -272,7 +310,7 @@ int papc_xyz_l1_bwd_finalize_f32(const float *partial, int parts, int64_t M, int
     PAPC_REQUIRE(parts >= 1 && M >= 1 && C >= 1 && C <= 256 && ldw >= xcol0 + 3 && xcol0 >= 0, PAPC_E_INVALID, "papc_xyz_l1_bwd_finalize_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);
-    hipLaunchKernelGGL(xyz_l1_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, parts, (double)M, C, gram, w, ldw, xcol0, bias, mean, invstd,
+    hipLaunchKernelGGL(xyz_l1_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, partial, parts, (double)M, C, gram, w, ldw, xcol0, bias, mean, invstd,
                        scale, dgamma, dbeta, dw, accumulate);
     return check_launch("papc_xyz_l1_bwd_finalize_f32");
 }

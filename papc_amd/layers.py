@@ -81,7 +81,19 @@ class PointNetSetAbstraction(nn.Module):
             xyz = xyz.float()
         _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=None if out is None else out[0])
         idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz, outs=None if out is None else [out[1]])[0]
+        if self._xyz_first(xyz.shape[0]):
+            # coordinates-only stack whose first layer runs through its input moments: the grouped centred coordinates and their
+            # moments are weight-independent too (mlp.xyz_pregroup) -- part of the plan
+            from .mlp import xyz_pregroup
+            xc, gpart = xyz_pregroup(xyz, new_xyz, idx, out=None if (out is None or len(out) < 4) else (out[2], out[3]))
+            return new_xyz, idx, xc, gpart
         return new_xyz, idx
+
+    def _xyz_first(self, B):
+        from .mlp import xyz_first_layer_ok
+        convs = self.mlp_convs
+        return (not self.group_all and convs[0].in_channels == 3 and len(convs) >= 3
+                and xyz_first_layer_ok(B * self.npoint * self.nsample, convs[0].out_channels, convs[1].out_channels, len(convs)))
 
     def forward(self, xyz, points, start_idx=None, sampled=None, wt_table=None):
         """xyz [B,3,N], points [B,D,N] or None -> new_xyz [B,3,S], new_points [B,D',S].
@@ -101,8 +113,10 @@ class PointNetSetAbstraction(nn.Module):
             idx = None
         else:                                                                   # sample_and_group :129-157
             S, K = self.npoint, self.nsample
+            xyz_pre = None
             if sampled is not None:
-                new_xyz, idx = sampled
+                new_xyz, idx = sampled[0], sampled[1]
+                xyz_pre = tuple(sampled[2:4]) if len(sampled) >= 4 else None
             else:
                 _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)
                 idx = F_._ball_query_raw([self.radius], [K], xyz, new_xyz)[0]
@@ -112,6 +126,8 @@ class PointNetSetAbstraction(nn.Module):
         spec = StackSpec(B, N, S, K, D, xyz_first=True, eps=self.mlp_bns[0].eps, momentum=0.9,
                          cut_gather_grad=self.reference_quirks)
         spec.wt_table = wt_table
+        if not self.group_all and feats is None:
+            spec.xyz_pre = xyz_pre
         out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx, params)   # :214-219
         new_points = out.view(B, S, -1).transpose(1, 2)                         # [B,D',S]
         # (group_all: new_xyz is the cached READ-ONLY zero centre of sample_and_group_all, :170 -- a clone here would put a copy kernel

@@ -41,6 +41,8 @@ class StackSpec:
         self.grad_targets = None
         # optional: W^T operands precomputed for THIS forward pass by the caller (precompute_wt); None = transpose in the backward
         self.wt_table = None
+        # optional: (xc, gram_partial) of xyz_pregroup for these very (xyz, new_xyz, idx): the coordinates-only first layer skips its grouping pass
+        self.xyz_pre = None
 
 
 def _group_src(spec, xyz, new_xyz, feats, idx):
@@ -105,6 +107,33 @@ def precompute_wt(weights):
     return table
 
 
+def xyz_first_layer_ok(M, c1, c2, n_layers):
+    """whether a coordinates-only stack of these widths takes the input-moment path of its first layer (xyz1.hip)"""
+    return bool(_XYZ1 and n_layers >= 3 and _lib.load().papc_mlp_xyz_ok(M, c1, c2))
+
+
+def xyz_pregroup(xyz, new_xyz, idx, out=None):
+    """The weight-independent part of that path -- grouped centred coordinates xc [M, 4] and their float64 partial moments -- so a
+    training loop can compute it with the sampling pyramid (layers.PointNetSetAbstraction.sample).  xyz [B,N,3] strided, new_xyz [B,S,3],
+    idx [B,S,K] int32.  ``out`` = optional preallocated (xc [M,4], gram [1,16] float64)."""
+    lib = _lib.load()
+    B, N = xyz.shape[0], xyz.shape[1]
+    S, K = idx.shape[1], idx.shape[2]
+    M = B * S * K
+    dev = xyz.device
+    if out is None:
+        out = (torch.empty(M, 4, device=dev, dtype=torch.float32), torch.empty(1, 16, device=dev, dtype=torch.float64))
+    gpart = torch.empty(lib.papc_xyz_parts(M), 16, device=dev, dtype=torch.float64)
+    g = GroupSrc()
+    g.xyz = xyz.data_ptr()
+    g.sb, g.sn, g.sc = xyz.stride(0), xyz.stride(1), xyz.stride(2)
+    g.new_xyz, g.feats, g.idx = new_xyz.data_ptr(), 0, idx.data_ptr()
+    g.N, g.S, g.K, g.D, g.xyz_first = N, S, K, 0, 1
+    check(lib.papc_xyz_group_f32(ctypes.byref(g), B, ptr(out[0]), ptr(gpart), stream_ptr()), "papc_xyz_group_f32")
+    check(lib.papc_xyz_gram_fold_f32(ptr(gpart), gpart.shape[0], ptr(out[1]), stream_ptr()), "papc_xyz_gram_fold_f32")
+    return out
+
+
 class SharedMLPMax(torch.autograd.Function):
     """out[g, :] = max_{k<K} relu(bn_L(conv_L(... relu(bn_1(conv_1(rows)))...)))   with rows gathered on the fly.
 
@@ -137,8 +166,8 @@ class SharedMLPMax(torch.autograd.Function):
                 and params[0].shape[0] % 4 == 0 and params[0].shape[0] <= 256 and feats.is_contiguous())
         # coordinates-only first layer (D = 0): its [M, C1] output is never stored -- BN statistics from the inputs' second moments, the
         # layer folded into the second layer's operand (xyz1.hip)
-        xyz1 = (_XYZ1 and not ev and not plain and idx is not None and feats is None and spec.D == 0 and L >= 3
-                and bool(lib.papc_mlp_xyz_ok(M, params[0].shape[0], params[4].shape[0])))
+        xyz1 = (not ev and not plain and idx is not None and feats is None and spec.D == 0
+                and xyz_first_layer_ok(M, params[0].shape[0], params[4].shape[0] if L >= 2 else 0, L))
         xc = wf = gram = None
         for l in range(L):
             w, b, gamma, beta = params[4 * l: 4 * l + 4]
@@ -161,10 +190,12 @@ class SharedMLPMax(torch.autograd.Function):
                 gm_ref = ctypes.byref(gm)
             if l == 0 and xyz1:
                 y = stats = None
-                xc = torch.empty(M, 4, device=dev, dtype=torch.float32)
-                nparts = lib.papc_xyz_parts(M)
-                gpart = torch.empty(nparts, 16, device=dev, dtype=torch.float64)
-                check(lib.papc_xyz_group_f32(ctypes.byref(grp), spec.B, ptr(xc), ptr(gpart), st), "papc_xyz_group_f32")
+                nparts = 1                         # (the moments arrive folded: xyz_pregroup)
+                if spec.xyz_pre is not None:       # grouped with the sampling pyramid (possibly on another stream, one step ahead)
+                    xc, gpart = spec.xyz_pre
+                    assert tuple(xc.shape) == (M, 4) and tuple(gpart.shape) == (1, 16)
+                else:
+                    xc, gpart = xyz_pregroup(xyz, new_xyz, idx)
                 cst = torch.empty(4, cout, device=dev, dtype=torch.float32)
                 wf = torch.empty(cout, 4, device=dev, dtype=torch.float32)
                 gram = torch.empty(16, device=dev, dtype=torch.float64)
