@@ -189,6 +189,10 @@ int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, cons
                            const float *y, const float *mean, const float *invstd, const float *scale,
                            const float *shift, int64_t M, int C, int n_parts, float *red_partial,
                            papc_stream_t stream);
+/* The MAX-mode reduction from the selected raw values alone (ysel, gout: [M/K, C]; y itself is not needed), optionally also writing
+ * psel [M/K, C] = scale * p -- the sparse operand papc_bn_max_prep_f32 would otherwise compute in a pass of its own (pass psel = NULL there). */
+int papc_bn_bwd_reduce_max_f32(const float *ysel, const float *gout, int K, const float *mean, const float *invstd, const float *scale,
+                               const float *shift, int64_t M, int C, int n_parts, float *red_partial, float *psel, papc_stream_t stream);
 
 /* Reduce red_partial -> dgamma[c] = sum p*xhat, dbeta[c] = sum p, and the two per-channel constants of
  * dy = scale*(p - c1 - xhat*c2): c1 = dbeta/M, c2 = dgamma/M.  bit 0 of accumulate adds into dgamma/dbeta; bit 1: eval-mode BN (below). */
@@ -425,7 +429,7 @@ int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int
  * y = A W^T + b, A = relu(bn(y_prev)):      dX = (s*p) W - A (W^T E W) + (f - e*b) W.
  * p is non-zero only at the argmax row of each (group, channel), so the first product is a GEMM over a sparse operand that is built
  * from [M/K, Cout] arrays, and the second one is a GEMM over the layer's INPUT (Cin channels).
- * papc_bn_max_prep_f32: psel [G,Co] = s*[s*ysel+shift > 0]*gout (ysel: papc_bn_select_max_f32), wcat [Ci, Co+Ci] = [W^T | -W^T E W],
+ * papc_bn_max_prep_f32: psel [G,Co] = s*[s*ysel+shift > 0]*gout (ysel: papc_bn_select_max_f32; NULL: skipped), wcat [Ci, Co+Ci] = [W^T | -W^T E W],
  * hbias [Ci] = (f - e*b) W, e [Co], q [Co] = f - e*b.   (w [Co,Ci]; bias may be NULL.)
  * papc_mlp_bwd_dx_max_f32: dx [M,Cin] = [P | relu(bn_scale*x + bn_shift)] . wcat^T + hbias, P[m,c] = (m%K == argmax[m/K,c]) ? psel : 0;
  * x [M,ldx] is the previous layer's pre-BN output; next_red as in papc_mlp_bwd_dx_f32.  Needs Cout % 16 == 0, Cin % 4 == 0 and 16-byte
@@ -436,6 +440,21 @@ int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scal
 int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, int64_t ldx, const float *bn_scale,
                             const float *bn_shift, const float *wcat, const float *hbias, int64_t M, int Cin, int Cout, float *dx,
                             const papc_bwd_red *next_red, papc_stream_t stream);
+
+/* The same layer without EVER storing its output (conv -> BN -> ReLU -> max over the K rows of a group,
+ * pointnet2_basic_layers.py:215-219 with the last mlp entry): what the pooled result and its backward need of y [M,Cout] is the
+ * per-group extrema (papc_group_max), its BN statistics, and sums over the layer's INPUT rows.
+ * papc_mlp_max_nostore_ok: 1 where all three row-streaming flavours exist (64 -> 128 channels, K in {32,64,128}, M % 128 == 0 and
+ * large).  There: papc_mlp_gemm_f32 accepts y = NULL with gmax != NULL (PAPC_A_BNRELU); dX is papc_mlp_bwd_dx_max_f32; and
+ * papc_mlp_bwd_dw_max_f32 forms dW [Cout,Cin] (accumulate != 0: += into dw) in one pass over x [M,Cin] (previous layer's pre-BN output):
+ *   dW = P'^T A - (scale*c1) (x) S - diag(e) W (A^T A - S S^T / M),  A = relu(bn_scale*x + bn_shift), S = column sums of A,
+ * psel / e from papc_bn_max_prep_f32, (scale, c1) the layer's BN scale and papc_bn_bwd_finalize_f32's c1.  workspace:
+ * papc_mlp_bwd_dw_max_ws_floats(M, Cin, Cout) floats, 16-byte aligned.  The bias gradient of such a layer is exactly 0. */
+int papc_mlp_max_nostore_ok(int64_t M, int Cin, int Cout, int K);
+int64_t papc_mlp_bwd_dw_max_ws_floats(int64_t M, int Cin, int Cout);
+int papc_mlp_bwd_dw_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, const float *bn_scale, const float *bn_shift,
+                            const float *w, const float *e, const float *scale, const float *c1, int64_t M, int Cin, int Cout,
+                            float *workspace, float *dw, int accumulate, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * First layer of a stack fed by coordinates only (sample_and_group with points = None, pointnet2_basic_layers.py:152-153; SA1 of the

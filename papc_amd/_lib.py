@@ -72,6 +72,7 @@ SIGNATURES = {
     "papc_bn_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "papc_bn_relu_max_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
     "papc_bn_relu_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_p]),
+    "papc_bn_bwd_reduce_max_f32": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
     "papc_bn_bwd_reduce_f32": (c_i, [c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p]),
     "papc_bn_bwd_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_bn_eval_consts_f32": (c_i, [c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p]),
@@ -107,6 +108,9 @@ SIGNATURES = {
     "papc_lingather_fwd_f32": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "papc_lingather_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     "papc_bn_max_prep_f32": (c_i, [c_p] * 10 + [c_l, c_i, c_i] + [c_p] * 6),
+    "papc_mlp_max_nostore_ok": (c_i, [c_l, c_i, c_i, c_i]),
+    "papc_mlp_bwd_dw_max_ws_floats": (c_l, [c_l, c_i, c_i]),
+    "papc_mlp_bwd_dw_max_f32": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_i, c_p]),
     "papc_mlp_bwd_dx_max_f32": (c_i, [c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
     "papc_mlp_xyz_ok": (c_i, [c_l, c_i, c_i]),
     "papc_xyz_parts": (c_i, [c_l]),

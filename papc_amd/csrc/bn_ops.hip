@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
                                                             const float *__restrict__ y, const float *__restrict__ mean,
                                                             const float *__restrict__ invstd, const float *__restrict__ scale,
                                                             const float *__restrict__ shift, int64_t M, int C,
-                                                            float *__restrict__ part)
+                                                            float *__restrict__ part, float *__restrict__ psel_out = nullptr)
 {
     __shared__ float red[2][256 * 4];
     const int CV = C / V;                       // channel groups
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
             const Vec<V> mu = Vec<V>::load(mean + c), is = Vec<V>::load(invstd + c);
             for (int64_t u = u0 + rl; u < u1; u += RL) {
                 if (MAXMODE) {
-                    const Vec<V> g = Vec<V>::load(gout + u * C + c);
+                    Vec<V> g = Vec<V>::load(gout + u * C + c);
                     Vec<V> ys;
                     if (dz) {        // MAX mode: dz carries ysel [M/K, C], the raw y at the argmax (papc_bn_select_max_f32)
                         ys = Vec<V>::load(dz + u * C + c);
@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
                         const float p = z > 0.f ? g[i] : 0.f;
                         a1[i] += p;
                         a2[i] = fmaf(p, (yv - mu[i]) * is[i], a2[i]);
+                        g[i] = sc[i] * p;
                     }
+                    if (psel_out) g.store(psel_out + u * C + c);   // scale * p: the sparse operand of papc_mlp_bwd_dx_max_f32 / _dw_max_f32
                 } else {
                     const Vec<V> d = Vec<V>::load(dz + u * C + c);
                     const Vec<V> yv = Vec<V>::load(y + u * C + c);
@@ -675,7 +677,8 @@ int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, cons
                            const float *y, const float *mean, const float *invstd, const float *scale,
                            const float *shift, int64_t M, int C, int n_parts, float *red_partial, papc_stream_t stream)
 {
-    PAPC_REQUIRE(y && mean && invstd && scale && shift && red_partial, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: null pointer");
+    PAPC_REQUIRE(mean && invstd && scale && shift && red_partial, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: null pointer");
+    PAPC_REQUIRE(y || (dz_mode != PAPC_DZ_DENSE && dz), PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: y may be NULL only in MAX mode with dz = ysel");
     PAPC_REQUIRE(M >= 1 && C >= 1 && n_parts >= 1, PAPC_E_INVALID, "papc_bn_bwd_reduce_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_REDUCE, st);
@@ -691,6 +694,19 @@ int papc_bn_bwd_reduce_f32(int dz_mode, const float *dz, const float *gout, cons
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, true>), dim3(n_parts), dim3(256), 0, st, dz, gout, argmax, K, y, mean, invstd, scale, shift, M, C, red_partial);
     }
     return check_launch("papc_bn_bwd_reduce_f32");
+}
+
+int papc_bn_bwd_reduce_max_f32(const float *ysel, const float *gout, int K, const float *mean, const float *invstd, const float *scale,
+                               const float *shift, int64_t M, int C, int n_parts, float *red_partial, float *psel, papc_stream_t stream)
+{
+    PAPC_REQUIRE(ysel && gout && mean && invstd && scale && shift && red_partial, PAPC_E_INVALID, "papc_bn_bwd_reduce_max_f32: null pointer");
+    PAPC_REQUIRE(M >= 1 && C >= 1 && n_parts >= 1 && K >= 1 && M % K == 0, PAPC_E_INVALID, "papc_bn_bwd_reduce_max_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_REDUCE, st);
+    const bool v4 = (C % 4 == 0) && aligned16(gout) && aligned16(ysel) && (!psel || aligned16(psel)) && aligned16(mean) && aligned16(invstd) && aligned16(scale) && aligned16(shift);
+    if (v4) hipLaunchKernelGGL((bn_bwd_reduce_kernel<4, true>), dim3(n_parts), dim3(256), 0, st, ysel, gout, (const int32_t *)nullptr, K, (const float *)nullptr, mean, invstd, scale, shift, M, C, red_partial, psel);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<1, true>), dim3(n_parts), dim3(256), 0, st, ysel, gout, (const int32_t *)nullptr, K, (const float *)nullptr, mean, invstd, scale, shift, M, C, red_partial, psel);
+    return check_launch("papc_bn_bwd_reduce_max_f32");
 }
 
 int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, int C, float *dgamma,
@@ -821,12 +837,12 @@ int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scal
                          const float *invstd, const float *c1, const float *c2, const float *w, const float *bias, int64_t G, int Co,
                          int Ci, float *psel, float *wcat, float *hbias, float *e_out, float *q_out, papc_stream_t stream)
 {
-    PAPC_REQUIRE(gout && ysel && scale && shift && mean && invstd && c1 && c2 && w && psel && wcat && hbias && e_out && q_out, PAPC_E_INVALID,
+    PAPC_REQUIRE(scale && shift && mean && invstd && c1 && c2 && w && wcat && hbias && e_out && q_out && (!psel || (gout && ysel)), PAPC_E_INVALID,
                  "papc_bn_max_prep_f32: null pointer");
     PAPC_REQUIRE(G >= 1 && Co >= 1 && Ci >= 1 && Co <= 8192, PAPC_E_INVALID, "papc_bn_max_prep_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_REDUCE, st);
-    hipLaunchKernelGGL(bn_max_psel_kernel, dim3(ew_grid(G * Co)), dim3(256), 0, st, gout, ysel, scale, shift, G * Co, Co, psel);
+    if (psel) hipLaunchKernelGGL(bn_max_psel_kernel, dim3(ew_grid(G * Co)), dim3(256), 0, st, gout, ysel, scale, shift, G * Co, Co, psel);   // (NULL: papc_bn_bwd_reduce_max_f32 wrote it)
     const size_t lds = (size_t)((Co + 1) & ~1) * sizeof(float) + 256 * sizeof(double);
     hipLaunchKernelGGL(bn_max_wcat_kernel, dim3((unsigned)Ci), dim3(256), lds, st, w, bias, scale, mean, invstd, c1, c2, Co, Ci, wcat, hbias, e_out, q_out);
     return check_launch("papc_bn_max_prep_f32");

@@ -62,6 +62,8 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_PG_DBG", 0, 0, 15},             // development aid for pg_gemm_kernel (timing only, results are garbage): 1 no MFMAs, 2 no fragment loads, 4 no LDS reads, 8 no epilogue
     {"PAPC_PG_NB", 0, 0, 2},               // pg_gemm_kernel column tile: 1 = 64, 2 = 128 columns (0 = per shape)
     {"PAPC_PG_NS", 0, 0, 3},               // ... stages of its LDS ring: 2 or 3 (0 = per tile flavour)
+    {"PAPC_STREAM_MAXCAT", 1, 0, 1},       // papc_mlp_bwd_dx_max_f32 on the row-streaming kernel where it has the flavour (0: tiled kernel)
+    {"PAPC_MAX_NOSTORE", 1, 0, 1},         // the max-pooled last layer without its stored output where all three kernels have the flavour (papc_mlp_max_nostore_ok)
 };
 static int g_knobs[KNOB_COUNT];
 static int knob_parse(int id, const char *e)

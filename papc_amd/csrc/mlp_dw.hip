@@ -902,6 +902,216 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
 }
 
 static unsigned long long *g_dw_dbg = nullptr;
+// ---------------------------------------------------------------------------------------------------------------------
+// dW of a max-pooled layer whose [M, Cout] output was never stored (papc_mlp_max_nostore_ok; 64 -> 128 channels).  With a = relu(bn(x))
+// the layer's input rows, P' the max-backward values (sc * gout at the winning row where the pooled output is alive, psel / argmax:
+// [G, Cout]) and z - mean = W (a - abar):
+//     dW = sum_m dz[m]^T a[m] = P'^T A  -  (sc c1) (x) S  -  diag(e) W (A^T A - S S^T / M),      S = sum_m a[m],  e = sc c2 invstd,
+// so one pass over the INPUT rows yields everything: T = P'^T A ([Cout, 64], the one-hot expansion of (psel, argmax) as the MFMA's row
+// operand), the Gram matrix A^T A ([64, 64], the transformed input against itself) and the column sums S.  Same streaming scheme as
+// dw_rows_kernel; a workgroup owns a row chunk, 64 channels of Cout and 32 rows of the Gram matrix (6 accumulator tiles per wave).
+// The pair of workgroups of one chunk is 8 apart in the flat id: same XCD, so the second reader of the rows finds them in its L2.
+struct DwMaxArgs {
+    const float *x, *xsc, *xsh, *psel;
+    const int *argmax;
+    float *partial;      // [chunks][part_ld]: T [Cout, 64] | G [64, 64] | S [64]
+    int64_t M, part_ld;
+    int K, Cout, rows_per_chunk, n_chunks;
+};
+
+__global__ __launch_bounds__(512, 2) void dw_rows_max_kernel(DwMaxArgs p)
+{
+    constexpr int NT = 3, NTI = 2, CI = 64;
+    __shared__ float slab[4][NT * NTI * 16][64];   // 96 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int yb = (blockIdx.x >> 3) & 1, chunk = (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7));
+    const int o0 = 64 * yb, Cout = p.Cout;
+    const int64_t mbeg = (int64_t)chunk * p.rows_per_chunk;
+    const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
+    const int n_kb = mbeg < mend ? (int)((mend - mbeg) >> 4) : 0;       // (M, rows_per_chunk % 16 == 0: whole blocks only)
+
+    float xs[NTI], xh[NTI], xsum[NTI];
+#pragma unroll
+    for (int b = 0; b < NTI; ++b) { xs[b] = p.xsc[32 * b + l31]; xh[b] = p.xsh[32 * b + l31]; xsum[b] = 0.f; }
+    floatx16 acc[NT][NTI];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NTI; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    struct Raw { float x[NTI][8]; float ps[2]; int am[2]; };
+    auto fetch = [&](int kb, Raw &w) {
+        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x[(r0 + j) * CI + 32 * b + l31];
+        const int64_t g = (mbeg + 16 * (int64_t)kb) / p.K;               // K % 16 == 0: the block's 16 rows share one group
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            w.ps[a] = p.psel[g * Cout + o0 + 32 * a + l31];
+            w.am[a] = p.argmax[g * Cout + o0 + 32 * a + l31];
+        }
+    };
+    auto compute = [&](int kb, const Raw &w) {
+        const int kin0 = (int)((mbeg + 16 * (int64_t)kb) % p.K) + 8 * hi;
+        bf16x8 pa[2][3], pb[NTI][3];
+#pragma unroll
+        for (int b = 0; b < NTI; ++b) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = fmaxf(fmaf(xs[b], w.x[b][j], xh[b]), 0.f); xsum[b] += v[j]; }
+            uint2 a0, a1, a2, b0, b1, b2;
+            split3(make_float4(v[0], v[1], v[2], v[3]), a0, a1, a2);
+            split3(make_float4(v[4], v[5], v[6], v[7]), b0, b1, b2);
+            pb[b][0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+            pb[b][1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+            pb[b][2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+        }
+        {   // the one-hot rows: the value's three planes, parked at row (argmax - kin0) of this lane's eight
+            uint2 q0, q1, q2;
+            split3(make_float4(w.ps[0], w.ps[1], 0.f, 0.f), q0, q1, q2);   // .x = (plane of ps[0]) | (plane of ps[1]) << 16
+            const unsigned pl[3] = {q0.x, q1.x, q2.x};
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int idx = w.am[a] - kin0;
+                const int dsel = (idx >= 0 && idx < 8) ? (idx >> 1) : -1;
+                const int sh = (idx & 1) * 16;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const unsigned bits = ((a ? pl[t] >> 16 : pl[t]) & 0xffffu) << sh;
+                    pa[a][t] = __builtin_bit_cast(bf16x8, make_uint4(dsel == 0 ? bits : 0u, dsel == 1 ? bits : 0u, dsel == 2 ? bits : 0u, dsel == 3 ? bits : 0u));
+                }
+            }
+        }
+        bf16x8 pg[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) pg[t] = yb ? pb[1][t] : pb[0][t];
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int b = 0; b < NTI; ++b) {
+                acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0][PA[t]], pb[b][PB[t]], acc[0][b], 0, 0, 0);
+                acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1][PA[t]], pb[b][PB[t]], acc[1][b], 0, 0, 0);
+                acc[2][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pg[PA[t]], pb[b][PB[t]], acc[2][b], 0, 0, 0);
+            }
+    };
+
+    Raw ra, rb;
+    int kb = wave;
+    if (kb < n_kb) fetch(kb, ra);
+    while (kb < n_kb) {
+        if (kb + 8 < n_kb) fetch(kb + 8, rb);
+        compute(kb, ra);
+        kb += 8;
+        if (kb >= n_kb) break;
+        if (kb + 8 < n_kb) fetch(kb + 8, ra);
+        compute(kb, rb);
+        kb += 8;
+    }
+
+    // ---- column sums of the transformed input: (wave, half) partials -> LDS, fixed-order sum (chunk's first workgroup only)
+    float *out = p.partial + (int64_t)chunk * p.part_ld;
+    if (yb == 0) {
+        float *sred = &slab[0][0][0];
+#pragma unroll
+        for (int b = 0; b < NTI; ++b) sred[(wave * 2 + hi) * CI + 32 * b + l31] = xsum[b];
+        __syncthreads();
+        if (tid < CI) {
+            float sacc = 0.f;
+            for (int q = 0; q < 16; ++q) sacc += sred[q * CI + tid];
+            out[(int64_t)(Cout + CI) * CI + tid] = sacc;
+        }
+        __syncthreads();
+    }
+    // ---- fold the 8 waves' tiles (fixed order, as dw_rows_kernel)
+#pragma unroll
+    for (int half = 4; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab[wave - half][(a * NTI + b) * 16 + r][lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (wave < half) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += slab[wave][(a * NTI + b) * 16 + r][lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {   // C/D layout: row = (r & 3) + 8 (r >> 2) + 4 half, col (cin) = lane & 31
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b < NTI; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int row = a < 2 ? o0 + 32 * a + rr : Cout + 32 * yb + rr;
+                    out[(int64_t)row * CI + 32 * b + l31] = acc[a][b][r];
+                }
+    }
+}
+
+// chunk partials -> double sums: 64 elements per workgroup, four quarter-ranges of the chunks in parallel (loads unrolled: a serial chain of
+// 128 L2 round trips otherwise), quarters added in fixed order
+__global__ __launch_bounds__(256) void dw_max_fold_kernel(const float *__restrict__ partial, int n_chunks, int64_t part_ld, int n, double *__restrict__ out)
+{
+    __shared__ double sm[4][64];
+    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + l;
+    const int per = (n_chunks + 3) / 4, c0 = q * per, c1 = min(n_chunks, c0 + per);
+    double s = 0.0;
+    if (e < n) {
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = partial[(int64_t)(c + j) * part_ld + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)v[j];
+        }
+        for (; c < c1; ++c) s += (double)partial[(int64_t)c * part_ld + e];
+    }
+    sm[q][l] = s;
+    __syncthreads();
+    if (q == 0 && e < n) out[e] = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+}
+
+// dW[c, i] = T[c, i] - sc_c c1_c S_i - e_c sum_j W[c, j] (G[j, i] - S_j S_i / M); four rows of dW per workgroup
+__global__ __launch_bounds__(256) void dw_max_finalize_kernel(const double *__restrict__ fold, const float *__restrict__ w, const float *__restrict__ e,
+                                                              const float *__restrict__ scale, const float *__restrict__ c1, double inv_m, int Cout,
+                                                              float *__restrict__ dw, int accumulate)
+{
+    constexpr int CI = 64;
+    __shared__ double gc[CI][CI];
+    const int tid = threadIdx.x;
+    const double *G = fold + (int64_t)Cout * CI, *S = G + CI * CI;
+    for (int q = tid; q < CI * CI; q += 256) {
+        const int j = q >> 6, i = q & 63;
+        gc[j][i] = G[q] - S[j] * S[i] * inv_m;
+    }
+    __syncthreads();
+    const int i = tid & 63, c = 4 * blockIdx.x + (tid >> 6);
+    if (c >= Cout) return;
+    double dot = 0.0;
+    for (int j = 0; j < CI; ++j) dot += (double)w[(int64_t)c * CI + j] * gc[j][i];
+    const double v = fold[(int64_t)c * CI + i] - (double)scale[c] * (double)c1[c] * S[i] - (double)e[c] * dot;
+    float *o = dw + (int64_t)c * CI + i;
+    *o = accumulate ? *o + (float)v : (float)v;
+}
+
 static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 {
     hipDeviceSynchronize();
@@ -1055,4 +1265,47 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     case A_BNRELU: return dense ? launch_dw<A_BNRELU, A_DY_DENSE>(p, vec, st) : launch_dw<A_BNRELU, A_DY_MAX>(p, vec, st);
     default: return dense ? launch_dw<A_GROUP, A_DY_DENSE>(p, vec, st) : launch_dw<A_GROUP, A_DY_MAX>(p, vec, st);
     }
+}
+
+static int dw_max_chunks()
+{
+    static int n = 0;
+    if (!n) {
+        hipDeviceProp_t prop;
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        n = std::max(8, (ncu / 2) & ~7);     // two workgroups per chunk, one residency wave, whole groups of 8
+    }
+    return n;
+}
+
+/* floats of workspace papc_mlp_bwd_dw_max_f32 needs (chunk partials + their double sums) */
+extern "C" int64_t papc_mlp_bwd_dw_max_ws_floats(int64_t M, int Cin, int Cout)
+{
+    (void)M;
+    const int64_t n = (int64_t)(Cout + Cin) * Cin + Cin;
+    return (int64_t)dw_max_chunks() * n + 2 * n + 2;
+}
+
+extern "C" int papc_mlp_bwd_dw_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, const float *bn_scale, const float *bn_shift,
+                                       const float *w, const float *e, const float *scale, const float *c1, int64_t M, int Cin, int Cout,
+                                       float *workspace, float *dw, int accumulate, papc_stream_t stream)
+{
+    PAPC_REQUIRE(psel && argmax && x && bn_scale && bn_shift && w && e && scale && c1 && workspace && dw, PAPC_E_INVALID, "papc_mlp_bwd_dw_max_f32: null pointer");
+    PAPC_REQUIRE(papc_mlp_max_nostore_ok(M, Cin, Cout, K), PAPC_E_UNSUPPORTED,
+                 "papc_mlp_bwd_dw_max_f32: not built for M=%lld Cin=%d Cout=%d K=%d (see papc_mlp_max_nostore_ok)", (long long)M, Cin, Cout, K);
+    PAPC_REQUIRE(aligned16(x) && aligned16(workspace), PAPC_E_INVALID, "papc_mlp_bwd_dw_max_f32: x / workspace must be 16-byte aligned");
+    DwMaxArgs p;
+    memset(&p, 0, sizeof(p));
+    const int n = (Cout + Cin) * Cin + Cin;
+    p.x = x; p.xsc = bn_scale; p.xsh = bn_shift; p.psel = psel; p.argmax = argmax; p.partial = workspace;
+    p.M = M; p.part_ld = n; p.K = K; p.Cout = Cout; p.n_chunks = dw_max_chunks();
+    p.rows_per_chunk = (int)(cdiv(cdiv(M, p.n_chunks), 64) * 64);
+    double *fold = reinterpret_cast<double *>(workspace + (((int64_t)p.n_chunks * n + 1) & ~(int64_t)1));
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_DW, st);
+    hipLaunchKernelGGL(dw_rows_max_kernel, dim3((unsigned)(2 * p.n_chunks)), dim3(512), 0, st, p);
+    hipLaunchKernelGGL(dw_max_fold_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, workspace, p.n_chunks, (int64_t)n, n, fold);
+    hipLaunchKernelGGL(dw_max_finalize_kernel, dim3((unsigned)cdiv(Cout, 4)), dim3(256), 0, st, fold, w, e, scale, c1, 1.0 / (double)M, Cout, dw, accumulate);
+    return check_launch("papc_mlp_bwd_dw_max_f32");
 }

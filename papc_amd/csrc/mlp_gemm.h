@@ -7,7 +7,7 @@ namespace papc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2, EPI_STORE_GMAX = 3 };
+enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2, EPI_STORE_GMAX = 3, EPI_GMAX = 4 };   // (EPI_GMAX: EPI_STORE_GMAX without the output itself; row-streaming kernel only)
 
 // EPI_STORE_RED (dX only): besides storing dz_prev = dX, accumulate the BN-backward reductions of the PREVIOUS layer
 // (p = dz_prev * [scale*y_prev + shift > 0]; sum p and sum p*xhat per channel) into the stats partials, so no separate

@@ -1000,7 +1000,7 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
                       int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
                       papc_stream_t stream)
 {
-    PAPC_REQUIRE(w && y, PAPC_E_INVALID, "papc_mlp_gemm_f32: null w/y");
+    PAPC_REQUIRE(w && (y || gmax), PAPC_E_INVALID, "papc_mlp_gemm_f32: null w/y");
     PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_gemm_f32: M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
     PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_mlp_gemm_f32: M=%lld >= 2^31 rows", (long long)M);
     GemmArgs p;
@@ -1019,6 +1019,13 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
                      "papc_mlp_gemm_f32: fused group max needs K in {32,64,128}, M %% 128 == 0, Cout > 32 (got K=%d M=%lld Cout=%d)",
                      gmax->K, (long long)M, Cout);
         p.gm.gmax = gmax->gmax; p.gm.gmin = gmax->gmin; p.gm.amax = gmax->amax; p.gm.amin = gmax->amin; p.gm.K = gmax->K;
+        if (!y) {   // the output exists only as its per-group extrema (papc_mlp_max_nostore_ok says where): row-streaming kernel or nothing
+            GemmArgs q = p;
+            q.parts = gemm_parts(p.M);
+            const int rc2 = a_mode == A_BNRELU ? stream_gemm_try(q, A_BNRELU, EPI_GMAX, vec, st) : 0;
+            if (rc2 == 0) { set_error("papc_mlp_gemm_f32: y = NULL (no stored output under the max) is not built for a_mode=%d M=%lld Cin=%d Cout=%d K=%d", a_mode, (long long)M, Cin, Cout, gmax->K); return PAPC_E_UNSUPPORTED; }
+            return rc2 < 0 ? rc2 : PAPC_OK;
+        }
         switch (a_mode) {
         case A_PLAIN: return launch_gemm<A_PLAIN, EPI_STORE_GMAX>(p, vec, st);
         case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE_GMAX>(p, vec, st);
@@ -1047,6 +1054,19 @@ int papc_mlp_xyz_ok(int64_t M, int C1, int C2)
     if (M % 64 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES)) return 0;
     if (C1 != 64 || !(C2 == 64 || C2 == 128)) return 0;
     if ((C1 / 64) * (C2 / 64) > knob(KNOB_DW_ROWS_BLOCKS)) return 0;
+    return 1;
+}
+
+/* 1 when the max-pooled last layer of a stack (Cin -> Cout over groups of K rows, BN+ReLU input) can run without ever storing its
+ * [M, Cout] output: forward with y = NULL (extrema only), dX by papc_mlp_bwd_dx_max_f32 and dW by papc_mlp_bwd_dw_max_f32, all three on
+ * their row-streaming flavours. */
+int papc_mlp_max_nostore_ok(int64_t M, int Cin, int Cout, int K)
+{
+    if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !knob(KNOB_STREAM_ASM) || !knob(KNOB_STREAM_MAXCAT) || !knob(KNOB_DW_ROWS) || knob(KNOB_DW_F32)) return 0;
+    if (!knob(KNOB_MAX_NOSTORE)) return 0;
+    if (M % 128 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES) || M >= (1ll << 31)) return 0;
+    if (!(K == 32 || K == 64 || K == 128) || !papc_mlp_gemm_gmax_ok(M, Cout, K)) return 0;
+    if (!(Cin == 64 && Cout == 128)) return 0;
     return 1;
 }
 
@@ -1127,6 +1147,12 @@ int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, con
     }
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DX, st);
+    if (next_red && knob(KNOB_STREAM_MAXCAT)) {      // the row-streaming flavour where it exists (Cout = 2 Cin = 128 / 256, big M)
+        GemmArgs q = p;
+        q.parts = gemm_parts(p.M);
+        const int rc = stream_gemm_try(q, A_MAXCAT, EPI_STORE_RED, true, st);
+        if (rc != 0) return rc < 0 ? rc : PAPC_OK;
+    }
     if (next_red) return launch_gemm_v<A_MAXCAT, EPI_STORE_RED, true, false>(p, st);
     return launch_gemm_v<A_MAXCAT, EPI_STORE, true, false>(p, st);
 }

@@ -72,7 +72,7 @@ struct StreamGeo {
     int kgshift;     // DY_MAX: rows per group = 1 << kgshift (>= 32)
 };
 
-// AMODE: A_PLAIN, A_BNRELU, A_DY_DENSE, A_DY_MAX.  EPI: EPI_STORE, EPI_STORE_GMAX (forward), EPI_STORE_RED (dX).
+// AMODE: A_PLAIN, A_BNRELU, A_DY_DENSE, A_DY_MAX, A_MAXCAT, A_XYZ.  EPI: EPI_STORE, EPI_STORE_GMAX / EPI_GMAX (forward), EPI_STORE_RED (dX).
 // KB16 = K / 16 k blocks, CK blocks per prefetch chunk, WN 32-column tiles per wave (N tile = 32 WN columns per workgroup).
 // ---- packed-f32 flavour of the operand transform + split (PAPC_STREAM_PK, default on).  A lane's 8 k values are 4 register pairs
 // (consecutive k, as the dwordx4 loads deliver them), so v_pk_fma_f32 / v_pk_add_f32 need no moves to form their 64-bit operands:
@@ -101,12 +101,18 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     constexpr int NCH = KB16 / CK;
     static_assert(KB16 % CK == 0 && NCH >= 2 && NCH % 2 == 0, "an even number of chunks per tile");
     constexpr bool DY = (AMODE == A_DY_DENSE || AMODE == A_DY_MAX);
+    constexpr bool GM = (EPI == EPI_STORE_GMAX || EPI == EPI_GMAX);   // per-group max / min of the raw output in the epilogue
     constexpr bool XYZ = (AMODE == A_XYZ);   // operand computed from the row's centred coordinates: no streamed operand, no asm ring
-    constexpr int NLD = (AMODE == A_DY_MAX) ? 6 : (AMODE == A_DY_DENSE ? 4 : 2);   // 16-byte loads per lane and k block
+    // A_MAXCAT (dX of a max-pooled last layer without its output y, papc_mlp_bwd_dx_max_f32): k blocks [0, KS) are the sparse max-backward
+    // operand (psel + argmax of the row's group: 4 loads), blocks [KS, KB16) the layer's BN+ReLU input (2 loads).  Cout = 2 Cin: KS = 2/3 KB16.
+    constexpr bool MC = (AMODE == A_MAXCAT);
+    constexpr int KS = MC ? KB16 * 2 / 3 : 0;
+    static_assert(!MC || (KB16 % 3 == 0 && CK == 1), "MAXCAT: Cout = 2 Cin, one k block per chunk");
+    constexpr int NLD = (AMODE == A_DY_MAX) ? 6 : ((AMODE == A_DY_DENSE || MC) ? 4 : 2);   // 16-byte loads per lane and k block (MAXCAT: at most)
     constexpr int CL = CK * NLD;                                                      // ... per chunk
     static_assert(CL <= 60, "vmcnt is a 6-bit field");
     constexpr int ROWB = 6 * K + 16;          // LDS bytes of one weight row: [plane 0 | plane 1 | plane 2] bf16 + 16 (odd number of 16-B slots)
-    constexpr int NCST = (AMODE == A_BNRELU) ? 2 : (DY ? 5 : (XYZ ? 4 : 0));
+    constexpr int NCST = (AMODE == A_BNRELU || MC) ? 2 : (DY ? 5 : (XYZ ? 4 : 0));
     constexpr int W_BYTES = NT * ROWB;
     constexpr int CST_BYTES = NCST * K * 4;
     constexpr int RED_BYTES = 2 * NW * NT * 4;
@@ -119,6 +125,8 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     const int hi = lane >> 5, l31 = lane & 31;
     const int n0 = blockIdx.y * NT;
     const int ldx = (int)(DY ? p.a.d.C : p.a.ldx);     // row stride (floats) of the streamed operand(s)
+    // loads of chunk ci (compile time): uniform except MAXCAT, whose sparse blocks take 4 and dense blocks 2
+    auto nld_of = [](int ci) constexpr -> int { return MC ? ((ci % NCH) < KS ? 4 : 2) : CL; };
 
     // ---- prologue: weights -> three bf16 planes in LDS (once per workgroup); folded per-channel constants
     {
@@ -148,6 +156,9 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         for (int k = tid; k < K; k += NW * 64) {
             if (AMODE == A_BNRELU) {
                 cf[k] = p.a.sc[k]; cf[K + k] = p.a.sh[k];
+            } else if (MC) {         // BN+ReLU constants of the dense region, stored at the concatenated k
+                const bool dn = k >= KS * 16;
+                cf[k] = dn ? p.a.sc[k - KS * 16] : 0.f; cf[K + k] = dn ? p.a.sh[k - KS * 16] : 0.f;
             } else if (XYZ) {        // folded first layer wf [K][4] -> four per-channel arrays
                 const float4 q = ld4(p.a.sc + 4 * k);
                 cf[k] = q.x; cf[K + k] = q.y; cf[2 * K + k] = q.z; cf[3 * K + k] = q.w;
@@ -187,6 +198,11 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             }
         } else {
             s.p0 = reinterpret_cast<const char *>(p.a.x + (int64_t)row0 * ldx);
+            if (MC) {
+                const int64_t g = row0 >> geo.kgshift;
+                s.p1 = reinterpret_cast<const char *>(p.a.d.gout + g * p.a.d.C);
+                s.p2 = reinterpret_cast<const char *>(p.a.d.argmax + g * p.a.d.C);
+            }
         }
         return s;
     };
@@ -205,6 +221,18 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         sfor<0, CK>([&](auto blk_) {
             constexpr int blk = decltype(blk_)::value;
             constexpr int off = (ci * CK + blk) * 64;
+            if constexpr (MC) {
+                if constexpr (ci < KS) {       // sparse block: 8 psel values and their argmax offsets of this row's group
+                    gload4<ASM, off, true>(buf[bi][0], voff_grp, s.p1);
+                    gload4<ASM, off + 16, false>(buf[bi][1], voff_grp, s.p1);
+                    gload4<ASM, off, true>(buf[bi][2], voff_grp, s.p2);
+                    gload4<ASM, off + 16, false>(buf[bi][3], voff_grp, s.p2);
+                } else {                       // dense block: the layer's input row
+                    gload4<ASM, (ci - KS) * 64, true>(buf[bi][0], voff_row, s.p0);
+                    gload4<ASM, (ci - KS) * 64 + 16, false>(buf[bi][1], voff_row, s.p0);
+                }
+                return;
+            }
             gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 0], voff_row, s.p0);
             gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 1], voff_row, s.p0);
             if constexpr (AMODE == A_DY_DENSE) {
@@ -287,7 +315,13 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 if constexpr (AMODE == A_PLAIN) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v2[j] = f32x2{r[j >> 1][2 * (j & 1)], r[j >> 1][2 * (j & 1) + 1]};
-                } else if constexpr (AMODE == A_BNRELU) {
+                } else if constexpr (MC && kb < KS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int h = j >> 1, i = 2 * (j & 1);
+                        v2[j] = f32x2{(__float_as_int(r[2 + h][i]) == kin) ? r[h][i] : 0.f, (__float_as_int(r[2 + h][i + 1]) == kin) ? r[h][i + 1] : 0.f};
+                    }
+                } else if constexpr (AMODE == A_BNRELU || MC) {
                     const f32x4 s0 = *reinterpret_cast<const f32x4 *>(cl + kb * 64), s1 = *reinterpret_cast<const f32x4 *>(cl + kb * 64 + 16);
                     const f32x4 h0 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64), h1 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64 + 16);
 #pragma unroll
@@ -422,10 +456,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 for (int r = 0; r < 16; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2);
                     const float v = acc[wn][r] + biasv[wn];
-                    yp[(int64_t)ro * ldy] = v;
+                    if (EPI != EPI_GMAX) yp[(int64_t)ro * ldy] = v;   // (EPI_GMAX: under the max the output itself stays unwritten)
                     s1[wn] += v;
                     s2[wn] = fmaf(v, v, s2[wn]);
-                    if (EPI == EPI_STORE_GMAX) {
+                    if (GM) {
                         const int off = sub * 32 + ro + 4 * hi;
                         if (v > gmx[wn]) { gmx[wn] = v; gix[wn] = off; }
                         if (v < gmn[wn]) { gmn[wn] = v; gin[wn] = off; }
@@ -434,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[wn][r] = 0.f;
-            if (EPI == EPI_STORE_GMAX && sub == U - 1) {
+            if (GM && sub == U - 1) {
                 // close the group: merge the two half-waves (first offset wins ties), lanes 0-31 write
                 float vmx = gmx[wn], vmn = gmn[wn];
                 int imx = gix[wn], imn = gin[wn];
@@ -476,12 +510,12 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         SB sa = bases(row0);
         issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sa);
         issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sa);
-        wait_vm<ASM, CL>();
+        wait_vm<ASM, nld_of(1)>();
         touch_buf(std::integral_constant<int, 0>{});
         for (int j = 0; j < my_tiles; ++j) {
             const int row0n = tile_row0(j + 1);
             const SB sn = bases(row0n);
-            if (AMODE == A_DY_MAX) kin = (row0 & ((1 << geo.kgshift) - 1)) + l31;
+            if (AMODE == A_DY_MAX || MC) kin = (row0 & ((1 << geo.kgshift) - 1)) + l31;
             // LATE1: the epilogue of the dX kernels issues compiler-visible loads (the layer below's y).  hipcc's own counted waits for
             // them proved unsound on hardware while asm loads it cannot see are in flight (late data landed in registers it had
             // already reused: wrong rows, timing dependent), so for that epilogue nothing hidden is outstanding: chunk 1 of the next
@@ -495,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 constexpr int c = decltype(c_)::value;
                 constexpr int bi = c & 1;
                 if constexpr (c > 0) {   // (chunk 0 was waited for before the previous tile's stores went out)
-                    wait_vm<ASM, CL>();   // (LATE1: chunk 1 was issued behind the epilogue's stores; chunk 2's loads are still the only younger ones)
+                    wait_vm<ASM, nld_of(c + 1)>();   // (LATE1: chunk 1 was issued behind the epilogue's stores; chunk c + 1's loads are still the only younger ones)
                     touch_buf(std::integral_constant<int, bi>{});
                 }
                 compute(std::integral_constant<int, bi>{}, c_);
@@ -504,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             });
             // chunk 0 of the next tile: in flight since chunk NCH - 2 was consumed; only chunk 1's loads are younger.  Waiting
             // here, BEFORE the stores, keeps fresh stores out of every counted wait (vmcnt counts them too).
-            wait_vm<ASM, LATE1 ? 0 : CL>();
+            wait_vm<ASM, LATE1 ? 0 : nld_of(1)>();
             touch_buf(std::integral_constant<int, 0>{});
             epilogue(row0, j & (U - 1));
             if constexpr (LATE1) issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sn);
@@ -559,7 +593,7 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
     constexpr int CK2 = (KB16 == 6) ? 1 : 2;   // (six k blocks: an even chunk count needs 1 or 3 per chunk, and 3 spills the asm-loaded ring)
-    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || (AMODE == A_DY_DENSE && WN == 4) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : CK2;
+    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || AMODE == A_MAXCAT || (AMODE == A_DY_DENSE && WN == 4) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : CK2;
     const int ncb = p.Nout / (32 * WN);
     // one workgroup per CU in total (weights + 8 waves of up to 256 registers fill it); column blocks of the same rows are
     // gridDim.x apart in the flat id, i.e. on the same XCD when gridDim.x % 8 == 0: the second reader of a row finds it in L2
@@ -569,6 +603,7 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     dim3 grid((unsigned)gx, (unsigned)ncb);
     if constexpr (AMODE == A_XYZ) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);   // (no streamed operand: no asm ring)
     else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true>), grid, dim3(512), 0, st, p, geo);
+    else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX) return 0;   // (the compiler-scheduled ring of these flavours spills: the caller falls back)
     else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);
     const int rc = check_launch("mlp stream gemm");
     return rc ? rc : 1;
@@ -586,7 +621,11 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
         else return 0;
     }
 #define STREAM_CASE(KB, WNN) if (kb == KB && wn == WNN) return stream_go<AMODE, EPI, KB, WNN>(p, geo, st)
-    if constexpr (AMODE == A_XYZ) {
+    if constexpr (EPI == EPI_GMAX) {
+        STREAM_CASE(4, 4); STREAM_CASE(8, 4);            // 64 -> 128 and 128 -> 256 under the max
+    } else if constexpr (AMODE == A_MAXCAT) {
+        STREAM_CASE(12, 2); STREAM_CASE(24, 2);          // [P (2 C) | relu(bn(x)) (C)] with C = 64 / 128
+    } else if constexpr (AMODE == A_XYZ) {
         // the layer above a coordinates-only first layer (xyz1.hip, papc_mlp_xyz_ok): 64 channels below, 64 or 128 above
         STREAM_CASE(4, 2); STREAM_CASE(4, 4);
     } else if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE) {
@@ -614,28 +653,31 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
 {
     if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !vec) return 0;
     if (p.M % 32 != 0 || p.M / 32 < knob(KNOB_STREAM_MINTILES)) return 0;
-    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > 256 || p.Nout % 32 != 0 || p.Nout < 64) return 0;
+    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > (amode == A_MAXCAT ? 384 : 256) || p.Nout % 32 != 0 || p.Nout < 64) return 0;
+    if (amode == A_MAXCAT && (p.a.d.C != 2 * p.Nout || p.Kin != 3 * p.Nout || p.a.ldx != p.Nout)) return 0;   // Cout = 2 Cin, dense input rows
     if (p.wmap || p.nmap || p.ldy != p.Nout) return 0;
     if (!(p.stats || epi == EPI_STORE)) return 0;
     StreamGeo geo;
     geo.ushift = 0; geo.kgshift = 5;
-    if (epi == EPI_STORE_GMAX) {
+    if (epi == EPI_STORE_GMAX || epi == EPI_GMAX) {
         const int s = ilog2_exact(p.gm.K);
         if (s < 5 || p.M % p.gm.K != 0) return 0;
         geo.ushift = s - 5;
     }
-    if (amode == A_DY_MAX) {
+    if (amode == A_DY_MAX || amode == A_MAXCAT) {
         const int s = ilog2_exact(p.a.d.K);
         if (s < 5) return 0;
         geo.kgshift = s;
     }
     geo.n_units = (int)((p.M / 32) >> geo.ushift);
     if (amode == A_BNRELU && epi == EPI_STORE) return stream_pick<A_BNRELU, EPI_STORE>(p, geo, st);
+    if (amode == A_BNRELU && epi == EPI_GMAX) return knob(KNOB_STREAM_ASM) ? stream_pick<A_BNRELU, EPI_GMAX>(p, geo, st) : 0;
     if (amode == A_BNRELU && epi == EPI_STORE_GMAX) return stream_pick<A_BNRELU, EPI_STORE_GMAX>(p, geo, st);
     if (amode == A_PLAIN && epi == EPI_STORE) return stream_pick<A_PLAIN, EPI_STORE>(p, geo, st);
     if (amode == A_DY_DENSE && epi == EPI_STORE_RED) return stream_pick<A_DY_DENSE, EPI_STORE_RED>(p, geo, st);
     if (amode == A_DY_DENSE && epi == EPI_STORE) return stream_pick<A_DY_DENSE, EPI_STORE>(p, geo, st);   // (layer above a Gram-path first layer: no BN-backward sums)
     if (amode == A_XYZ && epi == EPI_STORE) return stream_pick<A_XYZ, EPI_STORE>(p, geo, st);
+    if (amode == A_MAXCAT && epi == EPI_STORE_RED) return stream_pick<A_MAXCAT, EPI_STORE_RED>(p, geo, st);
     if (amode == A_DY_MAX && epi == EPI_STORE_RED) return stream_pick<A_DY_MAX, EPI_STORE_RED>(p, geo, st);
     return 0;
 }

@@ -62,6 +62,7 @@ _FUSE_RED = os.environ.get("PAPC_NO_RED") != "1"            # A/B switch for the
 _FUSE_GMAX = os.environ.get("PAPC_NO_GMAX") != "1"          # A/B switch for the fused neighbourhood-max epilogue
 _RESIDENT_WGS = int(os.environ.get("PAPC_PARTS", "512"))   # persistent-grid size (tuning knob shared with the C side)
 _LIN_GATHER = os.environ.get("PAPC_LIN_GATHER", "1") == "1"    # first grouped layer: linear map per source point, then gather-add (lingather.hip)
+_NOSTORE = os.environ.get("PAPC_NOSTORE", "1") == "1"   # the max-pooled last layer without its [M, C] output where the library has all three flavours (papc_mlp_max_nostore_ok)
 _SPARSE_MAX = os.environ.get("PAPC_SPARSE_MAX", "0") == "1"   # dX of the max-pooled last layer without reading its output y (papc_mlp_bwd_dx_max_f32)
 _DW_WGS = int(os.environ.get("PAPC_DW_WGS", "512"))         # workgroups of one dW launch (row chunks x output tiles)
 _XYZ1 = os.environ.get("PAPC_XYZ1", "1") == "1"             # coordinates-only first layer through its input moments, never materialised (xyz1.hip)
@@ -174,7 +175,6 @@ class SharedMLPMax(torch.autograd.Function):
             cout = w.shape[0]
             w2 = w.reshape(cout, cin)
             assert w2.is_contiguous()
-            y = torch.empty(M, cout, device=dev, dtype=torch.float32)
             stats = None if ev else torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
             parts_l = parts
             gm_ref = None
@@ -188,6 +188,11 @@ class SharedMLPMax(torch.autograd.Function):
                 gm.amax, gm.amin = gbuf_i[0].data_ptr(), gbuf_i[1].data_ptr()
                 gm.K = spec.K
                 gm_ref = ctypes.byref(gm)
+            if (gm_ref is not None and _NOSTORE and L >= 2 and l == L - 1 and prev_y is not None and not (l == 1 and xyz1)
+                    and lib.papc_mlp_max_nostore_ok(M, cin, cout, spec.K)):
+                y = None                           # the pooled layer's own output is never stored: extrema + statistics forward, input sums backward
+            else:
+                y = None if (l == 0 and xyz1) else torch.empty(M, cout, device=dev, dtype=torch.float32)
             if l == 0 and xyz1:
                 y = stats = None
                 nparts = 1                         # (the moments arrive folded: xyz_pregroup)
@@ -271,6 +276,7 @@ class SharedMLPMax(torch.autograd.Function):
         ctx.cin0 = cin0
         ctx.lin0 = lin0
         ctx.xyz1 = xyz1
+        ctx.nostore = spec.pool and L >= 1 and ys[L - 1] is None and not (xyz1 and L == 1)
         ysel = gbuf_f[0] if (spec.pool and gm_ref is not None) else None   # raw y at the argmax (left in gmax by select_max)
         if xyz1:
             ys[0] = xc                 # (slot of the first layer's output, which does not exist: the grouped coordinates instead)
@@ -309,8 +315,9 @@ class SharedMLPMax(torch.autograd.Function):
         need_wt = [l for l in range(L) if l > 0 or (plain and ctx.x_needs_grad) or ((not plain) and ctx.feats_needs_grad)]
         # last layer under the max: its dX can be formed from the [G, C] max-backward arrays and the layer's INPUT, without its output
         cL, cLi = params[4 * (L - 1)].shape[0], (params[4 * (L - 2)].shape[0] if L > 1 else 0)
-        sparse_max = (_SPARSE_MAX and spec.pool and L > 1 and ysel is not None and M >= 32768 and cL % 16 == 0 and cLi % 4 == 0
-                      and cL + cLi <= 512)
+        sparse_max = ctx.nostore or (_SPARSE_MAX and spec.pool and L > 1 and ysel is not None and M >= 32768 and cL % 16 == 0 and cLi % 4 == 0
+                                     and cL + cLi <= 512)
+        max_prep = None     # (psel, wcat, hbias, e) of the sparse-max backward, shared by its dW and dX
         if sparse_max:
             need_wt.remove(L - 1)
         if ctx.lin0 and 0 in need_wt:
@@ -382,14 +389,19 @@ class SharedMLPMax(torch.autograd.Function):
                 if gb_fresh:
                     grads[2], grads[3] = dgb[0], dgb[1]
                 break
-            dy.y = ys[l].data_ptr()
+            dy.y = ptr(ys[l])
             dy.mean, dy.invstd, dy.scale, dy.shift = (cst[i].data_ptr() for i in range(4))
             dy.c1, dy.c2 = c12[0].data_ptr(), c12[1].data_ptr()
             if fused_red is None:   # (sum p, sum p*xhat): separate pass, unless the dX kernel of layer l+1 already produced it
                 red, red_parts = torch.empty(n_parts, 2, cout, device=dev, dtype=torch.float32), n_parts
                 red_dz = ptr(ysel) if dy.dz_mode == DZ_MAX else dy.dz
-                check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, red_dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
-                                                 dy.shift, M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
+                if sparse_max and l == L - 1:     # the same pass also writes the sparse operand of this layer's dX / dW
+                    psel = torch.empty(M // spec.K, cout, device=dev, dtype=torch.float32)
+                    check(lib.papc_bn_bwd_reduce_max_f32(ptr(ysel), dy.gout, dy.K, dy.mean, dy.invstd, dy.scale, dy.shift, M, cout, n_parts,
+                                                         ptr(red), ptr(psel), st), "papc_bn_bwd_reduce_max_f32")
+                else:
+                    check(lib.papc_bn_bwd_reduce_f32(dy.dz_mode, red_dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
+                                                     dy.shift, M, cout, n_parts, ptr(red), st), "papc_bn_bwd_reduce_f32")
             else:
                 red, red_parts = fused_red, gemm_parts
             check(lib.papc_bn_bwd_finalize_f32(ptr(red), red_parts, M, cout, dgamma_p, dbeta_p,
@@ -446,47 +458,75 @@ class SharedMLPMax(torch.autograd.Function):
                     check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(Gs), cout, None, None, None, ptr(wft), None, BN_, cout, spec.D, ptr(grad_feats),
                                                 None, None, st), "papc_mlp_gemm_f32")
                 break
+            if sparse_max and l == L - 1:
+                G = M // spec.K
+                wcat = torch.empty(cin, cout + cin, device=dev, dtype=torch.float32)
+                hb = torch.empty(cin, device=dev, dtype=torch.float32)
+                eq = torch.empty(2, cout, device=dev, dtype=torch.float32)
+                check(lib.papc_bn_max_prep_f32(None, None, cst[2].data_ptr(), cst[3].data_ptr(), cst[0].data_ptr(),
+                                               cst[1].data_ptr(), c12[0].data_ptr(), c12[1].data_ptr(), ptr(w), ptr(params[4 * l + 1]),
+                                               G, cout, cin, None, ptr(wcat), ptr(hb), eq[0].data_ptr(), eq[1].data_ptr(), st),
+                      "papc_bn_max_prep_f32")      # (psel: written by the reduction above)
+                max_prep = (psel, wcat, hb, eq)
             # ---- dW, db
-            rpc = 0
-            x1 = xyz1 and l == 1             # the input of this layer is the recomputed activation of the coordinates-only first layer
-            if l > 0:                        # (the kernel's own preference where it has one: papc_mlp_bwd_dw_chunk_hint)
-                rpc = lib.papc_mlp_bwd_dw_chunk_hint(M, cin, cout, A_XYZ if x1 else A_BNRELU, dy.dz_mode, spec.K if dy.dz_mode == DZ_MAX else 0)
-            if rpc <= 0:
-                rpc = _dw_rows_per_chunk(M, cout, cin)
-            n_chunks = (M + rpc - 1) // rpc
-            pld = cout * cin + cout          # one partial buffer: chunk rows are [dW (cout*cin) | db (cout)]
-            part = torch.empty(n_chunks, pld, device=dev, dtype=torch.float32)
-            dwp_p, dbp_p = part.data_ptr(), part.data_ptr() + 4 * cout * cin
-            if l == 0 and plain:
-                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_PLAIN, ptr(x_rows), cin, None, None, None, M, cin, cout, rpc,
-                                              dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
-            elif l == 0:
-                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_GROUP, None, 0, ctypes.byref(grp), None, None, M, cin, cout, rpc,
-                                              dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
-            elif x1:
-                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_XYZ, ptr(xc), 4, None, ptr(wf), None, M, cin, cout, rpc, dwp_p, dbp_p, pld, st),
-                      "papc_mlp_bwd_dw_f32")
-            else:
+            if ctx.nostore and l == L - 1:
+                # no stored output: T = P'^T A, the Gram matrix of the input rows and their column sums in one pass, closed form for dW
                 pc = consts[l - 1]
-                check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_BNRELU, ys[l - 1].data_ptr(), cin, None, pc[2].data_ptr(),
-                                              pc[3].data_ptr(), M, cin, cout, rpc, dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
-            # the partials of all layers are folded in ONE launch once the stack's last dW kernel is enqueued (papc_reduce_partials_batch_f32)
-            if inplace:
-                reduce_jobs.append((part, n_chunks, pld, cout * cin, tgt[0].data_ptr(), cout, tgt[1].data_ptr(), 1))
-            else:
-                dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
-                db = torch.empty(cout, device=dev, dtype=torch.float32)
-                if spec.eval_bn:      # no batch-mean term removes the bias direction: db = sum_m dy = scale * sum_m p (tiny [C] op)
-                    check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, ptr(dw), cout, ptr(db), 0, st),
-                          "papc_reduce_partials2_f32")
-                    db = cst[2] * dgb[1]
+                ws = torch.empty(lib.papc_mlp_bwd_dw_max_ws_floats(M, cin, cout), device=dev, dtype=torch.float32)
+                if inplace:
+                    dw, acc = tgt[0].view(cout, cin), 1
                 else:
-                    reduce_jobs.append((part, n_chunks, pld, cout * cin, dw.data_ptr(), cout, db.data_ptr(), 0))
-                grads[4 * l + 0] = dw.reshape(w.shape)
-                grads[4 * l + 1] = None if (tgt is not None and tgt[1] is not None and not spec.eval_bn) else db
-                if not gb_inplace:
-                    grads[4 * l + 2] = dgb[0]
-                    grads[4 * l + 3] = dgb[1]
+                    dw, acc = torch.empty(cout, cin, device=dev, dtype=torch.float32), 0
+                check(lib.papc_mlp_bwd_dw_max_f32(ptr(max_prep[0]), ptr(argmax), spec.K, ys[l - 1].data_ptr(), pc[2].data_ptr(), pc[3].data_ptr(),
+                                                  ptr(w), max_prep[3][0].data_ptr(), cst[2].data_ptr(), c12[0].data_ptr(), M, cin, cout,
+                                                  ptr(ws), ptr(dw), acc, st), "papc_mlp_bwd_dw_max_f32")
+                if not inplace:
+                    grads[4 * l + 0] = dw.reshape(w.shape)
+                    grads[4 * l + 1] = None if (tgt is not None and tgt[1] is not None) else _lib.zeros((cout,), dev)   # (exact 0 under a train-mode BN)
+                    if not gb_inplace:
+                        grads[4 * l + 2] = dgb[0]
+                        grads[4 * l + 3] = dgb[1]
+            x1 = xyz1 and l == 1             # the input of this layer is the recomputed activation of the coordinates-only first layer
+            if not (ctx.nostore and l == L - 1):
+                rpc = 0
+                if l > 0:                        # (the kernel's own preference where it has one: papc_mlp_bwd_dw_chunk_hint)
+                    rpc = lib.papc_mlp_bwd_dw_chunk_hint(M, cin, cout, A_XYZ if x1 else A_BNRELU, dy.dz_mode, spec.K if dy.dz_mode == DZ_MAX else 0)
+                if rpc <= 0:
+                    rpc = _dw_rows_per_chunk(M, cout, cin)
+                n_chunks = (M + rpc - 1) // rpc
+                pld = cout * cin + cout          # one partial buffer: chunk rows are [dW (cout*cin) | db (cout)]
+                part = torch.empty(n_chunks, pld, device=dev, dtype=torch.float32)
+                dwp_p, dbp_p = part.data_ptr(), part.data_ptr() + 4 * cout * cin
+                if l == 0 and plain:
+                    check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_PLAIN, ptr(x_rows), cin, None, None, None, M, cin, cout, rpc,
+                                                  dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
+                elif l == 0:
+                    check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_GROUP, None, 0, ctypes.byref(grp), None, None, M, cin, cout, rpc,
+                                                  dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
+                elif x1:
+                    check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_XYZ, ptr(xc), 4, None, ptr(wf), None, M, cin, cout, rpc, dwp_p, dbp_p, pld, st),
+                          "papc_mlp_bwd_dw_f32")
+                else:
+                    pc = consts[l - 1]
+                    check(lib.papc_mlp_bwd_dw_f32(ctypes.byref(dy), A_BNRELU, ys[l - 1].data_ptr(), cin, None, pc[2].data_ptr(),
+                                                  pc[3].data_ptr(), M, cin, cout, rpc, dwp_p, dbp_p, pld, st), "papc_mlp_bwd_dw_f32")
+                # the partials of all layers are folded in ONE launch once the stack's last dW kernel is enqueued (papc_reduce_partials_batch_f32)
+                if inplace:
+                    reduce_jobs.append((part, n_chunks, pld, cout * cin, tgt[0].data_ptr(), cout, tgt[1].data_ptr(), 1))
+                else:
+                    dw = torch.empty(cout, cin, device=dev, dtype=torch.float32)
+                    db = torch.empty(cout, device=dev, dtype=torch.float32)
+                    if spec.eval_bn:      # no batch-mean term removes the bias direction: db = sum_m dy = scale * sum_m p (tiny [C] op)
+                        check(lib.papc_reduce_partials2_f32(ptr(part), n_chunks, pld, cout * cin, ptr(dw), cout, ptr(db), 0, st),
+                              "papc_reduce_partials2_f32")
+                        db = cst[2] * dgb[1]
+                    else:
+                        reduce_jobs.append((part, n_chunks, pld, cout * cin, dw.data_ptr(), cout, db.data_ptr(), 0))
+                    grads[4 * l + 0] = dw.reshape(w.shape)
+                    grads[4 * l + 1] = None if (tgt is not None and tgt[1] is not None and not spec.eval_bn) else db
+                    if not gb_inplace:
+                        grads[4 * l + 2] = dgb[0]
+                        grads[4 * l + 3] = dgb[1]
             # ---- dX
             fused_red = None
             if l > 0:
@@ -503,15 +543,7 @@ class SharedMLPMax(torch.autograd.Function):
                     nr.red_partial = fused_red.data_ptr()
                     nr_ref = ctypes.byref(nr)
                 if sparse_max and l == L - 1:
-                    G = M // spec.K
-                    psel = torch.empty(G, cout, device=dev, dtype=torch.float32)
-                    wcat = torch.empty(cin, cout + cin, device=dev, dtype=torch.float32)
-                    hb = torch.empty(cin, device=dev, dtype=torch.float32)
-                    eq = torch.empty(2, cout, device=dev, dtype=torch.float32)
-                    check(lib.papc_bn_max_prep_f32(ptr(gout), ptr(ysel), cst[2].data_ptr(), cst[3].data_ptr(), cst[0].data_ptr(),
-                                                   cst[1].data_ptr(), c12[0].data_ptr(), c12[1].data_ptr(), ptr(w), ptr(params[4 * l + 1]),
-                                                   G, cout, cin, ptr(psel), ptr(wcat), ptr(hb), eq[0].data_ptr(), eq[1].data_ptr(), st),
-                          "papc_bn_max_prep_f32")
+                    psel, wcat, hb, _ = max_prep
                     pc = consts[l - 1]
                     check(lib.papc_mlp_bwd_dx_max_f32(ptr(psel), ptr(argmax), spec.K, ys[l - 1].data_ptr(), cin, pc[2].data_ptr(),
                                                       pc[3].data_ptr(), ptr(wcat), ptr(hb), M, cin, cout, ptr(dz_prev), nr_ref, st),

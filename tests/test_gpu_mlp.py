@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import reference_np as R
+from papc_amd import _lib
 from papc_amd import functional as F
 from papc_amd.layers import PointNetSetAbstraction, PointNetSetAbstractionMsg
 from papc_amd.mlp import StackSpec, shared_mlp_max
@@ -144,6 +145,76 @@ def test_stack_backward_vs_torch(dev, B, N, S, K, D, mlp, xyz_first, use_idx):
             assert_close(got.cpu().numpy(), want.cpu().numpy(), gtol, "d%s layer %d" % (names[j], l))
     if feats is not None:
         assert_close(feats.grad.cpu().numpy(), f64.grad.cpu().numpy(), 2e-4, "dfeats")
+
+
+@pytest.mark.parametrize("D,K", [(0, 32), (16, 64)])
+def test_max_layer_without_stored_output_vs_stored_and_f64(dev, D, K):
+    """The max-pooled last layer (64 -> 128) whose [M, 128] output is never written (papc_mlp_max_nostore_ok: forward keeps the per-group
+    extrema only, dX = [P | A] wcat^T, dW from T = P'^T A, the input rows' Gram matrix and their column sums): the pooled output is
+    bit-identical to the stored-output path (same kernel minus the store), every gradient within 2e-4 of float64 torch and of the
+    stored-output path, with and without in-place gradient targets."""
+    from papc_amd import mlp as M_
+    B, N, S, mlp = 8, 1024, 8192 // K, [64, 64, 128]
+    x = make_clouds(B, N, 77)
+    xyz = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 1)).to(dev)
+    rng = np.random.default_rng(9)
+    feats0 = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev) if D else None
+    _, new_xyz = F._fps_raw(xyz, S, st)
+    idx = F._ball_query_raw([0.3], [K], xyz, new_xyz)[0]
+    ws = seeded_weights([D + 3] + mlp, 41)
+    assert _lib.load().papc_mlp_max_nostore_ok(B * S * K, 64, 128, K) == 1
+
+    def run(nostore, targets):
+        params = []
+        for (w, b, g, bt) in ws:
+            params += [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b, g, bt)]
+        feats = feats0.clone().requires_grad_(True) if D else None
+        spec = StackSpec(B, N, S, K, D, True)
+        tg = None
+        if targets:
+            tg = [torch.ones_like(p) for p in params]
+            spec.grad_targets = tg
+        old = M_._NOSTORE
+        M_._NOSTORE = nostore
+        try:
+            if targets:     # (shared_mlp_max derives the targets from the parameters' own flags: set them on the spec, call the Function)
+                out = M_.SharedMLPMax.apply(spec, None, xyz, new_xyz, feats, idx, None, *params)
+            else:
+                out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+        finally:
+            M_._NOSTORE = old
+        assert bool(out.grad_fn.nostore) == nostore
+        gout = torch.from_numpy(np.random.default_rng(10).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        if targets:
+            grads = [None if j % 4 == 1 else (t - 1.0) for j, t in enumerate(tg)]
+            assert all(params[j].grad is None for j in range(len(params)) if j % 4 != 1)
+        else:
+            grads = [p.grad for p in params]
+        return out.detach(), grads, (feats.grad if D else None), params, gout
+
+    out_n, g_n, gf_n, params, gout = run(True, False)
+    out_s, g_s, gf_s, _, _ = run(False, False)
+    _, g_t, _, _, _ = run(True, True)
+    assert torch.equal(out_n, out_s)
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    f64 = feats0.double().requires_grad_(True) if D else None
+    rows = torch_ref.group(xyz.double(), new_xyz.double(), f64, idx, True).reshape(B * S * K, D + 3)
+    ref = torch_ref.stack_max(rows, [tuple(p64[4 * l:4 * l + 4]) for l in range(3)], K, 1e-5)
+    assert_close(out_n.cpu().numpy(), ref.detach().cpu().numpy(), REL, "forward")
+    ref.backward(gout.double())
+    names = ["w", "b", "gamma", "beta"]
+    for l in range(3):
+        for j in (0, 2, 3):
+            want = p64[4 * l + j].grad.cpu().numpy()
+            assert_close(g_n[4 * l + j].cpu().numpy(), want, 2e-4, "no-store d%s layer %d vs f64" % (names[j], l))
+            assert_close(g_n[4 * l + j].cpu().numpy(), g_s[4 * l + j].cpu().numpy(), 2e-4, "no-store vs stored d%s layer %d" % (names[j], l))
+            assert_close(g_t[4 * l + j].reshape(want.shape).cpu().numpy(), want, 2e-4, "no-store in-place d%s layer %d" % (names[j], l))
+        assert g_n[4 * l + 1] is None or float(g_n[4 * l + 1].abs().max()) == 0.0 or l < 2
+    if D:
+        assert_close(gf_n.cpu().numpy(), f64.grad.cpu().numpy(), 2e-4, "dfeats")
+        assert_close(gf_n.cpu().numpy(), gf_s.cpu().numpy(), 2e-4, "dfeats vs stored")
 
 
 def test_full_size_sa1_properties(dev):
