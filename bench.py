@@ -490,6 +490,9 @@ def main():
                 with open(fams[-1]) as fh:
                     rec = json.load(fh).get(K_NAMES[dominant])
                 if rec:
+                    lps = max(1, dom_n // n_roof)
+                    if "traffic_MB_per_step" in rec:     # per step over THIS run's launches per step (an entry point may launch several kernels)
+                        rec = dict(rec, traffic_MB_per_launch=rec["traffic_MB_per_step"] / lps)
                     roof["traffic"] = round(rec["traffic_MB_per_launch"] * 1e6)     # bytes per launch, like `achieved`
                     roof["traffic_note"] = ("%s: 2 x FETCH_SIZE + WRITE_SIZE per launch of the family (separate rocprofv3 --pmc passes, gfx950 "
                                             "FETCH_SIZE correction x2), %.1f MB against %.1f MB algorithmic per launch"
