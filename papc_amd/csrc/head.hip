@@ -168,10 +168,10 @@ __global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
         mean /= (float)a.B;
         __syncthreads();
         float vacc = 0.f;
-        if (act && a.has_bn) for (int b = q; b < a.B; b += 8) { const float d = tile[b * TP + t] - mean; vacc += d * d; }
+        if (act && a.has_bn == 1) for (int b = q; b < a.B; b += 8) { const float d = tile[b * TP + t] - mean; vacc += d * d; }
         if (q < 8) s_part[q][t] = vacc;
         __syncthreads();
-        if (tid < ncol && a.has_bn) {
+        if (tid < ncol && a.has_bn == 1) {
             const int c = c0 + tid;
             float v = 0.f;
 #pragma unroll
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
         const float yv = tile[b * TP + t];
         if (a.y) a.y[o] = yv;
         float v = yv;
-        if (a.has_bn) {
-            v = (yv - s_mean[t]) * s_scale[t] + s_shift[t];
+        if (a.has_bn) {                   // 1: BatchNorm + ReLU + dropout; 2: ReLU + dropout (pointnet_base.py:26-33 has no norm in its head)
+            if (a.has_bn == 1) v = (yv - s_mean[t]) * s_scale[t] + s_shift[t];
             v = fmaxf(v, 0.f);
             bool k = true;
             if (drop) k = hash_uniform(seed, counter, (uint32_t)a.layer_tag, (uint32_t)o) >= a.drop_p;
@@ -256,7 +256,15 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
         }
         __syncthreads();
     }
-    if (a.has_bn) {
+    if (a.has_bn == 2) {          // ReLU + dropout only: dY = g * keep_scale where the output is alive
+        for (int e = tid; e < Bpad * 32; e += HT) {
+            const int b = e >> 5, t = e & 31;
+            float g = 0.f;
+            if (b < a.B && t < ncol) g = a.out[(int64_t)b * a.Cout + c0 + t] > 0.f ? gt[b * TP + t] * a.keep_scale : 0.f;
+            gt[b * TP + t] = g;
+        }
+        __syncthreads();
+    } else if (a.has_bn) {
         for (int e = tid; e < Bpad * 32; e += HT) {
             const int b = e >> 5, t = e & 31;
             float g = 0.f, h = 0.f;
@@ -422,7 +430,8 @@ int papc_head_fc_f32(const float *x, const float *w, const float *bias, const fl
     PAPC_REQUIRE(x && w && out, PAPC_E_INVALID, "papc_head_fc_f32: null pointer");
     PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_fc_f32: B=%d not in [1, %d]", B, HROWS_MAX);
     PAPC_REQUIRE(Cin >= 4 && Cin % 4 == 0 && Cout >= 1, PAPC_E_INVALID, "papc_head_fc_f32: Cin=%d must be a multiple of 4", Cin);
-    PAPC_REQUIRE(!has_bn || (gamma && beta && mean && invstd && y), PAPC_E_INVALID, "papc_head_fc_f32: BatchNorm needs gamma/beta/mean/invstd/y");
+    PAPC_REQUIRE(has_bn >= 0 && has_bn <= 2, PAPC_E_INVALID, "papc_head_fc_f32: has_bn=%d not in {0, 1, 2}", has_bn);
+    PAPC_REQUIRE(has_bn != 1 || (gamma && beta && mean && invstd && y), PAPC_E_INVALID, "papc_head_fc_f32: BatchNorm needs gamma/beta/mean/invstd/y");
     PAPC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, PAPC_E_INVALID, "papc_head_fc_f32: drop_p=%f", (double)drop_p);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
@@ -444,7 +453,9 @@ int papc_head_bwd_f32(const float *gnext, const float *wnext, int Cn, const floa
     PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_bwd_f32: B=%d not in [1, %d]", B, HROWS_MAX);
     PAPC_REQUIRE(Cout >= 1 && (!wnext || (Cn >= 4 && Cn % 4 == 0)), PAPC_E_INVALID, "papc_head_bwd_f32: Cn=%d must be a multiple of 4", Cn);
     PAPC_REQUIRE(wnext || Cn == Cout, PAPC_E_INVALID, "papc_head_bwd_f32: without wnext, gnext must be [B, Cout]");
-    PAPC_REQUIRE(!has_bn || (out && y && mean && invstd && gamma && dgamma && dbeta), PAPC_E_INVALID, "papc_head_bwd_f32: BatchNorm backward needs the saved forward");
+    PAPC_REQUIRE(has_bn >= 0 && has_bn <= 2, PAPC_E_INVALID, "papc_head_bwd_f32: has_bn=%d not in {0, 1, 2}", has_bn);
+    PAPC_REQUIRE(has_bn != 1 || (out && y && mean && invstd && gamma && dgamma && dbeta), PAPC_E_INVALID, "papc_head_bwd_f32: BatchNorm backward needs the saved forward");
+    PAPC_REQUIRE(has_bn != 2 || out, PAPC_E_INVALID, "papc_head_bwd_f32: ReLU backward needs the layer's output");
     PAPC_REQUIRE(!x || (dw && Cin >= 1), PAPC_E_INVALID, "papc_head_bwd_f32: x without dw");
     PAPC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, PAPC_E_INVALID, "papc_head_bwd_f32: drop_p=%f", (double)drop_p);
     hipStream_t st = as_stream(stream);

@@ -480,14 +480,19 @@ __global__ __launch_bounds__(768, 3) void dw_ws_kernel(DwArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// dW of a first layer fed by coordinates only (GROUP input with D = 0: Cin = 3; SA1 of the SSG / MSG classifiers).  A 128x32 MFMA
-// tile would carry 3 useful columns, so this is a streaming reduction instead: a lane owns 4 output channels (float4 loads of dz and
-// y), 16 lanes cover a 64-channel row, and each lane keeps 4 x 3 running sums of dY[m, c] * (xyz_j - centre)[m]; the 256-thread
-// workgroup reduces its row slots in LDS in fixed order.  HBM-bound on the (dz, y) stream.
+// dW of a first layer with a handful of input channels: a GROUP input with D = 0 (coordinates only, Cin = 3: SA1 of the SSG / MSG
+// classifiers) or D = 4 (coordinates + normals padded to four, Cin = 7: SA1 of the part-segmentation models,
+// segment/pointnet2/pointnet2.py:28-30).  A 128x32 MFMA tile would carry 3 (7) useful columns, so this is a streaming reduction
+// instead: a lane owns 4 output channels (float4 loads of dz and y), 16 lanes cover a 64-channel row, and each lane keeps
+// 4 x NC running sums of dY[m, c] * x[m, k] (k: the D feature columns, then xyz_j - centre); the 256-thread workgroup reduces its row
+// slots in LDS in fixed order.  HBM-bound on the (dz, y) stream.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int NF>      // float4 feature slots ahead of the coordinate slot (D = 4 NF)
 __global__ __launch_bounds__(256) void dw_xyz_kernel(DwArgs p)
 {
-    __shared__ float red[256 * 12];
+    constexpr int NC = 4 * NF + 3;           // input channels, internal order [feats, xyz]
+    constexpr int NS = NF + 1;               // float4 slots of a row
+    __shared__ float red[256 * 4 * NC];
     const int tid = threadIdx.x;
     const int CQ = p.Cout >> 2;              // channel quads per row (<= 64)
     const int RSL = 256 / CQ;                // row slots of the workgroup
@@ -501,9 +506,11 @@ __global__ __launch_bounds__(256) void dw_xyz_kernel(DwArgs p)
     const float4 kB = make_float4(ksc.x * c2.x * is.x, ksc.y * c2.y * is.y, ksc.z * c2.z * is.z, ksc.w * c2.w * is.w);
     const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
-    float a[4][3];
+    float a[4][NC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a[i][0] = a[i][1] = a[i][2] = 0.f;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) a[i][j] = 0.f;
     auto dyv = [&](float dz, float y, float sc, float sh, float mu, float A, float Bp) {
         const float z = fmaf(sc, y, sh);
         const float pp = z > 0.f ? dz : 0.f;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(256) void dw_xyz_kernel(DwArgs p)
     constexpr int U = 4;                     // rows in flight per lane
     if (act) {
         for (int64_t m0 = mbeg + slot; m0 < mend; m0 += (int64_t)U * RSL) {
-            float4 vy[U], vz[U], vx[U];
+            float4 vy[U], vz[U], vx[U][NS];
             bool ok[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -522,36 +529,46 @@ __global__ __launch_bounds__(256) void dw_xyz_kernel(DwArgs p)
                 vy[u] = ld4(d.y + mc * p.Cout + c);
                 vz[u] = ld4(d.dz + mc * p.Cout + c);
                 const RowCtx r = make_row<A_GROUP>(p.x, mc, p.M);
-                const Raw3 w = fetch_a4<A_GROUP, true>(p.x, r, 0, 3);
-                vx[u] = finish_a4<A_GROUP, true>(p.x, r, 0, 3, KConst{}, w);     // (x - cx, y - cy, z - cz, 0); zero for a no-hit row
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {     // slots 0 .. NF-1: features; slot NF: (x - cx, y - cy, z - cz, 0); zero for a no-hit row
+                    const Raw3 w = fetch_a4<A_GROUP, true>(p.x, r, 4 * sl, NC);
+                    vx[u][sl] = finish_a4<A_GROUP, true>(p.x, r, 4 * sl, NC, KConst{}, w);
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (!ok[u]) continue;
-                const float g0 = dyv(vz[u].x, vy[u].x, ksc.x, ksh.x, kmu.x, kA.x, kB.x);
-                const float g1 = dyv(vz[u].y, vy[u].y, ksc.y, ksh.y, kmu.y, kA.y, kB.y);
-                const float g2 = dyv(vz[u].z, vy[u].z, ksc.z, ksh.z, kmu.z, kA.z, kB.z);
-                const float g3 = dyv(vz[u].w, vy[u].w, ksc.w, ksh.w, kmu.w, kA.w, kB.w);
-                a[0][0] = fmaf(g0, vx[u].x, a[0][0]); a[0][1] = fmaf(g0, vx[u].y, a[0][1]); a[0][2] = fmaf(g0, vx[u].z, a[0][2]);
-                a[1][0] = fmaf(g1, vx[u].x, a[1][0]); a[1][1] = fmaf(g1, vx[u].y, a[1][1]); a[1][2] = fmaf(g1, vx[u].z, a[1][2]);
-                a[2][0] = fmaf(g2, vx[u].x, a[2][0]); a[2][1] = fmaf(g2, vx[u].y, a[2][1]); a[2][2] = fmaf(g2, vx[u].z, a[2][2]);
-                a[3][0] = fmaf(g3, vx[u].x, a[3][0]); a[3][1] = fmaf(g3, vx[u].y, a[3][1]); a[3][2] = fmaf(g3, vx[u].z, a[3][2]);
+                float g[4];
+                g[0] = dyv(vz[u].x, vy[u].x, ksc.x, ksh.x, kmu.x, kA.x, kB.x);
+                g[1] = dyv(vz[u].y, vy[u].y, ksc.y, ksh.y, kmu.y, kA.y, kB.y);
+                g[2] = dyv(vz[u].z, vy[u].z, ksc.z, ksh.z, kmu.z, kA.z, kB.z);
+                g[3] = dyv(vz[u].w, vy[u].w, ksc.w, ksh.w, kmu.w, kA.w, kB.w);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl) {
+                        const float4 x = vx[u][sl];
+                        a[i][4 * sl + 0] = fmaf(g[i], x.x, a[i][4 * sl + 0]);
+                        a[i][4 * sl + 1] = fmaf(g[i], x.y, a[i][4 * sl + 1]);
+                        a[i][4 * sl + 2] = fmaf(g[i], x.z, a[i][4 * sl + 2]);
+                        if (sl < NF) a[i][4 * sl + 3] = fmaf(g[i], x.w, a[i][4 * sl + 3]);     // (the coordinate slot's 4th element is a structural zero)
+                    }
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) red[tid * 12 + i * 3 + j] = act ? a[i][j] : 0.f;
+        for (int j = 0; j < NC; ++j) red[tid * (4 * NC) + i * NC + j] = act ? a[i][j] : 0.f;
     __syncthreads();
-    // thread t < Cout * 3: (channel, column); sum over the row slots in slot order
+    // thread t < Cout * NC: (channel, column); sum over the row slots in slot order
     float *out = p.dw_partial + (int64_t)blockIdx.x * p.part_ld;
-    for (int t = tid; t < p.Cout * 3; t += 256) {
-        const int ch = t / 3, j = t - ch * 3;
+    for (int t = tid; t < p.Cout * NC; t += 256) {
+        const int ch = t / NC, j = t - ch * NC;
         const int q = ch >> 2, i = ch & 3;
         float sacc = 0.f;
-        for (int sl = 0; sl < RSL; ++sl) sacc += red[(sl * CQ + q) * 12 + i * 3 + j];
-        out[(int64_t)ch * 3 + gk(p.x.g, j)] = sacc;       // internal xyz column j -> the caller's weight column (D = 0: identity)
+        for (int sl = 0; sl < RSL; ++sl) sacc += red[(sl * CQ + q) * (4 * NC) + i * NC + j];
+        out[(int64_t)ch * NC + gk(p.x.g, j)] = sacc;       // internal column j -> the caller's weight column
     }
     if (p.db_partial) {
         for (int t = tid; t < p.Cout; t += 256) p.db_partial[(int64_t)blockIdx.x * p.part_ld + t] = 0.f;   // exact (see dw_ws_kernel)
@@ -1198,6 +1215,12 @@ using namespace papc;
  * 64 x 64 tile per wave (241 registers: one workgroup per CU), so it wants ONE residency wave of workgroups -- ncu row chunks in all */
 extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mode, int dz_mode, int K)
 {
+    if (a_mode == PAPC_A_GROUP && dz_mode == PAPC_DZ_DENSE && (Cin == 3 || Cin == 7) && knob(KNOB_DW_XYZ) && Cout % 4 == 0 && Cout <= 256 && M >= 1) {
+        // the streaming reduction of a 3- / 7-input first layer (dw_xyz_kernel) is bound by the (dz, y) stream: enough workgroups for
+        // four waves per SIMD (~2048), chunks of at least 256 rows
+        const int64_t rpc = std::max<int64_t>(256, cdiv(cdiv(M, 2048), 64) * 64);
+        return (int)std::min<int64_t>(rpc, 1 << 24);
+    }
     if ((a_mode != PAPC_A_BNRELU && a_mode != PAPC_A_XYZ) || M < 1) return 0;
     const bool xk = dw_rowsx_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K);
     if (!xk && !dw_rows_eligible(Cin, Cout, dz_mode == PAPC_DZ_DENSE, K)) return 0;
@@ -1255,9 +1278,10 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     ProfScope prof(PAPC_K_BWD_DW, st);
     const bool dense = dy->dz_mode == PAPC_DZ_DENSE;
     const int xyz_on = knob(KNOB_DW_XYZ);
-    if (xyz_on && a_mode == A_GROUP && dense && vec && grp->D == 0 && Cin == 3 && Cout % 4 == 0 && Cout >= 4 && Cout <= 256) {
-        // coordinates-only first layer: streaming reduction instead of a 3-of-32-column MFMA tile
-        hipLaunchKernelGGL(dw_xyz_kernel, dim3((unsigned)cdiv(M, rows_per_chunk)), dim3(256), 0, st, p);
+    if (xyz_on && a_mode == A_GROUP && dense && vec && ((grp->D == 0 && Cin == 3) || (grp->D == 4 && Cin == 7)) && Cout % 4 == 0 && Cout >= 4 && Cout <= 256) {
+        // a first layer with 3 (coordinates) or 7 (+ four feature columns) inputs: streaming reduction instead of a 3- / 7-of-32-column MFMA tile
+        if (grp->D == 0) hipLaunchKernelGGL(dw_xyz_kernel<0>, dim3((unsigned)cdiv(M, rows_per_chunk)), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(dw_xyz_kernel<1>, dim3((unsigned)cdiv(M, rows_per_chunk)), dim3(256), 0, st, p);
         return check_launch("papc_mlp_bwd_dw_f32");
     }
     switch (a_mode) {

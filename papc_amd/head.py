@@ -125,6 +125,81 @@ def classifier_head(spec, x, fc1, bn1, drop1, fc2, bn2, drop2, fc3):
     return _Head.apply(spec, (bn1, bn2), (float(drop1.p), float(drop2.p)), x, *params)
 
 
+class _HeadPlain(torch.autograd.Function):
+    """fc(1024,512) - ReLU - fc(512,256) - ReLU - Dropout(p) - fc(256,classes): the head of PointNet_Basic_Clas
+    (/root/reference/PAPC/models/classify/pointnet_base/pointnet_base.py:26-33), no norm layers: the head kernels' ReLU-only mode."""
+
+    @staticmethod
+    def forward(ctx, spec, p, x0, w1, b1, w2, b2, w3, b3):
+        lib = _lib.load()
+        x0 = x0.contiguous()
+        B, dev, st = x0.shape[0], x0.device, stream_ptr()
+        rng = spec.state(dev)
+        outs, keep = [], None
+        x = x0
+        for li, (w, b, pl) in enumerate(((w1, b1, 0.0), (w2, b2, p))):
+            cout, cin = w.shape
+            out = torch.empty(B, cout, device=dev, dtype=torch.float32)
+            if pl > 0.0 and spec.export_masks:
+                keep = torch.empty(B, cout, device=dev, dtype=torch.uint8)
+            check(lib.papc_head_fc_f32(ptr(x), ptr(w), ptr(b), 0, 0, B, cin, cout, 2, 0.0, 0.0, 0, 0, 0, float(pl), ptr(rng), li + 1, 0,
+                                       0, 0, 0, ptr(keep) if pl > 0.0 else 0, ptr(out), st), "papc_head_fc_f32")
+            outs.append(out)
+            x = out
+        cout, cin = w3.shape
+        logits = torch.empty(B, cout, device=dev, dtype=torch.float32)
+        check(lib.papc_head_fc_f32(ptr(x), ptr(w3), ptr(b3), 0, 0, B, cin, cout, 0, 0.0, 0.0, 0, 0, 0, 0.0, 0, 3, ptr(rng),
+                                   0, 0, 0, 0, ptr(logits), st), "papc_head_fc_f32")
+        spec.masks = (keep,) if spec.export_masks else None
+        ctx.spec, ctx.p = spec, p
+        ctx.save_for_backward(x0, w1, w2, w3, *outs)
+        return logits
+
+    @staticmethod
+    def backward(ctx, glogits):
+        lib = _lib.load()
+        x0, w1, w2, w3, x1, x2 = ctx.saved_tensors
+        spec, p = ctx.spec, ctx.p
+        B, dev, st = x0.shape[0], x0.device, stream_ptr()
+        glogits = glogits.contiguous().float()
+        tg = spec.grad_targets
+        if tg is not None and any(t is None for t in tg):
+            tg = None
+        acc = 1 if tg is not None else 0
+        if tg is None:
+            tg = [torch.empty(s_, device=dev, dtype=torch.float32) for s_ in (w1.shape, (w1.shape[0],), w2.shape, (w2.shape[0],), w3.shape, (w3.shape[0],))]
+        dw1, db1, dw2, db2, dw3, db3 = tg
+        c1, c0 = w1.shape
+        c2, c3 = w2.shape[0], w3.shape[0]
+        dy2 = torch.empty(B, c2, device=dev, dtype=torch.float32)
+        dy1 = torch.empty(B, c1, device=dev, dtype=torch.float32)
+        need_dx = ctx.needs_input_grad[2]
+        dx0 = torch.empty(B, c0, device=dev, dtype=torch.float32) if need_dx else None
+        f = lib.papc_head_bwd_f32
+        check(f(ptr(glogits), 0, c3, 0, 0, 0, 0, 0, 0.0, 0, ptr(x2), B, c2, c3, 0, ptr(dw3), ptr(db3), 0, 0, acc, st), "papc_head_bwd_f32")
+        check(f(ptr(glogits), ptr(w3), c3, ptr(x2), 0, 0, 0, 0, float(p), 2, ptr(x1), B, c1, c2, ptr(dy2), ptr(dw2), ptr(db2), 0, 0, acc, st),
+              "papc_head_bwd_f32")
+        check(f(ptr(dy2), ptr(w2), c2, ptr(x1), 0, 0, 0, 0, 0.0, 2, ptr(x0), B, c0, c1, ptr(dy1), ptr(dw1), ptr(db1), 0, 0, acc, st),
+              "papc_head_bwd_f32")
+        if need_dx:
+            check(f(ptr(dy1), ptr(w1), c1, 0, 0, 0, 0, 0, 0.0, 0, 0, B, 0, c0, ptr(dx0), 0, 0, 0, 0, 0, st), "papc_head_bwd_f32")
+        grads = (None,) * 6 if acc else tuple(tg)
+        return (None, None, dx0) + grads
+
+
+def plain_usable(x, fc1, fc2, fc3, training):
+    return (training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= MAX_ROWS
+            and fc1.in_features % 4 == 0 and fc1.out_features % 4 == 0 and fc2.out_features % 4 == 0
+            and fc3.out_features % 4 == 0 and fc1.bias is not None and fc2.bias is not None and fc3.bias is not None)
+
+
+def plain_head(spec, x, fc1, fc2, drop, fc3):
+    """logits = fc3(drop(relu(fc2(relu(fc1(x))))))  in train mode, three launches each way."""
+    params = (fc1.weight, fc1.bias, fc2.weight, fc2.bias, fc3.weight, fc3.bias)
+    spec.grad_targets = grad_targets_of(params) if torch.is_grad_enabled() else None
+    return _HeadPlain.apply(spec, float(drop.p), x, *params)
+
+
 class _SoftmaxXent(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels):

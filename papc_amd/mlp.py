@@ -491,6 +491,8 @@ class SharedMLPMax(torch.autograd.Function):
                 rpc = 0
                 if l > 0:                        # (the kernel's own preference where it has one: papc_mlp_bwd_dw_chunk_hint)
                     rpc = lib.papc_mlp_bwd_dw_chunk_hint(M, cin, cout, A_XYZ if x1 else A_BNRELU, dy.dz_mode, spec.K if dy.dz_mode == DZ_MAX else 0)
+                elif not plain:
+                    rpc = lib.papc_mlp_bwd_dw_chunk_hint(M, cin, cout, A_GROUP, dy.dz_mode, spec.K if dy.dz_mode == DZ_MAX else 0)
                 if rpc <= 0:
                     rpc = _dw_rows_per_chunk(M, cout, cin)
                 n_chunks = (M + rpc - 1) // rpc

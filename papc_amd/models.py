@@ -193,6 +193,11 @@ class PointNet_Basic_Clas(nn.Module):
         for conv, bn in zip(self.convs, self.bns):
             ps += [conv.weight, conv.bias, bn.weight, bn.bias]
         feat = shared_mlp_max(spec, [(bn.running_mean, bn.running_var) for bn in self.bns], xyz, zero, None, None, ps)  # :42-44
+        if _FUSED_HEAD and _head.plain_usable(feat, self.fc[0], self.fc[2], self.fc[5], self.training):
+            spec = self.__dict__.get("_head_spec")
+            if spec is None:
+                spec = self.__dict__["_head_spec"] = _head.HeadSpec()
+            return _head.plain_head(spec, feat, self.fc[0], self.fc[2], self.fc[4], self.fc[5])      # :26-33, :45 on the head kernels
         return self.fc(feat)                                      # :45
 
 

@@ -89,6 +89,60 @@ def test_head_matches_float64(B, c3, accumulate, dims):
         assert int(bn.num_batches_tracked.item()) == 1
 
 
+@pytest.mark.parametrize("B,c3,dims", [(8, 16, None), (32, 40, None), (5, 12, (132, 72, 40)), (1, 16, None)])
+def test_plain_head_matches_float64(B, c3, dims):
+    """The PointNet-Basic head (Linear - ReLU - Linear - ReLU - Dropout(0.7) - Linear, pointnet_base.py:26-33) on the head kernels'
+    ReLU-only mode vs a float64 restatement with the same dropout mask; also through the model, which must take this path."""
+    from papc_amd import head
+    c0, c1, c2 = dims if dims else (1024, 512, 256)
+    torch.manual_seed(11 + B)
+    fc1, fc2, drop, fc3 = nn.Linear(c0, c1).cuda(), nn.Linear(c1, c2).cuda(), nn.Dropout(0.7), nn.Linear(c2, c3).cuda()
+    params = [fc1.weight, fc1.bias, fc2.weight, fc2.bias, fc3.weight, fc3.bias]
+    x0 = torch.randn(B, c0, device="cuda", requires_grad=True)
+    glog = torch.randn(B, c3, device="cuda")
+    spec = head.HeadSpec()
+    spec.export_masks = True
+    assert head.plain_usable(x0, fc1, fc2, fc3, True)
+    logits = head.plain_head(spec, x0, fc1, fc2, drop, fc3)
+    assert "HeadPlain" in type(logits.grad_fn).__name__
+    (keep,) = spec.masks
+    logits.backward(glog)
+    torch.cuda.synchronize()
+    frac = keep.float().mean().item()
+    assert abs(frac - 0.3) < 6.0 * (0.21 / keep.numel()) ** 0.5 + 1e-3
+    P = lambda t: t.detach().double().cpu().requires_grad_(True)
+    prm = [P(t) for t in params]
+    x = P(x0)
+    h = torch.relu(x @ prm[0].t() + prm[1])
+    h = torch.relu(h @ prm[2].t() + prm[3]) * keep.double().cpu() / 0.3
+    ref = h @ prm[4].t() + prm[5]
+    ref.backward(glog.double().cpu())
+
+    def close(got, want, tol=2e-5):
+        got = got.detach().double().cpu()
+        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+        assert err <= tol, err
+
+    close(logits, ref.detach(), 1e-5)
+    close(x0.grad, x.grad)
+    for p, w in zip(params, prm):
+        close(p.grad, w.grad)
+
+
+def test_basic_model_uses_plain_head(dev):
+    from papc_amd.models import PointNet_Basic_Clas
+    from papc_amd.synthetic import make_clouds
+    model = PointNet_Basic_Clas(num_classes=16).to(dev).train()
+    x = torch.from_numpy(make_clouds(4, 256, 3)).to(dev)
+    out = model(x)
+    assert "HeadPlain" in type(out.grad_fn).__name__
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    model.eval()
+    with torch.no_grad():
+        assert model(x).shape == (4, 16)
+
+
 def test_head_masks_advance_and_seed():
     from papc_amd import head
     mods = [m.cuda() for m in _modules(1024, 512, 256, 40, 1)]

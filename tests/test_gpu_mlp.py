@@ -94,6 +94,8 @@ def test_sa_msg_vs_oracle(dev):
     (2, 128, 1, 128, 64, [64, 128], True, False),          # group_all: identity rows
     (1, 200, 10, 8, 6, [16], True, True),                  # single-layer stack (MAX-mode dY with GROUP input)
     (4, 1024, 256, 32, 0, [64, 64, 128], True, True),      # M = 32768 rows: large enough for the opt-in sparse-max dX (PAPC_SPARSE_MAX=1)
+    (2, 512, 64, 32, 4, [32, 32, 64], False, True),        # 7 input channels (normals padded to four + xyz, MSG order): streaming first-layer dW
+    (2, 512, 64, 16, 4, [64, 96, 128], True, True),        # ... SSG column order
 ])
 def test_stack_backward_vs_torch(dev, B, N, S, K, D, mlp, xyz_first, use_idx):
     x = make_clouds(B, N, 31 + N)
