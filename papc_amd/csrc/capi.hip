@@ -58,7 +58,7 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_DW_RS64", 1, 0, 1},             // dW of 64 x 64 layers: 64-row stages (all producer threads busy)
     {"PAPC_DW_ROWS", 1, 0, 1},             // dW of layers with a 64-channel BN+ReLU input on the row-streaming kernel (dw_rows_kernel)
     {"PAPC_DW_ROWS_BLOCKS", 4, 1, 16},     // ... for layers of at most this many 64 x 64 output blocks (8: slower, each block transforms its operands again)
-    {"PAPC_DW_ROWSX", 0, 0, 1},            // experiment, off: dW of 128 -> 256k layers with dY streamed per wave and x staged once per workgroup (dw_rowsx_kernel: 161 vs 138 us)
+    {"PAPC_DW_ROWSX", 1, 0, 1},            // dW of 128 -> 256k layers with dY streamed per wave and x staged once per workgroup (dw_rowsx_kernel; 0: the staged kernel)
     {"PAPC_PG_DBG", 0, 0, 15},             // development aid for pg_gemm_kernel (timing only, results are garbage): 1 no MFMAs, 2 no fragment loads, 4 no LDS reads, 8 no epilogue
     {"PAPC_PG_NB", 0, 0, 2},               // pg_gemm_kernel column tile: 1 = 64, 2 = 128 columns (0 = per shape)
     {"PAPC_PG_NS", 0, 0, 3},               // ... stages of its LDS ring: 2 or 3 (0 = per tile flavour)

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
             }
         }
         if (DYMODE == A_DY_MAX) {   // K % 16 == 0 (host-checked): the block's 16 rows share one group
-            const int64_t g = (mbeg + 16 * (int64_t)kb) / d.K;
+            const int64_t g = fdiv((uint32_t)(mbeg + 16 * (int64_t)kb), d.divK);     // (M < 2^31; no 64-bit division between the loads)
 #pragma unroll
             for (int a = 0; a < NTO; ++a) {
                 w.z[a][0] = d.gout[g * Cout + o0 + 32 * a + l31];
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
         const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
         const bool tail = mbeg + 16 * (int64_t)kb + 16 > mend;
         int kin0 = 0;
-        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - ((mbeg + 16 * (int64_t)kb) / d.K) * d.K);
+        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - (int64_t)fdiv((uint32_t)(mbeg + 16 * (int64_t)kb), d.divK) * d.K);
         bf16x8 pa[NTO][3], pb[NTI][3];
 #pragma unroll
         for (int a = 0; a < NTO; ++a) {
@@ -710,18 +710,31 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[a][PA[t]], pb[b][PB[t]], acc[a][b], 0, 0, 0);
     };
 
-    // this wave's blocks: wave, wave + 8, ...; the next block's loads are in flight while the current one is computed
-    Raw ra, rb;
-    int kb = wave;
-    if (kb < n_kb) fetch(kb, ra);
-    while (kb < n_kb) {
-        if (kb + 8 < n_kb) fetch(kb + 8, rb);
-        compute(kb, ra);
-        kb += 8;
-        if (kb >= n_kb) break;
-        if (kb + 8 < n_kb) fetch(kb + 8, ra);
-        compute(kb, rb);
-        kb += 8;
+    // this wave's blocks: wave, wave + 8, ...; the raw operands of the next PF - 1 blocks are in flight while one is computed (a ring of PF
+    // register buffers, as deep as the flavour's registers allow).  No branch sits around a load (block indices past the chunk are clamped to
+    // the wave's last block: re-read, never used), no 64-bit division between them, and scheduling barriers keep loads ahead of the block's
+    // arithmetic: otherwise the compiler collapses the ring (loads sunk behind the next block's MFMAs, every wait a vmcnt(0))
+    constexpr int PF = (DYMODE == A_DY_MAX && !XYZ) ? 3 : 2;
+    const int nb = (n_kb - wave + 7) >> 3;          // blocks of this wave
+    if (nb > 0) {
+        const int last = wave + 8 * (nb - 1);
+        Raw rr[PF];
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i) fetch(min(wave + 8 * i, last), rr[i]);
+        const int n_main = nb - nb % PF;
+        for (int j0 = 0; j0 < n_main; j0 += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int kb = wave + 8 * (j0 + i);
+                fetch(min(kb + 8 * (PF - 1), last), rr[(i + PF - 1) % PF]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(kb, rr[i]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i)
+            if (n_main + i < nb) compute(wave + 8 * (n_main + i), rr[i]);
     }
 
     // ---- fold the 8 waves' tiles: 4 -> LDS, +4; 2 -> LDS, +2; 1 -> LDS, +1 (fixed order); slab[w][reg][lane]: conflict-free
@@ -808,7 +821,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
             if (DYMODE == A_DY_DENSE) w.z[j] = d.dz[row * Cout + co];
         }
         if (DYMODE == A_DY_MAX) {
-            const int64_t g = b0 / d.K;
+            const int64_t g = fdiv((uint32_t)b0, d.divK);      // (M < 2^31; a 64-bit division is a branchy call sequence between the loads)
             w.z[0] = d.gout[g * Cout + co];
             w.am = d.argmax[g * Cout + co];
         }
@@ -844,7 +857,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
         const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
         const bool tail = mbeg + 16 * (int64_t)kb + 16 > mend;
         int kin0 = 0;
-        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - ((mbeg + 16 * (int64_t)kb) / d.K) * d.K);
+        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - (int64_t)fdiv((uint32_t)(mbeg + 16 * (int64_t)kb), d.divK) * d.K);
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -878,31 +891,43 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[PA[t]], pb[b][PB[t]], acc[b], 0, 0, 0);
     };
 
-    // every wave walks ALL blocks of the chunk (it owns channels, not rows).  Iteration kb: put dY of block kb + 1 and x of block kb + 2 in
-    // flight, stage x of block kb + 1 (fetched one iteration ago) into the other LDS stage, compute block kb, one barrier.
-    Raw da, db;
-    RawX xa, xb;
+    // every wave walks ALL blocks of the chunk (it owns channels, not rows).  The HBM round trip (~2 us) is several blocks long (a block
+    // is ~0.6 us of issue), so the raw operands sit in a ring of PF register buffers: iteration kb puts dY and x of block kb + PF - 1 in
+    // flight, stages x of block kb + 1 (fetched PF - 2 iterations ago) into the other LDS stage, computes block kb, one barrier.
+    constexpr int PF = 4;
+    Raw dr[PF];
+    RawX xr[PF];
+    const int last = n_kb - 1;
     if (n_kb > 0) {
-        fetch(0, da);
-        fetch_x(0, xa);
-        if (n_kb > 1) fetch_x(1, xb);
-        stage_x(0, xa, xs_lds);
+        // (no branch sits around a load anywhere below: block indices past the chunk are clamped to its last block -- re-read, never used --
+        // so the compiler keeps COUNTED waits (vmcnt(n > 0)) in the steady loop instead of draining the ring at every control-flow merge)
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i) { fetch(min(i, last), dr[i]); fetch_x(min(i, last), xr[i]); }
+        stage_x(0, xr[0], xs_lds);
         lds_barrier();
     }
-    for (int kb = 0; kb < n_kb; kb += 2) {
-        // even block kb: dY in da, LDS stage 0; x of kb + 1 waits in xb
-        if (kb + 1 < n_kb) fetch(kb + 1, db);
-        if (kb + 2 < n_kb) fetch_x(kb + 2, xa);
-        if (kb + 1 < n_kb) stage_x(kb + 1, xb, xs_lds + STG);
-        compute(kb, da, xs_lds);
-        lds_barrier();
-        if (kb + 1 >= n_kb) break;
-        // odd block kb + 1: dY in db, LDS stage 1; x of kb + 2 waits in xa
-        if (kb + 2 < n_kb) fetch(kb + 2, da);
-        if (kb + 3 < n_kb) fetch_x(kb + 3, xb);
-        if (kb + 2 < n_kb) stage_x(kb + 2, xa, xs_lds);
-        compute(kb + 1, db, xs_lds + STG);
-        lds_barrier();
+    const int n_main = n_kb - n_kb % PF;
+    for (int kb0 = 0; kb0 < n_main; kb0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {          // (the ring indices are compile-time: the buffers stay in registers)
+            const int kb = kb0 + i;
+            constexpr int NXT = PF - 1;
+            fetch(min(kb + NXT, last), dr[(i + NXT) % PF]);
+            fetch_x(min(kb + NXT, last), xr[(i + NXT) % PF]);
+            stage_x(min(kb + 1, last), xr[(i + 1) % PF], xs_lds + ((kb + 1) & 1) * STG);
+            compute(kb, dr[i], xs_lds + (kb & 1) * STG);
+            lds_barrier();
+        }
+    }
+    // the last n_kb % PF blocks: their operands are already in the ring (slots 0 .. n_kb % PF - 1 of this round)
+#pragma unroll
+    for (int i = 0; i < PF - 1; ++i) {
+        const int kb = n_main + i;
+        if (kb < n_kb) {
+            if (kb + 1 < n_kb) stage_x(kb + 1, xr[(i + 1) % PF], xs_lds + ((kb + 1) & 1) * STG);
+            compute(kb, dr[i], xs_lds + (kb & 1) * STG);
+            lds_barrier();
+        }
     }
 
     // ---- this wave's 32 rows of the partial: row (cout) = (r & 3) + 8 (r >> 2) + 4 half, col (cin) = lane & 31
@@ -947,6 +972,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_max_kernel(DwMaxArgs p)
     const int64_t mbeg = (int64_t)chunk * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
     const int n_kb = mbeg < mend ? (int)((mend - mbeg) >> 4) : 0;       // (M, rows_per_chunk % 16 == 0: whole blocks only)
+    const int kshift = 31 - __clz(p.K);
 
     float xs[NTI], xh[NTI], xsum[NTI];
 #pragma unroll
@@ -966,7 +992,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_max_kernel(DwMaxArgs p)
         for (int j = 0; j < 8; ++j)
 #pragma unroll
             for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x[(r0 + j) * CI + 32 * b + l31];
-        const int64_t g = (mbeg + 16 * (int64_t)kb) / p.K;               // K % 16 == 0: the block's 16 rows share one group
+        const int64_t g = (mbeg + 16 * (int64_t)kb) >> kshift;           // K % 16 == 0: the block's 16 rows share one group (K a power of two)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             w.ps[a] = p.psel[g * Cout + o0 + 32 * a + l31];
@@ -974,7 +1000,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_max_kernel(DwMaxArgs p)
         }
     };
     auto compute = [&](int kb, const Raw &w) {
-        const int kin0 = (int)((mbeg + 16 * (int64_t)kb) % p.K) + 8 * hi;
+        const int kin0 = (int)((mbeg + 16 * (int64_t)kb) & (p.K - 1)) + 8 * hi;
         bf16x8 pa[2][3], pb[NTI][3];
 #pragma unroll
         for (int b = 0; b < NTI; ++b) {
@@ -1018,17 +1044,30 @@ __global__ __launch_bounds__(512, 2) void dw_rows_max_kernel(DwMaxArgs p)
             }
     };
 
-    Raw ra, rb;
-    int kb = wave;
-    if (kb < n_kb) fetch(kb, ra);
-    while (kb < n_kb) {
-        if (kb + 8 < n_kb) fetch(kb + 8, rb);
-        compute(kb, ra);
-        kb += 8;
-        if (kb >= n_kb) break;
-        if (kb + 8 < n_kb) fetch(kb + 8, ra);
-        compute(kb, rb);
-        kb += 8;
+    // this wave's blocks: wave, wave + 8, ...  The raw operands of the next PF - 1 blocks are in flight while one is computed.  No branch
+    // sits around a load (block indices past the chunk are clamped to the wave's last block: re-read, never used) and no 64-bit division
+    // between them: at every control-flow merge the compiler drains its register ring to vmcnt(0) instead of counting
+    constexpr int PF = 3;
+    const int nb = (n_kb - wave + 7) >> 3;          // blocks of this wave
+    if (nb > 0) {
+        const int last = wave + 8 * (nb - 1);
+        Raw rr[PF];
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i) fetch(min(wave + 8 * i, last), rr[i]);
+        const int n_main = nb - nb % PF;
+        for (int j0 = 0; j0 < n_main; j0 += PF) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                const int kb = wave + 8 * (j0 + i);
+                fetch(min(kb + 8 * (PF - 1), last), rr[(i + PF - 1) % PF]);
+                __builtin_amdgcn_sched_barrier(0);      // (keep the loads ahead of the block's arithmetic and the blocks in order: the scheduler
+                compute(kb, rr[i]);                     //  otherwise sinks loads behind MFMAs of the next block and waits them out at vmcnt(0))
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PF - 1; ++i)
+            if (n_main + i < nb) compute(wave + 8 * (n_main + i), rr[i]);
     }
 
     // ---- column sums of the transformed input: (wave, half) partials -> LDS, fixed-order sum (chunk's first workgroup only)

@@ -123,7 +123,7 @@ def test_dw_row_streaming_matches_staged_kernels(dev, chans, K):
             grads[flav] = [p.grad.clone() for p in prm]
     finally:
         _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWS", 1), "knob")
-        _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWSX", 0), "knob")   # (the hybrid kernel is an opt-in experiment)
+        _lib.check(lib.papc_knob_set(b"PAPC_DW_ROWSX", 1), "knob")
     for a, b in zip(grads[0], grads[1]):
         assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-7
 
