@@ -13,11 +13,21 @@
 // MFMAs of stage s and transformed + written to the other LDS buffer after them; one barrier per stage; two
 // workgroups per CU.  For gathered rows the neighbour indices of stage s+2 are prefetched as well, so the
 // idx -> address -> data dependency never sits in front of the matrix pipe.
+#include <type_traits>
 #include "mlp_loaders.h"
 
 namespace papc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void dw_sfor(F &&f)       // f(std::integral_constant<int, I>{}) for I in [I, N): compile-time indices
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        dw_sfor<I + 1, N>(f);
+    }
+}
 
 void fill_dy(DySrc &d, const papc_bwd_dy *s);
 int check_dy(const papc_bwd_dy *dy, int64_t M, int C, bool *vec, const char *who);
@@ -793,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
     const int co = blockIdx.y * 256 + wave * 32 + l31;       // this lane's dY channel
     const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
-    const int n_kb = mbeg < mend ? (int)((mend - mbeg + 15) >> 4) : 0;
+    const int n_kb = mbeg < mend ? (int)((mend - mbeg) >> 4) : 0;       // (whole 16-row blocks only: host-checked)
     const DySrc &d = p.dy.d;
     const int Cout = p.Cout;
 
@@ -811,41 +821,37 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
 
     struct Raw { float y[8], z[8]; int am; };
     struct RawX { float x[4]; };
+    // addresses: wave-uniform base + a 32-bit byte offset per lane (host-checked: M * Cout * 4 < 2^32 and whole 16-row blocks only), so a
+    // load costs one 32-bit add instead of a 64-bit multiply-add and a row clamp -- address arithmetic was a third of the loop's VALU work
+    auto ldg = [](const float *base, uint32_t byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
+    auto ldgi = [](const int *base, uint32_t byte_off) { return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + byte_off); };
+    const uint32_t ystride = (uint32_t)Cout * 4u;
+    const uint32_t oy_lane = (uint32_t)((mbeg + 8 * hi) * Cout + co) * 4u;        // row (mbeg + 8 hi) of this lane's channel
+    const uint32_t ox_lane = (uint32_t)((mbeg + 4 * xq) * CI + xc) * 4u;
     auto fetch = [&](int kb, Raw &w) {
-        const int64_t b0 = mbeg + 16 * (int64_t)kb;
+        const uint32_t o0 = oy_lane + (uint32_t)kb * 16u * ystride;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            int64_t row = b0 + 8 * hi + j;
-            row = row < mend ? row : mend - 1;
-            w.y[j] = d.y[row * Cout + co];
-            if (DYMODE == A_DY_DENSE) w.z[j] = d.dz[row * Cout + co];
+            w.y[j] = ldg(d.y, o0 + (uint32_t)j * ystride);
+            if (DYMODE == A_DY_DENSE) w.z[j] = ldg(d.dz, o0 + (uint32_t)j * ystride);
         }
         if (DYMODE == A_DY_MAX) {
-            const int64_t g = fdiv((uint32_t)b0, d.divK);      // (M < 2^31; a 64-bit division is a branchy call sequence between the loads)
-            w.z[0] = d.gout[g * Cout + co];
-            w.am = d.argmax[g * Cout + co];
+            const uint32_t g = fdiv((uint32_t)mbeg + 16u * (uint32_t)kb, d.divK);      // (no 64-bit division: a branchy call sequence between the loads)
+            const uint32_t og = (g * (uint32_t)Cout + (uint32_t)co) * 4u;
+            w.z[0] = ldg(d.gout, og);
+            w.am = ldgi(d.argmax, og);
         }
     };
     auto fetch_x = [&](int kb, RawX &w) {
-        const int64_t b0 = mbeg + 16 * (int64_t)kb;
+        const uint32_t o0 = ox_lane + (uint32_t)kb * (16u * CI * 4u);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int64_t row = b0 + 4 * xq + j;
-            row = row < mend ? row : mend - 1;
-            w.x[j] = p.x.x[row * CI + xc];
-        }
+        for (int j = 0; j < 4; ++j) w.x[j] = ldg(p.x.x, o0 + (uint32_t)j * (CI * 4u));
     };
     auto stage_x = [&](int kb, const RawX &w, char *stg) {   // this thread's 4 rows of channel xc -> three 8-byte plane pieces
-        const int64_t b0 = mbeg + 16 * (int64_t)kb + 4 * xq;
+        (void)kb;
         float4 v;
         v.x = fmaxf(fmaf(xsc, w.x[0], xsh), 0.f); v.y = fmaxf(fmaf(xsc, w.x[1], xsh), 0.f);
         v.z = fmaxf(fmaf(xsc, w.x[2], xsh), 0.f); v.w = fmaxf(fmaf(xsc, w.x[3], xsh), 0.f);
-        if (b0 + 3 >= mend) {
-            if (b0 + 0 >= mend) v.x = 0.f;
-            if (b0 + 1 >= mend) v.y = 0.f;
-            if (b0 + 2 >= mend) v.z = 0.f;
-            v.w = 0.f;
-        }
         uint2 q0, q1, q2;
         split3(v, q0, q1, q2);
         char *dst = stg + xc * CHS + xq * 8;
@@ -853,11 +859,13 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
         *reinterpret_cast<uint2 *>(dst + PLB) = q1;
         *reinterpret_cast<uint2 *>(dst + 2 * PLB) = q2;
     };
-    auto compute = [&](int kb, const Raw &w, const char *stg) {
-        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
-        const bool tail = mbeg + 16 * (int64_t)kb + 16 > mend;
+    // prep: dY of block kb (this lane's channel, its 8 rows) -> the three bf16 planes of the MFMA's row operand
+    auto prep = [&](int kb, const Raw &w, bf16x8 (&pa)[3]) {
         int kin0 = 0;
-        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - (int64_t)fdiv((uint32_t)(mbeg + 16 * (int64_t)kb), d.divK) * d.K);
+        if (DYMODE == A_DY_MAX) {
+            const uint32_t b0 = (uint32_t)mbeg + 16u * (uint32_t)kb;
+            kin0 = (int)(b0 - fdiv(b0, d.divK) * (uint32_t)d.K) + 8 * hi;
+        }
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -868,15 +876,16 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
             const float z = fmaf(ksc, y, ksh);
             const float pp = z > 0.f ? dz : 0.f;
             v[j] = fmaf(ksc, pp, -fmaf(kB, y - kmu, kA));
-            if (tail && r0 + j >= mend) v[j] = 0.f;
         }
         uint2 a0, a1, a2, b0, b1, b2;
         split3(make_float4(v[0], v[1], v[2], v[3]), a0, a1, a2);
         split3(make_float4(v[4], v[5], v[6], v[7]), b0, b1, b2);
-        bf16x8 pa[3];
         pa[0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
         pa[1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
         pa[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+    };
+    // mma: the staged x planes of a block against this wave's dY planes
+    auto mma = [&](const bf16x8 (&pa)[3], const char *stg) {
         bf16x8 pb[NTI][3];
 #pragma unroll
         for (int b = 0; b < NTI; ++b)
@@ -894,9 +903,83 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
     // every wave walks ALL blocks of the chunk (it owns channels, not rows).  The HBM round trip (~2 us) is several blocks long (a block
     // is ~0.6 us of issue), so the raw operands sit in a ring of PF register buffers: iteration kb puts dY and x of block kb + PF - 1 in
     // flight, stages x of block kb + 1 (fetched PF - 2 iterations ago) into the other LDS stage, computes block kb, one barrier.
-    constexpr int PF = 4;
+    // one block of MFMAs (this wave's dY planes pa against the staged x planes) with the NEXT block's operand work dealt out between them:
+    // after each of the 24 MFMAs one slice of VALU (fenced with scheduling barriers: the scheduler's own order puts all VALU behind the
+    // MFMAs) -- 8 slices transform dY, 5 split it into planes, 4 transform / split / store this thread's share of x
+    auto weave = [&](const bf16x8 (&pc)[3], const char *stg, int kbn, const Raw &w, bf16x8 (&pn)[3], const RawX &wx, char *stgn) {
+        bf16x8 pb[NTI][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)          // (plane-major: the first four MFMAs need the leading planes only, the rest is still in flight)
+#pragma unroll
+            for (int b = 0; b < NTI; ++b)
+                pb[b][pl] = *reinterpret_cast<const bf16x8 *>(stg + pl * PLB + (32 * b + l31) * CHS + hi * 16);
+        int kin0 = 0;
+        if (DYMODE == A_DY_MAX) {
+            const uint32_t b0 = (uint32_t)mbeg + 16u * (uint32_t)kbn;
+            kin0 = (int)(b0 - fdiv(b0, d.divK) * (uint32_t)d.K) + 8 * hi;
+        }
+        float v[8];
+        float4 ra, rb, rx;
+        uint2 a0, a1, a2, b0, b1, b2, q0, q1, q2;
+        // (pure arithmetic is sunk to its first use at the IR level, i.e. behind all 24 MFMAs, whatever the scheduling barriers say: an empty
+        // volatile asm on a slice's results pins the slice where it is written)
+        auto pin = [](float &x) { asm volatile("" : "+v"(x)); };
+        auto pin4 = [&](float4 &r) { pin(r.x); pin(r.y); pin(r.z); pin(r.w); };
+        auto pinu = [](uint2 &u) { asm volatile("" : "+v"(u.x), "+v"(u.y)); };
+        auto level = [](float4 &r, uint2 &pl) {      // one level of the exact split: the leading bf16 of each value, and what is left
+            pl.x = pack_bf16x2(r.x, r.y); pl.y = pack_bf16x2(r.z, r.w);
+            r.x -= bf16_lo(pl.x); r.y -= bf16_hi(pl.x); r.z -= bf16_lo(pl.y); r.w -= bf16_hi(pl.y);
+        };
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
+        dw_sfor<0, 24>([&](auto g_) {
+            constexpr int g = decltype(g_)::value, t = g / NTI, bb = g % NTI;
+            acc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pc[PA[t]], pb[bb][PB[t]], acc[bb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g < 8) {
+                const float y = w.y[g];
+                float dz;
+                if (DYMODE == A_DY_DENSE) dz = w.z[g];
+                else dz = (w.am == kin0 + g) ? w.z[0] : 0.f;
+                const float z = fmaf(ksc, y, ksh);
+                const float pp = z > 0.f ? dz : 0.f;
+                v[g] = fmaf(ksc, pp, -fmaf(kB, y - kmu, kA));
+                pin(v[g]);
+            } else if constexpr (g == 8) { ra = make_float4(v[0], v[1], v[2], v[3]); level(ra, a0); pin4(ra); pinu(a0); }
+            else if constexpr (g == 9) { level(ra, a1); pin4(ra); pinu(a1); }
+            else if constexpr (g == 10) {
+                a2.x = pack_bf16x2(ra.x, ra.y); a2.y = pack_bf16x2(ra.z, ra.w); rb = make_float4(v[4], v[5], v[6], v[7]); level(rb, b0);
+                pinu(a2); pin4(rb); pinu(b0);
+            } else if constexpr (g == 11) { level(rb, b1); pin4(rb); pinu(b1); }
+            else if constexpr (g == 12) {
+                b2.x = pack_bf16x2(rb.x, rb.y); b2.y = pack_bf16x2(rb.z, rb.w);
+                pinu(b2);
+                pn[0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+                pn[1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+                pn[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+            } else if constexpr (g == 13) {
+                rx.x = fmaxf(fmaf(xsc, wx.x[0], xsh), 0.f); rx.y = fmaxf(fmaf(xsc, wx.x[1], xsh), 0.f);
+                rx.z = fmaxf(fmaf(xsc, wx.x[2], xsh), 0.f); rx.w = fmaxf(fmaf(xsc, wx.x[3], xsh), 0.f);
+                pin4(rx);
+            } else if constexpr (g == 14) { level(rx, q0); pin4(rx); pinu(q0); }
+            else if constexpr (g == 15) { level(rx, q1); pin4(rx); pinu(q1); }
+            else if constexpr (g == 16) {
+                q2.x = pack_bf16x2(rx.x, rx.y); q2.y = pack_bf16x2(rx.z, rx.w);
+                char *dst = stgn + xc * CHS + xq * 8;
+                *reinterpret_cast<uint2 *>(dst) = q0;
+                *reinterpret_cast<uint2 *>(dst + PLB) = q1;
+                *reinterpret_cast<uint2 *>(dst + 2 * PLB) = q2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // Inside a wave the NEXT block's transform (VALU) is woven into the CURRENT block's MFMAs: the matrix pipe runs an MFMA for ~8 issue
+    // slots, and all 8 waves of the workgroup are in the same phase behind the per-block barrier, so without the weave VALU time and matrix
+    // time add up on every SIMD.
+    constexpr int PF = (DYMODE == A_DY_MAX) ? 3 : 2;      // (the dense flavour's raw block is twice as wide: registers)
     Raw dr[PF];
     RawX xr[PF];
+    bf16x8 pa[PF][3];       // (dY planes: a ring like the raw buffers -- block kb's planes sit in slot kb % PF whatever the parity of PF)
     const int last = n_kb - 1;
     if (n_kb > 0) {
         // (no branch sits around a load anywhere below: block indices past the chunk are clamped to its last block -- re-read, never used --
@@ -904,6 +987,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
 #pragma unroll
         for (int i = 0; i < PF - 1; ++i) { fetch(min(i, last), dr[i]); fetch_x(min(i, last), xr[i]); }
         stage_x(0, xr[0], xs_lds);
+        prep(0, dr[0], pa[0]);
         lds_barrier();
     }
     const int n_main = n_kb - n_kb % PF;
@@ -914,8 +998,9 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
             constexpr int NXT = PF - 1;
             fetch(min(kb + NXT, last), dr[(i + NXT) % PF]);
             fetch_x(min(kb + NXT, last), xr[(i + NXT) % PF]);
-            stage_x(min(kb + 1, last), xr[(i + 1) % PF], xs_lds + ((kb + 1) & 1) * STG);
-            compute(kb, dr[i], xs_lds + (kb & 1) * STG);
+            __builtin_amdgcn_sched_barrier(0);
+            weave(pa[i], xs_lds + (kb & 1) * STG, min(kb + 1, last), dr[(i + 1) % PF], pa[(i + 1) % PF], xr[(i + 1) % PF],
+                  xs_lds + ((kb + 1) & 1) * STG);
             lds_barrier();
         }
     }
@@ -924,8 +1009,11 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
     for (int i = 0; i < PF - 1; ++i) {
         const int kb = n_main + i;
         if (kb < n_kb) {
-            if (kb + 1 < n_kb) stage_x(kb + 1, xr[(i + 1) % PF], xs_lds + ((kb + 1) & 1) * STG);
-            compute(kb, dr[i], xs_lds + (kb & 1) * STG);
+            mma(pa[i], xs_lds + (kb & 1) * STG);
+            if (kb + 1 < n_kb) {
+                prep(kb + 1, dr[(i + 1) % PF], pa[(i + 1) % PF]);
+                stage_x(kb + 1, xr[(i + 1) % PF], xs_lds + ((kb + 1) & 1) * STG);
+            }
             lds_barrier();
         }
     }
@@ -1183,7 +1271,7 @@ static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 // blocks of Cout transform the input twice; dW family 0.85 -> 0.82 ms/step.
 static bool dw_rowsx_eligible(int Cin, int Cout, bool dense, int K)   // dw_rowsx_kernel: 128-channel input, 256-channel blocks of Cout
 {
-    return knob(KNOB_DW_ROWSX) != 0 && Cin == 128 && Cout % 256 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));
+    return knob(KNOB_DW_ROWSX) != 0 && Cin == 128 && Cout % 256 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));   // (+ dw_rowsx_rows_ok)
 }
 static bool dw_rows_eligible(int Cin, int Cout, bool dense, int K)
 {
@@ -1206,7 +1294,9 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     const int to = p.TOp / 32, ti = p.TIp / 32;  // 32-wide tiles per workgroup (upper bound)
     const bool off32 = (int64_t)p.rows_per_chunk * std::max<int64_t>(p.Cout, XMODE == A_GROUP ? 1 : p.x.ldx) * 4 < (1ll << 31);
     const bool k4 = DYMODE != A_DY_MAX || p.dy.d.K % 4 == 0;
-    if (VEC && XMODE == A_BNRELU && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
+    // (the kernel addresses with 32-bit byte offsets and walks whole 16-row blocks)
+    const bool rowsx_rows_ok = p.M % 16 == 0 && p.M * (int64_t)p.Cout * 4 < (1ll << 32);
+    if (VEC && XMODE == A_BNRELU && rowsx_rows_ok && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
         dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 256));
         hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE>), g2, dim3(512), 0, st, p);
         return check_launch("papc_mlp_bwd_dw_f32");
