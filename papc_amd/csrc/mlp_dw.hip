@@ -611,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
     const int o0 = blockIdx.y * 64, i0 = blockIdx.z * 64;
     const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
-    const int n_kb = mbeg < mend ? (int)((mend - mbeg + 15) >> 4) : 0;
+    const int n_kb = mbeg < mend ? (int)((mend - mbeg) >> 4) : 0;       // (whole 16-row blocks only: host-checked)
     const DySrc &d = p.dy.d;
     const int Cout = p.Cout, ldx = (int)p.x.ldx;
 
@@ -641,31 +641,36 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     struct Raw { float y[NTO][8], z[NTO][8], x[XYZ ? 3 : NTI][8]; int am[NTO]; };
+    // addresses: wave-uniform base + a 32-bit byte offset per lane (host-checked: M * max(Cout, ldx) * 4 < 2^32, whole 16-row blocks only):
+    // one 32-bit add per load instead of a 64-bit multiply-add and a row clamp
+    auto ldg = [](const float *base, uint32_t byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
+    auto ldgi = [](const int *base, uint32_t byte_off) { return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + byte_off); };
+    const uint32_t ystride = (uint32_t)Cout * 4u, xstride = (uint32_t)(XYZ ? 4 : ldx) * 4u;
+    const uint32_t oy_lane = (uint32_t)((mbeg + 8 * hi) * Cout + o0 + l31) * 4u;
+    const uint32_t ox_lane = XYZ ? (uint32_t)((mbeg + 8 * hi) * 4) * 4u : (uint32_t)((mbeg + 8 * hi) * ldx + i0 + l31) * 4u;
     auto fetch = [&](int kb, Raw &w) {
-        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
+        const uint32_t oy = oy_lane + (uint32_t)kb * 16u * ystride, ox = ox_lane + (uint32_t)kb * 16u * xstride;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            int64_t row = r0 + j;
-            row = row < mend ? row : mend - 1;    // (ragged last block: re-read a valid row, zeroed below)
 #pragma unroll
             for (int a = 0; a < NTO; ++a) {
-                w.y[a][j] = d.y[row * Cout + o0 + 32 * a + l31];
-                if (DYMODE == A_DY_DENSE) w.z[a][j] = d.dz[row * Cout + o0 + 32 * a + l31];
+                w.y[a][j] = ldg(d.y, oy + (uint32_t)j * ystride + 128u * a);
+                if (DYMODE == A_DY_DENSE) w.z[a][j] = ldg(d.dz, oy + (uint32_t)j * ystride + 128u * a);
             }
-            if (XYZ) {
-                const float *q = p.x.x + row * 4;            // (the same 12 bytes for the 32 lanes of a half: one broadcast line)
-                w.x[0][j] = q[0]; w.x[1][j] = q[1]; w.x[2][j] = q[2];
+            if (XYZ) {                                       // (the same 12 bytes for the 32 lanes of a half: one broadcast line)
+                w.x[0][j] = ldg(p.x.x, ox + (uint32_t)j * 16u); w.x[1][j] = ldg(p.x.x, ox + (uint32_t)j * 16u + 4u); w.x[2][j] = ldg(p.x.x, ox + (uint32_t)j * 16u + 8u);
             } else {
 #pragma unroll
-                for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x.x[row * ldx + i0 + 32 * b + l31];
+                for (int b = 0; b < NTI; ++b) w.x[b][j] = ldg(p.x.x, ox + (uint32_t)j * xstride + 128u * b);
             }
         }
         if (DYMODE == A_DY_MAX) {   // K % 16 == 0 (host-checked): the block's 16 rows share one group
-            const int64_t g = fdiv((uint32_t)(mbeg + 16 * (int64_t)kb), d.divK);     // (M < 2^31; no 64-bit division between the loads)
+            const uint32_t g = fdiv((uint32_t)mbeg + 16u * (uint32_t)kb, d.divK);     // (no 64-bit division between the loads)
+            const uint32_t og = (g * (uint32_t)Cout + (uint32_t)(o0 + l31)) * 4u;
 #pragma unroll
             for (int a = 0; a < NTO; ++a) {
-                w.z[a][0] = d.gout[g * Cout + o0 + 32 * a + l31];
-                w.am[a] = d.argmax[g * Cout + o0 + 32 * a + l31];
+                w.z[a][0] = ldg(d.gout, og + 128u * a);
+                w.am[a] = ldgi(d.argmax, og + 128u * a);
             }
         }
     };
@@ -678,10 +683,11 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
         pl[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
     };
     auto compute = [&](int kb, const Raw &w) {
-        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
-        const bool tail = mbeg + 16 * (int64_t)kb + 16 > mend;
         int kin0 = 0;
-        if (DYMODE == A_DY_MAX) kin0 = (int)(r0 - (int64_t)fdiv((uint32_t)(mbeg + 16 * (int64_t)kb), d.divK) * d.K);
+        if (DYMODE == A_DY_MAX) {
+            const uint32_t b0 = (uint32_t)mbeg + 16u * (uint32_t)kb;
+            kin0 = (int)(b0 - fdiv(b0, d.divK) * (uint32_t)d.K) + 8 * hi;
+        }
         bf16x8 pa[NTO][3], pb[NTI][3];
 #pragma unroll
         for (int a = 0; a < NTO; ++a) {
@@ -695,7 +701,6 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
                 const float z = fmaf(ksc[a], y, ksh[a]);
                 const float pp = z > 0.f ? dz : 0.f;
                 v[j] = fmaf(ksc[a], pp, -fmaf(kB[a], y - kmu[a], kA[a]));
-                if (tail && r0 + j >= mend) v[j] = 0.f;
             }
             split8(v, pa[a]);
         }
@@ -706,7 +711,6 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
             for (int j = 0; j < 8; ++j) {
                 if (XYZ) v[j] = fmaxf(fmaf(wfk[b].z, w.x[2][j], fmaf(wfk[b].y, w.x[1][j], fmaf(wfk[b].x, w.x[0][j], wfk[b].w))), 0.f);
                 else v[j] = fmaxf(fmaf(xs[b], w.x[b][j], xh[b]), 0.f);
-                if (tail && r0 + j >= mend) v[j] = 0.f;
             }
             split8(v, pb[b]);
         }
@@ -1074,21 +1078,28 @@ __global__ __launch_bounds__(512, 2) void dw_rows_max_kernel(DwMaxArgs p)
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     struct Raw { float x[NTI][8]; float ps[2]; int am[2]; };
+    // (32-bit byte offsets from wave-uniform bases -- M * 128 channels * 4 bytes < 2^32 is part of papc_mlp_max_nostore_ok's M < 2^31 / 4:
+    // host-checked -- instead of 64-bit index arithmetic per load)
+    auto ldg = [](const float *base, uint32_t byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
+    auto ldgi = [](const int *base, uint32_t byte_off) { return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + byte_off); };
+    const uint32_t ox_lane = (uint32_t)((mbeg + 8 * hi) * CI + l31) * 4u;
+    const uint32_t og_lane = (uint32_t)(o0 + l31) * 4u;
     auto fetch = [&](int kb, Raw &w) {
-        const int64_t r0 = mbeg + 16 * (int64_t)kb + 8 * hi;
+        const uint32_t o = ox_lane + (uint32_t)kb * (16u * CI * 4u);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-            for (int b = 0; b < NTI; ++b) w.x[b][j] = p.x[(r0 + j) * CI + 32 * b + l31];
-        const int64_t g = (mbeg + 16 * (int64_t)kb) >> kshift;           // K % 16 == 0: the block's 16 rows share one group (K a power of two)
+            for (int b = 0; b < NTI; ++b) w.x[b][j] = ldg(p.x, o + (uint32_t)(j * CI + 32 * b) * 4u);
+        const uint32_t g = ((uint32_t)mbeg + 16u * (uint32_t)kb) >> kshift;           // K % 16 == 0: the block's 16 rows share one group (K a power of two)
+        const uint32_t og = g * (uint32_t)Cout * 4u + og_lane;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            w.ps[a] = p.psel[g * Cout + o0 + 32 * a + l31];
-            w.am[a] = p.argmax[g * Cout + o0 + 32 * a + l31];
+            w.ps[a] = ldg(p.psel, og + 128u * a);
+            w.am[a] = ldgi(p.argmax, og + 128u * a);
         }
     };
     auto compute = [&](int kb, const Raw &w) {
-        const int kin0 = (int)((mbeg + 16 * (int64_t)kb) & (p.K - 1)) + 8 * hi;
+        const int kin0 = (int)(((uint32_t)mbeg + 16u * (uint32_t)kb) & (uint32_t)(p.K - 1)) + 8 * hi;
         bf16x8 pa[2][3], pb[NTI][3];
 #pragma unroll
         for (int b = 0; b < NTI; ++b) {
@@ -1301,7 +1312,8 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
         hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE>), g2, dim3(512), 0, st, p);
         return check_launch("papc_mlp_bwd_dw_f32");
     }
-    if (VEC && XMODE == A_BNRELU && dw_rows_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
+    const bool rows_rows_ok = p.M % 16 == 0 && p.M * (int64_t)std::max(p.Cout, p.Cin) * 4 < (1ll << 32);
+    if (VEC && XMODE == A_BNRELU && rows_rows_ok && dw_rows_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
         // narrow input (64 channels): row-streaming kernel, every thread loads + transforms + multiplies
         dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 64), (unsigned)(p.Cin / 64));
         hipLaunchKernelGGL((dw_rows_kernel<DYMODE>), g2, dim3(512), 0, st, p);
@@ -1383,7 +1395,8 @@ extern "C" int papc_mlp_bwd_dw_f32(const papc_bwd_dy *dy, int a_mode, const floa
     if (rc) return rc;
     if (a_mode == A_XYZ) {   // recomputed first-layer activations: only the row-streaming kernel has the flavour
         const bool dense_ = dy->dz_mode == PAPC_DZ_DENSE;
-        PAPC_REQUIRE(vdy && p.x.vec && dw_rows_eligible(Cin, Cout, dense_, dy->K) && rows_per_chunk % 16 == 0, PAPC_E_UNSUPPORTED,
+        PAPC_REQUIRE(vdy && p.x.vec && dw_rows_eligible(Cin, Cout, dense_, dy->K) && rows_per_chunk % 16 == 0 && M % 16 == 0 &&
+                     M * (int64_t)Cout * 4 < (1ll << 32), PAPC_E_UNSUPPORTED,
                      "papc_mlp_bwd_dw_f32: PAPC_A_XYZ is not built for Cin=%d Cout=%d (see papc_mlp_xyz_ok)", Cin, Cout);
         fill_dy(p.dy.d, dy);
         p.dy.d.C = Cout;

@@ -1053,6 +1053,7 @@ int papc_mlp_xyz_ok(int64_t M, int C1, int C2)
     if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !knob(KNOB_DW_ROWS) || knob(KNOB_DW_F32)) return 0;
     if (M % 64 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES)) return 0;
     if (C1 != 64 || !(C2 == 64 || C2 == 128)) return 0;
+    if (M * (int64_t)C2 * 4 >= (1ll << 32)) return 0;      // (the dW kernel addresses with 32-bit byte offsets)
     if ((C1 / 64) * (C2 / 64) > knob(KNOB_DW_ROWS_BLOCKS)) return 0;
     return 1;
 }
@@ -1064,7 +1065,7 @@ int papc_mlp_max_nostore_ok(int64_t M, int Cin, int Cout, int K)
 {
     if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !knob(KNOB_STREAM_ASM) || !knob(KNOB_STREAM_MAXCAT) || !knob(KNOB_DW_ROWS) || knob(KNOB_DW_F32)) return 0;
     if (!knob(KNOB_MAX_NOSTORE)) return 0;
-    if (M % 128 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES) || M >= (1ll << 31)) return 0;
+    if (M % 128 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES) || M * (int64_t)Cout * 4 >= (1ll << 32)) return 0;   // (the dW kernel addresses with 32-bit byte offsets)
     if (!(K == 32 || K == 64 || K == 128) || !papc_mlp_gemm_gmax_ok(M, Cout, K)) return 0;
     if (!(Cin == 64 && Cout == 128)) return 0;
     return 1;
