@@ -797,14 +797,17 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
 // LDS ([plane][channel][16 rows], 48-byte channel stride: conflict-free ds_read_b128), double-buffered, ONE barrier per block --
 // and since all waves do identical work the barrier costs little skew.  A wave accumulates 32 x 128 of dW (4 accumulators) and
 // stores its rows of the partial itself: no cross-wave fold.
-template <int DYMODE>
-__global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
+template <int DYMODE, int NW>      // NW waves = NW 32-channel groups of Cout per workgroup: 8 (256-channel blocks) or 4 (128-channel blocks, two workgroups per CU)
+__global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
 {
     constexpr int NTI = 4, CI = 128, CHS = 48, PLB = CI * CHS, STG = 3 * PLB;   // bytes: channel stride, plane, stage
+    constexpr int CB = 32 * NW;              // channels of Cout per workgroup
+    constexpr int RPT = 32 / NW;             // x rows per thread and block (the 64 NW threads share 16 rows x 128 channels): 4 or 8
+    constexpr int NX4 = RPT / 4;             // ... as float4 groups
     __shared__ __attribute__((aligned(16))) char xs_lds[2 * STG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int co = blockIdx.y * 256 + wave * 32 + l31;       // this lane's dY channel
+    const int co = blockIdx.y * CB + wave * 32 + l31;        // this lane's dY channel
     const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
     const int n_kb = mbeg < mend ? (int)((mend - mbeg) >> 4) : 0;       // (whole 16-row blocks only: host-checked)
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
 
     const float ksc = d.scale[co], ksh = d.shift[co], kmu = d.mean[co];
     const float kA = ksc * d.c1[co], kB = ksc * d.c2[co] * d.invstd[co];
-    // x producer role: channel xc, rows 4 xq .. 4 xq + 3 of the block
+    // x producer role: channel xc, rows RPT xq .. RPT xq + RPT - 1 of the block
     const int xc = tid & 127, xq = tid >> 7;
     const float xsc = p.x.sc[xc], xsh = p.x.sh[xc];
 
@@ -824,14 +827,14 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
     struct Raw { float y[8], z[8]; int am; };
-    struct RawX { float x[4]; };
+    struct RawX { float x[RPT]; };
     // addresses: wave-uniform base + a 32-bit byte offset per lane (host-checked: M * Cout * 4 < 2^32 and whole 16-row blocks only), so a
     // load costs one 32-bit add instead of a 64-bit multiply-add and a row clamp -- address arithmetic was a third of the loop's VALU work
     auto ldg = [](const float *base, uint32_t byte_off) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
     auto ldgi = [](const int *base, uint32_t byte_off) { return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + byte_off); };
     const uint32_t ystride = (uint32_t)Cout * 4u;
     const uint32_t oy_lane = (uint32_t)((mbeg + 8 * hi) * Cout + co) * 4u;        // row (mbeg + 8 hi) of this lane's channel
-    const uint32_t ox_lane = (uint32_t)((mbeg + 4 * xq) * CI + xc) * 4u;
+    const uint32_t ox_lane = (uint32_t)((mbeg + RPT * xq) * CI + xc) * 4u;
     auto fetch = [&](int kb, Raw &w) {
         const uint32_t o0 = oy_lane + (uint32_t)kb * 16u * ystride;
 #pragma unroll
@@ -849,19 +852,22 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
     auto fetch_x = [&](int kb, RawX &w) {
         const uint32_t o0 = ox_lane + (uint32_t)kb * (16u * CI * 4u);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w.x[j] = ldg(p.x.x, o0 + (uint32_t)j * (CI * 4u));
+        for (int j = 0; j < RPT; ++j) w.x[j] = ldg(p.x.x, o0 + (uint32_t)j * (CI * 4u));
     };
-    auto stage_x = [&](int kb, const RawX &w, char *stg) {   // this thread's 4 rows of channel xc -> three 8-byte plane pieces
+    auto stage_x = [&](int kb, const RawX &w, char *stg) {   // this thread's RPT rows of channel xc -> three (2 RPT)-byte plane pieces
         (void)kb;
-        float4 v;
-        v.x = fmaxf(fmaf(xsc, w.x[0], xsh), 0.f); v.y = fmaxf(fmaf(xsc, w.x[1], xsh), 0.f);
-        v.z = fmaxf(fmaf(xsc, w.x[2], xsh), 0.f); v.w = fmaxf(fmaf(xsc, w.x[3], xsh), 0.f);
-        uint2 q0, q1, q2;
-        split3(v, q0, q1, q2);
-        char *dst = stg + xc * CHS + xq * 8;
-        *reinterpret_cast<uint2 *>(dst) = q0;
-        *reinterpret_cast<uint2 *>(dst + PLB) = q1;
-        *reinterpret_cast<uint2 *>(dst + 2 * PLB) = q2;
+#pragma unroll
+        for (int h = 0; h < NX4; ++h) {
+            float4 v;
+            v.x = fmaxf(fmaf(xsc, w.x[4 * h + 0], xsh), 0.f); v.y = fmaxf(fmaf(xsc, w.x[4 * h + 1], xsh), 0.f);
+            v.z = fmaxf(fmaf(xsc, w.x[4 * h + 2], xsh), 0.f); v.w = fmaxf(fmaf(xsc, w.x[4 * h + 3], xsh), 0.f);
+            uint2 q0, q1, q2;
+            split3(v, q0, q1, q2);
+            char *dst = stg + xc * CHS + xq * (2 * RPT) + 8 * h;
+            *reinterpret_cast<uint2 *>(dst) = q0;
+            *reinterpret_cast<uint2 *>(dst + PLB) = q1;
+            *reinterpret_cast<uint2 *>(dst + 2 * PLB) = q2;
+        }
     };
     // prep: dY of block kb (this lane's channel, its 8 rows) -> the three bf16 planes of the MFMA's row operand
     auto prep = [&](int kb, const Raw &w, bf16x8 (&pa)[3]) {
@@ -960,18 +966,21 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
                 pn[0] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
                 pn[1] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
                 pn[2] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
-            } else if constexpr (g == 13) {
-                rx.x = fmaxf(fmaf(xsc, wx.x[0], xsh), 0.f); rx.y = fmaxf(fmaf(xsc, wx.x[1], xsh), 0.f);
-                rx.z = fmaxf(fmaf(xsc, wx.x[2], xsh), 0.f); rx.w = fmaxf(fmaf(xsc, wx.x[3], xsh), 0.f);
-                pin4(rx);
-            } else if constexpr (g == 14) { level(rx, q0); pin4(rx); pinu(q0); }
-            else if constexpr (g == 15) { level(rx, q1); pin4(rx); pinu(q1); }
-            else if constexpr (g == 16) {
-                q2.x = pack_bf16x2(rx.x, rx.y); q2.y = pack_bf16x2(rx.z, rx.w);
-                char *dst = stgn + xc * CHS + xq * 8;
-                *reinterpret_cast<uint2 *>(dst) = q0;
-                *reinterpret_cast<uint2 *>(dst + PLB) = q1;
-                *reinterpret_cast<uint2 *>(dst + 2 * PLB) = q2;
+            } else if constexpr (g >= 13 && g < 13 + 4 * NX4) {          // this thread's share of x: four slices per float4 group
+                constexpr int h = (g - 13) / 4, step = (g - 13) % 4;
+                if constexpr (step == 0) {
+                    rx.x = fmaxf(fmaf(xsc, wx.x[4 * h + 0], xsh), 0.f); rx.y = fmaxf(fmaf(xsc, wx.x[4 * h + 1], xsh), 0.f);
+                    rx.z = fmaxf(fmaf(xsc, wx.x[4 * h + 2], xsh), 0.f); rx.w = fmaxf(fmaf(xsc, wx.x[4 * h + 3], xsh), 0.f);
+                    pin4(rx);
+                } else if constexpr (step == 1) { level(rx, q0); pin4(rx); pinu(q0); }
+                else if constexpr (step == 2) { level(rx, q1); pin4(rx); pinu(q1); }
+                else {
+                    q2.x = pack_bf16x2(rx.x, rx.y); q2.y = pack_bf16x2(rx.z, rx.w);
+                    char *dst = stgn + xc * CHS + xq * (2 * RPT) + 8 * h;
+                    *reinterpret_cast<uint2 *>(dst) = q0;
+                    *reinterpret_cast<uint2 *>(dst + PLB) = q1;
+                    *reinterpret_cast<uint2 *>(dst + 2 * PLB) = q2;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -980,7 +989,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
     // Inside a wave the NEXT block's transform (VALU) is woven into the CURRENT block's MFMAs: the matrix pipe runs an MFMA for ~8 issue
     // slots, and all 8 waves of the workgroup are in the same phase behind the per-block barrier, so without the weave VALU time and matrix
     // time add up on every SIMD.
-    constexpr int PF = (DYMODE == A_DY_MAX) ? 3 : 2;      // (the dense flavour's raw block is twice as wide: registers)
+    constexpr int PF = 3;
     Raw dr[PF];
     RawX xr[PF];
     bf16x8 pa[PF][3];       // (dY planes: a ring like the raw buffers -- block kb's planes sit in slot kb % PF whatever the parity of PF)
@@ -1024,7 +1033,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
 
     // ---- this wave's 32 rows of the partial: row (cout) = (r & 3) + 8 (r >> 2) + 4 half, col (cin) = lane & 31
     float *out = p.dw_partial + (int64_t)blockIdx.x * p.part_ld;
-    const int cbase = blockIdx.y * 256 + wave * 32;
+    const int cbase = blockIdx.y * CB + wave * 32;
 #pragma unroll
     for (int b = 0; b < NTI; ++b)
 #pragma unroll
@@ -1032,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void dw_rowsx_kernel(DwArgs p)
             const int c = cbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
             out[(int64_t)c * CI + 32 * b + l31] = acc[b][r];
         }
-    if (p.db_partial && tid < 256) p.db_partial[(int64_t)blockIdx.x * p.part_ld + blockIdx.y * 256 + tid] = 0.f;
+    if (p.db_partial && tid < CB) p.db_partial[(int64_t)blockIdx.x * p.part_ld + blockIdx.y * CB + tid] = 0.f;
 }
 
 static unsigned long long *g_dw_dbg = nullptr;
@@ -1282,7 +1291,7 @@ static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 // blocks of Cout transform the input twice; dW family 0.85 -> 0.82 ms/step.
 static bool dw_rowsx_eligible(int Cin, int Cout, bool dense, int K)   // dw_rowsx_kernel: 128-channel input, 256-channel blocks of Cout
 {
-    return knob(KNOB_DW_ROWSX) != 0 && Cin == 128 && Cout % 256 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));   // (+ dw_rowsx_rows_ok)
+    return knob(KNOB_DW_ROWSX) != 0 && Cin == 128 && Cout % 128 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));   // (+ rowsx_rows_ok at the launch)
 }
 static bool dw_rows_eligible(int Cin, int Cout, bool dense, int K)
 {
@@ -1308,8 +1317,13 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     // (the kernel addresses with 32-bit byte offsets and walks whole 16-row blocks)
     const bool rowsx_rows_ok = p.M % 16 == 0 && p.M * (int64_t)p.Cout * 4 < (1ll << 32);
     if (VEC && XMODE == A_BNRELU && rowsx_rows_ok && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
-        dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 256));
-        hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE>), g2, dim3(512), 0, st, p);
+        if (p.Cout % 256 == 0) {
+            dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 256));
+            hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 8>), g2, dim3(512), 0, st, p);
+        } else {        // 128-channel blocks: four waves per workgroup, two workgroups per CU
+            dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 128));
+            hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 4>), g2, dim3(256), 0, st, p);
+        }
         return check_launch("papc_mlp_bwd_dw_f32");
     }
     const bool rows_rows_ok = p.M % 16 == 0 && p.M * (int64_t)std::max(p.Cout, p.Cin) * 4 < (1ll << 32);
@@ -1369,7 +1383,8 @@ extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mo
     int dev = 0;
     static int ncu = 0;
     if (!ncu) { ncu = 256; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    const int64_t want = xk ? std::max<int64_t>(1, ncu / (Cout / 256)) : std::max<int64_t>(1, ncu / ((Cout / 64) * (Cin / 64)));
+    const int64_t want = xk ? (Cout % 256 == 0 ? std::max<int64_t>(1, ncu / (Cout / 256)) : std::max<int64_t>(1, 2 * ncu / (Cout / 128)))
+                            : std::max<int64_t>(1, ncu / ((Cout / 64) * (Cin / 64)));
     int64_t rpc = cdiv(M, want);
     rpc = std::max<int64_t>(64, cdiv(rpc, 64) * 64);
     return (int)std::min<int64_t>(rpc, 1 << 24);
