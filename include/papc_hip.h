@@ -589,6 +589,17 @@ int papc_copy2d_f32(const float *src, int64_t src_ld, float *dst, int64_t dst_ld
                     papc_stream_t stream);
 int papc_reduce_partials_strided_f32(const float *partial, int n_chunks, int64_t ld, int rows, int cols, float *out,
                                      int64_t out_ld, int accumulate, papc_stream_t stream);
+/* count <= 8 strided 3-D copies in ONE launch (`jobs` is a HOST array read during the call):
+ *   dst[b*db + r*dr + c*dc] = src[b*sb + r*sr + c*sc]   for b < B, r < R, c < C   (strides in elements; a stride of 0 broadcasts)
+ * -- the concatenations / transposed copies around the layers (pointnet2_basic_layers.py:205, :280, :326-327;
+ * segment/pointnet2/pointnet2.py:45) and their backward splits, as one kernel instead of one library copy per piece. */
+typedef struct papc_copy_job {
+    const float *src;
+    float *dst;
+    int32_t B, R, C;
+    int64_t sb, sr, sc, db, dr, dc;
+} papc_copy_job;
+int papc_copy_strided_batch_f32(const papc_copy_job *jobs, int count, papc_stream_t stream);
 int papc_scale_by_f32(const float *x, const float *scalar, int64_t n, float *out, papc_stream_t stream);
 
 /* Adam with paddle semantics (L2 `weight_decay` added to the gradient): n contiguous params.  The betas are doubles:

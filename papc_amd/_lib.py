@@ -41,6 +41,12 @@ class BwdRed(ctypes.Structure):
     _fields_ = [("y", c_p), ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("red_partial", c_p)]
 
 
+class CopyJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("B", ctypes.c_int32), ("R", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("sb", ctypes.c_int64), ("sr", ctypes.c_int64), ("sc", ctypes.c_int64), ("db", ctypes.c_int64), ("dr", ctypes.c_int64),
+                ("dc", ctypes.c_int64)]
+
+
 class ReduceJob(ctypes.Structure):
     """papc_reduce_job"""
     _fields_ = [("partial", c_p), ("n_chunks", ctypes.c_int32), ("accumulate", ctypes.c_int32), ("ld", c_l), ("n1", c_l), ("n2", c_l),
@@ -130,6 +136,7 @@ SIGNATURES = {
     "papc_rotate_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_rotate_iou_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "papc_fill_f32": (c_i, [c_p, c_l, c_f, c_p]),
+    "papc_copy_strided_batch_f32": (c_i, [c_p, c_i, c_p]),
     "papc_copy2d_f32": (c_i, [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p]),
     "papc_reduce_partials_strided_f32": (c_i, [c_p, c_i, c_l, c_i, c_i, c_p, c_l, c_i, c_p]),
     "papc_scale_by_f32": (c_i, [c_p, c_p, c_l, c_p, c_p]),
@@ -207,6 +214,20 @@ def const_zeros(shape, device):
         if _capturing():     # a tensor born inside a hipGraph capture lives in that graph's pool and is only filled on replay: never cache it
             return torch.zeros(tuple(shape), device=device, dtype=torch.float32)
         t = _CONSTS[key] = torch.zeros(tuple(shape), device=device, dtype=torch.float32)
+    return t
+
+
+def const_idx3(B, N, device):
+    """cached read-only int32 [B, N, 3] = (0, 1, 2) per row: the neighbour indices the reference's sort-then-argsort yields
+    (pointnet2_basic_layers.py:316-317, see layers.PointNetFeaturePropagation)"""
+    import torch
+    key = ("idx3", int(B), int(N), str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        mk = lambda: torch.arange(3, device=device, dtype=torch.int32).expand(B, N, 3).contiguous()
+        if _capturing():
+            return mk()
+        t = _CONSTS[key] = mk()
     return t
 
 

@@ -392,6 +392,50 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const float *__restrict__ s
     }
 }
 
+// Up to 8 strided 3-D copies in one launch: dst[b*db + r*dr + c*dc] = src[b*sb + r*sr + c*sc] over a [B, R, C] index space each -- the
+// concatenations and transposed copies around the layers (torch.cat of the MSG branches, pointnet2_basic_layers.py:280; of points1 and the
+// interpolated features, :326-327; points.transpose(1, 2) :205) and their backward splits.  32 x 32 (r, c) tiles go through LDS so that both
+// the reads and the writes run along whichever index is contiguous on their side.
+struct CopyJobs {
+    const float *src[8];
+    float *dst[8];
+    int B[8], R[8], C[8];
+    int64_t sb[8], sr[8], sc[8], db[8], dr[8], dc[8];
+};
+
+__global__ __launch_bounds__(256) void copy_strided_batch_kernel(CopyJobs j)
+{
+    __shared__ float tile[32][33];
+    const int q = blockIdx.y;
+    const int R = j.R[q], C = j.C[q];
+    const int tr = (R + 31) >> 5, tc = (C + 31) >> 5;
+    const int64_t ntiles = (int64_t)j.B[q] * tr * tc;
+    const float *src = j.src[q];
+    float *dst = j.dst[q];
+    const int64_t sb = j.sb[q], sr = j.sr[q], sc = j.sc[q], db = j.db[q], dr = j.dr[q], dc = j.dc[q];
+    const bool src_along_c = sc == 1 || sr != 1, dst_along_c = dc == 1 || dr != 1;     // the index consecutive threads walk, per side
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = (int)(t / (tr * tc));
+        const int rem = (int)(t - (int64_t)b * tr * tc);
+        const int r0 = (rem / tc) * 32, c0 = (rem % tc) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = ty + 8 * i;                                    // slow index of the pass
+            const int r = r0 + (src_along_c ? a : tx), c = c0 + (src_along_c ? tx : a);
+            if (r < R && c < C) tile[r - r0][c - c0] = src[b * sb + r * sr + c * sc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int a = ty + 8 * i;
+            const int r = r0 + (dst_along_c ? a : tx), c = c0 + (dst_along_c ? tx : a);
+            if (r < R && c < C) dst[b * db + r * dr + c * dc] = tile[r - r0][c - c0];
+        }
+        __syncthreads();
+    }
+}
+
 // out[r * out_ld + c] (+)= sum_t part[t * ld + r * cols + c]   (fixed summation tree: deterministic)
 // A workgroup = 16 consecutive elements x 64 chunk slices: slice s sums chunks s, s+64, ... in order, then the 64 slice sums are folded
 // through LDS in a fixed binary tree.  (One thread per element walking all chunks took 80+ us for the 2048 x 192 gather-add partials.)
@@ -809,6 +853,26 @@ int papc_copy2d_f32(const float *src, int64_t src_ld, float *dst, int64_t dst_ld
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid((int64_t)rows * cols)), dim3(256), 0, st, src, src_ld, dst, dst_ld, rows, cols, transpose);
     return check_launch("papc_copy2d_f32");
+}
+
+int papc_copy_strided_batch_f32(const papc_copy_job *jobs, int count, papc_stream_t stream)
+{
+    PAPC_REQUIRE(jobs, PAPC_E_INVALID, "papc_copy_strided_batch_f32: null jobs");
+    PAPC_REQUIRE(count >= 1 && count <= 8, PAPC_E_INVALID, "papc_copy_strided_batch_f32: count=%d not in [1, 8]", count);
+    CopyJobs j;
+    memset(&j, 0, sizeof(j));
+    int64_t tmax = 0;
+    for (int i = 0; i < count; ++i) {
+        const papc_copy_job &c = jobs[i];
+        PAPC_REQUIRE(c.src && c.dst && c.B >= 1 && c.R >= 1 && c.C >= 1, PAPC_E_INVALID, "papc_copy_strided_batch_f32: null pointer or empty job %d", i);
+        j.src[i] = c.src; j.dst[i] = c.dst; j.B[i] = c.B; j.R[i] = c.R; j.C[i] = c.C;
+        j.sb[i] = c.sb; j.sr[i] = c.sr; j.sc[i] = c.sc; j.db[i] = c.db; j.dr[i] = c.dr; j.dc[i] = c.dc;
+        tmax = std::max(tmax, (int64_t)c.B * cdiv(c.R, 32) * cdiv(c.C, 32));
+    }
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(copy_strided_batch_kernel, dim3((unsigned)std::min<int64_t>(tmax, 4096), (unsigned)count), dim3(256), 0, st, j);
+    return check_launch("papc_copy_strided_batch_f32");
 }
 
 int papc_reduce_partials_strided_f32(const float *partial, int n_chunks, int64_t ld, int rows, int cols, float *out, int64_t out_ld,

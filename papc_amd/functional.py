@@ -202,7 +202,8 @@ class _ThreeInterpolate(torch.autograd.Function):
     def forward(ctx, points2, idx3, weight3):
         _need_cuda(points2, idx3, weight3)
         points2 = _f32c(points2)
-        idx3 = idx3.to(torch.int32).contiguous()
+        if idx3.dtype != torch.int32 or not idx3.is_contiguous():
+            idx3 = idx3.to(torch.int32).contiguous()
         weight3 = _f32c(weight3)
         B, S, D = points2.shape
         N = idx3.shape[1]
@@ -218,7 +219,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         idx3, weight3 = ctx.saved_tensors
         B, N, S, D = ctx.shape
         g = _f32c(g)
-        gp = torch.zeros(B, S, D, device=g.device, dtype=torch.float32)
+        gp = _lib.zeros((B, S, D), g.device)
         check(_lib.load().papc_three_interpolate_bwd_f32(ptr(g), ptr(idx3), ptr(weight3), B, N, S, D, ptr(gp), stream_ptr()),
               "papc_three_interpolate_bwd_f32")
         return gp, None, None

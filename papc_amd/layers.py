@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import functional as F_
+from .copyops import cat_copy, contiguous_copy, pad_cols
 from .mlp import StackSpec, shared_mlp_max
 
 
@@ -31,23 +32,23 @@ def _bn_buffers(bns):
     return [(bn.running_mean, bn.running_var) for bn in bns]
 
 
-def _pad_features(feats, params, xyz_first):
+def _pad_features(feats, params, xyz_first, feats_padded=None):
     """The gather kernels move features as float4: a feature count that is not a multiple of 4 (e.g. the 3 normal /
     xyz channels the segmentation nets feed to SA1) would fall to the element-wise path, ~10x slower.  Pad the features with
     zero channels and the first conv weight with matching zero columns instead (a view-level change: same result, the
     gradient flows back to the real columns through the concatenation)."""
-    D = feats.shape[2]
+    D = feats.shape[2] if feats_padded is None else feats_padded[1]
     pad = (-D) % 4
     if pad == 0:
         return feats, params, D
-    feats = torch.nn.functional.pad(feats, (0, pad))
+    if feats_padded is None:
+        feats = pad_cols(feats, D, pad)
+    else:
+        feats = feats_padded[0]               # (padded once by the caller for several stacks: the MSG branches)
     w = params[0]
     w2 = w.reshape(w.shape[0], -1)
-    z = w2.new_zeros(w2.shape[0], pad)
-    if xyz_first:   # columns [xyz(3), feats(D)] -> [xyz, feats, 0]
-        w_pad = torch.cat([w2, z], 1)
-    else:           # columns [feats(D), xyz(3)] -> [feats, 0, xyz]
-        w_pad = torch.cat([w2[:, :D], z, w2[:, D:]], 1)
+    # columns [xyz(3), feats(D)] -> [xyz, feats, 0]   or   [feats(D), xyz(3)] -> [feats, 0, xyz]
+    w_pad = pad_cols(w2, w2.shape[1] if xyz_first else D, pad)
     return feats, [w_pad] + list(params[1:]), D + pad
 
 
@@ -104,7 +105,7 @@ class PointNetSetAbstraction(nn.Module):
             xyz = xyz.float()
         feats = None
         if points is not None:
-            feats = points.transpose(1, 2).contiguous().float()                 # :205  [B,N,D]
+            feats = contiguous_copy(points.float().transpose(1, 2))                 # :205  [B,N,D]
         B, N, _ = xyz.shape
         D = 0 if feats is None else feats.shape[2]
         if self.group_all:                                                      # sample_and_group_all :160-176
@@ -162,7 +163,7 @@ class PointNetSetAbstractionMsg(nn.Module):
             xyz = xyz.float()
         feats = None
         if points is not None:
-            feats = points.transpose(1, 2).contiguous().float()
+            feats = contiguous_copy(points.float().transpose(1, 2))
         B, N, _ = xyz.shape
         D = 0 if feats is None else feats.shape[2]
         S = self.npoint
@@ -170,16 +171,19 @@ class PointNetSetAbstractionMsg(nn.Module):
         idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz)   # :260-262, one scan
         outs = []
         feats_in = feats
+        padded = None
+        if feats_in is not None and D % 4 != 0:          # (one padded copy of the features for all branches)
+            padded = (pad_cols(feats_in, D, (-D) % 4), D)
         for i, K in enumerate(self.nsample_list):
             params = _stack_params(self.conv_blocks[i], self.bn_blocks[i])
             Dp = D
             if feats_in is not None:
-                feats, params, Dp = _pad_features(feats_in, params, False)
+                feats, params, Dp = _pad_features(feats_in, params, False, padded)
             spec = StackSpec(B, N, S, K, Dp, xyz_first=False, eps=self.bn_blocks[i][0].eps, momentum=0.9,
                              cut_gather_grad=self.reference_quirks)             # feats first, then xyz (:267)
             o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats, idxs[i], params)   # :271-276
             outs.append(o.view(B, S, -1))
-        new_points_concat = torch.cat(outs, dim=2).transpose(1, 2)              # :280  [B,D',S]
+        new_points_concat = cat_copy(outs, 2).transpose(1, 2)                   # :280  [B,D',S]
         return new_xyz.transpose(1, 2), new_points_concat
 
 
@@ -222,7 +226,7 @@ class PointNetFeaturePropagation(nn.Module):
             return points2.expand(B, N, points2.shape[2])                        # paddle.tile (:312)
         _, idx3, w3 = F_.three_nn(xyz1, xyz2)
         if self.neighbours == "reference":
-            idx3 = torch.arange(3, device=idx3.device, dtype=torch.int32).expand(B, N, 3)   # argsort of a sorted row
+            idx3 = _lib.const_idx3(B, N, idx3.device)                                 # argsort of a sorted row: 0, 1, 2 (cached constant)
         return F_.three_interpolate(points2, idx3, w3)
 
     def forward(self, xyz1, xyz2, points1, points2):
@@ -232,7 +236,7 @@ class PointNetFeaturePropagation(nn.Module):
         B, N, _ = xyz1.shape
         interpolated = self.interpolate(xyz1, xyz2, points2)
         if points1 is not None:
-            new_points = torch.cat([points1.transpose(1, 2).float(), interpolated], dim=-1)   # :326-327
+            new_points = cat_copy([points1.transpose(1, 2).float(), interpolated], 2)         # :326-327
         else:
             new_points = interpolated
         rows = new_points.reshape(B * N, new_points.shape[2])

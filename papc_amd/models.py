@@ -15,6 +15,7 @@ from .layers import (PointNetFeaturePropagation, PointNetSetAbstraction, PointNe
                      _stack_params)
 from . import _lib
 from . import head as _head
+from .copyops import cat_copy
 from .mlp import StackSpec, shared_mlp_max
 
 import os
@@ -238,7 +239,7 @@ class _PartSegBase(nn.Module):
         l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)                                 # :42
         l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points)                                 # :43
         cls_label_one_hot = cls_label.reshape(B, self.num_classes, 1).expand(B, self.num_classes, N)   # :44
-        l0_points = self.fp1(l0_xyz, l1_xyz, torch.cat([cls_label_one_hot, l0_xyz, l0_points], 1), l1_points)   # :45
+        l0_points = self.fp1(l0_xyz, l1_xyz, cat_copy([cls_label_one_hot, l0_xyz.float(), l0_points.float()], 1), l1_points)   # :45
         rows = l0_points.transpose(1, 2).reshape(B * N, 128)            # point-major rows (a view of fp1's buffer)
         if self.training:                                               # :47 relu(bn1(conv1(.))) on the fused stack
             spec = StackSpec(B, N, N, 1, 128, True, eps=self.bn1.eps, momentum=0.9, pool=False)
