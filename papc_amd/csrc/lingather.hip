@@ -52,10 +52,16 @@ __device__ __forceinline__ LgRow lg_row(const LinGatherArgs &a, int64_t m)
     return r;
 }
 
-// y = P[j] + W_x d + b, per-workgroup column statistics; thread = (row slot, channel quad)
+constexpr int LG_ROWS = 256;                    // rows a workgroup stages metadata for at a time
+
+// y = P[j] + W_x d + b, per-workgroup column statistics; thread = (row slot, channel quad).  The per-row metadata (neighbour index, centred
+// coordinates) is fetched ONCE per row by one thread and staged in LDS: the C/4 threads of a row would otherwise each repeat the same
+// seven loads (the kernel was bound by memory instructions, as the backward one was)
 __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
 {
     __shared__ float red[LG_T * 8];
+    __shared__ int s_p[LG_ROWS];                 // b * N + j, or -1 for a no-hit row
+    __shared__ float s_dx[LG_ROWS], s_dy[LG_ROWS], s_dz[LG_ROWS];
     const int tid = threadIdx.x;
     const int CQ = a.C >> 2, RSL = LG_T / CQ;
     const int cq = tid % CQ, slot = tid / CQ;
@@ -72,32 +78,42 @@ __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
     const int64_t mbeg = (int64_t)blockIdx.x * a.rows_per_wg, mend = min(a.M, mbeg + a.rows_per_wg);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     constexpr int U = 4;
-    if (act) {
-        for (int64_t m0 = mbeg + slot; m0 < mend; m0 += (int64_t)U * RSL) {
-            LgRow r[U];
+    for (int64_t base = mbeg; base < mend; base += LG_ROWS) {
+        const int nrows = (int)min((int64_t)LG_ROWS, mend - base);
+        __syncthreads();
+        for (int rr = tid; rr < nrows; rr += LG_T) {
+            const LgRow r = lg_row(a, base + rr);
+            s_p[rr] = r.j < 0 ? -1 : r.b * a.N + r.j;
+            s_dx[rr] = r.dx; s_dy[rr] = r.dy; s_dz[rr] = r.dz;
+        }
+        __syncthreads();
+        if (!act) continue;
+        for (int r0 = slot; r0 < nrows; r0 += U * RSL) {
             float4 pv[U];
-            bool ok[U];
+            int pj[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t m = m0 + (int64_t)u * RSL;
-                ok[u] = m < mend;
-                r[u] = lg_row(a, ok[u] ? m : mbeg);
-                pv[u] = ld4(a.P + ((int64_t)r[u].b * a.N + (r[u].j < 0 ? 0 : r[u].j)) * a.C + c);
+                const int rr = min(r0 + u * RSL, nrows - 1);
+                pj[u] = s_p[rr];
+                pv[u] = ld4(a.P + (int64_t)(pj[u] < 0 ? 0 : pj[u]) * a.C + c);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (!ok[u]) continue;
-                float4 v = r[u].j < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : pv[u];
-                v.x = fmaf(r[u].dz, w2.x, fmaf(r[u].dy, w1.x, fmaf(r[u].dx, w0.x, v.x + bv.x)));
-                v.y = fmaf(r[u].dz, w2.y, fmaf(r[u].dy, w1.y, fmaf(r[u].dx, w0.y, v.y + bv.y)));
-                v.z = fmaf(r[u].dz, w2.z, fmaf(r[u].dy, w1.z, fmaf(r[u].dx, w0.z, v.z + bv.z)));
-                v.w = fmaf(r[u].dz, w2.w, fmaf(r[u].dy, w1.w, fmaf(r[u].dx, w0.w, v.w + bv.w)));
-                *reinterpret_cast<float4 *>(a.y + (m0 + (int64_t)u * RSL) * a.C + c) = v;
+                const int rr = r0 + u * RSL;
+                if (rr >= nrows) continue;
+                const float dx = s_dx[rr], dy = s_dy[rr], dz = s_dz[rr];
+                float4 v = pj[u] < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : pv[u];
+                v.x = fmaf(dz, w2.x, fmaf(dy, w1.x, fmaf(dx, w0.x, v.x + bv.x)));
+                v.y = fmaf(dz, w2.y, fmaf(dy, w1.y, fmaf(dx, w0.y, v.y + bv.y)));
+                v.z = fmaf(dz, w2.z, fmaf(dy, w1.z, fmaf(dx, w0.z, v.z + bv.z)));
+                v.w = fmaf(dz, w2.w, fmaf(dy, w1.w, fmaf(dx, w0.w, v.w + bv.w)));
+                *reinterpret_cast<float4 *>(a.y + (base + rr) * a.C + c) = v;
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
             }
         }
     }
+    __syncthreads();
     float *rd = red + tid * 8;
     rd[0] = act ? s1.x : 0.f; rd[1] = act ? s1.y : 0.f; rd[2] = act ? s1.z : 0.f; rd[3] = act ? s1.w : 0.f;
     rd[4] = act ? s2.x : 0.f; rd[5] = act ? s2.y : 0.f; rd[6] = act ? s2.z : 0.f; rd[7] = act ? s2.w : 0.f;
@@ -114,7 +130,6 @@ __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
 // G row (the quad-per-lane mapping of the forward kernel would issue four quarter-dense atomics instead).  Ball-query padding
 // repeats each group's first neighbour, often for half of the nsample slots: those rows are summed in a register per group and
 // flushed with one atomic.
-constexpr int LG_ROWS = 256;                    // rows a workgroup stages metadata for at a time
 __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
 {
     __shared__ float red[LG_T * 3];
