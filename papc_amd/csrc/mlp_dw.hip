@@ -527,45 +527,56 @@ __global__ __launch_bounds__(256) void dw_xyz_kernel(DwArgs p)
         return fmaf(sc, pp, -fmaf(Bp, y - mu, A));
     };
     constexpr int U = 4;                     // rows in flight per lane
-    if (act) {
-        for (int64_t m0 = mbeg + slot; m0 < mend; m0 += (int64_t)U * RSL) {
-            float4 vy[U], vz[U], vx[U][NS];
-            bool ok[U];
+    constexpr int XR = 256;                  // rows whose input is staged at a time
+    // the row's input (gathered features, centred coordinates) is fetched ONCE per row by one thread and staged in LDS: the Cout / 4 lanes
+    // of a row would otherwise each repeat the same index / feature / coordinate / centroid loads (ten memory instructions per lane and row
+    // against two useful ones)
+    __shared__ float4 xrow[XR][NS];
+    for (int64_t base = mbeg; base < mend; base += XR) {
+        const int nrows = (int)min((int64_t)XR, mend - base);
+        __syncthreads();
+        for (int rr = tid; rr < nrows; rr += 256) {
+            const RowCtx r = make_row<A_GROUP>(p.x, base + rr, p.M);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {     // slots 0 .. NF-1: features; slot NF: (x - cx, y - cy, z - cz, 0); zero for a no-hit row
+                const Raw3 w = fetch_a4<A_GROUP, true>(p.x, r, 4 * sl, NC);
+                xrow[rr][sl] = finish_a4<A_GROUP, true>(p.x, r, 4 * sl, NC, KConst{}, w);
+            }
+        }
+        __syncthreads();
+        if (!act) continue;
+        for (int r0 = slot; r0 < nrows; r0 += U * RSL) {
+            float4 vy[U], vz[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t m = m0 + (int64_t)u * RSL;
-                ok[u] = m < mend;
-                const int64_t mc = ok[u] ? m : mbeg;
-                vy[u] = ld4(d.y + mc * p.Cout + c);
-                vz[u] = ld4(d.dz + mc * p.Cout + c);
-                const RowCtx r = make_row<A_GROUP>(p.x, mc, p.M);
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {     // slots 0 .. NF-1: features; slot NF: (x - cx, y - cy, z - cz, 0); zero for a no-hit row
-                    const Raw3 w = fetch_a4<A_GROUP, true>(p.x, r, 4 * sl, NC);
-                    vx[u][sl] = finish_a4<A_GROUP, true>(p.x, r, 4 * sl, NC, KConst{}, w);
-                }
+                const int rr = min(r0 + u * RSL, nrows - 1);
+                vy[u] = ld4(d.y + (base + rr) * p.Cout + c);
+                vz[u] = ld4(d.dz + (base + rr) * p.Cout + c);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (!ok[u]) continue;
+                const int rr = r0 + u * RSL;
+                if (rr >= nrows) continue;
                 float g[4];
                 g[0] = dyv(vz[u].x, vy[u].x, ksc.x, ksh.x, kmu.x, kA.x, kB.x);
                 g[1] = dyv(vz[u].y, vy[u].y, ksc.y, ksh.y, kmu.y, kA.y, kB.y);
                 g[2] = dyv(vz[u].z, vy[u].z, ksc.z, ksh.z, kmu.z, kA.z, kB.z);
                 g[3] = dyv(vz[u].w, vy[u].w, ksc.w, ksh.w, kmu.w, kA.w, kB.w);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int sl = 0; sl < NS; ++sl) {
+                    const float4 x = xrow[rr][sl];
 #pragma unroll
-                    for (int sl = 0; sl < NS; ++sl) {
-                        const float4 x = vx[u][sl];
+                    for (int i = 0; i < 4; ++i) {
                         a[i][4 * sl + 0] = fmaf(g[i], x.x, a[i][4 * sl + 0]);
                         a[i][4 * sl + 1] = fmaf(g[i], x.y, a[i][4 * sl + 1]);
                         a[i][4 * sl + 2] = fmaf(g[i], x.z, a[i][4 * sl + 2]);
                         if (sl < NF) a[i][4 * sl + 3] = fmaf(g[i], x.w, a[i][4 * sl + 3]);     // (the coordinate slot's 4th element is a structural zero)
                     }
+                }
             }
         }
     }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
