@@ -19,11 +19,13 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 PLAIN, CONCAT, BNRELU, DY_DENSE, DY_MAX = 0, 1, 2, 3, 4
+DZ_DENSE = 0                                            # papc_bwd_dy.dz_mode of a dense upstream gradient (PAPC_DZ_DENSE)
 EPI_STORE, EPI_FWD, EPI_FWD_GMAX, EPI_RED = 0, 1, 2, 3
 K_MLP_GEMM, K_BWD_DX, K_BWD_DW = 3, 6, 7                # PAPC_K_* families for the event profiler
 GROUP = 128                                             # rows of a group = rows of a GEMM tile (fused max)
 ENABLED = os.environ.get("PAPC_PLANES", "1") == "1"     # A/B switch: 0 = every stack on the row kernels (mlp.SharedMLPMax)
 MAX_ROWS = int(os.environ.get("PAPC_PLANES_MAXROWS", "16384"))
+POINTWISE = os.environ.get("PAPC_PLANES_POINTWISE", "1") == "1"   # A/B switch: stacks without pooling (feature propagation) on the planes path too
 
 c_p, c_i, c_l, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -58,10 +60,14 @@ class PgFoldJob(ctypes.Structure):
 def eligible(spec, xyz, feats, idx, x_rows, params):
     """The stack shapes smallm.hip was built for: train-mode BN, max over groups of exactly 128 rows (one GEMM tile), no neighbour
     index (group_all or plain rows), few rows, channel counts in multiples of 8."""
-    if not ENABLED or spec.eval_bn or not spec.pool or idx is not None:
+    if not ENABLED or spec.eval_bn or idx is not None:
         return False
     M = spec.M
-    if spec.K != GROUP or M % GROUP or M > MAX_ROWS or M < GROUP:
+    if M % GROUP or M > MAX_ROWS or M < GROUP:
+        return False
+    if spec.pool and spec.K != GROUP:
+        return False
+    if not spec.pool and (x_rows is None or not POINTWISE):   # (no pooling: the point-wise stacks of feature propagation, plain rows only)
         return False
     if len(params) < 8:                                    # (a single layer gains nothing here)
         return False
@@ -151,11 +157,11 @@ class PlanesMLPMax(torch.autograd.Function):
             stats = torch.empty(T, 2, cout, device=dev, dtype=torch.float32)
             cst = torch.empty(4, cout, device=dev, dtype=torch.float32)   # mean, invstd, scale, shift
             g = PgGemm()
-            g.epi = EPI_FWD_GMAX if l == L - 1 else EPI_FWD
+            g.epi = EPI_FWD_GMAX if (l == L - 1 and spec.pool) else EPI_FWD
             g.a, g.b, g.R1, g.R2, g.K = P.data_ptr(), wp[l].data_ptr(), M, cout, ch[l]
             g.c, g.ldc, g.split, g.split_stride = y.data_ptr(), cout, 1, 0
             g.bias, g.stats, g.family = ptr(params[4 * l + 1]), stats.data_ptr(), K_MLP_GEMM
-            if l == L - 1:
+            if l == L - 1 and spec.pool:
                 gbuf_f = torch.empty(2, T, cout, device=dev, dtype=torch.float32)
                 gbuf_i = torch.empty(2, T, cout, device=dev, dtype=torch.int32)
                 g.gmax, g.gmin, g.amax, g.amin = gbuf_f[0].data_ptr(), gbuf_f[1].data_ptr(), gbuf_i[0].data_ptr(), gbuf_i[1].data_ptr()
@@ -170,6 +176,13 @@ class PlanesMLPMax(torch.autograd.Function):
                 prep(mode=BNRELU, M=M, C=cout, x=y.data_ptr(), ldx=cout, stats=stats.data_ptr(), parts=T, gamma=ptr(gamma), beta=ptr(beta),
                      eps=spec.eps, momentum=spec.momentum, running_mean=ptr(rm), running_var=ptr(rv), mean=cst[0].data_ptr(),
                      invstd=cst[1].data_ptr(), scale=cst[2].data_ptr(), shift=cst[3].data_ptr(), planes=P.data_ptr(), planes_t=ptr(PT[l + 1]))
+            elif not spec.pool:
+                # a point-wise stack (feature propagation, pointnet2_basic_layers.py:331-333): relu(bn(y)) of the last layer is the result
+                check(lib.papc_bn_finalize_f32(stats.data_ptr(), T, M, cout, ptr(gamma), ptr(beta), spec.eps, spec.momentum, cst[0].data_ptr(),
+                                               cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), ptr(rm), ptr(rv), st), "papc_bn_finalize_f32")
+                out = torch.empty(M, cout, device=dev, dtype=torch.float32)
+                check(lib.papc_bn_relu_f32(y.data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), M, cout, out.data_ptr(), st), "papc_bn_relu_f32")
+                argmax = None
             else:
                 out = torch.empty(T, cout, device=dev, dtype=torch.float32)
                 argmax = torch.empty(T, cout, device=dev, dtype=torch.int32)
@@ -182,7 +195,7 @@ class PlanesMLPMax(torch.autograd.Function):
         ctx.spec, ctx.L, ctx.ch, ctx.plain, ctx.in_grad, ctx.n_in = spec, L, ch, plain, in_grad, n_in
         ctx.n_pt = sum(t is not None for t in PT)
         ctx.wt_mask = [t is not None for t in wtp]
-        ysel = gbuf_f[0]                                     # raw y at the argmax (left there by papc_pg_final_f32)
+        ysel = gbuf_f[0] if spec.pool else None              # raw y at the argmax (left there by papc_pg_final_f32)
         ctx.save_for_backward(argmax, ysel, *params, *ys, *consts, *[t for t in PT if t is not None], *[t for t in wtp if t is not None])
         return out
 
@@ -235,7 +248,13 @@ class PlanesMLPMax(torch.autograd.Function):
             dypt = _planes(lib, cout, M, dev)
             common = dict(M=M, C=cout, x=ys[l].data_ptr(), ldx=cout, mean=cst[0].data_ptr(), invstd=cst[1].data_ptr(), scale=cst[2].data_ptr(),
                           shift=cst[3].data_ptr(), dgamma=dgamma_p, dbeta=dbeta_p, accumulate=int(gb_inplace), planes=ptr(dyp), planes_t=dypt.data_ptr())
-            if l == L - 1:
+            if l == L - 1 and not spec.pool:
+                # dense upstream gradient: the layer's BN-backward sums in a pass of their own (T partial rows, folded in the prep's prologue)
+                red = torch.empty(T, 2, cout, device=dev, dtype=torch.float32)
+                check(lib.papc_bn_bwd_reduce_f32(DZ_DENSE, gout.data_ptr(), None, None, 1, ys[l].data_ptr(), cst[0].data_ptr(), cst[1].data_ptr(),
+                                                 cst[2].data_ptr(), cst[3].data_ptr(), M, cout, T, red.data_ptr(), st), "papc_bn_bwd_reduce_f32")
+                prep(mode=DY_DENSE, dz=gout.data_ptr(), red=red.data_ptr(), red_parts=T, **common)
+            elif l == L - 1:
                 prep(mode=DY_MAX, gout=gout.data_ptr(), ysel=ysel.data_ptr(), argmax=argmax.data_ptr(), K=GROUP, **common)
             else:
                 prep(mode=DY_DENSE, dz=dz.data_ptr(), red=red.data_ptr(), red_parts=T, **common)

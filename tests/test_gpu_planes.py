@@ -167,3 +167,49 @@ def test_planes_path_is_taken_and_deterministic(dev):
         for j in (0, 2, 3):
             assert params[4 * l + j].grad is None
             assert torch.allclose(tg[4 * l + j] - 1.0, grads1[4 * l + j].reshape(tg[4 * l + j].shape), rtol=1e-4, atol=3e-6), (l, j)
+
+
+@pytest.mark.parametrize("M,chans", [(2048, [1536, 256, 256]), (8192, [576, 256, 128]), (1024, [64, 128, 64])])
+def test_planes_pointwise_stack_vs_rows_and_f64(dev, M, chans):
+    """The planes path on a stack WITHOUT pooling (the point-wise conv/BN/ReLU stacks of feature propagation,
+    /root/reference/PAPC/models/layers/pointnet2_basic_layers.py:331-333, at the part-segmentation models' fp3 / fp2 sizes): against the
+    row kernels and float64 torch, forward 1e-5, gradients (weights, norms, input rows) 2e-4."""
+    rng = np.random.default_rng(M)
+    x0 = torch.from_numpy(rng.normal(size=(M, chans[0])).astype(np.float32)).to(dev)
+    ws = seeded_weights(chans, 43)
+    gout = torch.from_numpy(rng.normal(size=(M, chans[-1])).astype(np.float32)).to(dev)
+
+    def run(planes):
+        x = x0.clone().requires_grad_(True)
+        ps = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+        spec = StackSpec(1, M, M, 1, chans[0], True, pool=False)
+        old = smallm.ENABLED
+        smallm.ENABLED = planes
+        try:
+            out = shared_mlp_max(spec, None, None, None, None, None, ps, x_rows=x)
+        finally:
+            smallm.ENABLED = old
+        assert ("Planes" in type(out.grad_fn).__name__) == planes
+        out.backward(gout)
+        return out.detach(), [p.grad for p in ps], x.grad
+
+    out_p, g_p, gx_p = run(True)
+    out_r, g_r, gx_r = run(False)
+    assert_close(out_p.cpu().numpy(), out_r.cpu().numpy(), 2e-6, "planes vs rows forward (no pooling)")
+    p64 = [torch.from_numpy(a).to(dev).double().requires_grad_(True) for tup in ws for a in tup]
+    x64 = x0.double().requires_grad_(True)
+    h = x64
+    for l in range(len(chans) - 1):
+        w, b, g, be = p64[4 * l:4 * l + 4]
+        y = h @ w.reshape(w.shape[0], -1).t() + b
+        mu, var = y.mean(0), y.var(0, unbiased=False)
+        h = torch.relu((y - mu) / torch.sqrt(var + 1e-5) * g + be)
+    assert_close(out_p.cpu().numpy(), h.detach().cpu().numpy(), 1e-5, "planes forward vs f64 (no pooling)")
+    h.backward(gout.double())
+    for l in range(len(chans) - 1):
+        for j, nm in ((0, "w"), (2, "gamma"), (3, "beta")):
+            want = p64[4 * l + j].grad.cpu().numpy()
+            assert_close(g_p[4 * l + j].cpu().numpy().reshape(want.shape), want, 2e-4, "planes d%s layer %d vs f64" % (nm, l))
+            assert_close(g_p[4 * l + j].cpu().numpy(), g_r[4 * l + j].cpu().numpy(), 2e-4, "planes vs rows d%s layer %d" % (nm, l))
+    assert_close(gx_p.cpu().numpy(), x64.grad.cpu().numpy(), 2e-4, "planes dx vs f64")
+    assert_close(gx_p.cpu().numpy(), gx_r.cpu().numpy(), 2e-4, "planes vs rows dx")
