@@ -403,13 +403,25 @@ int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int
 size_t papc_nms_workspace(int N);
 int papc_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *keep, int32_t *num_out, void *workspace,
                  size_t workspace_bytes, papc_stream_t stream);
-/* Rotated boxes, nms_gpu.py:179-653 (numba.cuda in the reference; typing follows that source: fp32 clipping, fp64 area and quotient).
+/* Rotated boxes, nms_gpu.py:179-653 (numba.cuda in the reference).  The intersection of two rectangles is computed by clipping one
+ * against the other's four half-planes (Sutherland-Hodgman, ordered vertex list in registers, fp64 distances / crossings / shoelace on
+ * the source's fp32 corners :366-389) -- not by the source's candidate list + angular sort; results agree with it to rounding wherever
+ * the source's strict edge tests are not ties (coincident edges, e.g. identical boxes at a general angle, are rounding noise there and
+ * exact here).
  * papc_rotate_nms_f32: rotate_nms_gpu (:453-488), dets [N,6] = (x, y, x_d, y_d, angle, score); outputs and workspace as papc_nms_f32.
  * papc_rotate_iou_f32: rotate_iou_gpu / rotate_iou_gpu_eval (:524-653), boxes [N,5], query_boxes [K,5] = (x, y, x_d, y_d, angle) ->
  * iou [N,K]; criterion -1: intersection over union, 0: over area(query), 1: over area(box), 2: the intersection area. */
 int papc_rotate_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *keep, int32_t *num_out, void *workspace,
                         size_t workspace_bytes, papc_stream_t stream);
 int papc_rotate_iou_f32(const float *boxes, const float *query_boxes, int N, int K, int criterion, float *iou, papc_stream_t stream);
+/* rbbox_iou of pointpillars/libs/ops/cc/box_ops.h:23-80 (boost::geometry on the host there): box_corners [N,4,2], qbox_corners [K,4,2]
+ * convex quadrilaterals, standup_iou [N,K] (may be NULL: computed from the corners' bounding boxes, iou_jit with eps = 0) ->
+ * overlaps [N,K] = |P n Q| / |P u Q| where standup_iou > standup_thresh, 0 elsewhere.
+ * papc_riou_f32: riou_cc of libs/ops/box_np_ops.py:16-27 in one launch -- rbboxes [N,5], qrbboxes [K,5] = (x, y, w, l, angle); corners
+ * (center_to_corner_box2d :363-383), standup boxes (:236-241) and their IoU (:654-682) are formed on the device. */
+int papc_rbbox_iou_f32(const float *box_corners, const float *qbox_corners, const float *standup_iou, float standup_thresh, int N, int K,
+                       float *overlaps, papc_stream_t stream);
+int papc_riou_f32(const float *rbboxes, const float *qrbboxes, float standup_thresh, int N, int K, float *overlaps, papc_stream_t stream);
 
 /* First layer of a GROUPED stack with the linear map taken before the gather (pointnet2_basic_layers.py:146-153 + conv1 :215-217):
  * a row is [xyz_j - centre | feats_j], so y[m] = P[j] + W_x (xyz_j - centre) + b with P = feats W_f^T [B*N, C] computed once per

@@ -601,7 +601,7 @@ def rbbox_to_corners(rbbox):
     return c
 
 
-def _point_in_quadrilateral(px, py, c):
+def _point_in_quadrilateral(px, py, c, _f=_f):
     """:323-339"""
     ab0, ab1, ad0, ad1 = _f(c[2] - c[0]), _f(c[3] - c[1]), _f(c[6] - c[0]), _f(c[7] - c[1])
     ap0, ap1 = _f(px - c[0]), _f(py - c[1])
@@ -610,7 +610,7 @@ def _point_in_quadrilateral(px, py, c):
     return abab >= abap and abap >= 0 and adad >= adap and adap >= 0
 
 
-def _line_segment_intersection(p1, p2, i, j):
+def _line_segment_intersection(p1, p2, i, j, _f=_f):
     """:235-278.  Returns the intersection point or None."""
     A0, A1, B0, B1 = p1[2 * i], p1[2 * i + 1], p1[2 * ((i + 1) % 4)], p1[2 * ((i + 1) % 4) + 1]
     C0, C1, D0, D1 = p2[2 * j], p2[2 * j + 1], p2[2 * ((j + 1) % 4)], p2[2 * ((j + 1) % 4) + 1]
@@ -632,18 +632,22 @@ def _line_segment_intersection(p1, p2, i, j):
 
 def rotate_inter(rbbox1, rbbox2):
     """inter(), :392-406 (quadrilateral_intersection :342-363, sort_vertex_in_convex_polygon :195-232, area :185-192).  The source's
-    scratch holds 8 points; degenerate overlaps can produce more candidates (it would write past the array) -- here, as in the HIP
-    kernel, up to 16 are kept."""
-    c1, c2 = rbbox_to_corners(rbbox1), rbbox_to_corners(rbbox2)
+    scratch holds 8 points; degenerate overlaps can produce more candidates (it would write past the array) -- here up to 16 are kept."""
+    return quad_inter(rbbox_to_corners(rbbox1), rbbox_to_corners(rbbox2), _f)
+
+
+def quad_inter(c1, c2, _f=_f):
+    """The source's intersection-area routine on two corner lists (8 floats each), with every intermediate rounded by ``_f``: np.float32 is
+    the numba typing (rotate_inter); np.float64 serves as the geometric value for rbbox_iou (boost::geometry in the reference)."""
     pts = []
     for i in range(4):
-        if _point_in_quadrilateral(c1[2 * i], c1[2 * i + 1], c2):
+        if _point_in_quadrilateral(c1[2 * i], c1[2 * i + 1], c2, _f):
             pts.append([c1[2 * i], c1[2 * i + 1]])
-        if _point_in_quadrilateral(c2[2 * i], c2[2 * i + 1], c1):
+        if _point_in_quadrilateral(c2[2 * i], c2[2 * i + 1], c1, _f):
             pts.append([c2[2 * i], c2[2 * i + 1]])
     for i in range(4):
         for j in range(4):
-            t = _line_segment_intersection(c1, c2, i, j)
+            t = _line_segment_intersection(c1, c2, i, j, _f)
             if t is not None:
                 pts.append([t[0], t[1]])
     pts = pts[:16]
@@ -724,3 +728,109 @@ def rotate_nms_gpu(dets, nms_overlap_thresh, return_ious=False):
     num = nms_postprocess(keep, mask.reshape(-1), n)
     res = list(order[keep[:num]])
     return (res, ious) if return_ious else res
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# riou_cc / rbbox_iou: libs/ops/box_np_ops.py:16-27 over libs/ops/cc/box_ops.h:23-80.  The C++ there hands the two
+# polygons to boost::geometry (intersection, union_, area) -- an un-vendored dependency; what it computes for convex quadrilaterals
+# is |P n Q| / |P u Q| with |P u Q| = |P| + |Q| - |P n Q|.  The geometric intersection area is restated as the convex hull (qhull, via
+# scipy) of {corners of P in Q} u {corners of Q in P} u {edge crossings} in float64 with a 1e-9 tolerance on the closed tests, so that
+# touching and coincident edges -- where the numba routine above returns rounding noise -- have their geometric value, as in boost.
+# ---------------------------------------------------------------------------------------------------------------------
+def convex_quad_inter_area(p, q, tol=1e-9):
+    """area of the intersection of two convex quadrilaterals given as 8 floats (x0, y0, ..., x3, y3), float64"""
+    from scipy.spatial import ConvexHull, QhullError
+    P = np.asarray(p, np.float64).reshape(4, 2)
+    Q = np.asarray(q, np.float64).reshape(4, 2)
+    scale = max(1.0, float(np.abs(P).max()), float(np.abs(Q).max()))
+    eps = tol * scale * scale
+
+    def inside(pt, poly):
+        sgn = []
+        for i in range(4):
+            a, b = poly[i], poly[(i + 1) % 4]
+            sgn.append((b[0] - a[0]) * (pt[1] - a[1]) - (b[1] - a[1]) * (pt[0] - a[0]))
+        return all(v >= -eps for v in sgn) or all(v <= eps for v in sgn)
+
+    pts = [c for c in P if inside(c, Q)] + [c for c in Q if inside(c, P)]
+    for i in range(4):
+        a, b = P[i], P[(i + 1) % 4]
+        for j in range(4):
+            c, d = Q[j], Q[(j + 1) % 4]
+            den = (b[0] - a[0]) * (d[1] - c[1]) - (b[1] - a[1]) * (d[0] - c[0])
+            if abs(den) <= eps:
+                continue                      # parallel edges: their overlap, if any, ends in corners already listed
+            t = ((c[0] - a[0]) * (d[1] - c[1]) - (c[1] - a[1]) * (d[0] - c[0])) / den
+            u = ((c[0] - a[0]) * (b[1] - a[1]) - (c[1] - a[1]) * (b[0] - a[0])) / den
+            if -tol <= t <= 1 + tol and -tol <= u <= 1 + tol:
+                pts.append(a + t * (b - a))
+    if len(pts) < 3:
+        return 0.0
+    try:
+        return float(ConvexHull(np.asarray(pts), qhull_options="QJ Pp").volume)
+    except QhullError:
+        return 0.0
+
+
+def center_to_corner_box2d(centers, dims, angles, origin=0.5):
+    """box_np_ops.py:363-383 with corners_nd :170-201 and rotation_2d :302-315 (clockwise corners from the minimum point, rotated
+    clockwise for positive angles), in the dtype of the inputs."""
+    dt = dims.dtype
+    corners_norm = np.array([[0, 0], [0, 1], [1, 1], [1, 0]], dt) - np.array(origin, dt)
+    corners = dims.reshape(-1, 1, 2) * corners_norm.reshape(1, 4, 2)
+    rot_sin, rot_cos = np.sin(angles), np.cos(angles)
+    rot_mat_T = np.stack([[rot_cos, -rot_sin], [rot_sin, rot_cos]])
+    corners = np.einsum("aij,jka->aik", corners, rot_mat_T)
+    return corners + centers.reshape(-1, 1, 2)
+
+
+def corner_to_standup_nd(boxes_corner):
+    """box_np_ops.py:236-241"""
+    return np.concatenate([np.min(boxes_corner, axis=1), np.max(boxes_corner, axis=1)], -1)
+
+
+def iou_jit(boxes, query_boxes, eps=0.0):
+    """box_np_ops.py:654-682"""
+    N, K = boxes.shape[0], query_boxes.shape[0]
+    overlaps = np.zeros((N, K), boxes.dtype)
+    for k in range(K):
+        box_area = (query_boxes[k, 2] - query_boxes[k, 0] + eps) * (query_boxes[k, 3] - query_boxes[k, 1] + eps)
+        for n in range(N):
+            iw = min(boxes[n, 2], query_boxes[k, 2]) - max(boxes[n, 0], query_boxes[k, 0]) + eps
+            if iw > 0:
+                ih = min(boxes[n, 3], query_boxes[k, 3]) - max(boxes[n, 1], query_boxes[k, 1]) + eps
+                if ih > 0:
+                    ua = (boxes[n, 2] - boxes[n, 0] + eps) * (boxes[n, 3] - boxes[n, 1] + eps) + box_area - iw * ih
+                    overlaps[n, k] = iw * ih / ua
+    return overlaps
+
+
+def _shoelace(c):
+    x, y = c[0::2], c[1::2]
+    return 0.5 * abs(sum(float(x[i]) * float(y[(i + 1) % 4]) - float(x[(i + 1) % 4]) * float(y[i]) for i in range(4)))
+
+
+def rbbox_iou(box_corners, qbox_corners, standup_iou, standup_thresh):
+    """cc/box_ops.h:23-80: overlaps[n, k] for the pairs with standup_iou[n, k] > standup_thresh, 0 elsewhere."""
+    N, K = box_corners.shape[0], qbox_corners.shape[0]
+    out = np.zeros((N, K), box_corners.dtype)
+    for k in range(K):
+        for n in range(N):
+            if standup_iou[n, k] <= standup_thresh:
+                continue
+            p = np.asarray(box_corners[n], np.float64).reshape(8)
+            q = np.asarray(qbox_corners[k], np.float64).reshape(8)
+            ai = convex_quad_inter_area(p, q)
+            if ai > 0:
+                un = _shoelace(p) + _shoelace(q) - ai
+                if un > 0:
+                    out[n, k] = ai / un
+    return out
+
+
+def riou_cc(rbboxes, qrbboxes, standup_thresh=0.0):
+    """box_np_ops.py:16-27"""
+    bc = center_to_corner_box2d(rbboxes[:, :2], rbboxes[:, 2:4], rbboxes[:, 4])
+    qc = center_to_corner_box2d(qrbboxes[:, :2], qrbboxes[:, 2:4], qrbboxes[:, 4])
+    su = iou_jit(corner_to_standup_nd(bc), corner_to_standup_nd(qc), eps=0.0)
+    return rbbox_iou(bc, qc, su, standup_thresh)

@@ -135,6 +135,8 @@ SIGNATURES = {
     "papc_transpose_batch_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_rotate_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_rotate_iou_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "papc_rbbox_iou_f32": (c_i, [c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p]),
+    "papc_riou_f32": (c_i, [c_p, c_p, c_f, c_i, c_i, c_p, c_p]),
     "papc_fill_f32": (c_i, [c_p, c_l, c_f, c_p]),
     "papc_copy_strided_batch_f32": (c_i, [c_p, c_i, c_p]),
     "papc_copy2d_f32": (c_i, [c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p]),

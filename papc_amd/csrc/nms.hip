@@ -97,99 +97,101 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// rotated boxes (x, y, x_d, y_d, angle): IoU by convex clipping, nms_gpu.py:179-414 (numba.cuda in the reference).  Typing
-// follows the numba source: corner / intersection arithmetic in fp32, the triangle-fan area and the IoU quotient in fp64
-// (``area_val = 0.0`` and ``/ 2.0`` are Python floats there).  -ffp-contract=off: no fused multiply-adds.
+// rotated boxes (x, y, x_d, y_d, angle): IoU of two rectangles.  What the reference computes (nms_gpu.py:179-414, numba.cuda) is the
+// area of a convex quadrilateral intersection; it gets there by collecting corner-in-box hits and edge-edge crossings, sorting them
+// by angle around their centroid and summing a triangle fan.  This file does not follow that route.  Here box A is CLIPPED against
+// the four half-planes of box B (Sutherland-Hodgman): the polygon stays an ordered vertex list throughout (at most 4 + 4 vertices),
+// so there is no candidate list, no angular sort and no scratch array, and touching / coincident edges are ordinary cases of the
+// signed-distance test instead of ties between strict comparisons (the source's IoU of two identical boxes at a general angle is
+// rounding noise; here it is 1).  Corners are formed in fp32 exactly as the source forms them (:366-389: they define the rectangles);
+// signed distances, crossing points and the shoelace sum are fp64, as are the area accumulator and the quotient in the source
+// (`area_val = 0.0`, `/ 2.0` are Python floats under numba).  -ffp-contract=off.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void rbbox_to_corners(float *c, const float *b)   // :366-389
+struct Quad { float x[4], y[4]; };
+
+__device__ __forceinline__ Quad corners_of(const float *b)   // (x, y, x_d, y_d, angle) -> corners, the source's order and arithmetic (:366-389)
 {
-    const float a_cos = cosf(b[4]), a_sin = sinf(b[4]);
+    const float c = cosf(b[4]), s = sinf(b[4]);
     const float hx = b[2] / 2.f, hy = b[3] / 2.f;
-    const float cx[4] = {-hx, -hx, hx, hx}, cy[4] = {-hy, hy, hy, -hy};
+    Quad q;
+    q.x[0] = c * -hx + s * -hy + b[0]; q.y[0] = -s * -hx + c * -hy + b[1];
+    q.x[1] = c * -hx + s * hy + b[0];  q.y[1] = -s * -hx + c * hy + b[1];
+    q.x[2] = c * hx + s * hy + b[0];   q.y[2] = -s * hx + c * hy + b[1];
+    q.x[3] = c * hx + s * -hy + b[0];  q.y[3] = -s * hx + c * -hy + b[1];
+    return q;
+}
+
+// twice the signed area of a quadrilateral (shoelace); its sign is the winding of the corner order
+__device__ __forceinline__ double quad_area2(const Quad &q)
+{
+    double a = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        c[2 * i] = a_cos * cx[i] + a_sin * cy[i] + b[0];
-        c[2 * i + 1] = -a_sin * cx[i] + a_cos * cy[i] + b[1];
+        const int j = (i + 1) & 3;
+        a += (double)q.x[i] * (double)q.y[j] - (double)q.x[j] * (double)q.y[i];
     }
+    return a;
 }
 
-__device__ __forceinline__ bool point_in_quad(float px, float py, const float *c)   // :323-339
+// Area of (convex quadrilateral A) n (convex quadrilateral B).  The vertex list lives in eight named slots per coordinate; every index
+// below is a compile-time constant after unrolling (a slot is picked with selects), so the lists stay in registers.
+__device__ double quad_intersection_area(const Quad &A, const Quad &B)
 {
-    const float ab0 = c[2] - c[0], ab1 = c[3] - c[1], ad0 = c[6] - c[0], ad1 = c[7] - c[1];
-    const float ap0 = px - c[0], ap1 = py - c[1];
-    const float abab = ab0 * ab0 + ab1 * ab1, abap = ab0 * ap0 + ab1 * ap1;
-    const float adad = ad0 * ad0 + ad1 * ad1, adap = ad0 * ap0 + ad1 * ap1;
-    return abab >= abap && abap >= 0.f && adad >= adap && adap >= 0.f;
-}
-
-__device__ __forceinline__ bool seg_intersection(const float *p1, const float *p2, int i, int j, float *out)   // :235-278
-{
-    const float A0 = p1[2 * i], A1 = p1[2 * i + 1], B0 = p1[2 * ((i + 1) & 3)], B1 = p1[2 * ((i + 1) & 3) + 1];
-    const float C0 = p2[2 * j], C1 = p2[2 * j + 1], D0 = p2[2 * ((j + 1) & 3)], D1 = p2[2 * ((j + 1) & 3) + 1];
-    const float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
-    const bool acd = DA1 * CA0 > CA1 * DA0;
-    const bool bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
-    if (acd != bcd) {
-        const bool abc = CA1 * BA0 > BA1 * CA0, abd = DA1 * BA0 > BA1 * DA0;
-        if (abc != abd) {
-            const float DC0 = D0 - C0, DC1 = D1 - C1;
-            const float ABBA = A0 * B1 - B0 * A1, CDDC = C0 * D1 - D0 * C1;
-            const float DH = BA1 * DC0 - BA0 * DC1;
-            const float Dx = ABBA * DC0 - BA0 * CDDC, Dy = ABBA * DC1 - BA1 * CDDC;
-            out[0] = Dx / DH; out[1] = Dy / DH;
-            return true;
-        }
-    }
-    return false;
-}
-
-__device__ double rotate_inter(const float *b1, const float *b2)   // inter(), :392-406
-{
-    float c1[8], c2[8], pts[16 * 2];   // (the source sizes int_pts at 16 floats = 8 points, the most a quad-quad clip yields generically;
-                                       //  degenerate overlaps can list up to 24 candidates, so the scratch here is larger)
-    rbbox_to_corners(c1, b1);
-    rbbox_to_corners(c2, b2);
-    int n = 0;
-    for (int i = 0; i < 4; ++i) {      // quadrilateral_intersection, :342-363
-        if (point_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { if (n < 16) { pts[2 * n] = c1[2 * i]; pts[2 * n + 1] = c1[2 * i + 1]; } ++n; }
-        if (point_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { if (n < 16) { pts[2 * n] = c2[2 * i]; pts[2 * n + 1] = c2[2 * i + 1]; } ++n; }
-    }
-    float t[2];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            if (seg_intersection(c1, c2, i, j, t)) { if (n < 16) { pts[2 * n] = t[0]; pts[2 * n + 1] = t[1]; } ++n; }
-    if (n > 16) n = 16;
-    if (n > 0) {                       // sort_vertex_in_convex_polygon, :195-232
-        float ctr0 = 0.f, ctr1 = 0.f;
-        for (int i = 0; i < n; ++i) { ctr0 += pts[2 * i]; ctr1 += pts[2 * i + 1]; }
-        ctr0 /= (float)n; ctr1 /= (float)n;
-        float vs[16];
-        for (int i = 0; i < n; ++i) {
-            float v0 = pts[2 * i] - ctr0, v1 = pts[2 * i + 1] - ctr1;
-            const float d = sqrtf(v0 * v0 + v1 * v1);
-            v0 = v0 / d; v1 = v1 / d;
-            if (v1 < 0.f) v0 = -2.f - v0;
-            vs[i] = v0;
-        }
-        for (int i = 1; i < n; ++i) {
-            if (vs[i - 1] > vs[i]) {
-                const float temp = vs[i], tx = pts[2 * i], ty = pts[2 * i + 1];
-                int j = i;
-                while (j > 0 && vs[j - 1] > temp) {
-                    vs[j] = vs[j - 1]; pts[2 * j] = pts[2 * j - 2]; pts[2 * j + 1] = pts[2 * j - 1];
-                    --j;
+    const double wind = quad_area2(B) < 0.0 ? -1.0 : 1.0;      // inside = left of every edge for counter-clockwise B, right for clockwise
+    double px[8], py[8];
+    int n = 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { px[i] = i < 4 ? (double)A.x[i] : 0.0; py[i] = i < 4 ? (double)A.y[i] : 0.0; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double cx = (double)B.x[e], cy = (double)B.y[e];
+        const double ex = (double)B.x[(e + 1) & 3] - cx, ey = (double)B.y[(e + 1) & 3] - cy;
+        // signed distance (times |edge|) of every live vertex to the edge's line, positive inside
+        double sd[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sd[i] = wind * (ex * (py[i] - cy) - ey * (px[i] - cx));
+        double qx[8], qy[8];
+        int m = 0;
+        // the vertex before slot 0 is the last live one
+        double lx = px[0], ly = py[0], ls = sd[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) if (i == n - 1) { lx = px[i]; ly = py[i]; ls = sd[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < n) {
+                const double vx = px[i], vy = py[i], vs = sd[i];
+                const bool in_v = vs >= 0.0, in_l = ls >= 0.0;
+                if (in_v != in_l) {                            // the boundary is crossed between the previous vertex and this one
+                    const double t = ls / (ls - vs);
+                    const double ix = lx + t * (vx - lx), iy = ly + t * (vy - ly);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (k == m) { qx[k] = ix; qy[k] = iy; }
+                    ++m;
                 }
-                vs[j] = temp; pts[2 * j] = tx; pts[2 * j + 1] = ty;
+                if (in_v) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (k == m) { qx[k] = vx; qy[k] = vy; }
+                    ++m;
+                }
+                lx = vx; ly = vy; ls = vs;
             }
         }
+        n = m < 8 ? m : 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { px[i] = qx[i]; py[i] = qy[i]; }
+        if (n == 0) return 0.0;
     }
-    double area = 0.0;                 // area(), :185-192
-    for (int i = 0; i < n - 2; ++i) {
-        const float a0 = pts[0], a1 = pts[1], b0 = pts[2 * i + 2], b1v = pts[2 * i + 3], c0 = pts[2 * i + 4], c1v = pts[2 * i + 5];
-        const float num = (a0 - c0) * (b1v - c1v) - (a1 - c1v) * (b0 - c0);      // trangle_area numerator in fp32 (:179-182)
-        area += fabs((double)num / 2.0);
-    }
-    return area;
+    // shoelace over the live vertices, relative to vertex 0 (keeps the products small)
+    double a2 = 0.0;
+#pragma unroll
+    for (int i = 1; i < 7; ++i)
+        if (i + 1 < n) a2 += (px[i] - px[0]) * (py[i + 1] - py[0]) - (px[i + 1] - px[0]) * (py[i] - py[0]);
+    return fabs(a2) * 0.5;
+}
+
+__device__ __forceinline__ double rotate_inter(const float *b1, const float *b2)   // inter(), :392-406
+{
+    return quad_intersection_area(corners_of(b1), corners_of(b2));
 }
 
 __device__ __forceinline__ double rotate_iou_eval(const float *b1, const float *b2, int criterion)   // :409-414, :562-574
@@ -241,6 +243,60 @@ __global__ __launch_bounds__(256) void rotate_iou_kernel(const float *__restrict
 #pragma unroll
     for (int c = 0; c < 5; ++c) { q[c] = query[(int64_t)k * 5 + c]; b[c] = boxes[(int64_t)n * 5 + c]; }
     iou[e] = (float)rotate_iou_eval(q, b, criterion);
+}
+
+// rbbox_iou (cc/box_ops.h:23-80, boost::geometry on the host in the reference): overlaps[n, k] = area(P_n n Q_k) / area(P_n u Q_k) for the
+// pairs whose axis-aligned "standup" IoU exceeds standup_thresh, 0 elsewhere.  Convex quadrilaterals: the union's area is
+// |P| + |Q| - |P n Q|.  CORNERS = false: the boxes arrive as (x, y, w, l, angle) and the corners (center_to_corner_box2d, box_np_ops.py:363-383:
+// the same rotation as rbbox_to_corners), the standup boxes (:236-241) and their IoU (iou_jit with eps = 0, :654-682) are formed here --
+// riou_cc (:16-27) in one launch.
+template <bool CORNERS>
+__global__ __launch_bounds__(256) void rbbox_iou_kernel(const float *__restrict__ boxes, const float *__restrict__ qboxes,
+                                                        const float *__restrict__ standup_iou, float standup_thresh, int N, int K,
+                                                        float *__restrict__ overlaps)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)N * K) return;
+    const int n = (int)(e / K), k = (int)(e - (int64_t)n * K);
+    Quad P, Q;
+    if (CORNERS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            P.x[i] = boxes[(int64_t)n * 8 + 2 * i]; P.y[i] = boxes[(int64_t)n * 8 + 2 * i + 1];
+            Q.x[i] = qboxes[(int64_t)k * 8 + 2 * i]; Q.y[i] = qboxes[(int64_t)k * 8 + 2 * i + 1];
+        }
+    } else {
+        float b[5], q[5];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) { b[c] = boxes[(int64_t)n * 5 + c]; q[c] = qboxes[(int64_t)k * 5 + c]; }
+        P = corners_of(b);
+        Q = corners_of(q);
+    }
+    float su;
+    if (CORNERS && standup_iou) su = standup_iou[e];
+    else {
+        float p0 = P.x[0], p1 = P.y[0], p2 = P.x[0], p3 = P.y[0], q0 = Q.x[0], q1 = Q.y[0], q2 = Q.x[0], q3 = Q.y[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            p0 = fminf(p0, P.x[i]); p1 = fminf(p1, P.y[i]); p2 = fmaxf(p2, P.x[i]); p3 = fmaxf(p3, P.y[i]);
+            q0 = fminf(q0, Q.x[i]); q1 = fminf(q1, Q.y[i]); q2 = fmaxf(q2, Q.x[i]); q3 = fmaxf(q3, Q.y[i]);
+        }
+        su = 0.f;
+        const float iw = fminf(p2, q2) - fmaxf(p0, q0);
+        if (iw > 0.f) {
+            const float ih = fminf(p3, q3) - fmaxf(p1, q1);
+            if (ih > 0.f) su = iw * ih / ((p2 - p0) * (p3 - p1) + (q2 - q0) * (q3 - q1) - iw * ih);
+        }
+    }
+    float out = 0.f;
+    if (su > standup_thresh) {
+        const double ai = quad_intersection_area(P, Q);
+        if (ai > 0.0) {
+            const double un = fabs(quad_area2(P)) * 0.5 + fabs(quad_area2(Q)) * 0.5 - ai;
+            if (un > 0.0) out = (float)(ai / un);
+        }
+    }
+    overlaps[e] = out;
 }
 
 }  // namespace papc
@@ -311,6 +367,29 @@ int papc_rotate_iou_f32(const float *boxes, const float *query_boxes, int N, int
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(rotate_iou_kernel, dim3((unsigned)cdiv((int64_t)N * K, 256)), dim3(256), 0, st, boxes, query_boxes, N, K, criterion, iou);
     return check_launch("papc_rotate_iou_f32");
+}
+
+int papc_rbbox_iou_f32(const float *box_corners, const float *qbox_corners, const float *standup_iou, float standup_thresh, int N, int K,
+                       float *overlaps, papc_stream_t stream)
+{
+    PAPC_REQUIRE(box_corners && qbox_corners && overlaps, PAPC_E_INVALID, "papc_rbbox_iou_f32: null pointer");
+    PAPC_REQUIRE(N >= 1 && K >= 1, PAPC_E_INVALID, "papc_rbbox_iou_f32: N=%d K=%d", N, K);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(rbbox_iou_kernel<true>, dim3((unsigned)cdiv((int64_t)N * K, 256)), dim3(256), 0, st, box_corners, qbox_corners, standup_iou,
+                       standup_thresh, N, K, overlaps);
+    return check_launch("papc_rbbox_iou_f32");
+}
+
+int papc_riou_f32(const float *rbboxes, const float *qrbboxes, float standup_thresh, int N, int K, float *overlaps, papc_stream_t stream)
+{
+    PAPC_REQUIRE(rbboxes && qrbboxes && overlaps, PAPC_E_INVALID, "papc_riou_f32: null pointer");
+    PAPC_REQUIRE(N >= 1 && K >= 1, PAPC_E_INVALID, "papc_riou_f32: N=%d K=%d", N, K);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(rbbox_iou_kernel<false>, dim3((unsigned)cdiv((int64_t)N * K, 256)), dim3(256), 0, st, rbboxes, qrbboxes, (const float *)nullptr,
+                       standup_thresh, N, K, overlaps);
+    return check_launch("papc_riou_f32");
 }
 
 }  // extern "C"

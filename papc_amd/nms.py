@@ -1,4 +1,4 @@
-"""Axis-aligned NMS on the device.
+"""Axis-aligned and rotated NMS / IoU on the device.
 
 Mirrors ``nms_gpu(dets, nms_overlap_thresh, device_id=0)`` of
 PAPC/models/detect/pointpillars/libs/ops/non_max_suppression/nms_gpu.py:130-164 (its pybind11 twin ``nms.non_max_suppression`` in
@@ -80,3 +80,39 @@ def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
 
 def rotate_iou_gpu(boxes, query_boxes, device_id=0):
     return rotate_iou_gpu_eval(boxes, query_boxes, -1, device_id)
+
+
+def rbbox_iou(box_corners, qbox_corners, standup_iou=None, standup_thresh=0.0, device_id=0):
+    """``box_ops_cc.rbbox_iou`` of libs/ops/cc/box_ops.h:23-80 (boost::geometry on the host in the reference): box_corners [N,4,2],
+    qbox_corners [K,4,2], standup_iou [N,K] or None (then taken from the corners' bounding boxes) -> overlaps [N,K].  numpy in ->
+    numpy out, tensor in -> tensor out."""
+    as_np = not torch.is_tensor(box_corners)
+    dev = "cuda:%d" % device_id
+    b = torch.as_tensor(box_corners, dtype=torch.float32).to(dev).contiguous() if as_np else box_corners.contiguous().float()
+    q = torch.as_tensor(qbox_corners, dtype=torch.float32).to(b.device).contiguous()
+    if not b.is_cuda:
+        raise _lib.PapcError("rbbox_iou needs CUDA (ROCm) tensors: there is no CPU fallback")
+    assert b.dim() == 3 and tuple(b.shape[1:]) == (4, 2) and q.dim() == 3 and tuple(q.shape[1:]) == (4, 2)
+    N, K = int(b.shape[0]), int(q.shape[0])
+    su = None if standup_iou is None else torch.as_tensor(standup_iou, dtype=torch.float32).to(b.device).contiguous()
+    assert su is None or tuple(su.shape) == (N, K)
+    out = torch.zeros(N, K, dtype=torch.float32, device=b.device)
+    if N and K:
+        check(_lib.load().papc_rbbox_iou_f32(ptr(b), ptr(q), ptr(su), float(standup_thresh), N, K, ptr(out), stream_ptr()), "papc_rbbox_iou_f32")
+    return out.cpu().numpy() if as_np else out
+
+
+def riou_cc(rbboxes, qrbboxes, standup_thresh=0.0, device_id=0):
+    """libs/ops/box_np_ops.py:16-27: rotated IoU of (x, y, w, l, angle) boxes behind an axis-aligned pre-test, one launch."""
+    as_np = not torch.is_tensor(rbboxes)
+    dev = "cuda:%d" % device_id
+    b = torch.as_tensor(rbboxes, dtype=torch.float32).to(dev).contiguous() if as_np else rbboxes.contiguous().float()
+    q = torch.as_tensor(qrbboxes, dtype=torch.float32).to(b.device).contiguous()
+    if not b.is_cuda:
+        raise _lib.PapcError("riou_cc needs CUDA (ROCm) tensors: there is no CPU fallback")
+    assert b.dim() == 2 and b.shape[1] == 5 and q.dim() == 2 and q.shape[1] == 5
+    N, K = int(b.shape[0]), int(q.shape[0])
+    out = torch.zeros(N, K, dtype=torch.float32, device=b.device)
+    if N and K:
+        check(_lib.load().papc_riou_f32(ptr(b), ptr(q), float(standup_thresh), N, K, ptr(out), stream_ptr()), "papc_riou_f32")
+    return out.cpu().numpy() if as_np else out

@@ -62,23 +62,79 @@ def _rboxes(rng, n, extent=20.0):
 
 @pytest.mark.parametrize("criterion", [-1, 0, 1, 2])
 def test_rotate_iou_matches_oracle(criterion):
-    """Tolerance 1e-5 absolute on IoU (areas relative): the device cosf/sinf and numpy's fp32 cos/sin may differ in the last place."""
+    """The kernel clips (Sutherland-Hodgman, fp64); the oracle is the source's candidate-list + angular-sort routine in its fp32 typing.
+    Two different algorithms for the same area: they agree to the source's fp32 rounding (1e-5 absolute on IoU, areas relative) on every
+    pair whose edges are not coincident.  Coincident edges (identical boxes at a general angle) are ties between the source's strict
+    comparisons -- its result there is rounding noise (the oracle returns anything from 0 to 1) -- and have their geometric value here."""
     from papc_amd.nms import rotate_iou_gpu_eval
     rng = np.random.default_rng(5)
     b, q = _rboxes(rng, 70), _rboxes(rng, 45)
-    q[:5] = b[:5]                                            # identical pairs
+    q[:5] = b[:5]                                            # identical pairs: excluded from the oracle comparison, held to geometry
     q[5, :4], q[5, 4] = b[5, :4], b[5, 4] + np.float32(np.pi / 2)
     want = R.rotate_iou_gpu_eval(b, q, criterion)
     got = rotate_iou_gpu_eval(b, q, criterion)
     assert got.shape == want.shape == (70, 45)
     scale = 1.0 if criterion != 2 else float(want.max())
-    assert np.abs(got - want).max() <= 1e-5 * scale
+    general = np.ones((70, 45), bool)
+    general[np.arange(5), np.arange(5)] = False
+    assert np.abs(got - want)[general].max() <= 1e-5 * scale
+    area = (b[:5, 2] * b[:5, 3]).astype(np.float64)
+    exact = {-1: np.ones(5), 0: np.ones(5), 1: np.ones(5), 2: area}[criterion]
+    assert np.abs(got[np.arange(5), np.arange(5)] - exact).max() <= 2e-6 * max(1.0, float(area.max()))
     if criterion == -1:
-        # (identical boxes at a general angle are a degenerate input of this clipping algorithm -- corners sit exactly on the other
-        #  box's edges and the strict edge tests drop them -- so their IoU is NOT 1 in the source's arithmetic; oracle and kernel agree)
-        assert (got >= 0).all() and (got <= 1 + 1e-5).all()
+        assert (got >= 0).all() and (got <= 1 + 1e-6).all()
         ax = np.array([[1, 2, 3, 4, 0]], np.float32)
         assert abs(float(rotate_iou_gpu_eval(ax, ax)[0, 0]) - 1.0) < 1e-6
+
+
+def test_rotate_iou_geometry_properties():
+    """Size-independent properties of the intersection area (criterion 2) on 300 x 300 random boxes: symmetric in its arguments, invariant
+    under a common rigid motion, bounded by both areas, and equal to the geometric oracle (float64 hull of the candidate points)."""
+    from papc_amd.nms import rotate_iou_gpu_eval
+    rng = np.random.default_rng(11)
+    b, q = _rboxes(rng, 300, 12.0), _rboxes(rng, 300, 12.0)
+    a = rotate_iou_gpu_eval(b, q, 2)
+    at = rotate_iou_gpu_eval(q, b, 2)
+    assert np.abs(a - at.T).max() <= 1e-5
+    assert (a <= np.minimum((b[:, 2] * b[:, 3])[:, None], (q[:, 2] * q[:, 3])[None, :]) * (1 + 1e-5) + 1e-6).all() and (a >= 0).all()
+    th = np.float32(0.4)
+    def move(x):
+        y = x.copy()
+        c, s = np.cos(th), np.sin(th)
+        y[:, 0] = c * x[:, 0] + s * x[:, 1] + 3.0      # the corner rotation of rbbox_to_corners is (x, y) -> (c x + s y, -s x + c y)
+        y[:, 1] = -s * x[:, 0] + c * x[:, 1] - 1.0
+        y[:, 4] = x[:, 4] + th
+        return y.astype(np.float32)
+    am = rotate_iou_gpu_eval(move(b), move(q), 2)
+    assert np.abs(a - am).max() <= 2e-4                  # (fp32 corners of the moved boxes differ by ~1e-6 relative)
+    for n in range(0, 300, 37):
+        for k in range(0, 300, 41):
+            want = R.convex_quad_inter_area(R.rbbox_to_corners(q[k]), R.rbbox_to_corners(b[n]))
+            assert abs(float(a[n, k]) - want) <= 1e-5 * max(1.0, want)
+
+
+def test_rbbox_iou_and_riou_cc_match_oracle():
+    """box_ops.h:23-80 / box_np_ops.py:16-27: corners in, standup pre-test, |P n Q| / |P u Q|; and the one-launch riou_cc."""
+    from papc_amd.nms import rbbox_iou, riou_cc
+    rng = np.random.default_rng(21)
+    b, q = _rboxes(rng, 40, 10.0), _rboxes(rng, 33, 10.0)
+    q[:3] = b[:3]
+    bc = R.center_to_corner_box2d(b[:, :2], b[:, 2:4], b[:, 4])
+    qc = R.center_to_corner_box2d(q[:, :2], q[:, 2:4], q[:, 4])
+    su = R.iou_jit(R.corner_to_standup_nd(bc), R.corner_to_standup_nd(qc), eps=0.0)
+    for thr in (0.0, 0.2):
+        want = R.rbbox_iou(bc, qc, su, thr)
+        got = rbbox_iou(bc, qc, su, thr)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-5
+        assert np.array_equal(got == 0, want == 0) or np.abs(got - want)[(got == 0) != (want == 0)].max() <= 1e-6
+        got2 = rbbox_iou(bc, qc, None, thr)              # standup IoU formed on the device
+        near = np.abs(su - thr) < 1e-6                   # (a pre-test within rounding of the threshold may fall either way)
+        assert np.abs(got2 - want)[~near].max() <= 1e-5
+        got3 = riou_cc(b, q, thr)
+        want3 = R.riou_cc(b, q, thr)
+        assert np.abs(got3 - want3)[~near].max() <= 1e-5
+    assert abs(float(got3[0, 0]) - 1.0) < 1e-6 and abs(float(got3[2, 2]) - 1.0) < 1e-6
+    assert rbbox_iou(np.zeros((0, 4, 2), np.float32), qc).shape == (0, 33)
 
 
 @pytest.mark.parametrize("n,thr", [(1, 0.5), (64, 0.3), (65, 0.5), (150, 0.1)])
@@ -99,7 +155,9 @@ def test_rotate_nms_matches_oracle(n, thr):
 def test_rotate_nms_edge_cases():
     from papc_amd.nms import rotate_nms_gpu, rotate_iou_gpu
     assert rotate_nms_gpu(np.zeros((0, 6), np.float32), 0.5) == []
-    same = np.tile(np.array([[3, 3, 2, 1, 0.0, 0.5]], np.float32), (70, 1))       # identical boxes (angle 0: see the IoU test), tied scores
+    same = np.tile(np.array([[3, 3, 2, 1, 0.0, 0.5]], np.float32), (70, 1))       # identical boxes, tied scores
+    assert rotate_nms_gpu(same, 0.5) == [69]
+    same[:, 4] = 0.7                               # ... at a general angle: exact duplicates suppress each other (the source's IoU is noise there)
     assert rotate_nms_gpu(same, 0.5) == [69]
     far = np.array([[10 * i, 0, 2, 1, 0.3 * i, 0.1 * i] for i in range(1, 6)], np.float32)
     assert rotate_nms_gpu(far, 0.1) == [4, 3, 2, 1, 0]

@@ -262,3 +262,26 @@ def test_rotate_iou_known_answers():
     dets = np.array([[0, 0, 2, 2, 0, 0.9], [0.1, 0, 2, 2, 0.05, 0.8], [5, 5, 2, 2, 1.0, 0.7], [5, 5.2, 2, 2, 1.1, 0.95]], np.float32)
     assert [int(i) for i in R.rotate_nms_gpu(dets, 0.5)] == [3, 0]
     assert [int(i) for i in R.rotate_nms_gpu(dets, 0.99)] == [3, 0, 1, 2]
+
+
+def test_rbbox_iou_oracle_known_answers():
+    """riou_cc / rbbox_iou restatement (box_np_ops.py:16-27, cc/box_ops.h:23-80) against hand-computed overlaps, and its geometric
+    intersection (float64 hull) against the numba routine's on general-position boxes."""
+    sq = np.array([[0, 0, 2, 2, 0]], np.float32)
+    assert abs(R.riou_cc(sq, sq)[0, 0] - 1.0) < 1e-6
+    tilted = np.array([[3, 4, 2, 1, 0.7]], np.float32)                        # identical boxes at a general angle: geometry says 1
+    assert abs(R.riou_cc(tilted, tilted)[0, 0] - 1.0) < 1e-6
+    shifted = np.array([[1, 0, 2, 2, 0]], np.float32)
+    assert abs(R.riou_cc(sq, shifted)[0, 0] - 2.0 / 6.0) < 1e-6
+    assert R.riou_cc(sq, shifted, standup_thresh=0.5)[0, 0] == 0.0            # standup IoU 1/3 <= 0.5: skipped
+    diamond = np.array([[0, 0, 2, 2, np.pi / 4]], np.float32)
+    oct_area = 8.0 * (np.sqrt(2.0) - 1.0)
+    assert abs(R.riou_cc(sq, diamond)[0, 0] - oct_area / (8.0 - oct_area)) < 1e-5
+    c = R.center_to_corner_box2d(np.array([[1.0, 2.0]], np.float32), np.array([[2.0, 4.0]], np.float32), np.array([0.0], np.float32))
+    assert np.allclose(c[0], [[0, 0], [0, 4], [2, 4], [2, 0]]) and np.allclose(R.corner_to_standup_nd(c), [[0, 0, 2, 4]])
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        b1 = np.concatenate([rng.uniform(0, 6, 2), rng.uniform(0.5, 4, 2), rng.uniform(-3, 3, 1)]).astype(np.float32)
+        b2 = np.concatenate([rng.uniform(0, 6, 2), rng.uniform(0.5, 4, 2), rng.uniform(-3, 3, 1)]).astype(np.float32)
+        c1, c2 = R.rbbox_to_corners(b1), R.rbbox_to_corners(b2)
+        assert abs(R.convex_quad_inter_area(c1, c2) - R.quad_inter(c1.astype(np.float64), c2.astype(np.float64), np.float64)) < 1e-9 * 50
