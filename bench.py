@@ -83,6 +83,22 @@ def prof_read(lib):
     return out
 
 
+def self_launch(n, force_dist=False):
+    """`python bench.py --gpus N` without a launcher: become the launcher -- one process per GPU under torch.distributed.run on this
+    node, rendezvous on 127.0.0.1 (the container's hostname may not resolve) -- and hand the same arguments on.  Does not return."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if force_dist:
+        env["PAPC_FORCE_DIST"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(max(1, n)), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +131,9 @@ def main():
                     "parameter buffer after the last one: tests/test_gpu_bench.py holds the graph-replayed, sampling-forked step "
                     "structure to the eager in-line one")
     args = ap.parse_args()
+    force1 = os.environ.get("PAPC_BENCH_SELF_LAUNCH") == "1"   # (tests, 1-GPU box) take the self-launch path with N = 1 and a forced 1-rank RCCL group
+    if (args.gpus > 1 or force1) and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, force1)
     if args.config != "ssg":
         import bench_configs
         return bench_configs.run(args)
@@ -126,7 +145,11 @@ def main():
     from papc_amd.synthetic import make_clouds, make_labels, make_start_idx
 
     rank, world, local = init_from_env()
-    assert world == max(1, args.gpus) or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world != max(1, args.gpus):
+        raise SystemExit("[bench] --gpus %d but the launcher started %d rank(s): use `python bench.py --gpus N` (self-launching) or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`" % (args.gpus, world))
+    if world > 1 and not args.no_graph:
+        args.require_graph = True                 # a multi-GPU run must not quietly measure the eager fallback
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -494,6 +517,10 @@ def main():
                     if "traffic_MB_per_step" in rec:     # per step over THIS run's launches per step (an entry point may launch several kernels)
                         rec = dict(rec, traffic_MB_per_launch=rec["traffic_MB_per_step"] / lps)
                     roof["traffic"] = round(rec["traffic_MB_per_launch"] * 1e6)     # bytes per launch, like `achieved`
+                    # the same fraction on COUNTER bytes (what the family really moved through HBM in the profiled run) beside the one on the
+                    # fixed SURVEY 8d algorithmic bytes: the latter still counts tensors that later rounds stopped storing
+                    if roof["bound"] == "hbm" and per_step_s == per_step_s:
+                        roof["frac_counter_bytes"] = round(rec["traffic_MB_per_launch"] * 1e6 * lps / per_step_s / (PEAK_HBM_GBS * 1e9), 4)
                     roof["traffic_note"] = ("%s: 2 x FETCH_SIZE + WRITE_SIZE per launch of the family (separate rocprofv3 --pmc passes, gfx950 "
                                             "FETCH_SIZE correction x2), %.1f MB against %.1f MB algorithmic per launch"
                                             % (os.path.join("profiles", os.path.basename(fams[-1])), rec["traffic_MB_per_launch"],

@@ -220,17 +220,19 @@ def const_zeros(shape, device):
 
 
 def const_idx3(B, N, device):
-    """cached read-only int32 [B, N, 3] = (0, 1, 2) per row: the neighbour indices the reference's sort-then-argsort yields
-    (pointnet2_basic_layers.py:316-317, see layers.PointNetFeaturePropagation)"""
+    """read-only int32 [B, N, 3] = (0, 1, 2) per row: the neighbour indices the reference's sort-then-argsort yields
+    (pointnet2_basic_layers.py:316-317, see layers.PointNetFeaturePropagation).  ONE buffer per device, grown to the largest B*N seen
+    and handed out as a narrowed contiguous view (segmentation over varying batch / point counts does not accumulate one tensor per shape)."""
     import torch
-    key = ("idx3", int(B), int(N), str(device))
+    key = ("idx3", str(device))
+    rows = int(B) * int(N)
     t = _CONSTS.get(key)
-    if t is None:
-        mk = lambda: torch.arange(3, device=device, dtype=torch.int32).expand(B, N, 3).contiguous()
+    if t is None or t.shape[0] < rows:
+        mk = lambda n: torch.arange(3, device=device, dtype=torch.int32).expand(n, 3).contiguous()
         if _capturing():
-            return mk()
-        t = _CONSTS[key] = mk()
-    return t
+            return mk(rows).view(B, N, 3)
+        t = _CONSTS[key] = mk(rows)
+    return t[:rows].view(B, N, 3)
 
 
 def const_vec(value, n, device):

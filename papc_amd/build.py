@@ -54,13 +54,14 @@ def _check_no_spills(remarks):
 
 
 def _audit_asm_ring(asm_path):
-    """Static audit of mlp_stream.hip's hidden operand ring (tools/probe/late1_isa.py): between an inline-asm global_load_dwordx4 and
+    """Static audit of mlp_stream.hip's hidden operand ring (papc_amd/_isa_audit.py): between an inline-asm global_load_dwordx4 and
     the hand-placed s_waitcnt that covers it no compiler instruction may touch the destination registers (a v_mov / AGPR copy of a
     register whose load is in flight copies stale data and the late data lands in a register that was given away).  Fails closed."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe", "late1_isa.py"), asm_path, "stream_kernel"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    if r.returncode != 0 or "clean" not in r.stdout or "scanned 0 " in r.stdout:
-        raise RuntimeError("mlp_stream.hip: the asm-ring audit failed\n" + r.stdout[-2000:])
+    from ._isa_audit import audit, report
+    res = audit(open(asm_path).read(), "stream_kernel")
+    if res["violations"] or not res["kernels"] or res["loads"] == 0:
+        raise RuntimeError("mlp_stream.hip: the asm-ring audit failed (%d kernels, %d hidden loads scanned)\n%s"
+                           % (len(res["kernels"]), res["loads"], report(res)[-2000:]))
 
 
 def _newest(paths):

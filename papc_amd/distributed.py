@@ -40,14 +40,18 @@ class FlatParams:
         self.params = [p for p in module.parameters() if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, torch.float32
-        n = sum(p.numel() for p in self.params)
-        pad = (-n) % 4
+        # every parameter starts on a 16-byte boundary (the kernels' vector loads of weights and constants want it: a parameter whose
+        # numel is not a multiple of 4 must not misalign everything laid out behind it); the gaps stay zero in data, grad and moments
+        self._offsets = []
+        n = 0
+        for p in self.params:
+            self._offsets.append(n)
+            n += p.numel() + ((-p.numel()) % 4)
         self.numel = n
-        self.data = torch.zeros(n + pad, device=dev, dtype=dt)
-        self.grad = torch.zeros(n + pad, device=dev, dtype=dt)
-        off = 0
+        self.data = torch.zeros(n, device=dev, dtype=dt)
+        self.grad = torch.zeros(n, device=dev, dtype=dt)
         with torch.no_grad():
-            for p in self.params:
+            for p, off in zip(self.params, self._offsets):
                 k = p.numel()
                 self.data[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.data[off:off + k].view(p.shape)
@@ -56,17 +60,14 @@ class FlatParams:
                 # reduction itself (allreduce_grads); do NOT wrap such a module in torch's DistributedDataParallel or hang
                 # post-accumulate-grad hooks on its parameters
                 p._papc_inplace_grad = True
-                off += k
 
     def offset_of(self, module):
         """Element offset in the flat buffers of ``module``'s first trainable parameter (parameters are laid out in
         ``module.parameters()`` order, so everything registered after it follows contiguously)."""
         first = next(p for p in module.parameters() if p.requires_grad)
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self._offsets):
             if p is first:
                 return off
-            off += p.numel()
         raise ValueError("module is not part of this FlatParams")
 
     def zero_grad(self):

@@ -115,9 +115,12 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
         if torch.is_grad_enabled() and xyz.is_cuda:
             # the W^T operands of the three stacks' dX GEMMs in one launch (SA1 / SA2: layers 2, 3; SA3 also its first layer, whose
             # input features carry a gradient)
+            from . import smallm
             from .mlp import precompute_wt
-            wt = precompute_wt([c.weight for c in list(self.sa1.mlp_convs)[1:]] + [c.weight for c in self.sa2.mlp_convs]
-                          + [c.weight for c in self.sa3.mlp_convs])     # (SA2's first layer: the feature block of its W^T, gather-add backward)
+            ws = [c.weight for c in list(self.sa1.mlp_convs)[1:]] + [c.weight for c in self.sa2.mlp_convs]   # (SA2's first layer: the feature block of its W^T, gather-add backward)
+            if not (smallm.takes_group_all(B, self.sa2.npoint, [c.weight.shape[0] for c in self.sa3.mlp_convs])):
+                ws += [c.weight for c in self.sa3.mlp_convs]    # (the planes path builds its own W^T planes: nothing to transpose for it)
+            wt = precompute_wt(ws)
         l1_xyz, l1_points = self.sa1(xyz, norm, s[0], sampled=pl[0], wt_table=wt)
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1], sampled=pl[1], wt_table=wt)
         if after_sa2 is not None:

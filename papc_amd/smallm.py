@@ -81,6 +81,13 @@ def eligible(spec, xyz, feats, idx, x_rows, params):
     return feats is None or (feats.is_contiguous() and feats.dtype == torch.float32)
 
 
+def takes_group_all(B, n_points, couts):
+    """eligible() for a sample_and_group_all stack of ``B`` clouds of ``n_points`` points, from shapes alone (train mode, contiguous fp32 CUDA
+    inputs assumed): lets a model skip work the planes path does not use (the W^T table of mlp.precompute_wt)."""
+    M = B * n_points
+    return bool(ENABLED and n_points == GROUP and M <= MAX_ROWS and len(couts) >= 2 and not any(c % 8 for c in couts))
+
+
 def _planes(lib, R, K, dev):
     return torch.empty(lib.papc_pg_planes_bytes(R, K), dtype=torch.uint8, device=dev)
 

@@ -39,3 +39,24 @@ def test_bench_forced_one_rank_rccl(dev, extra):
     assert "world 1" in out["config"]["collectives"] and "RCCL" in out["config"]["collectives"]
     assert out["n_gpus"] == 1 and out["steps"] == 6 and out["value"] > 0 and out["config"]["final_loss"] == out["config"]["final_loss"]
     assert "two-stage" in out["config"]["collectives"]
+
+
+def test_bench_self_launch_path(dev):
+    """`python bench.py --gpus N` with no RANK in the environment re-executes itself under torch.distributed.run (bench.self_launch); on
+    this 1-GPU box the same path is taken with N = 1 and a forced 1-rank RCCL group (PAPC_BENCH_SELF_LAUNCH=1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PAPC_BENCH_SELF_LAUNCH="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "bench.py", "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--require-graph"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "world 1" in out["config"]["collectives"] and "RCCL" in out["config"]["collectives"] and "hipGraph replay" in out["config"]["launch"]
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["value"] > 0
+
+
+def test_bench_rejects_a_rank_count_that_differs_from_gpus(dev):
+    """a launcher that started 1 rank for --gpus 2 gets a clear message, not an assert"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "self-launching" in (r.stderr + r.stdout)
