@@ -301,3 +301,32 @@ def test_msg_clas_sa1_backward_vs_f64(dev):
                 continue                                   # conv bias under a train-mode BN: true gradient 0
             assert_close(g.cpu().numpy(), w.grad.cpu().numpy(), 2e-4, "MSG SA1 branch %d (K = %d) param %d" % (i, ks[i], j))
     assert_close(pts.grad.cpu().numpy(), f64.grad.cpu().numpy(), 2e-4, "MSG SA1 d(points)")
+
+
+def test_full_size_config2_sa_vs_oracle(dev):
+    """BASELINE configs[1] at its own size (B=32, N=4096): SA1 (M = 524 288 rows, 3 -> 64 -> 64 -> 128: moment-path first layer, row-streaming
+    second, no-store max layer) and SA2 (M = 262 144 rows, 131 -> 128 -> 128 -> 256: gather-add first layer, row-streaming + fused group max)
+    forward activations against the float64 oracle at 1e-5 -- the kernels and sizes bench.py times, not a scaled-down stand-in.
+    pointnet2_basic_layers.py:194-221, classify/pointnet2/pointnet2.py:11-15."""
+    B, N = 32, 4096
+    x = make_clouds(B, N, 1234)
+    s1, s2 = make_start_idx(B, N, 1234), make_start_idx(B, 512, 1235)
+    w1, w2 = seeded_weights([3, 64, 64, 128], 31), seeded_weights([131, 128, 128, 256], 32)
+    ora1 = R.PointNetSetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False, w1)
+    ref_xyz1, ref1 = ora1.forward(x, None, s1, f64=True)
+    sa1 = PointNetSetAbstraction(512, 0.2, 32, 3, [64, 64, 128], False).to(dev)
+    sa2 = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False).to(dev)
+    _load_stack(sa1.mlp_convs, sa1.mlp_bns, w1)
+    _load_stack(sa2.mlp_convs, sa2.mlp_bns, w2)
+    with torch.no_grad():
+        l1_xyz, l1 = sa1(torch.from_numpy(x).to(dev), None, torch.from_numpy(s1).to(dev))
+    assert np.array_equal(l1_xyz.cpu().numpy(), ref_xyz1)
+    assert_close(l1.cpu().numpy(), ref1, 1e-5, "config-2 SA1 (M = 524288) vs f64 oracle")
+    # SA2 on the ORACLE's l1 features, so that it is held on its own
+    l1_ref = ref1.astype(np.float32)
+    ora2 = R.PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False, w2)
+    ref_xyz2, ref2 = ora2.forward(ref_xyz1, l1_ref, s2, f64=True)
+    with torch.no_grad():
+        l2_xyz, l2 = sa2(torch.from_numpy(ref_xyz1).to(dev), torch.from_numpy(l1_ref).to(dev), torch.from_numpy(s2).to(dev))
+    assert np.array_equal(l2_xyz.cpu().numpy(), ref_xyz2)
+    assert_close(l2.cpu().numpy(), ref2, 1e-5, "config-2 SA2 (M = 262144) vs f64 oracle")

@@ -127,7 +127,8 @@ def _stack_node(t):
     raise AssertionError("no stack node behind " + type(t.grad_fn).__name__)
 
 
-def test_whole_model_gradients_with_pinned_routing(dev):
+@pytest.mark.parametrize("B", [4, 8])     # B = 8: SA1 (M = 131072) and SA2 (M = 65536) run the kernels the bench times -- row-streaming forward / dX, dw_rows / dw_rowsx,
+def test_whole_model_gradients_with_pinned_routing(dev, B):   # the gather-add first layer, SA1's moment path and no-store max layer -- not the tiled fallback of B = 4
     """Every parameter gradient of one PointNet2_SSG_Clas step (sampling -> SA1 -> SA2 -> SA3 -> FC head -> cross-entropy,
     classify/pointnet2/pointnet2.py:33-39, train.py:106-109) against float64 torch autograd of the same graph at 2e-4 of max |grad|.
     A max-pooled gradient is a discontinuous function of the activations, so the float64 reference is routed through the kernels' own
@@ -136,7 +137,7 @@ def test_whole_model_gradients_with_pinned_routing(dev):
     near-tie allowance.  Where plain fp32 torch autograd on the same routed graph is itself worse than 2e-4 / 3 (ill-conditioned
     first-layer sums), the bar is 3x that.  Reports how many decisions differ from float64's own."""
     from tests import torch_ref
-    B, N = 4, 1024
+    N = 1024
     model = PointNet2_SSG_Clas(num_classes=16)
     copy_into_model(model, seeded_model_state(model, 99))
     model.drop1.p = model.drop2.p = 0.0

@@ -60,3 +60,32 @@ def copy_into_model(model, state):
     with torch.no_grad():
         for name, p in model.named_parameters():
             p.copy_(torch.from_numpy(state[name]).to(p.device))
+
+
+def kernel_decisions(out):
+    """The decisions the HIP stack behind ``out`` (a shared_mlp_max result that still has its autograd node) took in its forward pass,
+    read from the node's saved tensors: (argmax [G, C_L] int32, pooled_alive [G, C_L] bool, masks per non-pooled layer or None).
+    A ReLU mask is sign(scale * y + shift) of the kernel's own stored pre-BN output and folded BN constants, evaluated in float64
+    (the product of two fp32 numbers is exact there, so the sign is the sign of the kernel's fp32 fma).  Layers whose output the kernel
+    never stores (the moment-path first layer, the planes path) return None: their decisions stay the reference's own."""
+    fn = out.grad_fn
+    for _ in range(4):
+        if "MLPMax" in type(fn).__name__:
+            break
+        fn = fn.next_functions[0][0]
+    assert "MLPMax" in type(fn).__name__, type(out.grad_fn).__name__
+    saved = fn.saved_tensors
+    alive = out.detach() > 0
+    if "Planes" in type(fn).__name__:
+        return saved[0], alive, None
+    L = fn.L
+    argmax = saved[5]
+    ys, consts = saved[7 + 4 * L: 7 + 5 * L], saved[7 + 5 * L: 7 + 6 * L]
+    masks = []
+    for l in range(L - 1):
+        y, c = ys[l], consts[l]
+        if y is None or y.dim() != 2 or y.shape[1] != c.shape[1]:
+            masks.append(None)
+        else:
+            masks.append((c[2].double() * y.double() + c[3].double()) > 0)
+    return argmax, alive, masks
