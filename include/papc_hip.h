@@ -126,6 +126,9 @@ typedef struct papc_group_src {
     const int32_t *idx;    /* [B,S,K] */
     int N, S, K, D;
     int xyz_first;
+    /* compacted grouping (papc_compact_plan_f32; all NULL for the padded [B,S,K] lists): point index of every physical row, group of
+     * every 8-row segment, physical row count in device memory.  Read by the gather-add first layer (papc_lingather_*) only. */
+    const int32_t *cidx, *seg_grp, *rows_dev;
 } papc_group_src;
 
 /* One conv1x1 layer on rows with fp32 MFMA: y[M,Cout] = A(x)[M,Cin] . w[Cout,Cin]^T + bias.
@@ -150,6 +153,13 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
                       const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
                       int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
                       papc_stream_t stream);
+/* papc_mlp_gemm_f32 over the first rows_dev[0] rows only (a device-side count, <= M, a multiple of 128: the compacted stack of
+ * papc_compact_plan_f32; NULL = all M rows).  PLAIN / BNRELU operands on the row-streaming kernel's shapes (M >= 65 536 rows of capacity,
+ * Cin in 32..256, Cout % 64 == 0), no fused group max; PAPC_E_UNSUPPORTED elsewhere.  Rows beyond the count are neither read nor written. */
+int papc_mlp_gemm_rows_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
+                           const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
+                           int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
+                           const int32_t *rows_dev, papc_stream_t stream);
 /* out[g,c] = relu(scale*(scale >= 0 ? gmax : gmin) + shift), argmax[g,c] = the matching row offset.  On return gmax holds the
  * SELECTED raw value (ysel: y at the argmax) -- pass it to papc_bn_bwd_reduce_f32 (MAX) so the backward need not gather y. */
 int papc_bn_select_max_f32(float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
@@ -220,6 +230,12 @@ typedef struct papc_bwd_dy {
     int K;
     const float *y;        /* [M,C] pre-BN output of this layer (saved by forward) */
     const float *mean, *invstd, *scale, *shift, *c1, *c2; /* [C] */
+    /* compacted stack (papc_compact_plan_f32 below; all NULL for a padded one): per-row multiplicity weight of the BatchNorm-backward term,
+     * dy = scale p - wrow (A + B (y - mean)); group of every 8-row segment (ragged groups: gout / argmax rows are looked up through it
+     * and argmax holds ABSOLUTE rows); physical row count in device memory (M then is the capacity, a multiple of 128). */
+    const float *wrow;
+    const int32_t *seg_grp;
+    const int32_t *rows_dev;
 } papc_bwd_dy;
 
 /* dX[M,Cin] = dY[M,Cout] . w[Cout,Cin], dY produced on the fly from `dy` (never materialised).
@@ -433,6 +449,29 @@ int papc_riou_f32(const float *rbboxes, const float *qrbboxes, float standup_thr
  * (pre-zeroed by the caller, float atomics) and dwx_partial [papc_lingather_parts(M), C, 3] = partial sums of dY^T (xyz_j - centre);
  * the caller finishes with grad_feats = G W_f, dW_f = G^T feats, dW_x = sum of the partials. */
 int papc_lingather_parts(int64_t M);
+/* The COMPACTED form of a grouped stack: distinct neighbours only (csrc/compact.hip).  query_ball_point pads every neighbourhood to
+ * nsample slots with copies of its first hit (pointnet2_basic_layers.py:118-124); copies are identical rows through every layer of the
+ * stack (:214-217), do not change the max (:219) and enter the train-mode BatchNorm statistics and the backward sums only through their
+ * multiplicity -- so the stack is the same function, with the same gradients, on the distinct rows plus one weight per group.
+ * papc_compact_plan_f32: idx [G, K] int32 (ball-query lists, K % 8 == 0) -> start [G+1] (first physical row of each group; groups are
+ * the distinct neighbours in list order, then copies of the first one up to a multiple of 8 rows), rows [2] = {physical rows rounded up
+ * to 128 (the last group takes the tail), their exact count}, cidx [cap] point index per row, seg_grp [cap / 8], wrow [cap] = 1 +
+ * coef[g] on a group's first row and 1 elsewhere, coef [G] = nsample - rows of the group; cnt8 [G] scratch; cap = G * K.  Everything
+ * stays on the device: consumers take the row count from rows[0] (papc_mlp_gemm_rows_f32, papc_bwd_dy.rows_dev, papc_group_src.rows_dev).
+ * papc_bn_stats_corr_f32: the copies' share of a layer's statistics -- writes papc_compact_corr_parts() extra partial rows [r][2][C] =
+ * sum_g coef[g] (y, y^2)[start[g]] behind the kernel-written rows of stats_partial; papc_bn_finalize_f32 then takes n_tiles + that many
+ * rows and M = G * K.
+ * papc_bn_relu_max_seg_f32: the neighbourhood max over ragged groups, out [G,C] = max relu(bn(y)) over the rows of a group, argmax [G,C] =
+ * the first row attaining it (ABSOLUTE row), ysel [G,C] = y there. */
+/* 1 when a grouped stack of these widths can run compacted: first layer on the gather-add kernel (couts[0] == 128), then 128 -> 128 dense
+ * layers and a 128 -> 256 layer under the max (the flavours built so far: SA2 of the SSG classifier), capacity M = G * K >= 65 536 rows. */
+int papc_mlp_compact_ok(int64_t M, int K, int n_layers, const int *couts);
+int papc_compact_plan_f32(const int32_t *idx, int G, int K, int32_t *cnt8, int32_t *start, int32_t *rows, int32_t *cidx, int32_t *seg_grp,
+                          float *wrow, float *coef, papc_stream_t stream);
+int papc_compact_corr_parts(void);
+int papc_bn_stats_corr_f32(const float *y, int C, const int32_t *start, const float *coef, int G, float *stats_rows, papc_stream_t stream);
+int papc_bn_relu_max_seg_f32(const float *y, int C, const int32_t *start, const float *scale, const float *shift, int G, float *out,
+                             int32_t *argmax, float *ysel, papc_stream_t stream);
 int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, const float *w, int ldw, int xcol0, const float *bias, int C,
                            float *y, float *stats_partial, papc_stream_t stream);
 int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream);

@@ -46,7 +46,7 @@ def audit(asm_text, want="stream_kernel"):
             in_asm = False
             continue
         if in_asm:
-            if t.startswith("global_load_dwordx4"):
+            if t.startswith("global_load_dword"):     # (dwordx4 operand loads; dword loads of the compacted flavours' per-row weight / group)
                 inflight.append((_regs_of(t.split(",")[0]), i + 1))
                 nload += 1
             elif t.startswith("s_waitcnt") and "vmcnt" in t:

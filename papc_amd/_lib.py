@@ -22,13 +22,15 @@ class PapcError(RuntimeError):
 class GroupSrc(ctypes.Structure):
     """papc_group_src"""
     _fields_ = [("xyz", c_p), ("sb", c_l), ("sn", c_l), ("sc", c_l), ("new_xyz", c_p), ("feats", c_p),
-                ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("xyz_first", c_i)]
+                ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("xyz_first", c_i),
+                ("cidx", c_p), ("seg_grp", c_p), ("rows_dev", c_p)]
 
 
 class BwdDy(ctypes.Structure):
     """papc_bwd_dy"""
     _fields_ = [("dz_mode", c_i), ("dz", c_p), ("gout", c_p), ("argmax", c_p), ("K", c_i), ("y", c_p),
-                ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("c1", c_p), ("c2", c_p)]
+                ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("c1", c_p), ("c2", c_p),
+                ("wrow", c_p), ("seg_grp", c_p), ("rows_dev", c_p)]
 
 
 class GroupMax(ctypes.Structure):
@@ -74,6 +76,12 @@ SIGNATURES = {
     "papc_mlp_gemm_parts": (c_i, [c_l]),
     "papc_mlp_gemm_gmax_ok": (c_i, [c_l, c_i, c_i]),
     "papc_mlp_gemm_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "papc_mlp_gemm_rows_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "papc_compact_plan_f32": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_compact_corr_parts": (c_i, []),
+    "papc_mlp_compact_ok": (c_i, [c_l, c_i, c_i, c_p]),
+    "papc_bn_stats_corr_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_p]),
+    "papc_bn_relu_max_seg_f32": (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "papc_bn_select_max_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p]),
     "papc_bn_finalize_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "papc_bn_relu_max_f32": (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),

@@ -24,6 +24,9 @@ struct LinGatherArgs {
     int64_t M;
     float *y;                   // fwd: [M, C]
     float *stats;               // fwd: [gridDim.x][2][C] column sums / sums of squares of y
+    // compacted stack (compact.hip; all NULL for a padded one): point index per physical row, group of every 8-row segment, the physical
+    // row count in device memory (M then is the capacity); the backward's per-row multiplicity weight is d.wrow
+    const int32_t *cidx, *seg_grp, *rows_dev;
     DySrc d;                    // bwd: dz, y, BN constants (DENSE)
     float *G;                   // bwd: [B*N, C], pre-zeroed, atomically accumulated
     float *dwx;                 // bwd: [gridDim.x][C][3]
@@ -41,9 +44,9 @@ struct LgRow {
 __device__ __forceinline__ LgRow lg_row(const LinGatherArgs &a, int64_t m)
 {
     LgRow r;
-    const int g = (int)(m / a.K);
+    const int g = a.cidx ? a.seg_grp[m >> 3] : (int)(m / a.K);
     r.b = g / a.S;
-    int j = a.idx[m];
+    int j = a.cidx ? a.cidx[m] : a.idx[m];
     if (j < 0 || j >= a.N) { r.j = -1; r.dx = r.dy = r.dz = 0.f; return r; }
     r.j = j;
     const float *p = a.xyz + (int64_t)r.b * a.sb + (int64_t)j * a.sn;
@@ -75,7 +78,9 @@ __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
         w2 = make_float4(wp[2], wp[a.ldw + 2], wp[2 * a.ldw + 2], wp[3 * a.ldw + 2]);
         if (a.bias) bv = ld4(a.bias + c);
     }
-    const int64_t mbeg = (int64_t)blockIdx.x * a.rows_per_wg, mend = min(a.M, mbeg + a.rows_per_wg);
+    int64_t rows_all = a.M, rpw = a.rows_per_wg;
+    if (a.rows_dev) { rows_all = *a.rows_dev; rpw = (rows_all + gridDim.x - 1) / gridDim.x; }
+    const int64_t mbeg = (int64_t)blockIdx.x * rpw, mend = min(rows_all, mbeg + rpw);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     constexpr int U = 4;
     for (int64_t base = mbeg; base < mend; base += LG_ROWS) {
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
     __shared__ int s_j[LG_ROWS], s_b[LG_ROWS], s_grp[LG_ROWS];
     __shared__ float s_dx[LG_ROWS], s_dy[LG_ROWS], s_dz[LG_ROWS];
     __shared__ unsigned char s_dup[LG_ROWS];
+    __shared__ float s_w[LG_ROWS];               // compacted stack: the row's multiplicity weight (1 otherwise)
     const int tid = threadIdx.x;
     const int RSL = LG_T / a.C;                   // C <= 256 (host-checked)
     const int ch = tid % a.C, slot = tid / a.C;
@@ -145,7 +151,10 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
     const DySrc &d = a.d;
     const float ksc = d.scale[ch], ksh = d.shift[ch], kmu = d.mean[ch];
     const float kA = ksc * d.c1[ch], kB = ksc * d.c2[ch] * d.invstd[ch];
-    const int64_t mbeg = (int64_t)blockIdx.x * a.rows_per_wg, mend = min(a.M, mbeg + a.rows_per_wg);
+    int64_t rows_all = a.M, rpw = a.rows_per_wg;
+    if (a.rows_dev) { rows_all = *a.rows_dev; rpw = (rows_all + gridDim.x - 1) / gridDim.x; }
+    const int64_t mbeg = (int64_t)blockIdx.x * rpw, mend = min(rows_all, mbeg + rpw);
+    const bool cp = a.cidx != nullptr;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
     float dsum = 0.f;                             // pending sum of padding duplicates ...
     int dgrp = -1, djf = -1, dbat = 0;            // ... of group dgrp (first neighbour djf, cloud dbat)
@@ -155,10 +164,15 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
         for (int rr = tid; rr < nrows; rr += LG_T) {
             const int64_t m = base + rr;
             const LgRow r = lg_row(a, m);
-            const int grp = (int)(m / a.K);
-            const int jf = a.idx[(int64_t)grp * a.K];
-            s_j[rr] = r.j; s_b[rr] = r.b; s_grp[rr] = grp; s_dx[rr] = r.dx; s_dy[rr] = r.dy; s_dz[rr] = r.dz;
-            s_dup[rr] = (r.j == jf && m != (int64_t)grp * a.K) ? 1 : 0;
+            s_j[rr] = r.j; s_b[rr] = r.b; s_dx[rr] = r.dx; s_dy[rr] = r.dy; s_dz[rr] = r.dz;
+            if (cp) {             // (a compacted group holds at most 7 copies of its first neighbour: no pre-summing)
+                s_grp[rr] = 0; s_dup[rr] = 0; s_w[rr] = a.d.wrow[m];
+            } else {
+                const int grp = (int)(m / a.K);
+                const int jf = a.idx[(int64_t)grp * a.K];
+                s_grp[rr] = grp; s_w[rr] = 1.f;
+                s_dup[rr] = (r.j == jf && m != (int64_t)grp * a.K) ? 1 : 0;
+            }
         }
         __syncthreads();
         if (!act) continue;
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
                 if (j < 0) continue;
                 const float z = fmaf(ksc, vy[u], ksh);
                 const float pp = z > 0.f ? vz[u] : 0.f;
-                const float g = fmaf(ksc, pp, -fmaf(kB, vy[u] - kmu, kA));
+                const float g = cp ? fmaf(-s_w[rr], fmaf(kB, vy[u] - kmu, kA), ksc * pp) : fmaf(ksc, pp, -fmaf(kB, vy[u] - kmu, kA));
                 acc0 = fmaf(g, s_dx[rr], acc0); acc1 = fmaf(g, s_dy[rr], acc1); acc2 = fmaf(g, s_dz[rr], acc2);
                 if (s_dup[rr]) {                  // a padding duplicate of the group's first neighbour
                     const int grp = s_grp[rr];
@@ -217,6 +231,7 @@ static int lg_check(const papc_group_src *g, int B, int C, const char *who)
     PAPC_REQUIRE(B >= 1 && g->N >= 1 && g->S >= 1 && g->K >= 1, PAPC_E_INVALID, "%s: bad B/N/S/K", who);
     PAPC_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, PAPC_E_UNSUPPORTED, "%s: C=%d must be a multiple of 4 in [4, 1024]", who, C);
     PAPC_REQUIRE((int64_t)B * g->S * g->K < (1ll << 31), PAPC_E_UNSUPPORTED, "%s: >= 2^31 rows", who);
+    PAPC_REQUIRE(!g->cidx || (g->seg_grp && g->rows_dev), PAPC_E_INVALID, "%s: a compacted group source needs cidx, seg_grp and rows_dev", who);
     return 0;
 }
 
@@ -224,6 +239,7 @@ static void lg_fill(LinGatherArgs &a, const papc_group_src *g, int B, int C)
 {
     a.xyz = g->xyz; a.sb = g->sb; a.sn = g->sn; a.sc = g->sc; a.new_xyz = g->new_xyz; a.idx = g->idx;
     a.B = B; a.N = g->N; a.S = g->S; a.K = g->K; a.C = C; a.M = (int64_t)B * g->S * g->K;
+    a.cidx = g->cidx; a.seg_grp = g->seg_grp; a.rows_dev = g->rows_dev;
 }
 
 extern "C" {
@@ -268,7 +284,8 @@ int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int
     memset(&a, 0, sizeof(a));
     lg_fill(a, grp, B, C);
     a.d.dz = dy->dz; a.d.y = dy->y; a.d.mean = dy->mean; a.d.invstd = dy->invstd; a.d.scale = dy->scale; a.d.shift = dy->shift;
-    a.d.c1 = dy->c1; a.d.c2 = dy->c2; a.d.C = C;
+    a.d.c1 = dy->c1; a.d.c2 = dy->c2; a.d.C = C; a.d.wrow = dy->wrow;
+    PAPC_REQUIRE(!a.cidx == !dy->wrow, PAPC_E_INVALID, "papc_lingather_bwd_f32: compacted group source and compacted dY source go together");
     a.G = G; a.dwx = dwx_partial;
     const int parts = papc_lingather_parts(a.M);
     a.rows_per_wg = (int)((a.M + parts - 1) / parts);

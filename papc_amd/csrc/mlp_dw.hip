@@ -808,7 +808,10 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
 // LDS ([plane][channel][16 rows], 48-byte channel stride: conflict-free ds_read_b128), double-buffered, ONE barrier per block --
 // and since all waves do identical work the barrier costs little skew.  A wave accumulates 32 x 128 of dW (4 accumulators) and
 // stores its rows of the partial itself: no cross-wave fold.
-template <int DYMODE, int NW>      // NW waves = NW 32-channel groups of Cout per workgroup: 8 (256-channel blocks) or 4 (128-channel blocks, two workgroups per CU)
+// CP (compacted stack, compact.hip): the row count comes from device memory (the chunk size is derived from it here), dY carries the row's
+// multiplicity weight in its BatchNorm-backward term, groups are ragged multiples of 8 rows (a lane's 8 rows share a group: seg_grp) and
+// argmax holds absolute rows.
+template <int DYMODE, int NW, bool CP = false>      // NW waves = NW 32-channel groups of Cout per workgroup: 8 (256-channel blocks) or 4 (128-channel blocks, two workgroups per CU)
 __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
 {
     constexpr int NTI = 4, CI = 128, CHS = 48, PLB = CI * CHS, STG = 3 * PLB;   // bytes: channel stride, plane, stage
@@ -819,10 +822,15 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
     const int co = blockIdx.y * CB + wave * 32 + l31;        // this lane's dY channel
-    const int64_t mbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
-    const int64_t mend = min(p.M, mbeg + p.rows_per_chunk);
-    const int n_kb = mbeg < mend ? (int)((mend - mbeg) >> 4) : 0;       // (whole 16-row blocks only: host-checked)
     const DySrc &d = p.dy.d;
+    int64_t rows_all = p.M, rpc = p.rows_per_chunk;
+    if constexpr (CP) {      // one chunk per workgroup column of the grid, sized from the device-side row count (a multiple of 128)
+        rows_all = __builtin_amdgcn_readfirstlane(*d.rows_dev);
+        rpc = (((rows_all + gridDim.x - 1) / gridDim.x) + 15) & ~(int64_t)15;
+    }
+    const int64_t mbeg = (int64_t)blockIdx.x * rpc;
+    const int64_t mend = min(rows_all, mbeg + rpc);
+    const int n_kb = mbeg < mend ? (int)((mend - mbeg) >> 4) : 0;       // (whole 16-row blocks only: host-checked)
     const int Cout = p.Cout;
 
     const float ksc = d.scale[co], ksh = d.shift[co], kmu = d.mean[co];
@@ -837,7 +845,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 
-    struct Raw { float y[8], z[8]; int am; };
+    struct Raw { float y[8], z[8]; int am; float4 w0, w1; int g; };
     struct RawX { float x[RPT]; };
     // addresses: wave-uniform base + a 32-bit byte offset per lane (host-checked: M * Cout * 4 < 2^32 and whole 16-row blocks only), so a
     // load costs one 32-bit add instead of a 64-bit multiply-add and a row clamp -- address arithmetic was a third of the loop's VALU work
@@ -846,6 +854,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
     const uint32_t ystride = (uint32_t)Cout * 4u;
     const uint32_t oy_lane = (uint32_t)((mbeg + 8 * hi) * Cout + co) * 4u;        // row (mbeg + 8 hi) of this lane's channel
     const uint32_t ox_lane = (uint32_t)((mbeg + RPT * xq) * CI + xc) * 4u;
+    const uint32_t ow_lane = (uint32_t)(mbeg + 8 * hi) * 4u;                      // CP: weights of this lane's 8 rows
+    const uint32_t og_lane = (uint32_t)(((mbeg >> 3) + hi)) * 4u;                 // CP: group of this lane's 8-row segment
+    // CP, DY_MAX: the group of block kb's segment, fetched one ring round ahead of the block itself (its gout / argmax addresses depend on it)
+    auto fetch_g = [&](int kb, Raw &w) {
+        if constexpr (CP && DYMODE == A_DY_MAX) w.g = ldgi(d.seg_grp, og_lane + (uint32_t)kb * 8u);
+    };
     auto fetch = [&](int kb, Raw &w) {
         const uint32_t o0 = oy_lane + (uint32_t)kb * 16u * ystride;
 #pragma unroll
@@ -854,11 +868,22 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
             if (DYMODE == A_DY_DENSE) w.z[j] = ldg(d.dz, o0 + (uint32_t)j * ystride);
         }
         if (DYMODE == A_DY_MAX) {
-            const uint32_t g = fdiv((uint32_t)mbeg + 16u * (uint32_t)kb, d.divK);      // (no 64-bit division: a branchy call sequence between the loads)
+            uint32_t g;
+            if constexpr (CP) g = (uint32_t)w.g;
+            else g = fdiv((uint32_t)mbeg + 16u * (uint32_t)kb, d.divK);      // (no 64-bit division: a branchy call sequence between the loads)
             const uint32_t og = (g * (uint32_t)Cout + (uint32_t)co) * 4u;
             w.z[0] = ldg(d.gout, og);
             w.am = ldgi(d.argmax, og);
         }
+        if constexpr (CP) {
+            const char *wb = reinterpret_cast<const char *>(d.wrow) + ow_lane + (uint32_t)kb * 64u;
+            w.w0 = *reinterpret_cast<const float4 *>(wb);
+            w.w1 = *reinterpret_cast<const float4 *>(wb + 16);
+        }
+    };
+    auto wof = [](const Raw &w, int j) -> float {
+        const float a[8] = {w.w0.x, w.w0.y, w.w0.z, w.w0.w, w.w1.x, w.w1.y, w.w1.z, w.w1.w};
+        return a[j];
     };
     auto fetch_x = [&](int kb, RawX &w) {
         const uint32_t o0 = ox_lane + (uint32_t)kb * (16u * CI * 4u);
@@ -885,7 +910,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
         int kin0 = 0;
         if (DYMODE == A_DY_MAX) {
             const uint32_t b0 = (uint32_t)mbeg + 16u * (uint32_t)kb;
-            kin0 = (int)(b0 - fdiv(b0, d.divK) * (uint32_t)d.K) + 8 * hi;
+            kin0 = CP ? (int)b0 + 8 * hi : (int)(b0 - fdiv(b0, d.divK) * (uint32_t)d.K) + 8 * hi;
         }
         float v[8];
 #pragma unroll
@@ -896,7 +921,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
             else dz = (w.am == kin0 + j) ? w.z[0] : 0.f;
             const float z = fmaf(ksc, y, ksh);
             const float pp = z > 0.f ? dz : 0.f;
-            v[j] = fmaf(ksc, pp, -fmaf(kB, y - kmu, kA));
+            if constexpr (CP) v[j] = fmaf(-wof(w, j), fmaf(kB, y - kmu, kA), ksc * pp);
+            else v[j] = fmaf(ksc, pp, -fmaf(kB, y - kmu, kA));
         }
         uint2 a0, a1, a2, b0, b1, b2;
         split3(make_float4(v[0], v[1], v[2], v[3]), a0, a1, a2);
@@ -937,7 +963,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
         int kin0 = 0;
         if (DYMODE == A_DY_MAX) {
             const uint32_t b0 = (uint32_t)mbeg + 16u * (uint32_t)kbn;
-            kin0 = (int)(b0 - fdiv(b0, d.divK) * (uint32_t)d.K) + 8 * hi;
+            kin0 = CP ? (int)b0 + 8 * hi : (int)(b0 - fdiv(b0, d.divK) * (uint32_t)d.K) + 8 * hi;
         }
         float v[8];
         float4 ra, rb, rx;
@@ -963,7 +989,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
                 else dz = (w.am == kin0 + g) ? w.z[0] : 0.f;
                 const float z = fmaf(ksc, y, ksh);
                 const float pp = z > 0.f ? dz : 0.f;
-                v[g] = fmaf(ksc, pp, -fmaf(kB, y - kmu, kA));
+                if constexpr (CP) v[g] = fmaf(-wof(w, g), fmaf(kB, y - kmu, kA), ksc * pp);
+                else v[g] = fmaf(ksc, pp, -fmaf(kB, y - kmu, kA));
                 pin(v[g]);
             } else if constexpr (g == 8) { ra = make_float4(v[0], v[1], v[2], v[3]); level(ra, a0); pin4(ra); pinu(a0); }
             else if constexpr (g == 9) { level(ra, a1); pin4(ra); pinu(a1); }
@@ -1009,6 +1036,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
         // (no branch sits around a load anywhere below: block indices past the chunk are clamped to its last block -- re-read, never used --
         // so the compiler keeps COUNTED waits (vmcnt(n > 0)) in the steady loop instead of draining the ring at every control-flow merge)
 #pragma unroll
+        for (int i = 0; i < PF; ++i) fetch_g(min(i, last), dr[i]);
+#pragma unroll
         for (int i = 0; i < PF - 1; ++i) { fetch(min(i, last), dr[i]); fetch_x(min(i, last), xr[i]); }
         stage_x(0, xr[0], xs_lds);
         prep(0, dr[0], pa[0]);
@@ -1020,6 +1049,13 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
         for (int i = 0; i < PF; ++i) {          // (the ring indices are compile-time: the buffers stay in registers)
             const int kb = kb0 + i;
             constexpr int NXT = PF - 1;
+            // (CP: dr[i]'s block is already in its planes pa[i], so the slot is free for the group of block kb + PF -- one ring round ahead of
+            // that block's own loads; issued BEFORE this iteration's loads, so the wait for it next iteration leaves them in flight)
+            if constexpr (CP && DYMODE == A_DY_MAX) {
+                const int gnew = ldgi(d.seg_grp, og_lane + (uint32_t)min(kb + PF, last) * 8u);
+                fetch(min(kb + NXT, last), dr[(i + NXT) % PF]);
+                dr[i].g = gnew;
+            } else
             fetch(min(kb + NXT, last), dr[(i + NXT) % PF]);
             fetch_x(min(kb + NXT, last), xr[(i + NXT) % PF]);
             __builtin_amdgcn_sched_barrier(0);
@@ -1327,6 +1363,22 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     const bool k4 = DYMODE != A_DY_MAX || p.dy.d.K % 4 == 0;
     // (the kernel addresses with 32-bit byte offsets and walks whole 16-row blocks)
     const bool rowsx_rows_ok = p.M % 16 == 0 && p.M * (int64_t)p.Cout * 4 < (1ll << 32);
+    if (p.dy.d.wrow) {     // compacted stack: dw_rowsx_kernel's CP flavours or nothing
+        const bool ok = VEC && XMODE == A_BNRELU && rowsx_rows_ok && p.Cin == 128 && p.Cout % 128 == 0 && p.x.ldx == p.Cin && !dw_f32_exact() &&
+                        p.dy.d.rows_dev && (DYMODE != A_DY_MAX || p.dy.d.seg_grp) && p.M % 128 == 0;
+        if (!ok) {
+            set_error("papc_mlp_bwd_dw_f32: a compacted dY source needs a 128-channel BN+ReLU input and Cout %% 128 == 0 (got Cin=%d Cout=%d)", p.Cin, p.Cout);
+            return PAPC_E_UNSUPPORTED;
+        }
+        if (p.Cout % 256 == 0) {
+            dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 256));
+            hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 8, true>), g2, dim3(512), 0, st, p);
+        } else {
+            dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 128));
+            hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 4, true>), g2, dim3(256), 0, st, p);
+        }
+        return check_launch("papc_mlp_bwd_dw_f32 (compacted)");
+    }
     if (VEC && XMODE == A_BNRELU && rowsx_rows_ok && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
         if (p.Cout % 256 == 0) {
             dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 256));

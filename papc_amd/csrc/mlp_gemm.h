@@ -42,6 +42,7 @@ struct GemmArgs {
     ScatterDst sc;
     RedSrc rd;
     GmaxDst gm;
+    const int32_t *rows_dev;       // compacted stack (compact.hip): the physical row count in device memory (<= M, a multiple of 128); row-streaming kernel only
     unsigned long long *dbg;       // PAPC_GEMM_DBG=1: per-workgroup cycle counters (development aid)
     int tl;                        // host: the transposed-accumulator epilogue is legal (16-byte aligned dense dX store)
 };

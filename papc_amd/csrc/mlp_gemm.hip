@@ -906,6 +906,11 @@ static int launch_gemm(const GemmArgs &p, bool vec, hipStream_t st)
         const int rc = stream_gemm_try(q, AMODE, EPI, vec, st);
         if (rc != 0) return rc < 0 ? rc : PAPC_OK;
     }
+    if (p.rows_dev || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && p.a.d.wrow)) {
+        set_error("mlp gemm: a device-side row count / compacted dY source is only built for the row-streaming kernel's flavours (M=%lld Kin=%d Nout=%d)",
+                  (long long)p.M, p.Kin, p.Nout);
+        return PAPC_E_UNSUPPORTED;
+    }
     constexpr bool TLOK = (AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (EPI == EPI_STORE || EPI == EPI_STORE_RED);
     if constexpr (TLOK) {
         if (vec && p.tl) return launch_gemm_v<AMODE, EPI, true, true>(p, st);
@@ -927,6 +932,7 @@ void fill_dy(DySrc &d, const papc_bwd_dy *s)
     d.invstd = s->invstd; d.scale = s->scale; d.shift = s->shift; d.c1 = s->c1; d.c2 = s->c2;
     d.divK = make_fastdiv((uint32_t)d.K);
     d.C = 0;  // set by the entry points (channels of the layer)
+    d.wrow = s->wrow; d.seg_grp = s->seg_grp; d.rows_dev = s->rows_dev;
 }
 
 // validates a dY descriptor and says whether its VEC flavour is legal
@@ -1000,7 +1006,17 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
                       int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
                       papc_stream_t stream)
 {
+    return papc_mlp_gemm_rows_f32(a_mode, x, ldx, grp, bn_scale, bn_shift, w, bias, M, Cin, Cout, y, stats_partial, gmax, nullptr, stream);
+}
+
+int papc_mlp_gemm_rows_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
+                           const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
+                           int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
+                           const int32_t *rows_dev, papc_stream_t stream)
+{
     PAPC_REQUIRE(w && (y || gmax), PAPC_E_INVALID, "papc_mlp_gemm_f32: null w/y");
+    PAPC_REQUIRE(!rows_dev || (!gmax && (a_mode == A_PLAIN || a_mode == A_BNRELU)), PAPC_E_UNSUPPORTED,
+                 "papc_mlp_gemm_rows_f32: a device-side row count goes with plain / BN+ReLU rows and no fused group max");
     PAPC_REQUIRE(M >= 1 && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_gemm_f32: M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
     PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_mlp_gemm_f32: M=%lld >= 2^31 rows", (long long)M);
     GemmArgs p;
@@ -1008,6 +1024,7 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
     int rc = fill_asrc(p.a, a_mode, x, ldx, grp, bn_scale, bn_shift, Cin, "papc_mlp_gemm_f32");
     if (rc) return rc;
     p.w = w; p.ldw = Cin; p.bias = bias; p.M = M; p.Kin = Cin; p.Nout = Cout; p.y = y; p.ldy = Cout; p.stats = stats_partial;
+    p.rows_dev = rows_dev;
     p.wmap = (a_mode == A_GROUP) ? 1 : 0;  // GROUP: internal order [feats, xyz] -> caller's columns through gk()
     const bool vec = p.a.vec && (p.wmap || (aligned16(w) && Cin % 4 == 0));
     hipStream_t st = as_stream(stream);
@@ -1068,6 +1085,20 @@ int papc_mlp_max_nostore_ok(int64_t M, int Cin, int Cout, int K)
     if (M % 128 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES) || M * (int64_t)Cout * 4 >= (1ll << 32)) return 0;   // (the dW kernel addresses with 32-bit byte offsets)
     if (!(K == 32 || K == 64 || K == 128) || !papc_mlp_gemm_gmax_ok(M, Cout, K)) return 0;
     if (!(Cin == 64 && Cout == 128)) return 0;
+    return 1;
+}
+
+/* 1 when a grouped stack whose first layer is the gather-add kernel (papc_lingather_*) can run COMPACTED (papc_compact_plan_f32): every
+ * later layer needs the device-row-count flavours of the row-streaming forward, dX and dW kernels -- 128 -> 128 dense layers and a
+ * 128 -> 256 layer under the max, on a capacity of M >= 65 536 rows (M % 128 == 0), nsample % 8 == 0. */
+int papc_mlp_compact_ok(int64_t M, int K, int n_layers, const int *couts)
+{
+    if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !knob(KNOB_STREAM_ASM) || !knob(KNOB_DW_ROWSX) || knob(KNOB_DW_F32)) return 0;
+    if (!couts || n_layers < 2 || M % 128 != 0 || M / 32 < knob(KNOB_STREAM_MINTILES) || K < 8 || K % 8 != 0) return 0;
+    if (M * 256 * 4 >= (1ll << 32)) return 0;              // (32-bit byte offsets in the dW kernel)
+    if (couts[0] != 128) return 0;
+    for (int l = 1; l < n_layers; ++l)
+        if (couts[l] != (l == n_layers - 1 ? 256 : 128)) return 0;
     return 1;
 }
 

@@ -59,6 +59,9 @@ struct DySrc {
     const float *y; const float *mean, *invstd, *scale, *shift, *c1, *c2;
     FastDiv divK;
     int C;  // channels of the layer (row stride of y / dz / gout / argmax)
+    // compacted stack (compact.hip): per-row multiplicity weight of the BatchNorm-backward term, group of every 8-row segment (ragged
+    // groups; argmax then holds absolute rows), physical row count in device memory.  All NULL for a padded stack.
+    const float *wrow; const int32_t *seg_grp; const int32_t *rows_dev;
 };
 
 struct ASrc {

@@ -70,6 +70,11 @@ struct StreamGeo {
     int n_units;     // units of U consecutive 32-row tiles
     int ushift;      // U = 1 << ushift
     int kgshift;     // DY_MAX: rows per group = 1 << kgshift (>= 32)
+    // compacted stack (compact.hip): the physical row count lives in device memory (a multiple of 128; n_units is its upper bound), a DY
+    // operand weighs its BatchNorm-backward term with the row's multiplicity, and groups are ragged (multiples of 8 rows)
+    const int *rows_dev;
+    const float *wrow;       // [rows] (CP flavours)
+    const int *seg_grp;      // [rows / 8] group of every 8-row segment (CP, DY_MAX)
 };
 
 // AMODE: A_PLAIN, A_BNRELU, A_DY_DENSE, A_DY_MAX, A_MAXCAT, A_XYZ.  EPI: EPI_STORE, EPI_STORE_GMAX / EPI_GMAX (forward), EPI_STORE_RED (dX).
@@ -92,9 +97,13 @@ __device__ __forceinline__ void split3_pair(f32x2 x, unsigned &p0, unsigned &p1,
     p2 = pack_bf16x2(x.x, x.y);
 }
 
-template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM>
+// CP (dX of a compacted stack: DY operands, STORE_RED epilogue): per-row weight w in the BatchNorm-backward term, dy = sc p - w (A + B' (y - mean));
+// DY_MAX: the row's group comes from seg_grp (ragged groups), argmax holds absolute rows.  The weight of tile j + 1 and the group of tile
+// j + 2 are fetched between the full drain that precedes tile j's epilogue (LATE1 flavours) and the epilogue itself: no new wait in the loop.
+template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false>
 __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo geo)
 {
+    static_assert(!CP || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && EPI == EPI_STORE_RED && ASM && PAPC_STREAM_PK), "CP: dX flavours of the asm ring only");
     constexpr int NW = 8;
     constexpr int K = KB16 * 16;
     constexpr int NT = WN * 32;
@@ -177,21 +186,26 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     const int TW = (int)gridDim.x * NW;
     const int gw = (int)blockIdx.x * NW + wave;
     const int U = 1 << geo.ushift;
-    const int my_units = geo.n_units > gw ? (geo.n_units - gw + TW - 1) / TW : 0;
+    const int n_units = geo.rows_dev ? min(geo.n_units, (__builtin_amdgcn_readfirstlane(*geo.rows_dev) >> 5) >> geo.ushift) : geo.n_units;
+    const int my_units = n_units > gw ? (n_units - gw + TW - 1) / TW : 0;
     const int my_tiles = my_units << geo.ushift;
     auto tile_row0 = [&](int j) -> int {   // first row of this wave's j-th tile (clamped to its last one: the prefetch runs ahead)
         const int jj = j < my_tiles ? j : my_tiles - 1;
         const int u = gw + (jj >> geo.ushift) * TW;
         return ((u << geo.ushift) + (jj & (U - 1))) * 32;
     };
-    struct SB { const char *p0, *p1, *p2; };
+    struct SB { const char *p0, *p1, *p2; unsigned vg; };
+    const unsigned voff_grp0 = (unsigned)(8 * hi * 4);
     auto bases = [&](int row0) -> SB {
         SB s;
-        s.p1 = nullptr; s.p2 = nullptr;
+        s.p1 = nullptr; s.p2 = nullptr; s.vg = voff_grp0;
         if (DY) {
             s.p0 = reinterpret_cast<const char *>(p.a.d.y + (int64_t)row0 * ldx);
             if (AMODE == A_DY_DENSE) s.p1 = reinterpret_cast<const char *>(p.a.d.dz + (int64_t)row0 * ldx);
-            else {
+            else if (CP) {     // ragged groups: the per-lane group offset is SB::vg (set by the caller from seg_grp)
+                s.p1 = reinterpret_cast<const char *>(p.a.d.gout);
+                s.p2 = reinterpret_cast<const char *>(p.a.d.argmax);
+            } else {
                 const int64_t g = row0 >> geo.kgshift;
                 s.p1 = reinterpret_cast<const char *>(p.a.d.gout + g * ldx);
                 s.p2 = reinterpret_cast<const char *>(p.a.d.argmax + g * ldx);
@@ -207,13 +221,18 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         return s;
     };
     const unsigned voff_row = (unsigned)((l31 * ldx + 8 * hi) * 4);   // this lane's row and k half inside a tile
-    const unsigned voff_grp = (unsigned)(8 * hi * 4);                  // ... inside a per-group row (DY_MAX: gout / argmax)
+    const unsigned voff_grp = voff_grp0;                               // ... inside a per-group row (DY_MAX: gout / argmax)
 
     f32x4 buf[2][CL];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < CL; ++i) buf[b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < CL; ++i) {
+            // (CP flavours sit at the register limit: their ring registers are DEFINED here, behind the prologue's barrier, by an empty volatile asm
+            // instead of a zero the compiler hoists above the weight split and then spills across it)
+            if constexpr (CP) asm volatile("" : "=v"(buf[b][i]));
+            else buf[b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 
     // issue the loads of chunk `ci` (compile-time) of the tile whose bases are `s` into buffer `bi`
     auto issue = [&](auto bi_, auto ci_, const SB &s) {
@@ -240,10 +259,11 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 3], voff_row, s.p1);
             }
             if constexpr (AMODE == A_DY_MAX) {
-                gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 2], voff_grp, s.p1);
-                gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 3], voff_grp, s.p1);
-                gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 4], voff_grp, s.p2);
-                gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 5], voff_grp, s.p2);
+                const unsigned vg = CP ? s.vg : voff_grp;
+                gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 2], vg, s.p1);
+                gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 3], vg, s.p1);
+                gload4<ASM, off, blk == 0>(buf[bi][blk * NLD + 4], vg, s.p2);
+                gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 5], vg, s.p2);
             }
         });
     };
@@ -260,7 +280,8 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
 
     const char *wl = smem + l31 * ROWB + hi * 16;        // this lane's weight-fragment row (tile 0, plane 0, k block 0)
     const char *cl = cstb + hi * 32;                     // this lane's constants (k block 0)
-    int kin = 0;                                         // DY_MAX: this lane's row offset inside its group
+    int kin = 0;                                         // DY_MAX: this lane's row offset inside its group (CP: its absolute row)
+    float wcur = -1.f;                                   // CP: MINUS the multiplicity weight of this lane's row in the current tile
 
     // k block kb of a tile whose operand comes from the lane's centred coordinates (A_XYZ): relu(wf . x + t) for the lane's 8 channels
     auto compute_xyz = [&](auto kb_, const float4 &xv) {
@@ -350,8 +371,13 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                         const f32x2 c0 = f32x2{c[0][h][i], c[0][h][i + 1]};
                         const f32x2 z = pk_fma(c0, y, f32x2{c[1][h][i], c[1][h][i + 1]});
                         const f32x2 pp = f32x2{z.x > 0.f ? dz.x : 0.f, z.y > 0.f ? dz.y : 0.f};
-                        const f32x2 inner = pk_fma(c0, pp, -f32x2{c[3][h][i], c[3][h][i + 1]});
-                        v2[j] = pk_fma(-f32x2{c[4][h][i], c[4][h][i + 1]}, y - f32x2{c[2][h][i], c[2][h][i + 1]}, inner);
+                        if constexpr (CP) {
+                            const f32x2 t = pk_fma(f32x2{c[4][h][i], c[4][h][i + 1]}, y - f32x2{c[2][h][i], c[2][h][i + 1]}, f32x2{c[3][h][i], c[3][h][i + 1]});
+                            v2[j] = pk_fma(f32x2{wcur, wcur}, t, c0 * pp);
+                        } else {
+                            const f32x2 inner = pk_fma(c0, pp, -f32x2{c[3][h][i], c[3][h][i + 1]});
+                            v2[j] = pk_fma(-f32x2{c[4][h][i], c[4][h][i + 1]}, y - f32x2{c[2][h][i], c[2][h][i + 1]}, inner);
+                        }
                     }
                 }
                 unsigned q0[4], q1[4], q2[4];
@@ -425,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     for (int wn = 0; wn < WN; ++wn) {
         const int col = n0 + wn * 32 + l31;
         s1[wn] = 0.f; s2[wn] = 0.f;
-        biasv[wn] = p.bias ? p.bias[col] : 0.f;
+        biasv[wn] = (!CP && p.bias) ? p.bias[col] : 0.f;     // (CP: dX flavours only -- no bias; a compile-time zero frees WN registers at the limit)
         rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
         if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[col]; rsh[wn] = p.rd.shift[col]; rmu[wn] = p.rd.mean[col]; ris[wn] = p.rd.invstd[col]; }
         gmx[wn] = -INFINITY; gmn[wn] = INFINITY; gix[wn] = 0; gin[wn] = 0;
@@ -508,14 +534,26 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     if (!XYZ && my_tiles > 0) {
         int row0 = tile_row0(0);
         SB sa = bases(row0);
+        // CP: (w, group offset) of this lane's row in tiles j, j + 1, j + 2
+        unsigned vgnxt = voff_grp0;
+        auto vg_of = [&](int g) -> unsigned { return (unsigned)((g * ldx + 8 * hi) * 4); };
+        if constexpr (CP) {
+            const int r1 = tile_row0(1);
+            wcur = -geo.wrow[row0 + l31];            // (kept negated: the transform multiplies by -w)
+            if constexpr (AMODE == A_DY_MAX) {
+                sa.vg = vg_of(geo.seg_grp[(row0 + l31) >> 3]);
+                vgnxt = vg_of(geo.seg_grp[(r1 + l31) >> 3]);
+            }
+        }
         issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, sa);
         issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sa);
         wait_vm<ASM, nld_of(1)>();
         touch_buf(std::integral_constant<int, 0>{});
         for (int j = 0; j < my_tiles; ++j) {
             const int row0n = tile_row0(j + 1);
-            const SB sn = bases(row0n);
-            if (AMODE == A_DY_MAX || MC) kin = (row0 & ((1 << geo.kgshift) - 1)) + l31;
+            SB sn = bases(row0n);
+            if constexpr (CP) sn.vg = vgnxt;
+            if (AMODE == A_DY_MAX || MC) kin = CP ? row0 + l31 : (row0 & ((1 << geo.kgshift) - 1)) + l31;
             // LATE1: the epilogue of the dX kernels issues compiler-visible loads (the layer below's y).  hipcc's own counted waits for
             // them proved unsound on hardware while asm loads it cannot see are in flight (late data landed in registers it had
             // already reused: wrong rows, timing dependent), so for that epilogue nothing hidden is outstanding: chunk 1 of the next
@@ -540,7 +578,21 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             // here, BEFORE the stores, keeps fresh stores out of every counted wait (vmcnt counts them too).
             wait_vm<ASM, LATE1 ? 0 : nld_of(1)>();
             touch_buf(std::integral_constant<int, 0>{});
+            // CP: the weight of tile j + 1 and the group of tile j + 2, as ordinary (compiler-visible) loads issued HERE -- everything hidden has
+            // landed (LATE1 drains above), and the epilogue below waits for its own, younger loads, so these two have landed by its end at no
+            // extra wait; they are first read behind the epilogue
+            float wld = 0.f;
+            int gld = 0;
+            if constexpr (CP) {
+                static_assert(!CP || LATE1, "CP relies on the full drain ahead of the STORE_RED epilogue");
+                wld = geo.wrow[row0n + l31];
+                if constexpr (AMODE == A_DY_MAX) gld = geo.seg_grp[(tile_row0(j + 2) + l31) >> 3];
+            }
             epilogue(row0, j & (U - 1));
+            if constexpr (CP) {
+                wcur = -wld;
+                if constexpr (AMODE == A_DY_MAX) vgnxt = vg_of(gld);
+            }
             if constexpr (LATE1) issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, sn);
             row0 = row0n;
             sa = sn;
@@ -588,7 +640,7 @@ static int stream_ncu()
     return ncu;
 }
 
-template <int AMODE, int EPI, int KB16, int WN>
+template <int AMODE, int EPI, int KB16, int WN, bool CP = false>
 static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
@@ -601,6 +653,12 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     gx = std::min(gx, std::max(1, (geo.n_units + 7) / 8));
     if (gx > p.parts) gx = p.parts;
     dim3 grid((unsigned)gx, (unsigned)ncb);
+    if constexpr (CP) {
+        if (!knob(KNOB_STREAM_ASM)) return 0;
+        hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, true>), grid, dim3(512), 0, st, p, geo);
+        const int rc = check_launch("mlp stream gemm (compacted)");
+        return rc ? rc : 1;
+    }
     if constexpr (AMODE == A_XYZ) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);   // (no streamed operand: no asm ring)
     else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true>), grid, dim3(512), 0, st, p, geo);
     else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX) return 0;   // (the compiler-scheduled ring of these flavours spills: the caller falls back)
@@ -613,6 +671,11 @@ template <int AMODE, int EPI>
 static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     const int kb = p.Kin / 16;
+    if (geo.wrow) {      // dX of a compacted stack: the two flavours SA2-shaped stacks need (128 -> 128 dense, 256 -> 128 under the max)
+        if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE_RED) { if (kb == 8 && p.Nout == 128) return stream_go<AMODE, EPI, 8, 4, true>(p, geo, st); }
+        if constexpr (AMODE == A_DY_MAX && EPI == EPI_STORE_RED) { if (kb == 16 && p.Nout == 128) return stream_go<AMODE, EPI, 16, 2, true>(p, geo, st); }
+        return 0;
+    }
     // N tile: as many columns as the weights' LDS image allows (6 K + 16 bytes per column, <= ~100 KB), at most 128
     const int nt = p.Kin > 128 ? 64 : 128;
     int wn = std::min(p.Nout, nt) / 32;
@@ -659,12 +722,16 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
     if (!(p.stats || epi == EPI_STORE)) return 0;
     StreamGeo geo;
     geo.ushift = 0; geo.kgshift = 5;
+    geo.rows_dev = p.rows_dev; geo.wrow = nullptr; geo.seg_grp = nullptr;
+    if (amode == A_DY_DENSE || amode == A_DY_MAX) { geo.wrow = p.a.d.wrow; geo.seg_grp = p.a.d.seg_grp; }
+    if (p.rows_dev && (p.M % 128 != 0 || epi == EPI_STORE_GMAX || epi == EPI_GMAX)) return 0;   // (ragged groups: no fused group max)
+    if (geo.wrow && (!p.rows_dev || (amode == A_DY_MAX && !geo.seg_grp))) return 0;
     if (epi == EPI_STORE_GMAX || epi == EPI_GMAX) {
         const int s = ilog2_exact(p.gm.K);
         if (s < 5 || p.M % p.gm.K != 0) return 0;
         geo.ushift = s - 5;
     }
-    if (amode == A_DY_MAX || amode == A_MAXCAT) {
+    if ((amode == A_DY_MAX && !geo.wrow) || amode == A_MAXCAT) {
         const int s = ilog2_exact(p.a.d.K);
         if (s < 5) return 0;
         geo.kgshift = s;

@@ -66,9 +66,40 @@ class PointNetSetAbstraction(nn.Module):
         self.group_all = group_all
         self.reference_quirks = reference_quirks
         self.init_dist = init_dist   # the source initialises the FPS running distance with ones (:75)
+        # compacted stack (compact.py): None = decide once from the data (the first sampling outside a graph capture measures how many of the
+        # nsample slots are padding copies), True / False = forced
+        self.compact = None
+        self._compact_on = None
         if reference_quirks:
             for p in self.parameters():
                 p.requires_grad_(False)
+
+    def _compact_mode(self, B):
+        """None: this stack has no compacted flavour (or PAPC_COMPACT=0); True / False: decided; "probe": to be measured"""
+        from . import compact as C
+        convs = self.mlp_convs
+        D = convs[0].in_channels - 3
+        if self.group_all or self.compact is False or D < 16 or D % 4 or len(convs) < 2:
+            return None
+        if not C.stack_ok(B * self.npoint * self.nsample, self.nsample, [c.out_channels for c in convs]):
+            return None
+        if self.compact is True or C.POLICY == "1":
+            return True
+        return "probe" if self._compact_on is None else self._compact_on
+
+    def _compact_plan(self, idx, out=None):
+        """the compacted layout of these ball-query lists, or None when the layer runs padded"""
+        from . import compact as C
+        mode = self._compact_mode(idx.shape[0])
+        if mode is None or mode is False:
+            return None
+        if mode == "probe":
+            if _lib._capturing():          # undecided inside a capture: stay on the padded path (a decision needs a host read)
+                return None
+            cp = C.plan(idx, out)
+            self._compact_on = cp.fraction() <= C.AUTO_MAX_FRACTION
+            return cp if self._compact_on else None
+        return C.plan(idx, out)
 
     def sample(self, xyz, start_idx=None, out=None):
         """The weight-independent half of the layer (FPS + ball query, :143-145) on its own: xyz [B,3,N] ->
@@ -88,6 +119,9 @@ class PointNetSetAbstraction(nn.Module):
             from .mlp import xyz_pregroup
             xc, gpart = xyz_pregroup(xyz, new_xyz, idx, out=None if (out is None or len(out) < 4) else (out[2], out[3]))
             return new_xyz, idx, xc, gpart
+        cp = self._compact_plan(idx, out=None if (out is None or len(out) < 9) else tuple(out[2:9]))
+        if cp is not None:              # (new_xyz, idx, cnt8, start, rows, cidx, seg_grp, wrow, coef): part of the plan like the lists themselves
+            return (new_xyz, idx) + cp.tensors()
         return new_xyz, idx
 
     def _xyz_first(self, B):
@@ -115,12 +149,18 @@ class PointNetSetAbstraction(nn.Module):
         else:                                                                   # sample_and_group :129-157
             S, K = self.npoint, self.nsample
             xyz_pre = None
+            cplan = None
             if sampled is not None:
                 new_xyz, idx = sampled[0], sampled[1]
-                xyz_pre = tuple(sampled[2:4]) if len(sampled) >= 4 else None
+                xyz_pre = tuple(sampled[2:4]) if len(sampled) == 4 else None
+                if len(sampled) == 9:
+                    from .compact import CompactPlan
+                    cplan = CompactPlan(tuple(sampled[2:9]), B * S, K)
             else:
                 _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)
                 idx = F_._ball_query_raw([self.radius], [K], xyz, new_xyz)[0]
+                if feats is not None:
+                    cplan = self._compact_plan(idx)
         params = _stack_params(self.mlp_convs, self.mlp_bns)
         if feats is not None:
             feats, params, D = _pad_features(feats, params, True)
@@ -129,6 +169,8 @@ class PointNetSetAbstraction(nn.Module):
         spec.wt_table = wt_table
         if not self.group_all and feats is None:
             spec.xyz_pre = xyz_pre
+        if not self.group_all and feats is not None:
+            spec.compact = cplan
         out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx, params)   # :214-219
         new_points = out.view(B, S, -1).transpose(1, 2)                         # [B,D',S]
         # (group_all: new_xyz is the cached READ-ONLY zero centre of sample_and_group_all, :170 -- a clone here would put a copy kernel

@@ -43,6 +43,8 @@ class StackSpec:
         self.wt_table = None
         # optional: (xc, gram_partial) of xyz_pregroup for these very (xyz, new_xyz, idx): the coordinates-only first layer skips its grouping pass
         self.xyz_pre = None
+        # optional: compact.CompactPlan of these very idx lists -- the stack then runs on the distinct neighbours only (csrc/compact.hip)
+        self.compact = None
 
 
 def _group_src(spec, xyz, new_xyz, feats, idx):
@@ -170,15 +172,24 @@ class SharedMLPMax(torch.autograd.Function):
         xyz1 = (not ev and not plain and idx is not None and feats is None and spec.D == 0
                 and xyz_first_layer_ok(M, params[0].shape[0], params[4].shape[0] if L >= 2 else 0, L))
         xc = wf = gram = None
+        # compacted stack: distinct neighbours only, a weight on each group's first row (compact.py); the row count is a device-side number
+        cp = spec.compact if (lin0 and spec.pool and spec.compact is not None) else None
+        if cp is not None:
+            from . import compact as _cpm
+            if not _cpm.stack_ok(M, spec.K, [params[4 * l].shape[0] for l in range(L)]):
+                cp = None
+        R_c = lib.papc_compact_corr_parts() if cp is not None else 0     # extra statistics rows: the copies' share
+        if cp is not None:
+            grp.cidx, grp.seg_grp, grp.rows_dev = cp.cidx.data_ptr(), cp.seg_grp.data_ptr(), cp.rows.data_ptr()
         for l in range(L):
             w, b, gamma, beta = params[4 * l: 4 * l + 4]
             cout = w.shape[0]
             w2 = w.reshape(cout, cin)
             assert w2.is_contiguous()
-            stats = None if ev else torch.empty(parts, 2, cout, device=dev, dtype=torch.float32)
+            stats = None if ev else torch.empty(parts + R_c, 2, cout, device=dev, dtype=torch.float32)
             parts_l = parts
             gm_ref = None
-            if l == L - 1 and spec.pool and _FUSE_GMAX and not ev and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
+            if cp is None and l == L - 1 and spec.pool and _FUSE_GMAX and not ev and lib.papc_mlp_gemm_gmax_ok(M, cout, spec.K):
                 # last layer: the neighbourhood max is reduced in the GEMM epilogue (per-group max/min of the raw output)
                 G_ = M // spec.K
                 gbuf_f = torch.empty(2, G_, cout, device=dev, dtype=torch.float32)
@@ -230,15 +241,22 @@ class SharedMLPMax(torch.autograd.Function):
                 check(lib.papc_mlp_gemm_f32(A_PLAIN, ptr(feats), spec.D, None, None, None, ptr(wf), None, BN_, spec.D, cout, ptr(P), None,
                                             None, st), "papc_mlp_gemm_f32")
                 parts_l = lib.papc_lingather_parts(M)
-                stats = torch.empty(parts_l, 2, cout, device=dev, dtype=torch.float32)
+                stats = torch.empty(parts_l + R_c, 2, cout, device=dev, dtype=torch.float32)
                 check(lib.papc_lingather_fwd_f32(ptr(P), ctypes.byref(grp), spec.B, ptr(w2), cin, 0 if spec.xyz_first else spec.D,
                                                  ptr(b), cout, ptr(y), ptr(stats), st), "papc_lingather_fwd_f32")
             elif l == 0:
                 check(lib.papc_mlp_gemm_f32(A_GROUP, None, 0, ctypes.byref(grp), None, None, ptr(w2), ptr(b), M, cin, cout,
                                             ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
+            elif cp is not None:
+                check(lib.papc_mlp_gemm_rows_f32(A_BNRELU, ptr(prev_y), cin, None, ptr(prev_sc), ptr(prev_sh), ptr(w2), ptr(b), M, cin,
+                                                 cout, ptr(y), ptr(stats), None, cp.rows.data_ptr(), st), "papc_mlp_gemm_rows_f32")
             else:
                 check(lib.papc_mlp_gemm_f32(A_BNRELU, ptr(prev_y), cin, None, ptr(prev_sc), ptr(prev_sh), ptr(w2), ptr(b), M, cin,
                                             cout, ptr(y), ptr(stats), gm_ref, st), "papc_mlp_gemm_f32")
+            if cp is not None:      # what the copies add to this layer's statistics: R_c extra partial rows behind the kernel's own
+                check(lib.papc_bn_stats_corr_f32(ptr(y), cout, cp.start.data_ptr(), cp.coef.data_ptr(), cp.G,
+                                                 stats.data_ptr() + 4 * parts_l * 2 * cout, st), "papc_bn_stats_corr_f32")
+                parts_l += R_c
             cst = torch.empty(4, cout, device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
             rm, rv = (bn_buffers[l] if bn_buffers is not None else (None, None))
             if ev:
@@ -260,8 +278,13 @@ class SharedMLPMax(torch.autograd.Function):
         else:
             out = torch.empty(G, cin, device=dev, dtype=torch.float32)
             argmax = torch.empty(G, cin, device=dev, dtype=torch.int32)
+        ysel_c = None
         if not spec.pool:
             pass
+        elif cp is not None:            # ragged groups: the max runs over each group's physical rows; argmax = absolute row
+            ysel_c = torch.empty(G, cin, device=dev, dtype=torch.float32)
+            check(lib.papc_bn_relu_max_seg_f32(ptr(prev_y), cin, cp.start.data_ptr(), ptr(prev_sc), ptr(prev_sh), G, ptr(out), ptr(argmax),
+                                               ptr(ysel_c), st), "papc_bn_relu_max_seg_f32")
         elif gm_ref is not None:
             check(lib.papc_bn_select_max_f32(gbuf_f[0].data_ptr(), gbuf_f[1].data_ptr(), gbuf_i[0].data_ptr(), gbuf_i[1].data_ptr(),
                                              ptr(prev_sc), ptr(prev_sh), G, cin, ptr(out), ptr(argmax), st), "papc_bn_select_max_f32")
@@ -277,7 +300,8 @@ class SharedMLPMax(torch.autograd.Function):
         ctx.lin0 = lin0
         ctx.xyz1 = xyz1
         ctx.nostore = spec.pool and L >= 1 and ys[L - 1] is None and not (xyz1 and L == 1)
-        ysel = gbuf_f[0] if (spec.pool and gm_ref is not None) else None   # raw y at the argmax (left in gmax by select_max)
+        ysel = gbuf_f[0] if (spec.pool and gm_ref is not None) else ysel_c   # raw y at the argmax (left in gmax by select_max)
+        ctx.compact = cp
         if xyz1:
             ys[0] = xc                 # (slot of the first layer's output, which does not exist: the grouped coordinates instead)
             consts = consts + [wf, gram]
@@ -303,6 +327,9 @@ class SharedMLPMax(torch.autograd.Function):
         M = spec.M
         gout = gout.contiguous().float()
         grp = None if plain else _group_src(spec, xyz, new_xyz, feats, idx)
+        cp = ctx.compact
+        if cp is not None:
+            grp.cidx, grp.seg_grp, grp.rows_dev = cp.cidx.data_ptr(), cp.seg_grp.data_ptr(), cp.rows.data_ptr()
         n_parts = min(_RESIDENT_WGS, (M + 127) // 128)
         grads = [None] * (4 * L)
         reduce_jobs = []   # (partial tensor, n_chunks, ld, n1, out1 ptr, n2, out2 ptr, accumulate): see the dW section
@@ -358,6 +385,8 @@ class SharedMLPMax(torch.autograd.Function):
                 dgb = torch.empty(2, cout, device=dev, dtype=torch.float32)  # dgamma, dbeta
                 dgamma_p, dbeta_p = dgb[0].data_ptr(), dgb[1].data_ptr()
             dy = BwdDy()
+            if cp is not None:      # multiplicity weights, ragged groups, device-side row count
+                dy.wrow, dy.seg_grp, dy.rows_dev = cp.wrow.data_ptr(), cp.seg_grp.data_ptr(), cp.rows.data_ptr()
             if l == L - 1 and not spec.pool:
                 dy.dz_mode, dy.dz, dy.gout, dy.argmax, dy.K = DZ_DENSE, gout.data_ptr(), None, None, 1
             elif l == L - 1:

@@ -1,0 +1,160 @@
+"""The compacted form of a grouped stack (csrc/compact.hip, papc_amd/compact.py): distinct neighbours only, one weight per group.
+
+query_ball_point pads every neighbourhood with copies of its first hit (pointnet2_basic_layers.py:118-124); the compacted stack must be the
+SAME function with the SAME gradients as the padded one (:214-219) -- held here to the padded HIP path, to float64 torch autograd on the
+padded rows, and to a numpy restatement of the layout."""
+import numpy as np
+import pytest
+import torch
+
+from papc_amd import _lib
+from papc_amd import compact as C
+from papc_amd import functional as F
+from papc_amd.layers import PointNetSetAbstraction
+from papc_amd.mlp import StackSpec, shared_mlp_max
+from papc_amd.synthetic import make_clouds, make_start_idx
+from tests import torch_ref
+from tests.util import assert_close, seeded_weights
+
+pytestmark = pytest.mark.gpu
+
+
+def _lists(dev, B, N, S, K, radius, seed):
+    x = make_clouds(B, N, seed)
+    xyz = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, seed)).to(dev)
+    _, new_xyz = F._fps_raw(xyz, S, st)
+    idx = F._ball_query_raw([radius], [K], xyz, new_xyz)[0]
+    return xyz, new_xyz, idx
+
+
+@pytest.mark.parametrize("B,N,S,K,radius", [(4, 512, 128, 64, 0.4), (2, 1024, 64, 32, 0.2), (1, 256, 16, 8, 0.05), (3, 300, 20, 16, 2.5)])
+def test_compact_plan_matches_numpy(dev, B, N, S, K, radius):
+    """layout: per group the distinct neighbours in list order, then copies of the first up to a multiple of 8 rows; the last group takes the
+    tail up to a multiple of 128; weights sum to nsample per group"""
+    _, _, idx = _lists(dev, B, N, S, K, radius, 3)
+    cp = C.plan(idx)
+    torch.cuda.synchronize()
+    ii = idx.cpu().numpy().reshape(B * S, K)
+    G = B * S
+    cnt = np.array([1 + int((row[1:] != row[0]).sum()) for row in ii])
+    c8 = (cnt + 7) // 8 * 8
+    start = np.concatenate([[0], np.cumsum(c8)])
+    total = int(start[-1])
+    rows = (total + 127) // 128 * 128
+    assert cp.rows.cpu().tolist() == [rows, total]
+    assert np.array_equal(cp.start.cpu().numpy(), start)
+    cidx, wrow, seg, coef = cp.cidx.cpu().numpy(), cp.wrow.cpu().numpy(), cp.seg_grp.cpu().numpy(), cp.coef.cpu().numpy()
+    for g in range(G):
+        n = int(c8[g]) + (rows - total if g == G - 1 else 0)
+        s0 = int(start[g])
+        want = np.where(np.arange(n) < cnt[g], ii[g, np.minimum(np.arange(n), K - 1)], ii[g, 0])
+        assert np.array_equal(cidx[s0:s0 + n], want), g
+        assert coef[g] == K - n and wrow[s0] == 1 + K - n and (wrow[s0 + 1:s0 + n] == 1).all()
+        assert (seg[s0 // 8:(s0 + n) // 8] == g).all()
+    assert abs(float(wrow[:rows].sum()) - G * K) < 0.5           # multiplicities add up to the padded row count
+    if radius > 2:                                                # every ball full: nothing to compact
+        assert total == G * K
+
+
+def _sa2_like(dev, B, seed, compact):
+    """an SA2-shaped stack (gather-add first layer, 128 -> 128 -> 256, nsample 64) on B clouds of 512 points"""
+    N, S, K, D = 512, 128, 64, 128
+    xyz, new_xyz, idx = _lists(dev, B, N, S, K, 0.4, seed)
+    rng = np.random.default_rng(seed)
+    feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev).requires_grad_(True)
+    ws = seeded_weights([D + 3, 128, 128, 256], 50 + seed)
+    params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+    spec = StackSpec(B, N, S, K, D, True)
+    if compact:
+        spec.compact = C.plan(idx)
+    out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+    return xyz, new_xyz, idx, feats, params, spec, out
+
+
+@pytest.mark.parametrize("B,seed", [(8, 1), (16, 2)])
+def test_compacted_stack_equals_padded_stack_and_f64(dev, B, seed):
+    """forward 2e-6 / gradients 2e-5 against the padded HIP path (same products per row, other summation order in the statistics), and
+    1e-5 / 2e-4 against float64 torch autograd on the PADDED rows routed through the kernel's own decisions"""
+    from tests.util import kernel_decisions
+    rng = np.random.default_rng(100 + seed)
+    res = {}
+    for compact in (False, True):
+        xyz, new_xyz, idx, feats, params, spec, out = _sa2_like(dev, B, seed, compact)
+        node = out.grad_fn
+        assert (node.compact is not None) == compact, "the compacted path was %staken" % ("not " if compact else "")
+        dec = kernel_decisions(out)
+        gout = torch.from_numpy(np.random.default_rng(7).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        res[compact] = (out.detach(), [p.grad.clone() for p in params], feats.grad.clone(), dec, spec)
+    o0, g0, f0, _, _ = res[False]
+    o1, g1, f1, dec, spec = res[True]
+    frac = spec.compact.fraction()
+    print("physical rows / padded rows: %.3f" % frac)
+    assert frac < 0.8
+    assert_close(o1.cpu().numpy(), o0.cpu().numpy(), 2e-6, "compacted vs padded forward")
+    names = ["w", "b", "gamma", "beta"]
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        if i % 4 == 1:
+            continue                                                  # (conv bias under a train-mode BN: exactly 0 on both paths)
+        assert_close(a.cpu().numpy(), b.cpu().numpy(), 2e-5, "compacted vs padded d%s layer %d" % (names[i % 4], i // 4))
+    assert_close(f1.cpu().numpy(), f0.cpu().numpy(), 2e-5, "compacted vs padded dfeats")
+    # float64 on the padded rows, routed through the compacted kernel's decisions
+    argmax, alive, masks = dec
+    xyz, new_xyz, idx, feats, params, _, _ = _sa2_like(dev, B, seed, False)
+    p64 = [p.detach().double().requires_grad_(True) for p in params]
+    f64 = feats.detach().double().requires_grad_(True)
+    S, K, D = 128, 64, 128
+    rows = torch_ref.group(xyz.double(), new_xyz.double(), f64, idx, True).reshape(B * S * K, D + 3)
+    ref, stats = torch_ref.stack_routed(rows, [tuple(p64[4 * l:4 * l + 4]) for l in range(3)], K, 1e-5, argmax, alive, masks)
+    print("decisions that differ from float64's own:", stats)
+    assert_close(o1.cpu().numpy(), ref.detach().cpu().numpy(), 1e-5, "compacted forward vs f64")
+    gout = torch.from_numpy(np.random.default_rng(7).normal(size=tuple(o1.shape)).astype(np.float32)).to(dev)
+    ref.backward(gout.double())
+    for i, (a, b) in enumerate(zip(g1, p64)):
+        if i % 4 != 1:
+            assert_close(a.cpu().numpy(), b.grad.cpu().numpy(), 2e-4, "compacted d%s layer %d vs f64" % (names[i % 4], i // 4))
+    assert_close(f1.cpu().numpy(), f64.grad.cpu().numpy(), 2e-4, "compacted dfeats vs f64")
+
+
+def test_compacted_layer_follows_the_device_side_row_count(dev):
+    """one set of plan buffers, two different batches (what a replayed hipGraph does): the kernels take the row count from device memory"""
+    B = 8
+    layer = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False).to(dev)
+    layer.compact = True
+    ref = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False).to(dev)
+    ref.compact = False
+    ref.load_state_dict(layer.state_dict())
+    bufs = None
+    counts = []
+    for seed in (11, 12):
+        x = torch.from_numpy(make_clouds(B, 512, seed)).to(dev)
+        if seed == 12:
+            x = x * 0.6                                   # denser clouds: more neighbours per ball, another row count
+        pts = torch.from_numpy(np.random.default_rng(seed).normal(size=(B, 128, 512)).astype(np.float32)).to(dev)
+        st = torch.from_numpy(make_start_idx(B, 512, seed)).to(dev)
+        plan = layer.sample(x, st, out=bufs)
+        assert len(plan) == 9
+        if bufs is None:
+            bufs = plan
+        else:
+            assert all(a.data_ptr() == b.data_ptr() for a, b in zip(plan, bufs))
+        counts.append(int(plan[4][0].item()))
+        with torch.no_grad():
+            _, got = layer(x, pts, st, sampled=plan)
+            _, want = ref(x, pts, st)
+        assert_close(got.cpu().numpy(), want.cpu().numpy(), 2e-6, "compacted layer vs padded layer, batch %d" % seed)
+    assert counts[0] != counts[1]
+
+
+def test_auto_policy_measures_once(dev):
+    """compact=None: the first sampling outside a capture decides from the data; full balls keep the padded path"""
+    B = 8
+    x = torch.from_numpy(make_clouds(B, 512, 5)).to(dev)
+    st = torch.from_numpy(make_start_idx(B, 512, 5)).to(dev)
+    sparse = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False).to(dev)
+    assert len(sparse.sample(x, st)) == 9 and sparse._compact_on is True
+    full = PointNetSetAbstraction(128, 3.0, 64, 131, [128, 128, 256], False).to(dev)      # radius covers the cloud: every list is full
+    assert len(full.sample(x, st)) == 2 and full._compact_on is False
+    other = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 128], False).to(dev)     # widths without a compacted flavour
+    assert len(other.sample(x, st)) == 2 and other._compact_on is None

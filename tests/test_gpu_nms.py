@@ -82,7 +82,7 @@ def test_rotate_iou_matches_oracle(criterion):
     exact = {-1: np.ones(5), 0: np.ones(5), 1: np.ones(5), 2: area}[criterion]
     assert np.abs(got[np.arange(5), np.arange(5)] - exact).max() <= 2e-6 * max(1.0, float(area.max()))
     if criterion == -1:
-        assert (got >= 0).all() and (got <= 1 + 1e-6).all()
+        assert (got >= 0).all() and (got <= 1 + 1e-5).all()      # (the clipped area comes from fp32-rounded corners, the box areas from w * l: 1 +- a few 1e-6)
         ax = np.array([[1, 2, 3, 4, 0]], np.float32)
         assert abs(float(rotate_iou_gpu_eval(ax, ax)[0, 0]) - 1.0) < 1e-6
 

@@ -81,11 +81,23 @@ def kernel_decisions(out):
     L = fn.L
     argmax = saved[5]
     ys, consts = saved[7 + 4 * L: 7 + 5 * L], saved[7 + 5 * L: 7 + 6 * L]
+    rowmap = None
+    cp = getattr(fn, "compact", None)
+    if cp is not None:
+        # compacted stack (papc_amd/compact.py): rows are the distinct neighbours; padded slot (g, k) is physical row start[g] + k while k is
+        # inside the group's rows and a copy of its first row beyond; argmax holds absolute rows -> offsets in the padded group
+        import torch
+        start = cp.start.long()
+        n = (start[1:] - start[:-1])
+        k = torch.arange(cp.K, device=start.device).view(1, -1)
+        rowmap = (start[:-1].view(-1, 1) + torch.where(k < n.view(-1, 1), k, torch.zeros_like(k))).reshape(-1)
+        argmax = (argmax.long() - start[:-1].view(-1, 1)).to(argmax.dtype)
     masks = []
     for l in range(L - 1):
         y, c = ys[l], consts[l]
         if y is None or y.dim() != 2 or y.shape[1] != c.shape[1]:
             masks.append(None)
         else:
-            masks.append((c[2].double() * y.double() + c[3].double()) > 0)
+            m = (c[2].double() * y.double() + c[3].double()) > 0
+            masks.append(m if rowmap is None else m[rowmap])
     return argmax, alive, masks
