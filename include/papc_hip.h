@@ -456,7 +456,7 @@ int papc_lingather_parts(int64_t M);
  * papc_compact_plan_f32: idx [G, K] int32 (ball-query lists, K % 8 == 0) -> start [G+1] (first physical row of each group; groups are
  * the distinct neighbours in list order, then copies of the first one up to a multiple of 8 rows), rows [2] = {physical rows rounded up
  * to 128 (the last group takes the tail), their exact count}, cidx [cap] point index per row, seg_grp [cap / 8], wrow [cap] = 1 +
- * coef[g] on a group's first row and 1 elsewhere, coef [G] = nsample - rows of the group; cnt8 [G] scratch; cap = G * K.  Everything
+ * coef[g] on a group's first row and 1 elsewhere, coef [G] = nsample - rows of the group; cnt8 [G] scratch; cap = G * K rounded up to 128.  Everything
  * stays on the device: consumers take the row count from rows[0] (papc_mlp_gemm_rows_f32, papc_bwd_dy.rows_dev, papc_group_src.rows_dev).
  * papc_bn_stats_corr_f32: the copies' share of a layer's statistics -- writes papc_compact_corr_parts() extra partial rows [r][2][C] =
  * sum_g coef[g] (y, y^2)[start[g]] behind the kernel-written rows of stats_partial; papc_bn_finalize_f32 then takes n_tiles + that many

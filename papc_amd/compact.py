@@ -38,7 +38,7 @@ class CompactPlan:
 
 
 def alloc(G, K, device):
-    cap = G * K
+    cap = (G * K + 127) // 128 * 128              # (the last group takes the tail up to a multiple of 128 rows)
     i32 = dict(device=device, dtype=torch.int32)
     return (torch.empty(G, **i32), torch.empty(G + 1, **i32), torch.empty(2, **i32), torch.empty(cap, **i32), torch.empty(cap // 8, **i32),
             torch.empty(cap, device=device, dtype=torch.float32), torch.empty(G, device=device, dtype=torch.float32))

@@ -906,7 +906,7 @@ static int launch_gemm(const GemmArgs &p, bool vec, hipStream_t st)
         const int rc = stream_gemm_try(q, AMODE, EPI, vec, st);
         if (rc != 0) return rc < 0 ? rc : PAPC_OK;
     }
-    if (p.rows_dev || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && p.a.d.wrow)) {
+    if (p.rows_dev || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (p.a.d.wrow || p.a.d.rows_dev))) {
         set_error("mlp gemm: a device-side row count / compacted dY source is only built for the row-streaming kernel's flavours (M=%lld Kin=%d Nout=%d)",
                   (long long)p.M, p.Kin, p.Nout);
         return PAPC_E_UNSUPPORTED;

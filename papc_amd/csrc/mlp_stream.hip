@@ -714,26 +714,27 @@ static int ilog2_exact(int v)
 
 int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t st)
 {
-    if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !vec) return 0;
-    if (p.M % 32 != 0 || p.M / 32 < knob(KNOB_STREAM_MINTILES)) return 0;
-    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > (amode == A_MAXCAT ? 384 : 256) || p.Nout % 32 != 0 || p.Nout < 64) return 0;
-    if (amode == A_MAXCAT && (p.a.d.C != 2 * p.Nout || p.Kin != 3 * p.Nout || p.a.ldx != p.Nout)) return 0;   // Cout = 2 Cin, dense input rows
-    if (p.wmap || p.nmap || p.ldy != p.Nout) return 0;
-    if (!(p.stats || epi == EPI_STORE)) return 0;
+    auto why = [&](int site) -> int { if (getenv("PAPC_STREAM_WHY")) fprintf(stderr, "[stream_gemm_try] declined at site %d: amode %d epi %d M %lld Kin %d Nout %d vec %d\n", site, amode, epi, (long long)p.M, p.Kin, p.Nout, (int)vec); return 0; };
+    if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !vec) return why(1);
+    if (p.M % 32 != 0 || p.M / 32 < knob(KNOB_STREAM_MINTILES)) return why(2);
+    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > (amode == A_MAXCAT ? 384 : 256) || p.Nout % 32 != 0 || p.Nout < 64) return why(3);
+    if (amode == A_MAXCAT && (p.a.d.C != 2 * p.Nout || p.Kin != 3 * p.Nout || p.a.ldx != p.Nout)) return why(4);   // Cout = 2 Cin, dense input rows
+    if (p.wmap || p.nmap || p.ldy != p.Nout) return why(5);
+    if (!(p.stats || epi == EPI_STORE)) return why(6);
     StreamGeo geo;
     geo.ushift = 0; geo.kgshift = 5;
     geo.rows_dev = p.rows_dev; geo.wrow = nullptr; geo.seg_grp = nullptr;
-    if (amode == A_DY_DENSE || amode == A_DY_MAX) { geo.wrow = p.a.d.wrow; geo.seg_grp = p.a.d.seg_grp; }
-    if (p.rows_dev && (p.M % 128 != 0 || epi == EPI_STORE_GMAX || epi == EPI_GMAX)) return 0;   // (ragged groups: no fused group max)
-    if (geo.wrow && (!p.rows_dev || (amode == A_DY_MAX && !geo.seg_grp))) return 0;
+    if (amode == A_DY_DENSE || amode == A_DY_MAX) { geo.wrow = p.a.d.wrow; geo.seg_grp = p.a.d.seg_grp; geo.rows_dev = p.a.d.rows_dev; }
+    if (geo.rows_dev && (p.M % 128 != 0 || epi == EPI_STORE_GMAX || epi == EPI_GMAX)) return why(7);   // (ragged groups: no fused group max)
+    if (geo.wrow && (!geo.rows_dev || (amode == A_DY_MAX && !geo.seg_grp))) return why(8);
     if (epi == EPI_STORE_GMAX || epi == EPI_GMAX) {
         const int s = ilog2_exact(p.gm.K);
-        if (s < 5 || p.M % p.gm.K != 0) return 0;
+        if (s < 5 || p.M % p.gm.K != 0) return why(9);
         geo.ushift = s - 5;
     }
     if ((amode == A_DY_MAX && !geo.wrow) || amode == A_MAXCAT) {
         const int s = ilog2_exact(p.a.d.K);
-        if (s < 5) return 0;
+        if (s < 5) return why(10);
         geo.kgshift = s;
     }
     geo.n_units = (int)((p.M / 32) >> geo.ushift);
@@ -746,7 +747,7 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
     if (amode == A_XYZ && epi == EPI_STORE) return stream_pick<A_XYZ, EPI_STORE>(p, geo, st);
     if (amode == A_MAXCAT && epi == EPI_STORE_RED) return stream_pick<A_MAXCAT, EPI_STORE_RED>(p, geo, st);
     if (amode == A_DY_MAX && epi == EPI_STORE_RED) return stream_pick<A_DY_MAX, EPI_STORE_RED>(p, geo, st);
-    return 0;
+    return why(11);
 }
 
 }  // namespace papc
