@@ -90,20 +90,52 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(const int32_t *__rest
 
 // ---- forward: what the copies add to the BatchNorm statistics ----------------------------------------------------------------------------
 // out[r][0][c] = sum_{g in block r} coef[g] y[start[g], c], out[r][1][c] = ... y^2: extra rows of a layer's statistics partials.
+// Thread = (row lane, channel quad): the few groups a thread owns are independent loads, all in flight at once; the row lanes of a block
+// are folded through LDS in fixed order (deterministic).
 __global__ __launch_bounds__(256) void bn_stats_corr_kernel(const float *__restrict__ y, int C, const int32_t *__restrict__ start,
                                                             const float *__restrict__ coef, int G, float *__restrict__ out)
 {
+    __shared__ float4 red[2][256];
     const int r = blockIdx.x, R = gridDim.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int g = r; g < G; g += R) {
-            const float cf = coef[g];
-            const float v = y[(int64_t)start[g] * C + c];
-            s1 = fmaf(cf, v, s1);
-            s2 = fmaf(cf * v, v, s2);
+    const int CQ = C >> 2;                              // host-checked: C % 4 == 0, C <= 1024
+    const int RL = 256 / CQ > 0 ? 256 / CQ : 1;         // row lanes per pass
+    for (int c0 = 0; c0 < CQ; c0 += 256) {              // (C > 1024 channels would take several passes; one in practice)
+        const int cq = c0 + (int)threadIdx.x % (CQ < 256 ? CQ : 256), rl = (int)threadIdx.x / (CQ < 256 ? CQ : 256);
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        if (cq < CQ && rl < RL) {
+            constexpr int U = 4;
+            for (int g0 = r + R * rl; g0 < G; g0 += R * RL * U) {
+                float4 v[U];
+                float cf[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int g = g0 + u * R * RL;
+                    const int gg = g < G ? g : g0;
+                    cf[u] = g < G ? coef[gg] : 0.f;
+                    v[u] = *reinterpret_cast<const float4 *>(y + (int64_t)start[gg] * C + 4 * cq);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    s1.x = fmaf(cf[u], v[u].x, s1.x); s1.y = fmaf(cf[u], v[u].y, s1.y); s1.z = fmaf(cf[u], v[u].z, s1.z); s1.w = fmaf(cf[u], v[u].w, s1.w);
+                    s2.x = fmaf(cf[u] * v[u].x, v[u].x, s2.x); s2.y = fmaf(cf[u] * v[u].y, v[u].y, s2.y);
+                    s2.z = fmaf(cf[u] * v[u].z, v[u].z, s2.z); s2.w = fmaf(cf[u] * v[u].w, v[u].w, s2.w);
+                }
+            }
         }
-        out[((int64_t)r * 2 + 0) * C + c] = s1;
-        out[((int64_t)r * 2 + 1) * C + c] = s2;
+        red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+        __syncthreads();
+        const int cqn = CQ < 256 ? CQ : 256;
+        if ((int)threadIdx.x < cqn && c0 + (int)threadIdx.x < CQ) {
+            float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+            for (int l = 0; l < RL; ++l) {
+                const float4 a = red[0][l * cqn + threadIdx.x], b = red[1][l * cqn + threadIdx.x];
+                t1.x += a.x; t1.y += a.y; t1.z += a.z; t1.w += a.w;
+                t2.x += b.x; t2.y += b.y; t2.z += b.z; t2.w += b.w;
+            }
+            *reinterpret_cast<float4 *>(out + ((int64_t)r * 2 + 0) * C + 4 * (c0 + threadIdx.x)) = t1;
+            *reinterpret_cast<float4 *>(out + ((int64_t)r * 2 + 1) * C + 4 * (c0 + threadIdx.x)) = t2;
+        }
+        __syncthreads();
     }
 }
 
@@ -186,12 +218,12 @@ int papc_compact_plan_f32(const int32_t *idx, int G, int K, int32_t *cnt8, int32
     return check_launch("papc_compact_plan_f32");
 }
 
-int papc_compact_corr_parts(void) { return 128; }
+int papc_compact_corr_parts(void) { return 64; }
 
 int papc_bn_stats_corr_f32(const float *y, int C, const int32_t *start, const float *coef, int G, float *stats_rows, papc_stream_t stream)
 {
     PAPC_REQUIRE(y && start && coef && stats_rows, PAPC_E_INVALID, "papc_bn_stats_corr_f32: null pointer");
-    PAPC_REQUIRE(G >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_stats_corr_f32: bad sizes");
+    PAPC_REQUIRE(G >= 1 && C >= 4 && C % 4 == 0 && aligned16(y) && aligned16(stats_rows), PAPC_E_INVALID, "papc_bn_stats_corr_f32: C %% 4 == 0 and 16-byte aligned rows");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(bn_stats_corr_kernel, dim3((unsigned)papc_compact_corr_parts()), dim3(256), 0, st, y, C, start, coef, G, stats_rows);
