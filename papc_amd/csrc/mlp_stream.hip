@@ -184,7 +184,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
 
     // ---- this wave's tiles: units gw, gw + TW, ...; U consecutive tiles per unit
     const int TW = (int)gridDim.x * NW;
-    const int gw = (int)blockIdx.x * NW + wave;
+    // (device-side row count: the tile count is whatever the batch gives, so the last round is ragged -- wave-major numbering hands its few
+    // tiles to one wave each of as many different workgroups, where a lone wave runs at twice the issue rate, instead of to all eight waves
+    // of the first few workgroups while the other CUs idle)
+    const int gw = geo.rows_dev ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * NW + wave;
     const int U = 1 << geo.ushift;
     const int n_units = geo.rows_dev ? min(geo.n_units, (__builtin_amdgcn_readfirstlane(*geo.rows_dev) >> 5) >> geo.ushift) : geo.n_units;
     const int my_units = n_units > gw ? (n_units - gw + TW - 1) / TW : 0;

@@ -154,7 +154,9 @@ def test_whole_model_gradients_with_pinned_routing(dev, B):   # the gather-add f
     loss = softmax_cross_entropy(logits, labels)
     nodes = [_stack_node(t) for t in (l1, l2, l3)]
     assert "Planes" in type(nodes[2]).__name__                      # the group_all layer runs on the planes kernels
-    argmaxes = [(n.saved_tensors[0] if "Planes" in type(n).__name__ else n.saved_tensors[5]).clone() for n in nodes]
+    from tests.util import kernel_decisions
+    argmaxes = [kernel_decisions(t)[0].clone() for t in (l1, l2, l3)]      # (winner offsets in the padded groups, also for a compacted stack)
+    print("stack kernels:", [type(n).__name__ + (" (compacted)" if getattr(n, "compact", None) is not None else "") for n in nodes])
     pooled = [l1.detach().transpose(1, 2).reshape(-1, l1.shape[1]), l2.detach().transpose(1, 2).reshape(-1, l2.shape[1]),
               l3.detach().transpose(1, 2).reshape(-1, l3.shape[1])]
     loss.backward()
