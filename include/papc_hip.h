@@ -296,6 +296,86 @@ int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, in
                               float *out2, int accumulate, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * A whole shared-MLP stack in ONE call per direction (csrc/sa_mlp.hip) -- the boundary SURVEY 8b names `papc_sa_mlp_{fwd,bwd}`.
+ * Replaces, after the grouping, the body of PointNetSetAbstraction.forward (PAPC/models/layers/pointnet2_basic_layers.py:214-219:
+ * relu(bn(conv(.))) x L, max over nsample), of PointNetSetAbstractionMsg's branches (:271-276), of PointNetFeaturePropagation's
+ * Conv1D stack (:330-333, pool = 0) and of PointNet-Basic's (classify/pointnet_base/pointnet_base.py:7-25, :44).  The library picks
+ * the kernels per layer (gather-add first layer, coordinates-only first layer through its input moments, row-streaming / tiled
+ * GEMMs, fused neighbourhood max, a max layer that never stores its output, the compacted form) and lays out its own scratch; the
+ * caller owns three buffers: `saved` (forward -> backward), one scratch per direction.  Train-mode BatchNorm unless eval_bn.
+ *
+ *   papc_sa_desc   the stack: B clouds x S groups x K rows (M = B*S*K rows), layer widths; input = grouped rows [xyz_j - centre | feats_j]
+ *                  (or [feats | xyz] with xyz_first = 0; identity_rows: sample_and_group_all, S = 1, K = N, no idx) or plain rows [M, cin]
+ *   papc_sa_io     device pointers: inputs, per-layer parameters (+ running statistics, updated in place), out, the three buffers
+ *   papc_sa_plan   filled by papc_sa_mlp_plan: the path per layer and the byte sizes of saved / scratch (host struct; keep it for _bwd)
+ *   papc_sa_grads  backward: gout [G, c_L] (pool) or [M, c_L]; per layer dw [c_l, cin_l], db, dgamma, dbeta (db / dgamma / dbeta may be
+ *                  NULL = not wanted; acc_* != 0 adds into the buffer: gradient accumulation straight into a parameter's .grad);
+ *                  optional W^T operands [cin_l, c_l] made by the caller for this forward pass; grad_feats [B,N,D] / grad_x [M,cin] or NULL.
+ * Errors: PAPC_E_* as everywhere; nothing is launched after the first failing call. */
+#define PAPC_SA_MAX_LAYERS 8
+#define PAPC_SA_IN_GROUP 0
+#define PAPC_SA_IN_ROWS 1
+#define PAPC_SA_NO_LINGATHER 1u   /* `disable` bits: paths NOT to take (A/B, tests) */
+#define PAPC_SA_NO_XYZ1 2u
+#define PAPC_SA_NO_NOSTORE 4u
+#define PAPC_SA_NO_GMAX 8u
+#define PAPC_SA_NO_FUSED_RED 16u
+#define PAPC_SA_NO_COMPACT 32u
+typedef struct papc_sa_desc {
+    int32_t B, N, S, K, D;
+    int32_t n_layers;
+    int32_t cin;                          /* PAPC_SA_IN_ROWS: channels of x_rows (grouped input: D + 3) */
+    int32_t cout[PAPC_SA_MAX_LAYERS];
+    int32_t input;                        /* PAPC_SA_IN_GROUP / PAPC_SA_IN_ROWS */
+    int32_t identity_rows;                /* grouped input without idx: row m of cloud b is point m (sample_and_group_all) */
+    int32_t xyz_first, pool, eval_bn, cut_gather_grad;
+    float eps, momentum;
+    uint32_t disable;
+} papc_sa_desc;
+typedef struct papc_sa_layer {
+    const float *w, *b, *gamma, *beta;    /* [cout, cin], [cout] x 3 */
+    float *running_mean, *running_var;    /* [cout] or NULL */
+} papc_sa_layer;
+typedef struct papc_compact_src {        /* the tensors of papc_compact_plan_f32 */
+    const int32_t *start, *rows, *cidx, *seg_grp;
+    const float *wrow, *coef;
+    int32_t G;
+} papc_compact_src;
+typedef struct papc_sa_io {
+    const float *xyz; int64_t sb, sn, sc; /* strided cloud [B, N, 3] */
+    const float *new_xyz;                 /* [B, S, 3] */
+    const float *feats;                   /* [B, N, D] or NULL */
+    const int32_t *idx;                   /* [B, S, K] or NULL (identity_rows) */
+    const float *x_rows;                  /* PAPC_SA_IN_ROWS: [M, cin] */
+    const float *xc; const double *xc_gram;   /* optional: grouped centred coordinates [M, 4] and their folded moments [16] (papc_xyz_group_f32 +
+                                                 papc_xyz_gram_fold_f32), e.g. computed with the sampling pyramid one step ahead */
+    const papc_compact_src *compact;      /* optional: compacted grouping of idx */
+    const float *consts3; int32_t consts3_ld;   /* three rows of consts3_ld >= max cout floats: ones | zeros | 1e30 (identity BatchNorm constants) */
+    papc_sa_layer layer[PAPC_SA_MAX_LAYERS];
+    float *out;
+    void *saved, *scratch;
+} papc_sa_io;
+typedef struct papc_sa_plan {
+    papc_sa_desc d;
+    int32_t cin0;
+    int32_t lin0, xyz1, gmax, nostore, compact, sparse_max;
+    int64_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes;
+    /* where forward leaves what a caller may want to look at, as byte offsets into `saved` (-1: not stored on this path):
+     * pre-BN outputs y_l [M, c_l], BatchNorm constants [4, c_l] (mean | invstd | scale | shift), argmax [G, c_L] int32 */
+    int64_t off_y[PAPC_SA_MAX_LAYERS], off_cst[PAPC_SA_MAX_LAYERS], off_argmax;
+} papc_sa_plan;
+typedef struct papc_sa_grads {
+    const float *gout;
+    float *dw[PAPC_SA_MAX_LAYERS], *db[PAPC_SA_MAX_LAYERS], *dgamma[PAPC_SA_MAX_LAYERS], *dbeta[PAPC_SA_MAX_LAYERS];
+    int32_t acc_w[PAPC_SA_MAX_LAYERS], acc_gb[PAPC_SA_MAX_LAYERS];
+    const float *wt[PAPC_SA_MAX_LAYERS];
+    float *grad_feats, *grad_x;
+} papc_sa_grads;
+int papc_sa_mlp_plan(const papc_sa_desc *desc, const papc_sa_io *io, papc_sa_plan *plan);
+int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_t stream);
+int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_sa_grads *grads, papc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * PointPillars PillarFeatureNet (PAPC/models/detect/pointpillars/models/bones/pillars.py)
  * ---------------------------------------------------------------------------------------------- */
 

@@ -1,0 +1,527 @@
+// sa_mlp.hip -- ONE call per direction for a whole shared-MLP stack: papc_sa_mlp_plan / _fwd / _bwd (host code; gfx950 kernels live in
+// the other files of this directory).
+//
+// What the reference does in PointNetSetAbstraction.forward after the grouping -- relu(bn(conv(.))) x L, max over the neighbourhood
+// (PAPC/models/layers/pointnet2_basic_layers.py:214-219; the Msg variant :271-276; PointNetFeaturePropagation's Conv1D stack :330-333;
+// PointNet-Basic's, classify/pointnet_base/pointnet_base.py:7-25, :44) -- is here a sequence of 10-25 launches whose choice depends on
+// the shapes: gather-add first layer, coordinates-only first layer through its input moments, row-streaming or tiled GEMMs, fused or
+// separate neighbourhood max, a max layer that never stores its output, the compacted (distinct-neighbours) form.  This file owns
+// that choice and the scratch layout, so a host binds three functions instead of re-implementing the sequence:
+//
+//   papc_sa_mlp_plan   descriptor -> which path each layer takes + bytes of `saved` (forward -> backward) and of scratch per direction
+//   papc_sa_mlp_fwd    inputs + parameters -> out (+ running statistics), fills `saved`
+//   papc_sa_mlp_bwd    gout + `saved` -> parameter gradients (written or accumulated in place), grad_feats / grad_x
+//
+// All buffers are caller-owned device memory; nothing is allocated, nothing synchronises, every launch goes to the given stream.
+#include "common.h"
+
+namespace papc {
+
+constexpr int A_PLAIN_ = PAPC_A_PLAIN, A_BNRELU_ = PAPC_A_BNRELU, A_GROUP_ = PAPC_A_GROUP, A_XYZ_ = PAPC_A_XYZ;
+
+struct Carver {                       // hands out 256-byte aligned pieces of one buffer; base == nullptr: sizes only
+    char *base;
+    size_t off;
+    template <class T>
+    T *take(size_t n)
+    {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+struct SavedPtrs {
+    float *y[PAPC_SA_MAX_LAYERS];       // pre-BN outputs [M, c_l] (nullptr where a layer's output is never stored)
+    float *cst[PAPC_SA_MAX_LAYERS];     // [4, c_l]: mean, invstd, scale, shift
+    int32_t *argmax;                    // [G, c_L]
+    float *gbuf_f;                      // [2, G, c_L]: per-group max | min of the raw output; [0] becomes ysel (fused / ragged max)
+    float *xc; double *gram; float *wf; // coordinates-only first layer: grouped coordinates [M, 4] (unless handed in), moments [16], folded layer [c_0, 4]
+};
+struct FwdPtrs {
+    float *stats;                       // [max parts + corr rows, 2, max c]
+    int32_t *gbuf_i;                    // [2, G, c_L]
+    float *P, *wfeat;                   // gather-add first layer: per-point products [B*N, c_0], feature block of its weight [c_0, D]
+    double *gpart;                      // coordinates-only first layer: partial moments
+};
+struct BwdPtrs {
+    float *c12[PAPC_SA_MAX_LAYERS];     // [2, c_l]
+    float *wt[PAPC_SA_MAX_LAYERS];      // W^T [cin_l, c_l] where the caller gave none
+    float *part[PAPC_SA_MAX_LAYERS];    // dW / db partials [n_chunks, c_l * cin_l + c_l]
+    float *red, *fused_red[2];          // BN-backward partial sums
+    float *dz[2];                       // ping-pong [M, max cin]
+    float *psel, *wcat, *hb, *eq, *dwmax_ws;
+    float *bpart;                       // xyz1
+    float *dwx_part, *Gs, *part_g, *wft;   // gather-add first layer
+    float *tmp_gb;                      // [2, max c] throw-away gamma / beta gradients
+};
+
+static inline int64_t rows_of(const papc_sa_desc &d) { return (int64_t)d.B * d.S * d.K; }
+static inline int cin_of(const papc_sa_plan &p, int l) { return l == 0 ? p.cin0 : p.d.cout[l - 1]; }
+
+static int dw_rows_per_chunk(int64_t M, int cout, int cin)      // (mlp.py::_dw_rows_per_chunk: one residency wave of workgroups in total)
+{
+    const bool wide = cin > 128 && cin <= 160;
+    const int tiles = ((cout + 127) / 128) * (wide ? 1 : (cin + 127) / 128);
+    const int want = std::max(1, 512 / tiles);
+    int64_t rpc = (M + want - 1) / want;
+    rpc = std::max<int64_t>(256, ((rpc + 63) / 64) * 64);
+    return (int)rpc;
+}
+
+static int dw_chunk(const papc_sa_plan &p, int l, int a_mode, int dz_mode)
+{
+    const int64_t M = rows_of(p.d);
+    int rpc = 0;
+    const bool plain = p.d.input == PAPC_SA_IN_ROWS;
+    if (l > 0 || !plain) rpc = papc_mlp_bwd_dw_chunk_hint(M, cin_of(p, l), p.d.cout[l], a_mode, dz_mode, dz_mode == PAPC_DZ_MAX ? p.d.K : 0);
+    if (rpc <= 0) rpc = dw_rows_per_chunk(M, p.d.cout[l], cin_of(p, l));
+    return rpc;
+}
+
+static size_t layout_saved(const papc_sa_plan &p, void *base, SavedPtrs &s)
+{
+    Carver c{reinterpret_cast<char *>(base), 0};
+    const int L = p.d.n_layers;
+    const int64_t M = rows_of(p.d), G = (int64_t)p.d.B * p.d.S;
+    memset(&s, 0, sizeof(s));
+    for (int l = 0; l < L; ++l) {
+        const bool stored = !(l == 0 && p.xyz1) && !(l == L - 1 && p.nostore);
+        s.y[l] = stored ? c.take<float>((size_t)M * p.d.cout[l] + 64) : nullptr;
+        s.cst[l] = c.take<float>(4 * (size_t)p.d.cout[l]);
+    }
+    if (p.d.pool) {
+        s.argmax = c.take<int32_t>((size_t)G * p.d.cout[L - 1]);
+        if (p.gmax || p.compact) s.gbuf_f = c.take<float>(2 * (size_t)G * p.d.cout[L - 1]);
+    }
+    if (p.xyz1) {
+        s.xc = c.take<float>((size_t)M * 4);
+        s.gram = c.take<double>(16);
+        s.wf = c.take<float>(4 * (size_t)p.d.cout[0]);
+    }
+    return c.off;
+}
+
+static size_t layout_fwd(const papc_sa_plan &p, void *base, FwdPtrs &f)
+{
+    Carver c{reinterpret_cast<char *>(base), 0};
+    const int L = p.d.n_layers;
+    const int64_t M = rows_of(p.d), G = (int64_t)p.d.B * p.d.S;
+    memset(&f, 0, sizeof(f));
+    int cmax = 0;
+    for (int l = 0; l < L; ++l) cmax = std::max(cmax, p.d.cout[l]);
+    const int rows = std::max(papc_mlp_gemm_parts(M), p.lin0 ? papc_lingather_parts(M) : 0) + (p.compact ? papc_compact_corr_parts() : 0);
+    f.stats = c.take<float>((size_t)rows * 2 * cmax * L);          // one region per layer: a layer's finalize may still read while the next GEMM writes
+    if (p.gmax) f.gbuf_i = c.take<int32_t>(2 * (size_t)G * p.d.cout[L - 1]);
+    if (p.lin0) {
+        f.P = c.take<float>((size_t)p.d.B * p.d.N * p.d.cout[0]);
+        f.wfeat = c.take<float>((size_t)p.d.cout[0] * p.d.D);
+    }
+    if (p.xyz1) f.gpart = c.take<double>((size_t)papc_xyz_parts(M) * 16 + 16);
+    return c.off;
+}
+
+static size_t layout_bwd(const papc_sa_plan &p, void *base, BwdPtrs &b)
+{
+    Carver c{reinterpret_cast<char *>(base), 0};
+    const int L = p.d.n_layers;
+    const int64_t M = rows_of(p.d), G = (int64_t)p.d.B * p.d.S;
+    memset(&b, 0, sizeof(b));
+    int cmax = p.cin0;
+    for (int l = 0; l < L; ++l) cmax = std::max(cmax, p.d.cout[l]);
+    const int n_parts = (int)std::min<int64_t>(512, (M + 127) / 128);
+    const int gparts = papc_mlp_gemm_parts(M);
+    for (int l = 0; l < L; ++l) {
+        const int cin = cin_of(p, l), cout = p.d.cout[l];
+        b.c12[l] = c.take<float>(2 * (size_t)cout);
+        b.wt[l] = c.take<float>((size_t)cin * cout);
+        // (dW partials: sized for the larger of the two operand flavours a layer can take)
+        const int dzm = (l == L - 1 && p.d.pool) ? PAPC_DZ_MAX : PAPC_DZ_DENSE;
+        const int am = l == 0 ? (p.d.input == PAPC_SA_IN_ROWS ? A_PLAIN_ : A_GROUP_) : ((l == 1 && p.xyz1) ? A_XYZ_ : A_BNRELU_);
+        const int rpc = dw_chunk(p, l, am, dzm);
+        const int64_t n_chunks = (M + rpc - 1) / rpc;
+        b.part[l] = c.take<float>((size_t)n_chunks * ((size_t)cout * cin + cout));
+    }
+    b.red = c.take<float>((size_t)n_parts * 2 * cmax);
+    b.fused_red[0] = c.take<float>((size_t)gparts * 2 * cmax);
+    b.fused_red[1] = c.take<float>((size_t)gparts * 2 * cmax);
+    if (L > 1 || p.d.input == PAPC_SA_IN_ROWS) {
+        b.dz[0] = c.take<float>((size_t)M * cmax + 64);
+        if (L > 2) b.dz[1] = c.take<float>((size_t)M * cmax + 64);
+    }
+    if (p.d.pool && L > 1) {
+        const int cL = p.d.cout[L - 1], cLi = p.d.cout[L - 2];
+        b.psel = c.take<float>((size_t)G * cL);
+        b.wcat = c.take<float>((size_t)cLi * (cL + cLi));
+        b.hb = c.take<float>((size_t)cLi);
+        b.eq = c.take<float>(2 * (size_t)cL);
+        if (p.nostore) b.dwmax_ws = c.take<float>((size_t)papc_mlp_bwd_dw_max_ws_floats(M, cLi, cL) + 4);
+    }
+    if (p.xyz1) b.bpart = c.take<float>((size_t)papc_xyz_bwd_parts(M) * p.d.cout[0] * 4);
+    if (p.lin0) {
+        const int c0 = p.d.cout[0];
+        const int64_t BN = (int64_t)p.d.B * p.d.N;
+        b.dwx_part = c.take<float>((size_t)papc_lingather_parts(M) * c0 * 3);
+        b.Gs = c.take<float>((size_t)BN * c0);
+        const int rpc_g = dw_rows_per_chunk(BN, c0, p.d.D);
+        b.part_g = c.take<float>((size_t)((BN + rpc_g - 1) / rpc_g) * ((size_t)c0 * p.d.D + c0));
+        b.wft = c.take<float>((size_t)p.d.D * c0);
+    }
+    b.tmp_gb = c.take<float>(2 * (size_t)cmax);
+    return c.off;
+}
+
+static void fill_grp(papc_group_src &g, const papc_sa_desc &d, const papc_sa_io &io, bool compact)
+{
+    memset(&g, 0, sizeof(g));
+    g.xyz = io.xyz; g.sb = io.sb; g.sn = io.sn; g.sc = io.sc; g.new_xyz = io.new_xyz; g.feats = io.feats; g.idx = io.idx;
+    g.N = d.N; g.S = d.S; g.K = d.K; g.D = d.D; g.xyz_first = d.xyz_first;
+    if (compact && io.compact) { g.cidx = io.compact->cidx; g.seg_grp = io.compact->seg_grp; g.rows_dev = io.compact->rows; }
+}
+
+__global__ void mul_vec_kernel(const float *__restrict__ a, const float *__restrict__ b, int n, float *__restrict__ out, int accumulate)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = accumulate ? out[i] + a[i] * b[i] : a[i] * b[i];
+}
+
+}  // namespace papc
+
+using namespace papc;
+
+#define SA_CALL(expr)                 \
+    do {                              \
+        const int rc__ = (expr);      \
+        if (rc__ != PAPC_OK) return rc__; \
+    } while (0)
+
+extern "C" {
+
+int papc_sa_mlp_plan(const papc_sa_desc *desc, const papc_sa_io *io, papc_sa_plan *plan)
+{
+    PAPC_REQUIRE(desc && plan, PAPC_E_INVALID, "papc_sa_mlp_plan: null pointer");
+    const papc_sa_desc &d = *desc;
+    PAPC_REQUIRE(d.n_layers >= 1 && d.n_layers <= PAPC_SA_MAX_LAYERS, PAPC_E_UNSUPPORTED, "papc_sa_mlp_plan: %d layers (1..%d)", d.n_layers, PAPC_SA_MAX_LAYERS);
+    PAPC_REQUIRE(d.B >= 1 && d.N >= 1 && d.S >= 1 && d.K >= 1 && d.D >= 0, PAPC_E_INVALID, "papc_sa_mlp_plan: bad B/N/S/K/D");
+    const int64_t M = rows_of(d);
+    PAPC_REQUIRE(M < (1ll << 31), PAPC_E_UNSUPPORTED, "papc_sa_mlp_plan: >= 2^31 rows");
+    for (int l = 0; l < d.n_layers; ++l) PAPC_REQUIRE(d.cout[l] >= 1, PAPC_E_INVALID, "papc_sa_mlp_plan: cout[%d] = %d", l, d.cout[l]);
+    memset(plan, 0, sizeof(*plan));
+    plan->d = d;
+    const int L = d.n_layers;
+    const bool plain = d.input == PAPC_SA_IN_ROWS, ev = d.eval_bn != 0;
+    plan->cin0 = plain ? d.cin : d.D + 3;
+    PAPC_REQUIRE(plan->cin0 >= 1, PAPC_E_INVALID, "papc_sa_mlp_plan: no input channels");
+    const bool has_idx = !plain && d.identity_rows == 0, has_feats = !plain && d.D > 0;
+    plan->lin0 = !(d.disable & PAPC_SA_NO_LINGATHER) && !ev && !plain && has_idx && has_feats && L >= 2 && d.D % 4 == 0 && d.D >= 16 &&
+                 d.cout[0] % 4 == 0 && d.cout[0] <= 256;
+    plan->xyz1 = !(d.disable & PAPC_SA_NO_XYZ1) && !ev && !plain && has_idx && !has_feats && d.D == 0 && L >= 3 &&
+                 papc_mlp_xyz_ok(M, d.cout[0], d.cout[1]);
+    plan->compact = plan->lin0 && d.pool && !(d.disable & PAPC_SA_NO_COMPACT) && io && io->compact && papc_mlp_compact_ok(M, d.K, L, d.cout);
+    const int cL = d.cout[L - 1], cLi = L > 1 ? d.cout[L - 2] : plan->cin0;
+    plan->gmax = !plan->compact && d.pool && !(d.disable & PAPC_SA_NO_GMAX) && !ev && papc_mlp_gemm_gmax_ok(M, cL, d.K);
+    plan->nostore = plan->gmax && !(d.disable & PAPC_SA_NO_NOSTORE) && L >= 2 && !(L == 2 && plan->xyz1) && papc_mlp_max_nostore_ok(M, cLi, cL, d.K);
+    plan->sparse_max = plan->nostore;
+    SavedPtrs s; FwdPtrs f; BwdPtrs b;
+    {   // offsets for the caller: lay `saved` out on a fake base
+        char *fake = reinterpret_cast<char *>((uintptr_t)1 << 40);
+        layout_saved(*plan, fake, s);
+        for (int l = 0; l < PAPC_SA_MAX_LAYERS; ++l) {
+            plan->off_y[l] = (l < L && s.y[l]) ? (int64_t)(reinterpret_cast<char *>(s.y[l]) - fake) : -1;
+            plan->off_cst[l] = (l < L && s.cst[l]) ? (int64_t)(reinterpret_cast<char *>(s.cst[l]) - fake) : -1;
+        }
+        plan->off_argmax = s.argmax ? (int64_t)(reinterpret_cast<char *>(s.argmax) - fake) : -1;
+    }
+    plan->saved_bytes = (int64_t)layout_saved(*plan, nullptr, s) + 256;
+    plan->fwd_scratch_bytes = (int64_t)layout_fwd(*plan, nullptr, f) + 256;
+    plan->bwd_scratch_bytes = (int64_t)layout_bwd(*plan, nullptr, b) + 256;
+    return PAPC_OK;
+}
+
+int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_t st)
+{
+    PAPC_REQUIRE(plan && io && io->out && io->saved && io->scratch, PAPC_E_INVALID, "papc_sa_mlp_fwd: null pointer");
+    const papc_sa_plan &p = *plan;
+    const papc_sa_desc &d = p.d;
+    const int L = d.n_layers;
+    const int64_t M = rows_of(d), G = (int64_t)d.B * d.S;
+    const bool plain = d.input == PAPC_SA_IN_ROWS, ev = d.eval_bn != 0;
+    PAPC_REQUIRE(plain ? io->x_rows != nullptr : (io->xyz && io->new_xyz), PAPC_E_INVALID, "papc_sa_mlp_fwd: missing input");
+    PAPC_REQUIRE(plain || d.identity_rows || io->idx, PAPC_E_INVALID, "papc_sa_mlp_fwd: grouped input without idx (set identity_rows for sample_and_group_all)");
+    PAPC_REQUIRE(plain || d.D == 0 || io->feats, PAPC_E_INVALID, "papc_sa_mlp_fwd: D = %d but feats is NULL", d.D);
+    PAPC_REQUIRE(!p.compact || io->compact, PAPC_E_INVALID, "papc_sa_mlp_fwd: the plan is compacted but io->compact is NULL");
+    SavedPtrs s; FwdPtrs f;
+    layout_saved(p, io->saved, s);
+    layout_fwd(p, io->scratch, f);
+    const int parts = papc_mlp_gemm_parts(M);
+    const int R_c = p.compact ? papc_compact_corr_parts() : 0;
+    papc_group_src grp;
+    if (!plain) fill_grp(grp, d, *io, p.compact);
+    int cmax = 0;
+    for (int l = 0; l < L; ++l) cmax = std::max(cmax, d.cout[l]);
+    const size_t stats_stride = (size_t)(std::max(parts, p.lin0 ? papc_lingather_parts(M) : 0) + R_c) * 2 * cmax;
+
+    const float *prev_y = nullptr, *prev_sc = nullptr, *prev_sh = nullptr;
+    int cin = p.cin0;
+    const float *xc = nullptr;
+    papc_group_max gm;
+    memset(&gm, 0, sizeof(gm));
+    for (int l = 0; l < L; ++l) {
+        const papc_sa_layer &ly = io->layer[l];
+        PAPC_REQUIRE(ly.w && ly.gamma && ly.beta, PAPC_E_INVALID, "papc_sa_mlp_fwd: layer %d lacks w / gamma / beta", l);
+        PAPC_REQUIRE(!ev || (ly.running_mean && ly.running_var), PAPC_E_INVALID, "papc_sa_mlp_fwd: eval_bn needs the running statistics");
+        const int cout = d.cout[l];
+        float *stats = ev ? nullptr : f.stats + (size_t)l * stats_stride;
+        int parts_l = parts;
+        const papc_group_max *gm_ref = nullptr;
+        if (l == L - 1 && p.gmax) {
+            gm.gmax = s.gbuf_f; gm.gmin = s.gbuf_f + G * cout; gm.amax = f.gbuf_i; gm.amin = f.gbuf_i + G * cout; gm.K = d.K;
+            gm_ref = &gm;
+        }
+        float *y = s.y[l];
+        float *cst = s.cst[l];
+        if (l == 0 && p.xyz1) {
+            const double *gpart1;
+            if (io->xc && io->xc_gram) { xc = io->xc; gpart1 = io->xc_gram; }
+            else {
+                SA_CALL(papc_xyz_group_f32(&grp, d.B, s.xc, f.gpart + 16, st));
+                SA_CALL(papc_xyz_gram_fold_f32(f.gpart + 16, papc_xyz_parts(M), f.gpart, st));
+                xc = s.xc; gpart1 = f.gpart;
+            }
+            SA_CALL(papc_xyz_l1_finalize_f32(gpart1, 1, M, ly.w, cin, 0, ly.b, ly.gamma, ly.beta, d.eps, d.momentum, cout, cst, cst + cout, cst + 2 * cout,
+                                             cst + 3 * cout, ly.running_mean, ly.running_var, s.wf, s.gram, st));
+            prev_y = nullptr; prev_sc = cst + 2 * cout; prev_sh = cst + 3 * cout;
+            cin = cout;
+            continue;
+        }
+        if (l == 1 && p.xyz1) {
+            SA_CALL(papc_mlp_gemm_f32(A_XYZ_, xc, 4, nullptr, s.wf, nullptr, ly.w, ly.b, M, cin, cout, y, stats, gm_ref, st));
+        } else if (l == 0 && plain) {
+            SA_CALL(papc_mlp_gemm_f32(A_PLAIN_, io->x_rows, cin, nullptr, nullptr, nullptr, ly.w, ly.b, M, cin, cout, y, stats, gm_ref, st));
+        } else if (l == 0 && p.lin0) {
+            // W_f feats_j depends on the source point only: one [B*N, D] x [D, cout] product on the feature block of the weight, then a gather-add
+            const int fcol0 = d.xyz_first ? 3 : 0;
+            SA_CALL(papc_copy2d_f32(ly.w + fcol0, cin, f.wfeat, d.D, cout, d.D, 0, st));
+            const int64_t BN = (int64_t)d.B * d.N;
+            SA_CALL(papc_mlp_gemm_f32(A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, f.wfeat, nullptr, BN, d.D, cout, f.P, nullptr, nullptr, st));
+            parts_l = papc_lingather_parts(M);
+            SA_CALL(papc_lingather_fwd_f32(f.P, &grp, d.B, ly.w, cin, d.xyz_first ? 0 : d.D, ly.b, cout, y, stats, st));
+        } else if (l == 0) {
+            SA_CALL(papc_mlp_gemm_f32(A_GROUP_, nullptr, 0, &grp, nullptr, nullptr, ly.w, ly.b, M, cin, cout, y, stats, gm_ref, st));
+        } else if (p.compact) {
+            SA_CALL(papc_mlp_gemm_rows_f32(A_BNRELU_, prev_y, cin, nullptr, prev_sc, prev_sh, ly.w, ly.b, M, cin, cout, y, stats, nullptr, io->compact->rows, st));
+        } else {
+            SA_CALL(papc_mlp_gemm_f32(A_BNRELU_, prev_y, cin, nullptr, prev_sc, prev_sh, ly.w, ly.b, M, cin, cout, y, stats, gm_ref, st));
+        }
+        if (p.compact) {      // what the copies add to this layer's statistics: extra partial rows behind the kernel's own
+            SA_CALL(papc_bn_stats_corr_f32(y, cout, io->compact->start, io->compact->coef, io->compact->G, stats + (size_t)parts_l * 2 * cout, st));
+            parts_l += R_c;
+        }
+        if (ev) SA_CALL(papc_bn_eval_consts_f32(ly.running_mean, ly.running_var, ly.gamma, ly.beta, d.eps, cout, cst, cst + cout, cst + 2 * cout, cst + 3 * cout, st));
+        else SA_CALL(papc_bn_finalize_f32(stats, parts_l, M, cout, ly.gamma, ly.beta, d.eps, d.momentum, cst, cst + cout, cst + 2 * cout, cst + 3 * cout,
+                                          ly.running_mean, ly.running_var, st));
+        prev_y = y; prev_sc = cst + 2 * cout; prev_sh = cst + 3 * cout;
+        cin = cout;
+    }
+    if (!d.pool) return papc_bn_relu_f32(prev_y, prev_sc, prev_sh, M, cin, io->out, st);
+    if (p.compact) return papc_bn_relu_max_seg_f32(prev_y, cin, io->compact->start, prev_sc, prev_sh, (int)G, io->out, s.argmax, s.gbuf_f, st);
+    if (p.gmax) return papc_bn_select_max_f32(s.gbuf_f, s.gbuf_f + G * cin, f.gbuf_i, f.gbuf_i + G * cin, prev_sc, prev_sh, G, cin, io->out, s.argmax, st);
+    return papc_bn_relu_max_f32(prev_y, prev_sc, prev_sh, G, d.K, cin, io->out, s.argmax, st);
+}
+
+int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_sa_grads *gr, papc_stream_t st)
+{
+    PAPC_REQUIRE(plan && io && gr && gr->gout && io->saved && io->scratch, PAPC_E_INVALID, "papc_sa_mlp_bwd: null pointer");
+    const papc_sa_plan &p = *plan;
+    const papc_sa_desc &d = p.d;
+    const int L = d.n_layers;
+    const int64_t M = rows_of(d), G = (int64_t)d.B * d.S;
+    const bool plain = d.input == PAPC_SA_IN_ROWS, ev = d.eval_bn != 0;
+    SavedPtrs s; BwdPtrs b;
+    layout_saved(p, io->saved, s);
+    layout_bwd(p, io->scratch, b);
+    const float *xc = p.xyz1 ? ((io->xc && io->xc_gram) ? io->xc : s.xc) : nullptr;
+    papc_group_src grp;
+    if (!plain) fill_grp(grp, d, *io, p.compact);
+    const int n_parts = (int)std::min<int64_t>(512, (M + 127) / 128);
+    const int gemm_parts = papc_mlp_gemm_parts(M);
+    const bool x_needs = plain && gr->grad_x, f_needs = !plain && d.D > 0 && gr->grad_feats && !d.cut_gather_grad;
+    const float *ysel = (p.gmax || p.compact) ? s.gbuf_f : nullptr;
+    const float *ones = io->consts3, *zeros = nullptr, *big = nullptr;
+    int cmaxc = 0;
+    for (int l = 0; l < L; ++l) cmaxc = std::max(cmaxc, d.cout[l]);
+    if (p.lin0) {
+        PAPC_REQUIRE(io->consts3 && io->consts3_ld >= d.cout[0], PAPC_E_INVALID, "papc_sa_mlp_bwd: the gather-add first layer needs consts3 (ones | zeros | 1e30 rows of >= %d floats)", d.cout[0]);
+        zeros = io->consts3 + io->consts3_ld; big = io->consts3 + 2 * (int64_t)io->consts3_ld;
+    }
+
+    // ---- W^T operands of the dX GEMMs: from the caller's table, else one batched transpose
+    bool need_wt[PAPC_SA_MAX_LAYERS];
+    const float *wts[PAPC_SA_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) {
+        need_wt[l] = l > 0 || x_needs || f_needs;
+        wts[l] = nullptr;
+    }
+    if (p.sparse_max) need_wt[L - 1] = false;
+    if (p.lin0) need_wt[0] = false;
+    {
+        const float *srcs[8]; float *dsts[8]; int rws[8], cls[8];
+        int n = 0;
+        for (int l = 0; l < L; ++l) {
+            if (!need_wt[l]) continue;
+            if (gr->wt[l]) { wts[l] = gr->wt[l]; continue; }
+            srcs[n] = io->layer[l].w; dsts[n] = b.wt[l]; rws[n] = d.cout[l]; cls[n] = cin_of(p, l);
+            wts[l] = b.wt[l];
+            if (++n == 8) { SA_CALL(papc_transpose_batch_f32(srcs, dsts, rws, cls, n, st)); n = 0; }
+        }
+        if (n) SA_CALL(papc_transpose_batch_f32(srcs, dsts, rws, cls, n, st));
+    }
+
+    papc_reduce_job jobs[PAPC_SA_MAX_LAYERS];
+    int n_jobs = 0;
+    const float *dz = nullptr;
+    const float *fused_red = nullptr;
+    int flip = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const papc_sa_layer &ly = io->layer[l];
+        const int cout = d.cout[l], cin = cin_of(p, l);
+        const float *cst = s.cst[l];
+        float *c12 = b.c12[l];
+        const bool acc_w = gr->acc_w[l] != 0, acc_gb = gr->acc_gb[l] != 0 && !ev;
+        float *dgamma = gr->dgamma[l] ? gr->dgamma[l] : b.tmp_gb, *dbeta = gr->dbeta[l] ? gr->dbeta[l] : b.tmp_gb + cmaxc;
+        PAPC_REQUIRE(gr->dw[l], PAPC_E_INVALID, "papc_sa_mlp_bwd: dw[%d] is NULL", l);
+        papc_bwd_dy dy;
+        memset(&dy, 0, sizeof(dy));
+        if (p.compact) { dy.wrow = io->compact->wrow; dy.seg_grp = io->compact->seg_grp; dy.rows_dev = io->compact->rows; }
+        if (l == L - 1 && !d.pool) { dy.dz_mode = PAPC_DZ_DENSE; dy.dz = gr->gout; dy.K = 1; }
+        else if (l == L - 1) { dy.dz_mode = PAPC_DZ_MAX; dy.gout = gr->gout; dy.argmax = s.argmax; dy.K = d.K; }
+        else { dy.dz_mode = PAPC_DZ_DENSE; dy.dz = dz; dy.K = 1; }
+        if (l == 0 && p.xyz1) {
+            // the whole backward of the coordinates-only layer from one pass over dz and the inputs' moments
+            PAPC_REQUIRE(!gr->dgamma[l] || (gr->acc_gb[l] != 0) == (gr->acc_w[l] != 0), PAPC_E_UNSUPPORTED,
+                         "papc_sa_mlp_bwd: the coordinates-only first layer takes ONE accumulate flag for dw / dgamma / dbeta");
+            const int nbp = papc_xyz_bwd_parts(M);
+            SA_CALL(papc_xyz_l1_bwd_f32(dz, xc, s.wf, M, cout, b.bpart, st));
+            SA_CALL(papc_xyz_l1_bwd_finalize_f32(b.bpart, nbp, M, cout, s.gram, ly.w, cin, 0, ly.b, cst, cst + cout, cst + 2 * cout, dgamma, dbeta, gr->dw[l],
+                                                 acc_w ? 1 : 0, st));
+            if (gr->db[l] && !acc_w) SA_CALL(papc_fill_f32(gr->db[l], cout, 0.f, st));
+            break;
+        }
+        dy.y = s.y[l];
+        dy.mean = cst; dy.invstd = cst + cout; dy.scale = cst + 2 * cout; dy.shift = cst + 3 * cout;
+        dy.c1 = c12; dy.c2 = c12 + cout;
+        const float *red;
+        int red_parts;
+        if (!fused_red) {     // (sum p, sum p*xhat): separate pass, unless the dX kernel of layer l+1 already produced it
+            red = b.red; red_parts = n_parts;
+            if (p.sparse_max && l == L - 1)
+                SA_CALL(papc_bn_bwd_reduce_max_f32(ysel, dy.gout, dy.K, dy.mean, dy.invstd, dy.scale, dy.shift, M, cout, n_parts, b.red, b.psel, st));
+            else
+                SA_CALL(papc_bn_bwd_reduce_f32(dy.dz_mode, dy.dz_mode == PAPC_DZ_MAX ? ysel : dy.dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
+                                               dy.shift, M, cout, n_parts, b.red, st));
+        } else { red = fused_red; red_parts = gemm_parts; }
+        SA_CALL(papc_bn_bwd_finalize_f32(red, red_parts, M, cout, dgamma, dbeta, c12, c12 + cout, (acc_gb ? 1 : 0) | (ev ? 2 : 0), st));
+        if (l == 0 && p.lin0) {
+            // G[j] = sum of the dY rows that gathered point j (+ the xyz columns of dW, streamed); the D-wide products run on B*N rows
+            const int64_t BN = (int64_t)d.B * d.N;
+            const int parts_l = papc_lingather_parts(M);
+            SA_CALL(papc_fill_f32(b.Gs, BN * cout, 0.f, st));
+            SA_CALL(papc_lingather_bwd_f32(&dy, &grp, d.B, cout, b.Gs, b.dwx_part, st));
+            const int fcol0 = d.xyz_first ? 3 : 0, xcol0 = d.xyz_first ? 0 : d.D;
+            float *dw = gr->dw[l];
+            const int acc = acc_w ? 1 : 0;
+            SA_CALL(papc_reduce_partials_strided_f32(b.dwx_part, parts_l, (int64_t)cout * 3, cout, 3, dw + xcol0, cin, acc, st));
+            // dW_f = G^T feats on the library's own dW kernel: G plays dY with BN constants that make dY = dz (scale 1, shift huge, c1 = c2 = 0)
+            papc_bwd_dy dyg;
+            memset(&dyg, 0, sizeof(dyg));
+            dyg.dz_mode = PAPC_DZ_DENSE; dyg.dz = b.Gs; dyg.K = 1; dyg.y = b.Gs;
+            dyg.mean = zeros; dyg.invstd = ones; dyg.scale = ones; dyg.shift = big; dyg.c1 = zeros; dyg.c2 = zeros;
+            const int rpc_g = dw_rows_per_chunk(BN, cout, d.D);
+            const int n_chunks_g = (int)((BN + rpc_g - 1) / rpc_g);
+            const int64_t pld_g = (int64_t)cout * d.D + cout;
+            SA_CALL(papc_mlp_bwd_dw_f32(&dyg, A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, BN, d.D, cout, rpc_g, b.part_g, b.part_g + (int64_t)cout * d.D, pld_g, st));
+            SA_CALL(papc_reduce_partials_strided_f32(b.part_g, n_chunks_g, pld_g, cout, d.D, dw + fcol0, cin, acc, st));
+            if (gr->db[l] && !acc_w) SA_CALL(papc_fill_f32(gr->db[l], cout, 0.f, st));      // (a bias feeding a train-mode BN: gradient exactly 0)
+            if (f_needs) {
+                const float *wft;
+                if (gr->wt[l]) wft = gr->wt[l] + (int64_t)fcol0 * cout;     // rows of the precomputed W^T [cin, cout]: the feature block, contiguous
+                else {
+                    SA_CALL(papc_copy2d_f32(ly.w + fcol0, cin, b.wft, cout, cout, d.D, 1, st));
+                    wft = b.wft;
+                }
+                SA_CALL(papc_mlp_gemm_f32(A_PLAIN_, b.Gs, cout, nullptr, nullptr, nullptr, wft, nullptr, BN, cout, d.D, gr->grad_feats, nullptr, nullptr, st));
+            }
+            break;
+        }
+        if (p.sparse_max && l == L - 1) {
+            SA_CALL(papc_bn_max_prep_f32(nullptr, nullptr, cst + 2 * cout, cst + 3 * cout, cst, cst + cout, c12, c12 + cout, ly.w, ly.b, G, cout, cin, nullptr,
+                                         b.wcat, b.hb, b.eq, b.eq + cout, st));     // (psel: written by the reduction above)
+        }
+        const bool x1 = p.xyz1 && l == 1;     // the input of this layer is the recomputed activation of the coordinates-only first layer
+        // ---- dW, db
+        if (p.nostore && l == L - 1) {
+            const float *pc = s.cst[l - 1];
+            SA_CALL(papc_mlp_bwd_dw_max_f32(b.psel, s.argmax, d.K, s.y[l - 1], pc + 2 * cin, pc + 3 * cin, ly.w, b.eq, cst + 2 * cout, c12, M, cin, cout, b.dwmax_ws,
+                                            gr->dw[l], acc_w ? 1 : 0, st));
+            if (gr->db[l] && !acc_w) SA_CALL(papc_fill_f32(gr->db[l], cout, 0.f, st));
+        } else {
+            const int am = l == 0 ? (plain ? A_PLAIN_ : A_GROUP_) : (x1 ? A_XYZ_ : A_BNRELU_);
+            const int rpc = dw_chunk(p, l, am, dy.dz_mode);
+            const int n_chunks = (int)((M + rpc - 1) / rpc);
+            const int64_t pld = (int64_t)cout * cin + cout;
+            float *dwp = b.part[l], *dbp = b.part[l] + (int64_t)cout * cin;
+            if (l == 0 && plain) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_PLAIN_, io->x_rows, cin, nullptr, nullptr, nullptr, M, cin, cout, rpc, dwp, dbp, pld, st));
+            else if (l == 0) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_GROUP_, nullptr, 0, &grp, nullptr, nullptr, M, cin, cout, rpc, dwp, dbp, pld, st));
+            else if (x1) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_XYZ_, xc, 4, nullptr, s.wf, nullptr, M, cin, cout, rpc, dwp, dbp, pld, st));
+            else {
+                const float *pc = s.cst[l - 1];
+                SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_BNRELU_, s.y[l - 1], cin, nullptr, pc + 2 * cin, pc + 3 * cin, M, cin, cout, rpc, dwp, dbp, pld, st));
+            }
+            // the partials of all layers are folded in ONE launch once the stack's last dW kernel is enqueued
+            papc_reduce_job &j = jobs[n_jobs++];
+            j.partial = b.part[l]; j.n_chunks = n_chunks; j.accumulate = acc_w ? 1 : 0; j.ld = pld; j.n1 = (int64_t)cout * cin; j.out1 = gr->dw[l];
+            const bool want_db = gr->db[l] && !ev;
+            j.n2 = want_db ? cout : 0; j.out2 = want_db ? gr->db[l] : nullptr;
+            if (ev && gr->db[l]) {     // no batch-mean term removes the bias direction: db = sum_m dy = scale * sum_m p
+                hipLaunchKernelGGL(mul_vec_kernel, dim3((unsigned)cdiv(cout, 256)), dim3(256), 0, as_stream(st), cst + 2 * cout, dbeta, cout, gr->db[l], acc_w ? 1 : 0);
+                SA_CALL(check_launch("papc_sa_mlp_bwd (eval-mode bias gradient)"));
+            }
+        }
+        // ---- dX
+        fused_red = nullptr;
+        if (l > 0) {
+            float *dz_prev = b.dz[flip];
+            flip ^= (b.dz[1] ? 1 : 0);
+            papc_bwd_red nr;
+            const papc_bwd_red *nr_ref = nullptr;
+            if (!(d.disable & PAPC_SA_NO_FUSED_RED) && !x1) {     // (x1: the layer below takes its BN-backward sums from its own pass over dz)
+                const float *pc = s.cst[l - 1];
+                nr.y = s.y[l - 1]; nr.mean = pc; nr.invstd = pc + cin; nr.scale = pc + 2 * cin; nr.shift = pc + 3 * cin;
+                float *fr = b.fused_red[l & 1];
+                nr.red_partial = fr;
+                nr_ref = &nr;
+                fused_red = fr;
+            }
+            if (p.sparse_max && l == L - 1) {
+                const float *pc = s.cst[l - 1];
+                SA_CALL(papc_mlp_bwd_dx_max_f32(b.psel, s.argmax, d.K, s.y[l - 1], cin, pc + 2 * cin, pc + 3 * cin, b.wcat, b.hb, M, cin, cout, dz_prev, nr_ref, st));
+            } else {
+                SA_CALL(papc_mlp_bwd_dx_f32(&dy, wts[l], M, cin, cout, dz_prev, nullptr, nr_ref, st));
+            }
+            dz = dz_prev;
+        } else if (x_needs) {
+            SA_CALL(papc_mlp_bwd_dx_f32(&dy, wts[l], M, cin, cout, gr->grad_x, nullptr, nullptr, st));
+        } else if (f_needs) {
+            SA_CALL(papc_fill_f32(gr->grad_feats, (int64_t)d.B * d.N * d.D, 0.f, st));
+            papc_scatter_dst sc;
+            memset(&sc, 0, sizeof(sc));
+            sc.grad_feats = gr->grad_feats; sc.idx = io->idx; sc.N = d.N; sc.S = d.S; sc.K = d.K; sc.D = d.D; sc.col0 = d.xyz_first ? 3 : 0;
+            SA_CALL(papc_mlp_bwd_dx_f32(&dy, wts[l], M, cin, cout, nullptr, &sc, nullptr, st));
+        }
+    }
+    if (n_jobs) SA_CALL(papc_reduce_partials_batch_f32(jobs, n_jobs, st));
+    return PAPC_OK;
+}
+
+}  // extern "C"

@@ -67,6 +67,7 @@ _LIN_GATHER = os.environ.get("PAPC_LIN_GATHER", "1") == "1"    # first grouped l
 _NOSTORE = os.environ.get("PAPC_NOSTORE", "1") == "1"   # the max-pooled last layer without its [M, C] output where the library has all three flavours (papc_mlp_max_nostore_ok)
 _SPARSE_MAX = os.environ.get("PAPC_SPARSE_MAX", "0") == "1"   # dX of the max-pooled last layer without reading its output y (papc_mlp_bwd_dx_max_f32)
 _DW_WGS = int(os.environ.get("PAPC_DW_WGS", "512"))         # workgroups of one dW launch (row chunks x output tiles)
+_PY_ORCH = os.environ.get("PAPC_PY_ORCH", "0") == "1"      # this module's own launch sequence instead of the library's papc_sa_mlp_fwd / _bwd (stack.py)
 _XYZ1 = os.environ.get("PAPC_XYZ1", "1") == "1"             # coordinates-only first layer through its input moments, never materialised (xyz1.hip)
 
 
@@ -631,4 +632,7 @@ def shared_mlp_max(spec, bn_buffers, xyz, new_xyz, feats, idx, params, x_rows=No
     from . import smallm
     if smallm.eligible(spec, xyz, feats, idx, x_rows, params):      # few rows, groups of 128 (group_all layers): csrc/smallm.hip
         return smallm.PlanesMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)
-    return SharedMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)
+    if _PY_ORCH or _SPARSE_MAX:       # the call sequence spelled out in Python (A/B against the library's own orchestration, csrc/sa_mlp.hip)
+        return SharedMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)
+    from .stack import SharedMLPStack
+    return SharedMLPStack.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)

@@ -8,6 +8,7 @@ from papc_amd import _lib
 from papc_amd import functional as F
 from papc_amd.layers import PointNetSetAbstraction, PointNetSetAbstractionMsg
 from papc_amd.mlp import StackSpec, shared_mlp_max
+from papc_amd.stack import SharedMLPStack
 from papc_amd.synthetic import make_clouds, make_start_idx
 from tests import torch_ref
 from tests.util import assert_close, seeded_weights
@@ -183,7 +184,7 @@ def test_max_layer_without_stored_output_vs_stored_and_f64(dev, D, K):
         M_._NOSTORE = nostore
         try:
             if targets:     # (shared_mlp_max derives the targets from the parameters' own flags: set them on the spec, call the Function)
-                out = M_.SharedMLPMax.apply(spec, None, xyz, new_xyz, feats, idx, None, *params)
+                out = SharedMLPStack.apply(spec, None, xyz, new_xyz, feats, idx, None, *params)
             else:
                 out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
         finally:
@@ -342,7 +343,8 @@ def test_backward_near_ties_explain_the_seed40_excess(dev):
     out = shared_mlp_max(spec, None, xyz, new_xyz, None, idx, params)
     rng = np.random.default_rng(8)
     gout = torch.from_numpy(rng.normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
-    kernel_argmax = out.grad_fn.saved_tensors[5].clone()                        # [B*S, C] int32: saved by the stack node for its backward
+    from tests.util import kernel_decisions
+    kernel_argmax = kernel_decisions(out)[0].clone()                            # [B*S, C] int32: kept by the stack node for its backward
     assert kernel_argmax.dtype == torch.int32 and tuple(kernel_argmax.shape) == (B * S, mlp[-1])
     out.backward(gout)
     o = out.detach().double()
@@ -441,8 +443,7 @@ def test_xyz_first_layer_gram_path_vs_rows_and_f64(dev, mlp):
     tg = [torch.ones_like(p) for p in params]
     spec = StackSpec(B, N, S, K, 0, True)
     spec.grad_targets = tg
-    from papc_amd.mlp import SharedMLPMax
-    o3 = SharedMLPMax.apply(spec, None, xyz, new_xyz, None, idx, None, *params)
+    o3 = SharedMLPStack.apply(spec, None, xyz, new_xyz, None, idx, None, *params)
     for p in params:
         p.grad = None
     o3.backward(gout)

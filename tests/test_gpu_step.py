@@ -121,7 +121,7 @@ def _stack_node(t):
     """the autograd node of the MLP stack behind a set-abstraction output [B, D', S] (transpose <- view <- stack)"""
     fn = t.grad_fn
     for _ in range(4):
-        if "MLPMax" in type(fn).__name__:
+        if "MLPMax" in type(fn).__name__ or "MLPStack" in type(fn).__name__:
             return fn
         fn = fn.next_functions[0][0]
     raise AssertionError("no stack node behind " + type(t.grad_fn).__name__)

@@ -70,17 +70,21 @@ def kernel_decisions(out):
     never stores (the moment-path first layer, the planes path) return None: their decisions stay the reference's own."""
     fn = out.grad_fn
     for _ in range(4):
-        if "MLPMax" in type(fn).__name__:
+        if "MLPMax" in type(fn).__name__ or "MLPStack" in type(fn).__name__:
             break
         fn = fn.next_functions[0][0]
-    assert "MLPMax" in type(fn).__name__, type(out.grad_fn).__name__
+    assert "MLPMax" in type(fn).__name__ or "MLPStack" in type(fn).__name__, type(out.grad_fn).__name__
     saved = fn.saved_tensors
     alive = out.detach() > 0
     if "Planes" in type(fn).__name__:
         return saved[0], alive, None
     L = fn.L
-    argmax = saved[5]
-    ys, consts = saved[7 + 4 * L: 7 + 5 * L], saved[7 + 5 * L: 7 + 6 * L]
+    if "Stack" in type(fn).__name__:       # the library-orchestrated node (papc_amd/stack.py): views into its saved buffer
+        from papc_amd.stack import SharedMLPStack
+        argmax, ys, consts = SharedMLPStack.views(fn)
+    else:
+        argmax = saved[5]
+        ys, consts = saved[7 + 4 * L: 7 + 5 * L], saved[7 + 5 * L: 7 + 6 * L]
     rowmap = None
     cp = getattr(fn, "compact", None)
     if cp is not None:
