@@ -375,6 +375,29 @@ int papc_sa_mlp_plan(const papc_sa_desc *desc, const papc_sa_io *io, papc_sa_pla
 int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_t stream);
 int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_sa_grads *grads, papc_stream_t stream);
 
+/* PillarFeatureNet.forward with its single last PFNLayer (PAPC/models/detect/pointpillars/models/bones/pillars.py:79-108 over :29-37; the
+ * shipped configuration num_filters: [64], with_distance = false) in ONE call per direction: decorate + mask + Linear(9 -> C, no bias) +
+ * BatchNorm1D(eps, paddle momentum) + ReLU + max over the T points.  features [P,T,4] f32, num_voxels [P] i32, coors [P,4] i32
+ * (batch, z, y, x), w [C,9], gamma / beta [C]; out [P,C].  `saved` / `scratch`: papc_pfn_workspace bytes (saved carries forward ->
+ * backward).  papc_pfn_bwd: gout [P,C] -> dw [C,9], dgamma, dbeta (accumulate != 0 adds in place).  training = 0: running statistics. */
+typedef struct papc_pfn_desc {
+    int32_t P, T, C;
+    float vx, vy, x_offset, y_offset;     /* pillars.py:74-77 */
+    float eps, momentum;
+    int32_t training;
+} papc_pfn_desc;
+typedef struct papc_pfn_io {
+    const float *features; const int32_t *num_voxels, *coors;
+    const float *w, *gamma, *beta;
+    float *running_mean, *running_var;    /* [C] or NULL (training) */
+    float *out;
+    void *saved, *scratch;
+} papc_pfn_io;
+int papc_pfn_workspace(const papc_pfn_desc *desc, int64_t *saved_bytes, int64_t *scratch_bytes);
+int papc_pfn_fwd(const papc_pfn_desc *desc, const papc_pfn_io *io, papc_stream_t stream);
+int papc_pfn_bwd(const papc_pfn_desc *desc, const papc_pfn_io *io, const float *gout, float *dw, float *dgamma, float *dbeta, int accumulate,
+                 papc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * PointPillars PillarFeatureNet (PAPC/models/detect/pointpillars/models/bones/pillars.py)
  * ---------------------------------------------------------------------------------------------- */

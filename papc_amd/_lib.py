@@ -80,6 +80,9 @@ SIGNATURES = {
     "papc_sa_mlp_plan": (c_i, [c_p, c_p, c_p]),
     "papc_sa_mlp_fwd": (c_i, [c_p, c_p, c_p]),
     "papc_sa_mlp_bwd": (c_i, [c_p, c_p, c_p, c_p]),
+    "papc_pfn_workspace": (c_i, [c_p, c_p, c_p]),
+    "papc_pfn_fwd": (c_i, [c_p, c_p, c_p]),
+    "papc_pfn_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_compact_plan_f32": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "papc_compact_corr_parts": (c_i, []),
     "papc_mlp_compact_ok": (c_i, [c_l, c_i, c_i, c_p]),

@@ -524,4 +524,64 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
     return PAPC_OK;
 }
 
+/* ---- PillarFeatureNet with its single (last) PFNLayer: pillars.py:79-108 over PFNLayer :29-37 -- decorate, mask, Linear(9 -> C, no bias),
+ * train-mode BatchNorm1D, ReLU, max over the T points of a pillar -- in ONE call per direction (the Gram-matrix path of csrc/pfn.hip) */
+static void pfn_layout(const papc_pfn_desc &d, void *saved, void *scratch, float *&cst, int32_t *&argmax, double *&gram, double *&gpart, float *&part, float *&sums)
+{
+    Carver cs{reinterpret_cast<char *>(saved), 0};
+    cst = cs.take<float>(4 * (size_t)d.C);
+    argmax = cs.take<int32_t>((size_t)d.P * d.C);
+    gram = cs.take<double>(256);
+    Carver cw{reinterpret_cast<char *>(scratch), 0};
+    gpart = cw.take<double>((size_t)papc_pfn_gram_blocks(d.P) * 256);
+    part = cw.take<float>((size_t)papc_pfn_num_blocks(d.P) * 11 * d.C);
+    sums = cw.take<float>(11 * (size_t)d.C);
+}
+
+int papc_pfn_workspace(const papc_pfn_desc *desc, int64_t *saved_bytes, int64_t *scratch_bytes)
+{
+    PAPC_REQUIRE(desc && saved_bytes && scratch_bytes, PAPC_E_INVALID, "papc_pfn_workspace: null pointer");
+    PAPC_REQUIRE(desc->P >= 1 && desc->T >= 1 && desc->C >= 1 && desc->C <= 64, PAPC_E_UNSUPPORTED, "papc_pfn_workspace: P=%d T=%d C=%d (C in 1..64)", desc->P, desc->T, desc->C);
+    const papc_pfn_desc &d = *desc;
+    *saved_bytes = 256 + ((4 * (int64_t)d.C * 4 + 255) & ~255ll) + (((int64_t)d.P * d.C * 4 + 255) & ~255ll) + 2048;
+    *scratch_bytes = 256 + (((int64_t)papc_pfn_gram_blocks(d.P) * 2048 + 255) & ~255ll) + (((int64_t)papc_pfn_num_blocks(d.P) * 11 * d.C * 4 + 255) & ~255ll) + 11 * d.C * 4 + 256;
+    return PAPC_OK;
+}
+
+int papc_pfn_fwd(const papc_pfn_desc *desc, const papc_pfn_io *io, papc_stream_t st)
+{
+    PAPC_REQUIRE(desc && io && io->features && io->num_voxels && io->coors && io->w && io->out && io->saved && io->scratch, PAPC_E_INVALID, "papc_pfn_fwd: null pointer");
+    const papc_pfn_desc &d = *desc;
+    float *cst, *part, *sums; int32_t *argmax; double *gram, *gpart;
+    pfn_layout(d, io->saved, io->scratch, cst, argmax, gram, gpart, part, sums);
+    const int C = d.C;
+    if (d.training) {
+        // batch statistics from the inputs' Gram matrix: one float64-MFMA pass over the points instead of a C-channel pass over [P*T, C]
+        const int ng = papc_pfn_gram_blocks(d.P);
+        SA_CALL(papc_pfn_gram_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, gpart, st));
+        SA_CALL(papc_pfn_gram_finalize_f32(gpart, ng, (int64_t)d.P * d.T, io->w, C, io->gamma, io->beta, d.eps, d.momentum, cst, cst + C, cst + 2 * C, cst + 3 * C,
+                                           io->running_mean, io->running_var, gram, st));
+    } else {
+        PAPC_REQUIRE(io->running_mean && io->running_var, PAPC_E_INVALID, "papc_pfn_fwd: eval mode needs the running statistics");
+        SA_CALL(papc_bn_eval_consts_f32(io->running_mean, io->running_var, io->gamma, io->beta, d.eps, C, cst, cst + C, cst + 2 * C, cst + 3 * C, st));
+    }
+    return papc_pfn_apply_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, io->w, C, cst + 2 * C, cst + 3 * C, io->out, argmax, st);
+}
+
+int papc_pfn_bwd(const papc_pfn_desc *desc, const papc_pfn_io *io, const float *gout, float *dw, float *dgamma, float *dbeta, int accumulate, papc_stream_t st)
+{
+    PAPC_REQUIRE(desc && io && io->features && io->num_voxels && io->coors && io->w && io->saved && io->scratch && gout && dw && dgamma && dbeta, PAPC_E_INVALID,
+                 "papc_pfn_bwd: null pointer");
+    const papc_pfn_desc &d = *desc;
+    float *cst, *part, *sums; int32_t *argmax; double *gram, *gpart;
+    pfn_layout(d, io->saved, io->scratch, cst, argmax, gram, gpart, part, sums);
+    const int C = d.C, nb = papc_pfn_num_blocks(d.P);
+    if (!d.training) SA_CALL(papc_fill_f32(reinterpret_cast<float *>(gram), 512, 0.f, st));     // eval-mode BN: the Gram terms carry zero weight
+    // sparse pass (one argmax row per (pillar, channel)): sum p, sum p*xhat, sum p*x_k; the dense part of dW comes from the Gram matrix
+    SA_CALL(papc_pfn_bwd_sparse_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, io->w, C, gout, argmax, cst, cst + C,
+                                    cst + 2 * C, cst + 3 * C, part, st));
+    SA_CALL(papc_reduce_partials_f32(part, nb, 11 * (int64_t)C, sums, 0, st));
+    return papc_pfn_bwd_finalize_f32(sums, (int64_t)d.P * d.T, io->w, C, gram, cst, cst + C, cst + 2 * C, dgamma, dbeta, dw, (d.training ? 0 : 1) | (accumulate ? 2 : 0), st);
+}
+
 }  // extern "C"

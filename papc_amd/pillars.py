@@ -14,6 +14,8 @@ backward (papc_group_max_bwd_f32) and the concat of :39-41.  ``model.eval()`` sw
 paddle's ``nn.Linear.weight`` is ``[in,out]``; here the weight is torch-style ``[out,in]`` (transpose when
 importing a paddle checkpoint).  BatchNorm1D(momentum=0.01) in paddle weighs the RUNNING value by 0.01.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -22,74 +24,65 @@ from ._lib import check, ptr, stream_ptr
 from .mlp import StackSpec, shared_mlp_max
 
 
+class PfnDesc(ctypes.Structure):
+    """papc_pfn_desc"""
+    _fields_ = [("P", ctypes.c_int32), ("T", ctypes.c_int32), ("C", ctypes.c_int32), ("vx", ctypes.c_float), ("vy", ctypes.c_float),
+                ("x_offset", ctypes.c_float), ("y_offset", ctypes.c_float), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
+                ("training", ctypes.c_int32)]
+
+
+class PfnIo(ctypes.Structure):
+    """papc_pfn_io"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("features", "num_voxels", "coors", "w", "gamma", "beta", "running_mean", "running_var", "out",
+                                               "saved", "scratch")]
+
+
 class _PFNFused(torch.autograd.Function):
+    """the single-layer PillarFeatureNet (pillars.py:79-108) through the library's coarse entry points: papc_pfn_fwd / papc_pfn_bwd"""
+
     @staticmethod
     def forward(ctx, geom, features, num_voxels, coors, w, gamma, beta, rmean, rvar, eps, momentum, training=True):
         lib = _lib.load()
-        st = stream_ptr()
         P, T, _ = features.shape
         C = w.shape[0]
-        vx, vy, xo, yo = geom
         dev = features.device
-        cst = torch.empty(4, C, device=dev, dtype=torch.float32)
-        gram = None
-        if training:
-            # batch statistics from the inputs' Gram matrix (csrc/pfn.hip header): one float64-MFMA pass over the 19 MB of points
-            # instead of a 64-channel pass over [P*T, C]
-            ng = lib.papc_pfn_gram_blocks(P)
-            gpart = torch.empty(ng, 256, device=dev, dtype=torch.float64)
-            gram = torch.empty(256, device=dev, dtype=torch.float64)
-            check(lib.papc_pfn_gram_f32(ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(gpart), st), "papc_pfn_gram_f32")
-            check(lib.papc_pfn_gram_finalize_f32(ptr(gpart), ng, P * T, ptr(w), C, ptr(gamma), ptr(beta), eps, momentum, cst[0].data_ptr(),
-                                                 cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), ptr(rmean), ptr(rvar), ptr(gram), st),
-                  "papc_pfn_gram_finalize_f32")
-        else:   # eval: running statistics, left untouched (self.norm is a registered BatchNorm1D in the source, :24)
-            check(lib.papc_bn_eval_consts_f32(ptr(rmean), ptr(rvar), ptr(gamma), ptr(beta), eps, C, cst[0].data_ptr(),
-                                              cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr(), st), "papc_bn_eval_consts_f32")
+        d = PfnDesc(P, T, C, geom[0], geom[1], geom[2], geom[3], eps, momentum, int(bool(training)))
+        sb, wb = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib.papc_pfn_workspace(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(wb)), "papc_pfn_workspace")
+        saved = torch.empty(sb.value, device=dev, dtype=torch.uint8)
+        scratch = torch.empty(wb.value, device=dev, dtype=torch.uint8)
         out = torch.empty(P, C, device=dev, dtype=torch.float32)
-        argmax = torch.empty(P, C, device=dev, dtype=torch.int32)
-        check(lib.papc_pfn_apply_f32(ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(w), C,
-                                     cst[2].data_ptr(), cst[3].data_ptr(), ptr(out), ptr(argmax), st), "papc_pfn_apply_f32")
-        ctx.geom = geom
-        ctx.training = bool(training)
+        io = PfnIo(ptr(features), ptr(num_voxels), ptr(coors), ptr(w), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(out), ptr(saved), ptr(scratch))
+        check(lib.papc_pfn_fwd(ctypes.byref(d), ctypes.byref(io), stream_ptr()), "papc_pfn_fwd")
+        ctx.desc, ctx.saved = d, saved
+        ctx.bufs = (rmean, rvar)
         from .mlp import grad_targets_of
         ctx.grad_targets = grad_targets_of([w, gamma, beta]) if torch.is_grad_enabled() or w.requires_grad else None
-        ctx.save_for_backward(features, num_voxels, coors, w, cst, argmax, gram if gram is not None else cst.new_zeros(1))
+        ctx.save_for_backward(features, num_voxels, coors, w, gamma, beta)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         lib = _lib.load()
-        st = stream_ptr()
-        features, num_voxels, coors, w, cst, argmax, gram = ctx.saved_tensors
-        vx, vy, xo, yo = ctx.geom
-        P, T, _ = features.shape
-        C = w.shape[0]
+        features, num_voxels, coors, w, gamma, beta = ctx.saved_tensors
+        d = ctx.desc
         dev = features.device
         gout = gout.contiguous().float()
-        nb = lib.papc_pfn_num_blocks(P)
-        geo = (ptr(features), ptr(num_voxels), ptr(coors), P, T, vx, vy, xo, yo, ptr(w), C)
-        bn = (cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(), cst[3].data_ptr())
-        if not ctx.training:       # eval-mode BN: only the sparse sums are needed, the Gram terms carry zero weight
-            gram = torch.zeros(256, device=dev, dtype=torch.float64)
-        # sparse pass (one argmax row per (pillar, channel)): sum p, sum p*xhat, sum p*x_k; the dense part of dW comes from G
-        part = torch.empty(nb, 11, C, device=dev, dtype=torch.float32)
-        check(lib.papc_pfn_bwd_sparse_f32(*geo, ptr(gout), ptr(argmax), *bn, ptr(part), st), "papc_pfn_bwd_sparse_f32")
-        sums = torch.empty(11, C, device=dev, dtype=torch.float32)
-        check(lib.papc_reduce_partials_f32(ptr(part), nb, 11 * C, ptr(sums), 0, st), "papc_reduce_partials_f32")
-        flags = 0 if ctx.training else 1
+        sb, wb = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib.papc_pfn_workspace(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(wb)), "papc_pfn_workspace")
+        scratch = torch.empty(wb.value, device=dev, dtype=torch.uint8)
+        io = PfnIo(ptr(features), ptr(num_voxels), ptr(coors), ptr(w), ptr(gamma), ptr(beta), ptr(ctx.bufs[0]), ptr(ctx.bufs[1]), None, ptr(ctx.saved),
+                   ptr(scratch))
         tg = ctx.grad_targets            # (w.grad, gamma.grad, beta.grad) of parameters that opted in to in-place accumulation, or None
         if tg is not None and any(t is None for t in tg):
             tg = None
         if tg is not None:
-            check(lib.papc_pfn_bwd_finalize_f32(ptr(sums), P * T, ptr(w), C, ptr(gram), cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
-                                                tg[1].data_ptr(), tg[2].data_ptr(), tg[0].data_ptr(), flags | 2, st), "papc_pfn_bwd_finalize_f32")
+            check(lib.papc_pfn_bwd(ctypes.byref(d), ctypes.byref(io), ptr(gout), tg[0].data_ptr(), tg[1].data_ptr(), tg[2].data_ptr(), 1, stream_ptr()),
+                  "papc_pfn_bwd")
             return (None,) * 12
-        dgb = torch.empty(2, C, device=dev, dtype=torch.float32)
-        dw = torch.empty(C, 9, device=dev, dtype=torch.float32)
-        check(lib.papc_pfn_bwd_finalize_f32(ptr(sums), P * T, ptr(w), C, ptr(gram), cst[0].data_ptr(), cst[1].data_ptr(), cst[2].data_ptr(),
-                                            dgb[0].data_ptr(), dgb[1].data_ptr(), ptr(dw), flags, st),
-              "papc_pfn_bwd_finalize_f32")
+        dgb = torch.empty(2, d.C, device=dev, dtype=torch.float32)
+        dw = torch.empty(d.C, 9, device=dev, dtype=torch.float32)
+        check(lib.papc_pfn_bwd(ctypes.byref(d), ctypes.byref(io), ptr(gout), ptr(dw), dgb[0].data_ptr(), dgb[1].data_ptr(), 0, stream_ptr()), "papc_pfn_bwd")
         return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None, None
 
 

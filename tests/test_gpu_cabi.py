@@ -205,3 +205,46 @@ def test_library_orchestration_equals_the_python_launch_sequence(dev, shape):
         assert torch.equal(x0, x1)
     if f0 is not None:      # (float atomics in the gather-add backward: same terms, run-dependent order)
         assert float((f0 - f1).abs().max()) <= 1e-5 * float(f0.abs().max())
+
+
+def test_pfn_through_raw_c_entry_points_vs_oracle(dev):
+    """PillarFeatureNet.forward (pillars.py:79-108) as papc_pfn_fwd / papc_pfn_bwd through raw ctypes: the pooled features against the float64
+    oracle at 1e-5, the three parameter gradients against float64 torch autograd on the oracle's decorated rows at 2e-4"""
+    from papc_amd.pillars import PfnDesc, PfnIo
+    from papc_amd.synthetic import make_pillars
+    lib = _lib.load()
+    P, T, Cc = 1500, 100, 64
+    voxels, nump, coors = make_pillars(P, T, seed=7)
+    rng = np.random.default_rng(3)
+    w = (rng.normal(size=(Cc, 9)) * 0.3).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, Cc).astype(np.float32) * rng.choice([1.0, -1.0], Cc).astype(np.float32)
+    b = (rng.normal(size=Cc) * 0.2).astype(np.float32)
+    vs, pr = (0.16, 0.16, 4.0), (0.0, -39.68, -3.0, 69.12, 39.68, 1.0)
+    ref = R.pillar_feature_net(voxels, nump, coors, [(w, g, b)], vs, pr, f64=True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    feat, nv, co, wt, gt, bt = t(voxels), t(nump), t(coors), t(w), t(g), t(b)
+    d = PfnDesc(P, T, Cc, vs[0], vs[1], vs[0] / 2 + pr[0], vs[1] / 2 + pr[1], 1e-3, 0.01, 1)
+    sb, wb = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.papc_pfn_workspace(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(wb)), "papc_pfn_workspace")
+    saved = torch.empty(sb.value, device=dev, dtype=torch.uint8)
+    scr = torch.empty(wb.value, device=dev, dtype=torch.uint8)
+    out = torch.empty(P, Cc, device=dev)
+    rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    io = PfnIo(feat.data_ptr(), nv.data_ptr(), co.data_ptr(), wt.data_ptr(), gt.data_ptr(), bt.data_ptr(), rm.data_ptr(), rv.data_ptr(), out.data_ptr(),
+               saved.data_ptr(), scr.data_ptr())
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.papc_pfn_fwd(ctypes.byref(d), ctypes.byref(io), st), "papc_pfn_fwd")
+    assert_close(out.cpu().numpy(), np.asarray(ref).reshape(P, Cc), 1e-5, "papc_pfn_fwd vs f64 oracle")
+    gout = torch.from_numpy(rng.normal(size=(P, Cc)).astype(np.float32)).to(dev)
+    dw, dg, db = torch.empty(Cc, 9, device=dev), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+    _lib.check(lib.papc_pfn_bwd(ctypes.byref(d), ctypes.byref(io), gout.data_ptr(), dw.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, st), "papc_pfn_bwd")
+    rows = torch.from_numpy(R.pillar_decorate(voxels, nump, coors, vs[0], vs[1], vs[0] / 2 + pr[0], vs[1] / 2 + pr[1])).to(dev).double().reshape(P * T, 9)
+    w64, g64, b64 = (x.double().requires_grad_(True) for x in (wt, gt, bt))
+    y = rows @ w64.t()
+    z = (y - y.mean(0)) / torch.sqrt(y.var(0, unbiased=False) + 1e-3) * g64 + b64
+    o64 = torch.relu(z).reshape(P, T, Cc).max(1).values
+    o64.backward(gout.double())
+    assert_close(dw.cpu().numpy(), w64.grad.cpu().numpy(), 2e-4, "papc_pfn_bwd dW")
+    assert_close(dg.cpu().numpy(), g64.grad.cpu().numpy(), 2e-4, "papc_pfn_bwd dgamma")
+    assert_close(db.cpu().numpy(), b64.grad.cpu().numpy(), 2e-4, "papc_pfn_bwd dbeta")
+    assert abs(float(rm.abs().max())) > 0                                # running statistics were updated (paddle momentum 0.01 weighs the OLD value)
