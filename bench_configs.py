@@ -83,7 +83,10 @@ def run(args):
         tgt = torch.randint(0, 50, (B * N,), device=dev)
         st = (torch.from_numpy(make_start_idx(B, N, 3)).to(dev), torch.from_numpy(make_start_idx(B, 512, 4)).to(dev))
         from papc_amd.head import softmax_cross_entropy
-        loss_fn = lambda: softmax_cross_entropy(model((x, cls), st).reshape(B * N, 50), tgt)
+        loss_fn = lambda plan=None: softmax_cross_entropy(model((x, cls), st, plan=plan).reshape(B * N, 50), tgt)
+        # everything that depends on the coordinates only (FPS, the multi-radius ball queries, compact plans, the 3-NN searches of the
+        # feature-propagation levels) is weight-independent: the NEXT batch's runs as a second branch of this batch's graph (side stream)
+        plan_fn = lambda out=None: model.plan_sampling((x, cls), st, out=out)
         units, unit, metric = B, "point-clouds/s", "point-clouds/sec (fwd+bwd) PointNet++MSG segment B=16 N=2048"
         workload = "PointNet++MSG part-segmentation whole model fwd+bwd+Adam, B=16, N=2048, 3-radius grouping (BASELINE configs[2])"
         S1, S2 = B * 512, B * 128
@@ -121,15 +124,24 @@ def run(args):
         work = {8: (2.0 * P * T * 9 * 64 + 2.0 * P * T * 11 * 11, 3 * feat + P * 64 * 4.0 * 4)}
     flat = FlatParams(model)
     opt = FlatAdam(flat, lr=1e-3, weight_decay=1e-3)
+    overlap = args.config == "msg_seg" and getattr(args, "overlap", True)
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream() if overlap else None
 
-    def fwd_bwd():
+    def fwd_bwd(plan_in=None, plan_out=None):
         flat.zero_grad()
         if loss_fn is None:                        # PFN: forward + backward of the layer under a given upstream gradient
             out = model(tv, tn, tc)
             out.backward(gout)
             return out
-        loss = loss_fn()
+        if plan_out is not None:                   # fork: the next batch's sampling branch fills the other graph's plan buffers in place
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                plan_fn(plan_out)
+        loss = loss_fn(plan_in) if plan_in is not None else loss_fn()
         loss.backward(one)
+        if plan_out is not None:
+            main.wait_stream(side)                 # join: the branch is part of this step
         return loss
 
     def step_eager():
@@ -138,15 +150,29 @@ def run(args):
         return loss
 
     # zero_grad + forward + loss + backward captured once into a hipGraph and replayed (as in bench.py); Adam stays an eager launch
-    graph = {"g": None, "loss": None}
+    graph = {"g": None, "loss": None, "i": 0}
+
+    def _clone(t):
+        return None if t is None else (tuple(_clone(u) for u in t) if isinstance(t, (tuple, list)) else t.clone())
 
     def capture():
         torch.cuda.synchronize()
         try:
+            if overlap:     # two alternating graphs: each reads one set of plan buffers and fills the other on its side branch
+                bufs = [_clone(plan_fn()) for _ in range(2)]
+                torch.cuda.synchronize()
+                gs, losses = [], []
+                for i in range(2):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                        losses.append(fwd_bwd(bufs[i], bufs[1 - i]))
+                    gs.append(g)
+                graph["g"], graph["loss"], graph["bufs"] = gs, losses, bufs
+                return
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                graph["loss"] = fwd_bwd()
-            graph["g"] = g
+                graph["loss"] = [fwd_bwd()]
+            graph["g"] = [g]
         except Exception as e:   # noqa: BLE001
             import sys
             print("[bench] hipGraph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, e), file=sys.stderr)
@@ -156,9 +182,11 @@ def run(args):
     def step():
         if graph["g"] is None:
             return step_eager()
-        graph["g"].replay()
+        i = graph["i"] % len(graph["g"])
+        graph["i"] += 1
+        graph["g"][i].replay()
         opt.step(flat.allreduce_grads())
-        return graph["loss"]
+        return graph["loss"][i]
 
     for _ in range(max(1, args.warmup)):
         loss = step()
@@ -233,6 +261,8 @@ def run(args):
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
            "config": {"workload": workload, "final_loss": round(final_loss, 4), "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager Adam" if use_graph else "eager",
+                      "sampling": ("software-pipelined: batch i+1's FPS / ball queries / compact plans / 3-NN searches run as a second branch (side stream) of "
+                                   "batch i's graph, two alternating graphs; every timed step computes one full set") if (overlap and use_graph) else "in-line",
                       "families_ms_per_step": {K_NAMES[k]: round(v[0] / 3, 4) for k, v in fam.items() if v[0] > 0}},
            "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(out))

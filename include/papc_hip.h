@@ -104,6 +104,11 @@ int papc_three_interpolate_f32(const float *points2, const int32_t *idx3, const 
 /* gradient w.r.t. points2: grad_points2[b, idx3[b,n,j], :] += w_j * grad_out[b,n,:]   (grad_points2 pre-zeroed) */
 int papc_three_interpolate_bwd_f32(const float *grad_out, const int32_t *idx3, const float *weight3, int B, int N,
                                    int S, int D, float *grad_points2, papc_stream_t stream);
+/* The same backward when idx3 is the constant (0, 1, 2) of every query -- the neighbours the reference's sort-then-argsort yields
+ * (pointnet2_basic_layers.py:316-317): a per-cloud column reduction, no atomics, deterministic; writes ALL of grad_points2 [B,S,D]
+ * (rows 0..2 the sums, zeros elsewhere: no pre-zeroing).  S >= 3. */
+int papc_three_interpolate_bwd_first3_f32(const float *grad_out, const float *weight3, int B, int N, int S, int D, float *grad_points2,
+                                          papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Shared pointwise MLP: relu(bn(conv1x1(x))) stacks + max  (pointnet2_basic_layers.py:215-219, :271-276;

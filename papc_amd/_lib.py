@@ -73,6 +73,7 @@ SIGNATURES = {
     "papc_three_nn_f32": (c_i, [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_three_interpolate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "papc_three_interpolate_bwd_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "papc_three_interpolate_bwd_first3_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "papc_mlp_gemm_parts": (c_i, [c_l]),
     "papc_mlp_gemm_gmax_ok": (c_i, [c_l, c_i, c_i]),
     "papc_mlp_gemm_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),

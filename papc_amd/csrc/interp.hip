@@ -107,6 +107,38 @@ __global__ __launch_bounds__(256) void interpolate_bwd_kernel(const float *__res
     }
 }
 
+// The same gradient when every query's neighbours are support points 0, 1, 2 -- what the reference's sort-then-argsort computes
+// (pointnet2_basic_layers.py:316-317, layers.PointNetFeaturePropagation neighbours="reference"): gpoints2[b, j, :] = sum_n w3[b, n, j] g[b, n, :]
+// for j < 3 and zero for every other support point.  A column reduction per cloud instead of 3 N D atomics on three rows: one workgroup
+// per (cloud, 64-channel slice), 16 row lanes, fixed-order LDS fold (deterministic); the workgroup also writes its slice's zeros, so the
+// output needs no fill.
+__global__ __launch_bounds__(1024) void interpolate_bwd_first3_kernel(const float *__restrict__ gout, const float *__restrict__ w3, int N, int S, int D,
+                                                                      float *__restrict__ gpoints2)
+{
+    __shared__ float red[3][16][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const bool cok = c < D;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float *g = gout + (int64_t)b * N * D + (cok ? c : 0);
+    const float *w = w3 + (int64_t)b * N * 3;
+    for (int n = rl; n < N; n += 16) {
+        const float v = cok ? g[(int64_t)n * D] : 0.f;
+        a0 = fmaf(v, w[n * 3 + 0], a0); a1 = fmaf(v, w[n * 3 + 1], a1); a2 = fmaf(v, w[n * 3 + 2], a2);
+    }
+    red[0][rl][threadIdx.x & 63] = a0; red[1][rl][threadIdx.x & 63] = a1; red[2][rl][threadIdx.x & 63] = a2;
+    __syncthreads();
+    float *o = gpoints2 + (int64_t)b * S * D;
+    if (threadIdx.x < 192) {
+        const int j = threadIdx.x >> 6, cc = blockIdx.x * 64 + (threadIdx.x & 63);
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[j][l][threadIdx.x & 63];
+        if (cc < D && j < S) o[(int64_t)j * D + cc] = t;
+    }
+    for (int s = 3 + rl; s < S; s += 16)
+        if (cok) o[(int64_t)s * D + c] = 0.f;
+}
+
 static inline unsigned ew_grid(int64_t total) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(total, 256), 256 * 16)); }
 
 }  // namespace papc
@@ -155,6 +187,17 @@ int papc_three_interpolate_bwd_f32(const float *grad_out, const int32_t *idx3, c
     const int64_t rows = (int64_t)B * N;
     hipLaunchKernelGGL(interpolate_bwd_kernel, dim3(ew_grid(rows * D)), dim3(256), 0, st, grad_out, idx3, weight3, S, D, rows, N, grad_points2);
     return check_launch("papc_three_interpolate_bwd_f32");
+}
+
+int papc_three_interpolate_bwd_first3_f32(const float *grad_out, const float *weight3, int B, int N, int S, int D, float *grad_points2,
+                                          papc_stream_t stream)
+{
+    PAPC_REQUIRE(grad_out && weight3 && grad_points2, PAPC_E_INVALID, "papc_three_interpolate_bwd_first3_f32: null pointer");
+    PAPC_REQUIRE(B >= 1 && B <= 65535 && N >= 1 && S >= 3 && D >= 1, PAPC_E_INVALID, "papc_three_interpolate_bwd_first3_f32: B=%d N=%d S=%d D=%d (S >= 3)", B, N, S, D);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_GROUP, st);
+    hipLaunchKernelGGL(interpolate_bwd_first3_kernel, dim3((unsigned)cdiv(D, 64), (unsigned)B), dim3(1024), 0, st, grad_out, weight3, N, S, D, grad_points2);
+    return check_launch("papc_three_interpolate_bwd_first3_f32");
 }
 
 }  // extern "C"

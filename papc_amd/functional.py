@@ -177,7 +177,7 @@ def sample_and_group_all(xyz, points):
     return new_xyz, new_points
 
 
-def three_nn(xyz1, xyz2):
+def three_nn(xyz1, xyz2, out=None):
     """The neighbour search of PointNetFeaturePropagation.forward (:315-322) in one kernel: xyz1 [B,N,3], xyz2 [B,S,3]
     (any strides, S >= 3) -> (dist3 [B,N,3] the three smallest ``square_distance`` values ascending, idx3 [B,N,3]
     int32 the TRUE neighbour indices (stable order), weight3 [B,N,3] = (1/(d+1e-8)) / sum).  No [B,N,S] matrix and
@@ -188,9 +188,12 @@ def three_nn(xyz1, xyz2):
     B, N, C = xyz1.shape
     S = xyz2.shape[1]
     assert C == 3 and xyz2.shape[0] == B and xyz2.shape[2] == 3
-    dist3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
-    idx3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int32)
-    w3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+    if out is not None:       # preallocated (dist3, idx3, w3): a captured step's plan buffers
+        dist3, idx3, w3 = out
+    else:
+        dist3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
+        idx3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.int32)
+        w3 = torch.empty(B, N, 3, device=xyz1.device, dtype=torch.float32)
     check(_lib.load().papc_three_nn_f32(ptr(xyz1), xyz1.stride(0), xyz1.stride(1), xyz1.stride(2), ptr(xyz2), xyz2.stride(0),
                                         xyz2.stride(1), xyz2.stride(2), B, N, S, ptr(dist3), ptr(idx3), ptr(w3), stream_ptr()),
           "papc_three_nn_f32")
@@ -199,7 +202,7 @@ def three_nn(xyz1, xyz2):
 
 class _ThreeInterpolate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, points2, idx3, weight3):
+    def forward(ctx, points2, idx3, weight3, first3=False):
         _need_cuda(points2, idx3, weight3)
         points2 = _f32c(points2)
         if idx3.dtype != torch.int32 or not idx3.is_contiguous():
@@ -212,6 +215,7 @@ class _ThreeInterpolate(torch.autograd.Function):
               "papc_three_interpolate_f32")
         ctx.save_for_backward(idx3, weight3)
         ctx.shape = (B, N, S, D)
+        ctx.first3 = bool(first3) and S >= 3
         return out
 
     @staticmethod
@@ -219,13 +223,19 @@ class _ThreeInterpolate(torch.autograd.Function):
         idx3, weight3 = ctx.saved_tensors
         B, N, S, D = ctx.shape
         g = _f32c(g)
+        if ctx.first3:       # every query's neighbours are support points 0, 1, 2: a column reduction per cloud, no atomics, no fill
+            gp = torch.empty(B, S, D, device=g.device, dtype=torch.float32)
+            check(_lib.load().papc_three_interpolate_bwd_first3_f32(ptr(g), ptr(weight3), B, N, S, D, ptr(gp), stream_ptr()),
+                  "papc_three_interpolate_bwd_first3_f32")
+            return gp, None, None, None
         gp = _lib.zeros((B, S, D), g.device)
         check(_lib.load().papc_three_interpolate_bwd_f32(ptr(g), ptr(idx3), ptr(weight3), B, N, S, D, ptr(gp), stream_ptr()),
               "papc_three_interpolate_bwd_f32")
-        return gp, None, None
+        return gp, None, None, None
 
 
-def three_interpolate(points2, idx3, weight3):
+def three_interpolate(points2, idx3, weight3, first3=False):
     """sum(index_points(points2, idx) * weight[..., None], axis=2)  (:323): points2 [B,S,D], idx3/weight3 [B,N,3] ->
-    [B,N,D].  Differentiable w.r.t. ``points2`` (the weights depend on coordinates only)."""
-    return _ThreeInterpolate.apply(points2, idx3, weight3)
+    [B,N,D].  Differentiable w.r.t. ``points2`` (the weights depend on coordinates only).  ``first3=True``: the caller vouches that idx3 is
+    the constant (0, 1, 2) of every query (the reference's sort-then-argsort neighbours): the backward is then a reduction, not a scatter."""
+    return _ThreeInterpolate.apply(points2, idx3, weight3, first3)

@@ -195,11 +195,61 @@ class PointNetSetAbstractionMsg(nn.Module):
             self.bn_blocks.append(bns)
         self.reference_quirks = reference_quirks
         self.init_dist = init_dist
+        self.compact = None            # compacted branches (compact.py): None = decide once per branch from the data, True / False = forced
+        self._compact_on = {}
         if reference_quirks:
             for p in self.parameters():
                 p.requires_grad_(False)
 
-    def forward(self, xyz, points, start_idx=None):
+    def _branch_compact_mode(self, i, B):
+        """None: branch i has no compacted flavour; True / False: decided; "probe": to be measured (see PointNetSetAbstraction)"""
+        from . import compact as C
+        convs = self.conv_blocks[i]
+        D = convs[0].in_channels - 3
+        Dp = D + ((-D) % 4)
+        if self.compact is False or Dp < 16 or len(convs) < 2:
+            return None
+        if not C.stack_ok(B * self.npoint * self.nsample_list[i], self.nsample_list[i], [c.out_channels for c in convs]):
+            return None
+        if self.compact is True or C.POLICY == "1":
+            return True
+        on = self._compact_on.get(i)
+        return "probe" if on is None else on
+
+    def _branch_plan(self, i, idx, out=None):
+        from . import compact as C
+        mode = self._branch_compact_mode(i, idx.shape[0])
+        if mode is None or mode is False:
+            return None
+        if mode == "probe":
+            if _lib._capturing():
+                return None
+            cp = C.plan(idx, out)
+            self._compact_on[i] = cp.fraction() <= C.AUTO_MAX_FRACTION
+            return cp if self._compact_on[i] else None
+        return C.plan(idx, out)
+
+    def sample(self, xyz, start_idx=None, out=None):
+        """The weight-independent half (one FPS, one ball-query scan for all radii, :258-262) on its own: xyz [B,3,N] ->
+        (new_xyz [B,S,3], idx_0 .. idx_{R-1} [B,S,K_r] int32, then the 7 compact-plan tensors of every branch that runs compacted).
+        ``out`` = a previous result of this method for the same shapes: the kernels write into it."""
+        xyz = xyz.transpose(1, 2)
+        if xyz.dtype != torch.float32:
+            xyz = xyz.float()
+        R = len(self.radius_list)
+        _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=None if out is None else out[0])
+        idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz, outs=None if out is None else list(out[1:1 + R]))
+        res = [new_xyz] + list(idxs)
+        pos = 1 + R
+        for i in range(R):
+            have = out is not None and self._compact_on.get(i) is True and len(out) >= pos + 7
+            cp = self._branch_plan(i, idxs[i], out=tuple(out[pos:pos + 7]) if have else None)
+            if cp is not None:
+                res += list(cp.tensors())
+                pos += 7
+        return tuple(res)
+
+    def forward(self, xyz, points, start_idx=None, sampled=None):
         xyz = xyz.transpose(1, 2)                                               # :252
         if xyz.dtype != torch.float32:
             xyz = xyz.float()
@@ -209,8 +259,21 @@ class PointNetSetAbstractionMsg(nn.Module):
         B, N, _ = xyz.shape
         D = 0 if feats is None else feats.shape[2]
         S = self.npoint
-        _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)             # :258 (one FPS for all radii)
-        idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz)   # :260-262, one scan
+        R = len(self.radius_list)
+        cplans = [None] * R
+        if sampled is not None:
+            from .compact import CompactPlan
+            new_xyz, idxs = sampled[0], list(sampled[1:1 + R])
+            pos = 1 + R
+            for i in range(R):
+                if self._compact_on.get(i) is True and self._branch_compact_mode(i, B) is True and len(sampled) >= pos + 7:
+                    cplans[i] = CompactPlan(tuple(sampled[pos:pos + 7]), B * S, self.nsample_list[i])
+                    pos += 7
+        else:
+            _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)             # :258 (one FPS for all radii)
+            idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz)   # :260-262, one scan
+            if feats is not None:
+                cplans = [self._branch_plan(i, idxs[i]) for i in range(R)]
         outs = []
         feats_in = feats
         padded = None
@@ -223,6 +286,8 @@ class PointNetSetAbstractionMsg(nn.Module):
                 feats, params, Dp = _pad_features(feats_in, params, False, padded)
             spec = StackSpec(B, N, S, K, Dp, xyz_first=False, eps=self.bn_blocks[i][0].eps, momentum=0.9,
                              cut_gather_grad=self.reference_quirks)             # feats first, then xyz (:267)
+            if feats_in is not None:
+                spec.compact = cplans[i]
             o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats, idxs[i], params)   # :271-276
             outs.append(o.view(B, S, -1))
         new_points_concat = cat_copy(outs, 2).transpose(1, 2)                   # :280  [B,D',S]
@@ -258,7 +323,14 @@ class PointNetFeaturePropagation(nn.Module):
             for p in self.parameters():
                 p.requires_grad_(False)
 
-    def interpolate(self, xyz1, xyz2, points2):
+    def plan(self, xyz1, xyz2, out=None):
+        """The weight-independent part of the layer -- the 3-NN search (:315-322) -- on its own: xyz1 [B,3,N], xyz2 [B,3,S] ->
+        (dist3, idx3, w3) or None when S == 1.  A training loop can compute it with the sampling pyramid (models.*.plan_sampling)."""
+        if xyz2.shape[2] == 1:
+            return None
+        return F_.three_nn(xyz1.transpose(1, 2), xyz2.transpose(1, 2), out=out)
+
+    def interpolate(self, xyz1, xyz2, points2, planned=None):
         """:311-323 on point-major tensors: xyz1 [B,N,3], xyz2 [B,S,3], points2 [B,S,D] -> [B,N,D]"""
         B, N, _ = xyz1.shape
         S = xyz2.shape[1]
@@ -266,17 +338,18 @@ class PointNetFeaturePropagation(nn.Module):
             points2 = points2.detach()
         if S == 1:
             return points2.expand(B, N, points2.shape[2])                        # paddle.tile (:312)
-        _, idx3, w3 = F_.three_nn(xyz1, xyz2)
-        if self.neighbours == "reference":
+        _, idx3, w3 = planned if planned is not None else F_.three_nn(xyz1, xyz2)
+        first3 = self.neighbours == "reference"
+        if first3:
             idx3 = _lib.const_idx3(B, N, idx3.device)                                 # argsort of a sorted row: 0, 1, 2 (cached constant)
-        return F_.three_interpolate(points2, idx3, w3)
+        return F_.three_interpolate(points2, idx3, w3, first3=first3)
 
-    def forward(self, xyz1, xyz2, points1, points2):
+    def forward(self, xyz1, xyz2, points1, points2, planned=None):
         xyz1 = xyz1.transpose(1, 2)                                              # :305-306
         xyz2 = xyz2.transpose(1, 2)
         points2 = points2.transpose(1, 2)                                        # :308
         B, N, _ = xyz1.shape
-        interpolated = self.interpolate(xyz1, xyz2, points2)
+        interpolated = self.interpolate(xyz1, xyz2, points2, planned)
         if points1 is not None:
             new_points = cat_copy([points1.transpose(1, 2).float(), interpolated], 2)         # :326-327
         else:

@@ -223,7 +223,7 @@ class _PartSegBase(nn.Module):
         self.drop1 = nn.Dropout(0.5)
         self.conv2 = nn.Conv1d(128, num_parts, 1)
 
-    def _encode(self, l0_xyz, l0_points, start_idx):
+    def _encode(self, l0_xyz, l0_points, start_idx, plan=(None, None, None, None)):
         raise NotImplementedError
 
     def sa1_first_weight(self):
@@ -231,18 +231,38 @@ class _PartSegBase(nn.Module):
         sa1 = self.sa1
         return (sa1.mlp_convs[0] if hasattr(sa1, "mlp_convs") else sa1.conv_blocks[0][0]).weight
 
-    def forward(self, inputs, start_idx=None):
+    def plan_sampling(self, inputs, start_idx=None, out=None):
+        """Everything of one batch that depends on the coordinates only: both sampling levels (FPS + ball queries, compact plans) and the
+        3-NN searches of fp2 / fp1 -> (sa1 plan, sa2 plan, fp2 neighbours, fp1 neighbours).  Pass it to forward(plan=...); a training
+        loop computes it for batch i + 1 on a side stream / graph branch while batch i trains (bench_configs.py).  ``out`` = a previous
+        result for the same shapes that the kernels fill in place."""
+        xyz = torch.as_tensor(inputs[0] if isinstance(inputs, (tuple, list)) else inputs)
+        l0_xyz = xyz[:, :3, :] if self.normal_channel else xyz
+        s = _starts(start_idx, 2)
+        o = out if out is not None else (None, None, None, None)
+        with torch.no_grad():
+            p1 = self.sa1.sample(l0_xyz, s[0], out=o[0])
+            l1_xyz = p1[0].transpose(1, 2)
+            p2 = self.sa2.sample(l1_xyz, s[1], out=o[1])
+            l2_xyz = p2[0].transpose(1, 2)
+            n2 = self.fp2.plan(l1_xyz, l2_xyz, out=o[2])
+            n1 = self.fp1.plan(l0_xyz, l1_xyz, out=o[3])
+        return p1, p2, n2, n1
+
+    def forward(self, inputs, start_idx=None, plan=None):
         xyz = torch.as_tensor(inputs[0])
         dev = xyz.device
         cls_label = Categorical(inputs[1], self.num_classes).to(dev)                               # :28
         B, C, N = xyz.shape
         l0_points = xyz                                                                            # :32-37
         l0_xyz = xyz[:, :3, :] if self.normal_channel else xyz
-        (l1_xyz, l1_points), (l2_xyz, l2_points), (l3_xyz, l3_points) = self._encode(l0_xyz, l0_points, start_idx)
+        pl = plan if plan is not None else (None, None, None, None)
+        (l1_xyz, l1_points), (l2_xyz, l2_points), (l3_xyz, l3_points) = self._encode(l0_xyz, l0_points, start_idx, pl)
         l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)                                 # :42
-        l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points)                                 # :43
+        l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points, planned=pl[2])                  # :43
         cls_label_one_hot = cls_label.reshape(B, self.num_classes, 1).expand(B, self.num_classes, N)   # :44
-        l0_points = self.fp1(l0_xyz, l1_xyz, cat_copy([cls_label_one_hot, l0_xyz.float(), l0_points.float()], 1), l1_points)   # :45
+        l0_points = self.fp1(l0_xyz, l1_xyz, cat_copy([cls_label_one_hot, l0_xyz.float(), l0_points.float()], 1), l1_points,
+                             planned=pl[3])                                                        # :45
         rows = l0_points.transpose(1, 2).reshape(B * N, 128)            # point-major rows (a view of fp1's buffer)
         if self.training:                                               # :47 relu(bn1(conv1(.))) on the fused stack
             spec = StackSpec(B, N, N, 1, 128, True, eps=self.bn1.eps, momentum=0.9, pool=False)
@@ -280,10 +300,10 @@ class PointNet2_SSG_Seg(_PartSegBase):
         self.fp1 = PointNetFeaturePropagation(in_channel=128 + 16 + 6 + additional_channel, mlp=[128, 128, 128], **f)
         self._head_init(num_parts)
 
-    def _encode(self, l0_xyz, l0_points, start_idx):
+    def _encode(self, l0_xyz, l0_points, start_idx, plan=(None, None, None, None)):
         s = _starts(start_idx, 2)
-        l1 = self.sa1(l0_xyz, l0_points, s[0])                                                     # :38
-        l2 = self.sa2(l1[0], l1[1], s[1])                                                          # :39
+        l1 = self.sa1(l0_xyz, l0_points, s[0], sampled=plan[0])                                    # :38
+        l2 = self.sa2(l1[0], l1[1], s[1], sampled=plan[1])                                         # :39
         l3 = self.sa3(l2[0], l2[1])                                                                # :40
         return l1, l2, l3
 
@@ -307,9 +327,9 @@ class PointNet2_MSG_Seg(_PartSegBase):
         self.fp1 = PointNetFeaturePropagation(in_channel=150 + additional_channel, mlp=[128, 128], **f)
         self._head_init(num_parts)
 
-    def _encode(self, l0_xyz, l0_points, start_idx):
+    def _encode(self, l0_xyz, l0_points, start_idx, plan=(None, None, None, None)):
         s = _starts(start_idx, 2)
-        l1 = self.sa1(l0_xyz, l0_points, s[0])                                                     # :86
-        l2 = self.sa2(l1[0], l1[1], s[1])                                                          # :87
+        l1 = self.sa1(l0_xyz, l0_points, s[0], sampled=plan[0])                                    # :86
+        l2 = self.sa2(l1[0], l1[1], s[1], sampled=plan[1])                                         # :87
         l3 = self.sa3(l2[0], l2[1])                                                                # :88
         return l1, l2, l3

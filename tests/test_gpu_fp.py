@@ -171,3 +171,26 @@ def test_golden_fp_fixture(dev):
         assert np.array_equal(interp.cpu().numpy(), g["interp_" + nb])
         out = fp(t(x1), t(x2), t(g["points1"]), t(g["points2"]))
         assert_close(out.detach().cpu().numpy(), g["out_" + nb], 1e-5, "golden FP " + nb)
+
+
+@pytest.mark.parametrize("B,N,S,D", [(2, 300, 17, 40), (4, 2048, 512, 128), (1, 64, 3, 7)])
+def test_three_interpolate_constant_neighbours_backward_is_a_reduction(dev, B, N, S, D):
+    """idx3 == (0, 1, 2) for every query (the reference's sort-then-argsort, :316-317): papc_three_interpolate_bwd_first3_f32 (column
+    reduction, writes the whole output) against the atomic scatter and float64"""
+    from papc_amd import functional as F
+    rng = np.random.default_rng(5)
+    p2 = torch.from_numpy(rng.normal(size=(B, S, D)).astype(np.float32)).to(dev)
+    w3 = torch.from_numpy(rng.uniform(0.1, 1.0, size=(B, N, 3)).astype(np.float32)).to(dev)
+    idx3 = torch.arange(3, device=dev, dtype=torch.int32).expand(B, N, 3).contiguous()
+    g = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev)
+    grads = []
+    for first3 in (False, True):
+        p = p2.clone().requires_grad_(True)
+        out = F.three_interpolate(p, idx3, w3, first3=first3)
+        out.backward(g)
+        grads.append(p.grad.clone())
+    want = torch.zeros(B, S, D, device=dev, dtype=torch.float64)
+    want[:, :3] = torch.einsum("bnj,bnd->bjd", w3.double(), g.double())
+    assert float((grads[1].double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float(grads[1][:, 3:].abs().max()) == 0.0 if S > 3 else True
