@@ -180,10 +180,11 @@ def test_seg_planned_sampling_equals_in_line(dev, cls_):
     plan = m.plan_sampling((x, cls), st)
     bufs = tuple(None if lvl is None else tuple(t.clone().zero_() if t.dtype != torch.float32 else torch.zeros_like(t) for t in lvl) for lvl in plan)
     plan2 = m.plan_sampling((x, cls), st, out=bufs)
-    for a, b in zip(plan, plan2):
-        for ta, tb in zip(a, b):
-            assert torch.equal(ta[..., :1].flatten()[:8], tb[..., :1].flatten()[:8]) or True
-        assert all(tb.data_ptr() == bb.data_ptr() for tb, bb in zip(b, bufs[plan2.index(b)]))      # filled in place
+    for a, b, bb in zip(plan, plan2, bufs):
+        assert len(a) == len(b) == len(bb)
+        for ta, tb, tbuf in zip(a, b, bb):
+            assert tb.data_ptr() == tbuf.data_ptr()                     # the kernels wrote into the given buffers
+    assert torch.equal(plan[0][0], plan2[0][0]) and torch.equal(plan[1][1], plan2[1][1]) and torch.equal(plan[3][1], plan2[3][1])
     outs = []
     for pl in (None, plan2):
         for p in m.parameters():
@@ -194,4 +195,4 @@ def test_seg_planned_sampling_equals_in_line(dev, cls_):
     (l0, g0), (l1, g1) = outs
     assert torch.equal(l0, l1), "logits differ between the planned and the in-line sampling"
     for a, b in zip(g0, g1):      # (float atomics in the gather-add backward: same terms, run-dependent order)
-        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-6      # (+ 1e-6: conv biases under a train-mode BN hold rounding noise around their exact 0)
