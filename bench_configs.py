@@ -249,7 +249,24 @@ def run(args):
     roof["ms_per_step"] = round(dom_ms / n_roof, 4)
     roof["timing"] = ("HIP event pairs around every launch of the family, %d eager steps right after the graph-replayed timed region" % n_roof) if use_graph \
         else "HIP event pairs around every launch of the family over the timed region (eager launches)"
-    roof["traffic_note"] = "PMC traffic of this configuration: profiles/r02_cfg_%s_pmc.txt where collected" % args.config
+    # HBM traffic of the family from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/refresh_profiles.sh),
+    # read back from the committed per-family summary of the latest round
+    import glob
+    roof["traffic_note"] = "no profiles/r*_cfg_%s_pmc_family.json found" % args.config
+    fams = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_cfg_%s_pmc_family.json" % args.config)))
+    if fams:
+        try:
+            with open(fams[-1]) as fh:
+                rec = json.load(fh).get(K_NAMES[dominant])
+            if rec:
+                lps = max(1, dom_n // n_roof)
+                roof["traffic"] = round(rec["traffic_MB_per_step"] * 1e6 / lps)         # bytes per launch of the family, like `achieved`
+                if roof["bound"] == "hbm":
+                    roof["frac_counter_bytes"] = round(rec["traffic_MB_per_step"] * 1e6 / per_step_s / (PEAK_HBM_GBS * 1e9), 4)
+                roof["traffic_note"] = ("%s: 2 x FETCH_SIZE + WRITE_SIZE of the family per step (gfx950 FETCH_SIZE correction x2), %.1f MB measured "
+                                        "against %.1f MB algorithmic per step" % (os.path.join("profiles", os.path.basename(fams[-1])), rec["traffic_MB_per_step"], byts / 1e6))
+        except (OSError, ValueError, KeyError) as e:
+            roof["traffic_note"] = "could not read %s: %s" % (fams[-1], e)
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import torch_cpu_reference as T

@@ -16,8 +16,10 @@ for c in msg_seg pfn basic; do
   timeout 400 python bench.py --config $c > $O/bench_line_$c.json 2> $O/bench_line_$c.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_$c -o run -- python bench.py --config $c --no-cpu-baseline --steps 20 --warmup 5 > $O/prof_stats_$c.log 2>&1
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_pfn_$c -o run -- python bench.py --config pfn --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_pfn_$c.log 2>&1
+for cfg in pfn msg_seg basic; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${cfg}_$c -o run -- python bench.py --config $cfg --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_${cfg}_$c.log 2>&1
+  done
 done
 find $O -name "*.csv" | head -40
 tail -c 300 $O/bench_line.json

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Turn gpurun_out/ of tools/refresh_profiles.sh into the committed summaries under profiles/ (round tag = $1, default r01).
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out
 P=profiles
 cp $O/prof_stats/run_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
@@ -30,4 +30,7 @@ done
   python tools/pmc_summary.py $O/pmc_pfn_FETCH_SIZE 8
   python tools/pmc_summary.py $O/pmc_pfn_WRITE_SIZE 8
 } > $P/${R}_cfg_pfn_pmc.txt
+for c in pfn msg_seg basic; do
+  python tools/pmc_family.py $O/pmc_${c}_FETCH_SIZE $O/pmc_${c}_WRITE_SIZE > $P/${R}_cfg_${c}_pmc_family.json
+done
 wc -l $P/${R}_*
