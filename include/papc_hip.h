@@ -326,6 +326,8 @@ int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, in
 #define PAPC_SA_NO_GMAX 8u
 #define PAPC_SA_NO_FUSED_RED 16u
 #define PAPC_SA_NO_COMPACT 32u
+#define PAPC_SA_NO_PLANES 64u            /* few-row stacks (sample_and_group_all, M <= 16 384) on the row kernels instead of the planes kernels */
+#define PAPC_SA_NO_PLANES_POINTWISE 128u /* ... only the un-pooled point-wise stacks */
 typedef struct papc_sa_desc {
     int32_t B, N, S, K, D;
     int32_t n_layers;
@@ -336,6 +338,8 @@ typedef struct papc_sa_desc {
     int32_t xyz_first, pool, eval_bn, cut_gather_grad;
     float eps, momentum;
     uint32_t disable;
+    int32_t inference;                    /* != 0: no backward will follow (the planes path then skips the transposed operands it keeps for dW) */
+    int32_t want_input_grad;              /* != 0: papc_sa_mlp_bwd will be asked for grad_feats / grad_x (the planes path prepares W_1^T with the forward) */
 } papc_sa_desc;
 typedef struct papc_sa_layer {
     const float *w, *b, *gamma, *beta;    /* [cout, cin], [cout] x 3 */
@@ -363,7 +367,7 @@ typedef struct papc_sa_io {
 typedef struct papc_sa_plan {
     papc_sa_desc d;
     int32_t cin0;
-    int32_t lin0, xyz1, gmax, nostore, compact, sparse_max;
+    int32_t lin0, xyz1, gmax, nostore, compact, sparse_max, planes;
     int64_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes;
     /* where forward leaves what a caller may want to look at, as byte offsets into `saved` (-1: not stored on this path):
      * pre-BN outputs y_l [M, c_l], BatchNorm constants [4, c_l] (mean | invstd | scale | shift), argmax [G, c_L] int32 */

@@ -15,6 +15,12 @@
 // All buffers are caller-owned device memory; nothing is allocated, nothing synchronises, every launch goes to the given stream.
 #include "common.h"
 
+#define SA_CALL(expr)                 \
+    do {                              \
+        const int rc__ = (expr);      \
+        if (rc__ != PAPC_OK) return rc__; \
+    } while (0)
+
 namespace papc {
 
 constexpr int A_PLAIN_ = PAPC_A_PLAIN, A_BNRELU_ = PAPC_A_BNRELU, A_GROUP_ = PAPC_A_GROUP, A_XYZ_ = PAPC_A_XYZ;
@@ -172,6 +178,229 @@ static size_t layout_bwd(const papc_sa_plan &p, void *base, BwdPtrs &b)
     return c.off;
 }
 
+// ---- the planes path (csrc/smallm.hip): few-row stacks -- sample_and_group_all (pointnet2_basic_layers.py:160-176), point-wise stacks ------
+constexpr int PG_GROUP = 128, PG_MAX_ROWS = 16384;
+struct PlanesSaved {
+    float *y[PAPC_SA_MAX_LAYERS], *cst[PAPC_SA_MAX_LAYERS];
+    int32_t *argmax; float *gbuf_f;
+    void *PT[PAPC_SA_MAX_LAYERS];       // input^T planes of every layer (dW operands)
+    void *wtp[PAPC_SA_MAX_LAYERS];      // W^T planes (dX operands)
+};
+struct PlanesFwd { void *wp[PAPC_SA_MAX_LAYERS]; void *P; float *stats[PAPC_SA_MAX_LAYERS]; int32_t *gbuf_i; };
+struct PlanesBwd { void *dyp, *dypt; float *dz[2], *red[3], *part[PAPC_SA_MAX_LAYERS], *tmp_gb; };
+
+static int pg_split_for(int R1, int R2, int nst)      // (smallm.py::_split_for: about one workgroup per CU, >= 8 k32 stages each, a power of two dividing nst)
+{
+    const int tiles = ((R1 + 127) / 128) * ((R2 + 127) / 128);
+    int s = 1;
+    while (s * 2 * tiles <= 256 && nst % (s * 2) == 0 && nst / (s * 2) >= 8) s *= 2;
+    return s;
+}
+static inline int pg_n_in(const papc_sa_plan &p) { return p.d.input == PAPC_SA_IN_ROWS ? p.cin0 : p.d.D; }
+
+static size_t layout_planes_saved(const papc_sa_plan &p, void *base, PlanesSaved &s)
+{
+    Carver c{reinterpret_cast<char *>(base), 0};
+    const int L = p.d.n_layers;
+    const int64_t M = rows_of(p.d), T = M / PG_GROUP;
+    memset(&s, 0, sizeof(s));
+    for (int l = 0; l < L; ++l) {
+        s.y[l] = c.take<float>((size_t)M * p.d.cout[l]);
+        s.cst[l] = c.take<float>(4 * (size_t)p.d.cout[l]);
+    }
+    if (p.d.pool) {
+        s.argmax = c.take<int32_t>((size_t)T * p.d.cout[L - 1]);
+        s.gbuf_f = c.take<float>(2 * (size_t)T * p.d.cout[L - 1]);
+    }
+    if (!p.d.inference)
+        for (int l = 0; l < L; ++l) {
+            s.PT[l] = c.take<char>(papc_pg_planes_bytes(cin_of(p, l), M));
+            if (l > 0) s.wtp[l] = c.take<char>(papc_pg_planes_bytes(cin_of(p, l), p.d.cout[l]));
+            else if (p.d.want_input_grad) s.wtp[0] = c.take<char>(papc_pg_planes_bytes(pg_n_in(p), p.d.cout[0]));
+        }
+    return c.off;
+}
+
+static size_t layout_planes_fwd(const papc_sa_plan &p, void *base, PlanesFwd &f)
+{
+    Carver c{reinterpret_cast<char *>(base), 0};
+    const int L = p.d.n_layers;
+    const int64_t M = rows_of(p.d), T = M / PG_GROUP;
+    memset(&f, 0, sizeof(f));
+    size_t pmax = papc_pg_planes_bytes(M, p.cin0);
+    for (int l = 0; l < L; ++l) {
+        f.wp[l] = c.take<char>(papc_pg_planes_bytes(p.d.cout[l], cin_of(p, l)));
+        f.stats[l] = c.take<float>((size_t)T * 2 * p.d.cout[l]);
+        if (l < L - 1) pmax = std::max(pmax, papc_pg_planes_bytes(M, p.d.cout[l]));
+    }
+    f.P = c.take<char>(pmax);
+    if (p.d.pool) f.gbuf_i = c.take<int32_t>(2 * (size_t)T * p.d.cout[L - 1]);
+    return c.off;
+}
+
+static size_t layout_planes_bwd(const papc_sa_plan &p, void *base, PlanesBwd &b)
+{
+    Carver c{reinterpret_cast<char *>(base), 0};
+    const int L = p.d.n_layers;
+    const int64_t M = rows_of(p.d), T = M / PG_GROUP;
+    memset(&b, 0, sizeof(b));
+    int cmax = p.cin0;
+    size_t pm = 0, pmt = 0;
+    for (int l = 0; l < L; ++l) {
+        cmax = std::max(cmax, p.d.cout[l]);
+        pm = std::max(pm, papc_pg_planes_bytes(M, p.d.cout[l]));
+        pmt = std::max(pmt, papc_pg_planes_bytes(p.d.cout[l], M));
+        b.part[l] = c.take<float>((size_t)pg_split_for(p.d.cout[l], cin_of(p, l), (int)(M / 32)) * p.d.cout[l] * cin_of(p, l));
+    }
+    b.dyp = c.take<char>(pm);
+    b.dypt = c.take<char>(pmt);
+    b.dz[0] = c.take<float>((size_t)M * cmax);
+    b.dz[1] = c.take<float>((size_t)M * cmax);
+    for (int i = 0; i < 3; ++i) b.red[i] = c.take<float>((size_t)T * 2 * cmax);
+    b.tmp_gb = c.take<float>(2 * (size_t)cmax);
+    return c.off;
+}
+
+static int planes_fwd(const papc_sa_plan &p, const papc_sa_io &io, papc_stream_t st)
+{
+    const papc_sa_desc &d = p.d;
+    const int L = d.n_layers;
+    const int64_t M = rows_of(d), T = M / PG_GROUP;
+    const bool plain = d.input == PAPC_SA_IN_ROWS, want_bwd = !d.inference;
+    PlanesSaved s; PlanesFwd f;
+    layout_planes_saved(p, io.saved, s);
+    layout_planes_fwd(p, io.scratch, f);
+    // ---- weights -> planes: W_l [c_l x c_(l-1)] for the forward, W_l^T [c_(l-1) x c_l] for dX (layer 1: the gradient-carrying columns)
+    {
+        papc_pg_wjob jobs[2 * PAPC_SA_MAX_LAYERS];
+        int n = 0;
+        const int fcol0 = plain ? 0 : (d.xyz_first ? 3 : 0);
+        for (int l = 0; l < L; ++l) {
+            const int cin = cin_of(p, l), cout = d.cout[l];
+            jobs[n++] = papc_pg_wjob{io.layer[l].w, cin, 1, cout, cin, f.wp[l]};
+            if (s.wtp[l]) {
+                if (l > 0) jobs[n++] = papc_pg_wjob{io.layer[l].w, 1, cin, cin, cout, s.wtp[l]};
+                else jobs[n++] = papc_pg_wjob{io.layer[l].w + fcol0, 1, cin, pg_n_in(p), cout, s.wtp[l]};
+            }
+        }
+        for (int j0 = 0; j0 < n; j0 += 8) SA_CALL(papc_pg_prep_weights_f32(jobs + j0, std::min(8, n - j0), st));
+    }
+    // ---- layer 1 operand: the rows of sample_and_group_all (or the caller's rows)
+    papc_pg_prep a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.C = p.cin0; a.planes = f.P; a.planes_t = want_bwd ? s.PT[0] : nullptr;
+    if (plain) { a.mode = PAPC_PG_PLAIN; a.x = io.x_rows; a.ldx = p.cin0; }
+    else { a.mode = PAPC_PG_CONCAT; a.xyz = io.xyz; a.sb = io.sb; a.sn = io.sn; a.sc = io.sc; a.feats = io.feats; a.N = d.N; a.D = d.D; a.xyz_first = d.xyz_first; }
+    SA_CALL(papc_pg_prep_rows_f32(&a, st));
+    for (int l = 0; l < L; ++l) {
+        const papc_sa_layer &ly = io.layer[l];
+        const int cout = d.cout[l], cin = cin_of(p, l);
+        float *cst = s.cst[l];
+        const bool last_pool = l == L - 1 && d.pool;
+        papc_pg_gemm g;
+        memset(&g, 0, sizeof(g));
+        g.epi = last_pool ? PAPC_PG_FWD_GMAX : PAPC_PG_FWD;
+        g.a = f.P; g.b = f.wp[l]; g.R1 = (int)M; g.R2 = cout; g.K = cin;
+        g.c = s.y[l]; g.ldc = cout; g.split = 1; g.bias = ly.b; g.stats = f.stats[l]; g.family = PAPC_K_MLP_GEMM;
+        if (last_pool) { g.gmax = s.gbuf_f; g.gmin = s.gbuf_f + T * cout; g.amax = f.gbuf_i; g.amin = f.gbuf_i + T * cout; }
+        SA_CALL(papc_pg_gemm_f32(&g, st));
+        if (l < L - 1) {
+            // BN statistics of this layer folded in the prologue of the NEXT layer's operand prep (relu(bn(y)) -> planes)
+            papc_pg_prep b;
+            memset(&b, 0, sizeof(b));
+            b.mode = PAPC_PG_BNRELU; b.M = M; b.C = cout; b.x = s.y[l]; b.ldx = cout; b.stats = f.stats[l]; b.parts = (int)T;
+            b.gamma = ly.gamma; b.beta = ly.beta; b.eps = d.eps; b.momentum = d.momentum; b.running_mean = ly.running_mean; b.running_var = ly.running_var;
+            b.mean = cst; b.invstd = cst + cout; b.scale = cst + 2 * cout; b.shift = cst + 3 * cout;
+            b.planes = f.P; b.planes_t = want_bwd ? s.PT[l + 1] : nullptr;
+            SA_CALL(papc_pg_prep_rows_f32(&b, st));
+        } else if (!d.pool) {
+            SA_CALL(papc_bn_finalize_f32(f.stats[l], (int)T, M, cout, ly.gamma, ly.beta, d.eps, d.momentum, cst, cst + cout, cst + 2 * cout, cst + 3 * cout,
+                                         ly.running_mean, ly.running_var, st));
+            SA_CALL(papc_bn_relu_f32(s.y[l], cst + 2 * cout, cst + 3 * cout, M, cout, io.out, st));
+        } else {
+            SA_CALL(papc_pg_final_f32(f.stats[l], (int)T, M, cout, ly.gamma, ly.beta, d.eps, d.momentum, cst, cst + cout, cst + 2 * cout, cst + 3 * cout,
+                                      ly.running_mean, ly.running_var, s.gbuf_f, s.gbuf_f + T * cout, f.gbuf_i, f.gbuf_i + T * cout, T, io.out, s.argmax, st));
+        }
+    }
+    return PAPC_OK;
+}
+
+static int planes_bwd(const papc_sa_plan &p, const papc_sa_io &io, const papc_sa_grads &gr, papc_stream_t st)
+{
+    const papc_sa_desc &d = p.d;
+    const int L = d.n_layers;
+    const int64_t M = rows_of(d), T = M / PG_GROUP;
+    const bool plain = d.input == PAPC_SA_IN_ROWS;
+    PAPC_REQUIRE(!d.inference, PAPC_E_INVALID, "papc_sa_mlp_bwd: the forward ran with desc.inference set");
+    PlanesSaved s; PlanesBwd b;
+    layout_planes_saved(p, io.saved, s);
+    layout_planes_bwd(p, io.scratch, b);
+    int cmaxc = 0;
+    for (int l = 0; l < L; ++l) cmaxc = std::max(cmaxc, d.cout[l]);
+    float *grad_in = plain ? gr.grad_x : gr.grad_feats;
+    PAPC_REQUIRE(!grad_in || s.wtp[0], PAPC_E_INVALID, "papc_sa_mlp_bwd: an input gradient needs desc.want_input_grad at the forward");
+    papc_pg_fold_job fold[PAPC_SA_MAX_LAYERS];
+    int n_fold = 0;
+    const float *dz = nullptr, *red = nullptr;
+    int flip = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        const int cout = d.cout[l], cin = cin_of(p, l);
+        const float *cst = s.cst[l];
+        const bool acc_w = gr.acc_w[l] != 0, acc_gb = gr.acc_gb[l] != 0;
+        float *dgamma = gr.dgamma[l] ? gr.dgamma[l] : b.tmp_gb, *dbeta = gr.dbeta[l] ? gr.dbeta[l] : b.tmp_gb + cmaxc;
+        PAPC_REQUIRE(gr.dw[l], PAPC_E_INVALID, "papc_sa_mlp_bwd: dw[%d] is NULL", l);
+        const bool need_dx = l > 0 || grad_in;
+        // dY of this layer as planes, both orientations; c1 / c2 / dgamma / dbeta folded in the prologue
+        papc_pg_prep a;
+        memset(&a, 0, sizeof(a));
+        a.M = M; a.C = cout; a.x = s.y[l]; a.ldx = cout; a.mean = const_cast<float *>(cst); a.invstd = const_cast<float *>(cst + cout);
+        a.scale = const_cast<float *>(cst + 2 * cout); a.shift = const_cast<float *>(cst + 3 * cout);
+        a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = (acc_gb && gr.dgamma[l]) ? 1 : 0; a.planes = need_dx ? b.dyp : nullptr; a.planes_t = b.dypt;
+        if (l == L - 1 && !d.pool) {
+            // dense upstream gradient: the layer's BN-backward sums in a pass of their own (T partial rows, folded in the prep's prologue)
+            SA_CALL(papc_bn_bwd_reduce_f32(PAPC_DZ_DENSE, gr.gout, nullptr, nullptr, 1, s.y[l], cst, cst + cout, cst + 2 * cout, cst + 3 * cout, M, cout, (int)T, b.red[2], st));
+            a.mode = PAPC_PG_DY_DENSE; a.dz = gr.gout; a.red = b.red[2]; a.red_parts = (int)T;
+        } else if (l == L - 1) {
+            a.mode = PAPC_PG_DY_MAX; a.gout = gr.gout; a.ysel = s.gbuf_f; a.argmax = s.argmax; a.K = PG_GROUP;
+        } else {
+            a.mode = PAPC_PG_DY_DENSE; a.dz = dz; a.red = red; a.red_parts = (int)T;
+        }
+        SA_CALL(papc_pg_prep_rows_f32(&a, st));
+        // ---- dX
+        float *dz_prev = nullptr, *red_prev = nullptr;
+        if (l > 0) {
+            const float *pc = s.cst[l - 1];
+            dz_prev = b.dz[flip]; red_prev = b.red[flip];
+            flip ^= 1;
+            papc_pg_gemm g;
+            memset(&g, 0, sizeof(g));
+            g.epi = PAPC_PG_RED; g.a = b.dyp; g.b = s.wtp[l]; g.R1 = (int)M; g.R2 = cin; g.K = cout;
+            g.c = dz_prev; g.ldc = cin; g.split = 1; g.stats = red_prev; g.family = PAPC_K_BWD_DX;
+            g.y_prev = s.y[l - 1]; g.mean = pc; g.invstd = pc + cin; g.scale = pc + 2 * cin; g.shift = pc + 3 * cin;
+            SA_CALL(papc_pg_gemm_f32(&g, st));
+        } else if (grad_in) {
+            const int n_in = pg_n_in(p);
+            papc_pg_gemm g;
+            memset(&g, 0, sizeof(g));
+            g.epi = PAPC_PG_STORE; g.a = b.dyp; g.b = s.wtp[0]; g.R1 = (int)M; g.R2 = n_in; g.K = cout;
+            g.c = grad_in; g.ldc = n_in; g.split = 1; g.family = PAPC_K_BWD_DX;
+            SA_CALL(papc_pg_gemm_f32(&g, st));
+        }
+        // ---- dW = dY^T . input: contraction over the M rows, split over workgroups, partials folded at the end
+        const int split = pg_split_for(cout, cin, (int)(M / 32));
+        papc_pg_gemm g;
+        memset(&g, 0, sizeof(g));
+        g.epi = PAPC_PG_STORE; g.a = b.dypt; g.b = s.PT[l]; g.R1 = cout; g.R2 = cin; g.K = (int)M;
+        g.c = b.part[l]; g.ldc = cin; g.split = split; g.split_stride = (int64_t)cout * cin; g.family = PAPC_K_BWD_DW;
+        SA_CALL(papc_pg_gemm_f32(&g, st));
+        fold[n_fold++] = papc_pg_fold_job{b.part[l], split, (int64_t)cout * cin, (int64_t)cout * cin, gr.dw[l], acc_w ? 1 : 0};
+        if (gr.db[l] && !acc_w) SA_CALL(papc_fill_f32(gr.db[l], cout, 0.f, st));      // (a bias feeding a train-mode BN: gradient exactly 0)
+        if (l > 0) { dz = dz_prev; red = red_prev; }
+    }
+    for (int j0 = 0; j0 < n_fold; j0 += 8) SA_CALL(papc_pg_fold_f32(fold + j0, std::min(8, n_fold - j0), st));
+    return PAPC_OK;
+}
+
 static void fill_grp(papc_group_src &g, const papc_sa_desc &d, const papc_sa_io &io, bool compact)
 {
     memset(&g, 0, sizeof(g));
@@ -189,12 +418,6 @@ __global__ void mul_vec_kernel(const float *__restrict__ a, const float *__restr
 }  // namespace papc
 
 using namespace papc;
-
-#define SA_CALL(expr)                 \
-    do {                              \
-        const int rc__ = (expr);      \
-        if (rc__ != PAPC_OK) return rc__; \
-    } while (0)
 
 extern "C" {
 
@@ -214,6 +437,27 @@ int papc_sa_mlp_plan(const papc_sa_desc *desc, const papc_sa_io *io, papc_sa_pla
     plan->cin0 = plain ? d.cin : d.D + 3;
     PAPC_REQUIRE(plan->cin0 >= 1, PAPC_E_INVALID, "papc_sa_mlp_plan: no input channels");
     const bool has_idx = !plain && d.identity_rows == 0, has_feats = !plain && d.D > 0;
+    {   // few rows in groups of exactly 128 (one GEMM tile), no neighbour index, widths in multiples of 8: the planes kernels (smallm.hip)
+        bool ok = !(d.disable & PAPC_SA_NO_PLANES) && !ev && !has_idx && M % PG_GROUP == 0 && M >= PG_GROUP && M <= PG_MAX_ROWS && L >= 2;
+        ok = ok && (d.pool ? d.K == PG_GROUP : (plain && !(d.disable & PAPC_SA_NO_PLANES_POINTWISE)));
+        for (int l = 0; l < L; ++l) ok = ok && d.cout[l] % 8 == 0;
+        ok = ok && (plain ? plan->cin0 % 8 == 0 : d.S == 1);
+        plan->planes = ok ? 1 : 0;
+    }
+    if (plan->planes) {
+        PlanesSaved ps; PlanesFwd pf; PlanesBwd pb;
+        char *fake = reinterpret_cast<char *>((uintptr_t)1 << 40);
+        layout_planes_saved(*plan, fake, ps);
+        for (int l = 0; l < PAPC_SA_MAX_LAYERS; ++l) {
+            plan->off_y[l] = l < L ? (int64_t)(reinterpret_cast<char *>(ps.y[l]) - fake) : -1;
+            plan->off_cst[l] = l < L ? (int64_t)(reinterpret_cast<char *>(ps.cst[l]) - fake) : -1;
+        }
+        plan->off_argmax = ps.argmax ? (int64_t)(reinterpret_cast<char *>(ps.argmax) - fake) : -1;
+        plan->saved_bytes = (int64_t)layout_planes_saved(*plan, nullptr, ps) + 256;
+        plan->fwd_scratch_bytes = (int64_t)layout_planes_fwd(*plan, nullptr, pf) + 256;
+        plan->bwd_scratch_bytes = (int64_t)layout_planes_bwd(*plan, nullptr, pb) + 256;
+        return PAPC_OK;
+    }
     plan->lin0 = !(d.disable & PAPC_SA_NO_LINGATHER) && !ev && !plain && has_idx && has_feats && L >= 2 && d.D % 4 == 0 && d.D >= 16 &&
                  d.cout[0] % 4 == 0 && d.cout[0] <= 256;
     plan->xyz1 = !(d.disable & PAPC_SA_NO_XYZ1) && !ev && !plain && has_idx && !has_feats && d.D == 0 && L >= 3 &&
@@ -251,6 +495,10 @@ int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_
     PAPC_REQUIRE(plain || d.identity_rows || io->idx, PAPC_E_INVALID, "papc_sa_mlp_fwd: grouped input without idx (set identity_rows for sample_and_group_all)");
     PAPC_REQUIRE(plain || d.D == 0 || io->feats, PAPC_E_INVALID, "papc_sa_mlp_fwd: D = %d but feats is NULL", d.D);
     PAPC_REQUIRE(!p.compact || io->compact, PAPC_E_INVALID, "papc_sa_mlp_fwd: the plan is compacted but io->compact is NULL");
+    if (p.planes) {
+        for (int l = 0; l < L; ++l) PAPC_REQUIRE(io->layer[l].w && io->layer[l].gamma && io->layer[l].beta, PAPC_E_INVALID, "papc_sa_mlp_fwd: layer %d lacks w / gamma / beta", l);
+        return planes_fwd(p, *io, st);
+    }
     SavedPtrs s; FwdPtrs f;
     layout_saved(p, io->saved, s);
     layout_fwd(p, io->scratch, f);
@@ -338,6 +586,7 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
     const int L = d.n_layers;
     const int64_t M = rows_of(d), G = (int64_t)d.B * d.S;
     const bool plain = d.input == PAPC_SA_IN_ROWS, ev = d.eval_bn != 0;
+    if (p.planes) return planes_bwd(p, *io, *gr, st);
     SavedPtrs s; BwdPtrs b;
     layout_saved(p, io->saved, s);
     layout_bwd(p, io->scratch, b);

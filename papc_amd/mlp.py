@@ -629,10 +629,10 @@ def shared_mlp_max(spec, bn_buffers, xyz, new_xyz, feats, idx, params, x_rows=No
     # re-evaluated on every forward: a cached list would go stale when the optimizer replaces the .grad tensors
     # (e.g. zero_grad(set_to_none=True)) and gradients would silently land in orphaned buffers
     spec.grad_targets = grad_targets_of(params) if (torch.is_grad_enabled() and not spec.eval_bn) else None
-    from . import smallm
-    if smallm.eligible(spec, xyz, feats, idx, x_rows, params):      # few rows, groups of 128 (group_all layers): csrc/smallm.hip
-        return smallm.PlanesMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)
-    if _PY_ORCH or _SPARSE_MAX:       # the call sequence spelled out in Python (A/B against the library's own orchestration, csrc/sa_mlp.hip)
+    if _PY_ORCH or _SPARSE_MAX:       # the call sequences spelled out in Python (A/B against the library's own orchestration, csrc/sa_mlp.hip)
+        from . import smallm
+        if smallm.eligible(spec, xyz, feats, idx, x_rows, params):      # few rows, groups of 128 (group_all layers): csrc/smallm.hip
+            return smallm.PlanesMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)
         return SharedMLPMax.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)
     from .stack import SharedMLPStack
     return SharedMLPStack.apply(spec, bn_buffers, xyz, new_xyz, feats, idx, x_rows, *params)

@@ -16,14 +16,14 @@ from ._lib import check, ptr, stream_ptr
 
 MAXL = 8
 c_p, c_i, c_l, c_f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
-NO_LINGATHER, NO_XYZ1, NO_NOSTORE, NO_GMAX, NO_FUSED_RED, NO_COMPACT = 1, 2, 4, 8, 16, 32
+NO_LINGATHER, NO_XYZ1, NO_NOSTORE, NO_GMAX, NO_FUSED_RED, NO_COMPACT, NO_PLANES, NO_PLANES_POINTWISE = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class SaDesc(ctypes.Structure):
     """papc_sa_desc"""
     _fields_ = [("B", c_i), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("n_layers", c_i), ("cin", c_i), ("cout", c_i * MAXL),
                 ("input", c_i), ("identity_rows", c_i), ("xyz_first", c_i), ("pool", c_i), ("eval_bn", c_i), ("cut_gather_grad", c_i),
-                ("eps", c_f), ("momentum", c_f), ("disable", ctypes.c_uint32)]
+                ("eps", c_f), ("momentum", c_f), ("disable", ctypes.c_uint32), ("inference", c_i), ("want_input_grad", c_i)]
 
 
 class SaLayer(ctypes.Structure):
@@ -46,7 +46,7 @@ class SaIo(ctypes.Structure):
 class SaPlan(ctypes.Structure):
     """papc_sa_plan"""
     _fields_ = [("d", SaDesc), ("cin0", c_i), ("lin0", c_i), ("xyz1", c_i), ("gmax", c_i), ("nostore", c_i), ("compact", c_i), ("sparse_max", c_i),
-                ("saved_bytes", c_l), ("fwd_scratch_bytes", c_l), ("bwd_scratch_bytes", c_l), ("off_y", c_l * MAXL), ("off_cst", c_l * MAXL),
+                ("planes", c_i), ("saved_bytes", c_l), ("fwd_scratch_bytes", c_l), ("bwd_scratch_bytes", c_l), ("off_y", c_l * MAXL), ("off_cst", c_l * MAXL),
                 ("off_argmax", c_l)]
 
 
@@ -78,6 +78,9 @@ def _disable_bits():
     if not mlp._NOSTORE: bits |= NO_NOSTORE
     if not mlp._FUSE_GMAX: bits |= NO_GMAX
     if not mlp._FUSE_RED: bits |= NO_FUSED_RED
+    from . import smallm
+    if not smallm.ENABLED: bits |= NO_PLANES
+    if not smallm.POINTWISE: bits |= NO_PLANES_POINTWISE
     return bits
 
 
@@ -131,7 +134,11 @@ class SharedMLPStack(torch.autograd.Function):
         d.eps, d.momentum = spec.eps, spec.momentum
         d.disable = _disable_bits()
         if feats is not None and not feats.is_contiguous():
-            d.disable |= NO_LINGATHER
+            d.disable |= NO_LINGATHER | NO_PLANES
+        if plain and not x_rows.is_contiguous():
+            d.disable |= NO_PLANES
+        d.inference = int(not any(ctx.needs_input_grad))
+        d.want_input_grad = int((plain and x_rows.requires_grad) or ((not plain) and feats is not None and feats.requires_grad and not spec.cut_gather_grad))
         keep = []
         io = SaIo()
         _fill_io(io, spec, xyz, new_xyz, feats, idx, x_rows, params, bn_buffers, keep)
@@ -147,7 +154,7 @@ class SharedMLPStack(torch.autograd.Function):
         check(lib.papc_sa_mlp_fwd(ctypes.byref(plan), ctypes.byref(io), stream_ptr()), "papc_sa_mlp_fwd")
         ctx.spec, ctx.L, ctx.plan, ctx.saved = spec, L, plan, saved
         ctx.compact = spec.compact if plan.compact else None
-        ctx.nostore, ctx.xyz1, ctx.lin0 = bool(plan.nostore), bool(plan.xyz1), bool(plan.lin0)     # (which paths the library took)
+        ctx.nostore, ctx.xyz1, ctx.lin0, ctx.planes = bool(plan.nostore), bool(plan.xyz1), bool(plan.lin0), bool(plan.planes)     # (which paths the library took)
         ctx.bn_buffers = bn_buffers
         ctx.wt_table = spec.wt_table
         ctx.feats_needs_grad = feats is not None and feats.requires_grad and not spec.cut_gather_grad

@@ -156,6 +156,7 @@ def test_group_all_stack_through_raw_c_entry_points_vs_oracle(dev):
     feats = torch.from_numpy(np.ascontiguousarray(pts.transpose(0, 2, 1))).to(dev)
     gout = torch.zeros(B, 1024, device=dev)
     out, grads, gf, plan, _ = _raw_stack(dev, B, N, 1, N, D, chans, xyz, torch.zeros(B, 1, 3, device=dev), feats, None, ws, gout)
+    assert plan.planes, "the group_all stack must take the planes kernels inside the library"
     assert_close(out.cpu().numpy().reshape(B, 1024), ref64.reshape(B, 1024), 1e-5, "group_all via the C entry points vs f64 oracle")
 
 
@@ -248,3 +249,37 @@ def test_pfn_through_raw_c_entry_points_vs_oracle(dev):
     assert_close(dg.cpu().numpy(), g64.grad.cpu().numpy(), 2e-4, "papc_pfn_bwd dgamma")
     assert_close(db.cpu().numpy(), b64.grad.cpu().numpy(), 2e-4, "papc_pfn_bwd dbeta")
     assert abs(float(rm.abs().max())) > 0                                # running statistics were updated (paddle momentum 0.01 weighs the OLD value)
+
+
+@pytest.mark.parametrize("pool", [True, False])
+def test_library_planes_orchestration_equals_the_python_one(dev, pool):
+    """few-row stacks (sample_and_group_all / point-wise): papc_sa_mlp_fwd / _bwd sequence the planes kernels (csrc/smallm.hip) exactly as
+    papc_amd.smallm.PlanesMLPMax does in Python -- bit-identical outputs and gradients (no atomics on this path)"""
+    from papc_amd import smallm
+    rng = np.random.default_rng(2)
+    if pool:
+        B, N, D, chans = 8, 128, 256, [259, 256, 512, 1024]
+        xyz = torch.from_numpy(np.ascontiguousarray(make_clouds(B, N, 5).transpose(0, 2, 1))).to(dev)
+        feats0 = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev)
+        args = lambda f: (StackSpec(B, N, 1, N, D, True), None, xyz, torch.zeros(B, 1, 3, device=dev), f, None, None)
+        gshape = (B, 1024)
+    else:
+        Mr, chans = 2048, [576, 256, 128]
+        x0 = torch.from_numpy(rng.normal(size=(Mr, 576)).astype(np.float32)).to(dev)
+        args = lambda xr: (StackSpec(1, Mr, Mr, 1, 573, True, pool=False), None, None, None, None, None, xr)
+        gshape = (Mr, 128)
+    ws = seeded_weights(chans, 12)
+    gout = torch.from_numpy(rng.normal(size=gshape).astype(np.float32)).to(dev)
+    res = []
+    for fn in (smallm.PlanesMLPMax, SharedMLPStack):
+        params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+        inp = (feats0 if pool else x0).clone().requires_grad_(True)
+        out = fn.apply(*args(inp), *params)
+        if fn is SharedMLPStack:
+            assert out.grad_fn.planes
+        out.backward(gout)
+        res.append((out.detach(), [p.grad for p in params], inp.grad))
+    (o0, g0, i0), (o1, g1, i1) = res
+    assert torch.equal(o0, o1) and torch.equal(i0, i1)
+    for a, b in zip(g0, g1):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
