@@ -727,6 +727,13 @@ int papc_pg_gemm_f32(const papc_pg_gemm *args, papc_stream_t stream);
 int papc_pg_final_f32(const float *stats, int parts, int64_t M, int C, const float *gamma, const float *beta, float eps, float momentum,
                       float *mean, float *invstd, float *scale, float *shift, float *running_mean, float *running_var, float *gmax,
                       const float *gmin, const int32_t *amax, const int32_t *amin, int64_t G, float *out, int32_t *argmax, papc_stream_t stream);
+/* The same when a group spans tiles_per_group >= 2 consecutive 128-row tiles (nsample = 128 tiles_per_group: the max over the N = 1024 points
+ * of a cloud in PointNet-Basic, classify/pointnet_base/pointnet_base.py:44): gmax / gmin / amax / amin are per TILE [M/128, C] (the
+ * PAPC_PG_FWD_GMAX epilogue), out / argmax / ysel per GROUP [G, C], G = M / (128 tiles_per_group); argmax = row offset inside the group. */
+int papc_pg_final_groups_f32(const float *stats, int parts, int64_t M, int C, const float *gamma, const float *beta, float eps, float momentum,
+                             float *mean, float *invstd, float *scale, float *shift, float *running_mean, float *running_var, const float *gmax,
+                             const float *gmin, const int32_t *amax, const int32_t *amin, int64_t G, int tiles_per_group, float *out, int32_t *argmax,
+                             float *ysel, papc_stream_t stream);
 
 /* count <= 8 split-K partial sets folded in one launch, fixed order: out[e] (+)= sum_t partial[t*stride + e], e < n.  HOST array. */
 typedef struct papc_pg_fold_job {

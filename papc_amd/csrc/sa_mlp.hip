@@ -182,7 +182,8 @@ static size_t layout_bwd(const papc_sa_plan &p, void *base, BwdPtrs &b)
 constexpr int PG_GROUP = 128, PG_MAX_ROWS = 16384;
 struct PlanesSaved {
     float *y[PAPC_SA_MAX_LAYERS], *cst[PAPC_SA_MAX_LAYERS];
-    int32_t *argmax; float *gbuf_f;
+    int32_t *argmax; float *gbuf_f;     // argmax [G, c_L]; per-TILE max | min [2, T, c_L]
+    float *ysel;                        // [G, c_L] raw y at the argmax (= gbuf_f when a group is one tile)
     void *PT[PAPC_SA_MAX_LAYERS];       // input^T planes of every layer (dW operands)
     void *wtp[PAPC_SA_MAX_LAYERS];      // W^T planes (dX operands)
 };
@@ -211,6 +212,7 @@ static size_t layout_planes_saved(const papc_sa_plan &p, void *base, PlanesSaved
     if (p.d.pool) {
         s.argmax = c.take<int32_t>((size_t)T * p.d.cout[L - 1]);
         s.gbuf_f = c.take<float>(2 * (size_t)T * p.d.cout[L - 1]);
+        s.ysel = p.d.K > PG_GROUP ? c.take<float>((size_t)(M / p.d.K) * p.d.cout[L - 1]) : s.gbuf_f;
     }
     if (!p.d.inference)
         for (int l = 0; l < L; ++l) {
@@ -317,6 +319,10 @@ static int planes_fwd(const papc_sa_plan &p, const papc_sa_io &io, papc_stream_t
             SA_CALL(papc_bn_finalize_f32(f.stats[l], (int)T, M, cout, ly.gamma, ly.beta, d.eps, d.momentum, cst, cst + cout, cst + 2 * cout, cst + 3 * cout,
                                          ly.running_mean, ly.running_var, st));
             SA_CALL(papc_bn_relu_f32(s.y[l], cst + 2 * cout, cst + 3 * cout, M, cout, io.out, st));
+        } else if (d.K > PG_GROUP) {     // a group spans several 128-row tiles: the extreme of the tiles' extrema
+            SA_CALL(papc_pg_final_groups_f32(f.stats[l], (int)T, M, cout, ly.gamma, ly.beta, d.eps, d.momentum, cst, cst + cout, cst + 2 * cout, cst + 3 * cout,
+                                             ly.running_mean, ly.running_var, s.gbuf_f, s.gbuf_f + T * cout, f.gbuf_i, f.gbuf_i + T * cout, M / d.K, d.K / PG_GROUP,
+                                             io.out, s.argmax, s.ysel, st));
         } else {
             SA_CALL(papc_pg_final_f32(f.stats[l], (int)T, M, cout, ly.gamma, ly.beta, d.eps, d.momentum, cst, cst + cout, cst + 2 * cout, cst + 3 * cout,
                                       ly.running_mean, ly.running_var, s.gbuf_f, s.gbuf_f + T * cout, f.gbuf_i, f.gbuf_i + T * cout, T, io.out, s.argmax, st));
@@ -361,7 +367,7 @@ static int planes_bwd(const papc_sa_plan &p, const papc_sa_io &io, const papc_sa
             SA_CALL(papc_bn_bwd_reduce_f32(PAPC_DZ_DENSE, gr.gout, nullptr, nullptr, 1, s.y[l], cst, cst + cout, cst + 2 * cout, cst + 3 * cout, M, cout, (int)T, b.red[2], st));
             a.mode = PAPC_PG_DY_DENSE; a.dz = gr.gout; a.red = b.red[2]; a.red_parts = (int)T;
         } else if (l == L - 1) {
-            a.mode = PAPC_PG_DY_MAX; a.gout = gr.gout; a.ysel = s.gbuf_f; a.argmax = s.argmax; a.K = PG_GROUP;
+            a.mode = PAPC_PG_DY_MAX; a.gout = gr.gout; a.ysel = s.ysel; a.argmax = s.argmax; a.K = d.K;
         } else {
             a.mode = PAPC_PG_DY_DENSE; a.dz = dz; a.red = red; a.red_parts = (int)T;
         }
@@ -439,7 +445,7 @@ int papc_sa_mlp_plan(const papc_sa_desc *desc, const papc_sa_io *io, papc_sa_pla
     const bool has_idx = !plain && d.identity_rows == 0, has_feats = !plain && d.D > 0;
     {   // few rows in groups of exactly 128 (one GEMM tile), no neighbour index, widths in multiples of 8: the planes kernels (smallm.hip)
         bool ok = !(d.disable & PAPC_SA_NO_PLANES) && !ev && !has_idx && M % PG_GROUP == 0 && M >= PG_GROUP && M <= PG_MAX_ROWS && L >= 2;
-        ok = ok && (d.pool ? d.K == PG_GROUP : (plain && !(d.disable & PAPC_SA_NO_PLANES_POINTWISE)));
+        ok = ok && (d.pool ? (d.K % PG_GROUP == 0 && d.K / PG_GROUP <= 64) : (plain && !(d.disable & PAPC_SA_NO_PLANES_POINTWISE)));
         for (int l = 0; l < L; ++l) ok = ok && d.cout[l] % 8 == 0;
         ok = ok && (plain ? plan->cin0 % 8 == 0 : d.S == 1);
         plan->planes = ok ? 1 : 0;

@@ -13,16 +13,26 @@ typedef unsigned int u32;
 // =====================================================================================================
 // FPS  (pointnet2_basic_layers.py:65-95)
 //
-// One workgroup per cloud (the npoint-long argmax chain is serial; a cloud never spans CUs).  Each lane
-// keeps PPT points (x,y,z,running distance) in VGPRs for the whole kernel; a copy of xyz sits in LDS so
-// the winner's coordinates are one broadcast ds_read away.  Per iteration: PPT distance updates with a
-// thread-local argmax, then the wave argmax as TWO 32-bit DPP reductions (max distance, then the LOWEST
-// index among the lanes holding it -- 64-bit key compares are quarter rate on gfx950).  The lowest-index rule
-// is the reference's argmax (first maximum) and matters: ties at exactly 1.0 happen in the first iterations
-// of every unit-sphere cloud because the running distance starts at 1.0 (:75).  Each wave posts {max, index}
-// to an LDS slot, ONE barrier (slots double-buffered by iteration parity), then every wave combines the <=16
-// slots with the same two passes as a 16-lane DPP row reduce.
+// One workgroup per cloud (the npoint-long argmax chain is serial; a cloud never spans CUs), and the CU's vector ALUs are what
+// bounds an iteration: N points x (distance, running minimum, argmax) on 4 x 16 lanes.  So the loop is written for instruction
+// count.  Each lane keeps PPT points in VGPRs for the whole kernel, as PAIRS: the distance update runs on packed f32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32: two points per instruction, each element rounded exactly like the scalar op -- the file is built
+// with -ffp-contract=off, nothing fuses).  A copy of xyz sits in LDS so the winner's coordinates are one broadcast ds_read away.
+// Running distances live as the BIT PATTERNS of non-negative floats: unsigned min / max / compare equal the float ones.
+//
+// argmax(distance, -1) returns the FIRST maximum (:93) and that matters: ties at exactly 1.0 happen in the first iterations of
+// every unit-sphere cloud because the running distance starts at 1.0 (:75).  Per iteration:
+//   thread  max over its PPT points (v_max3_u32 tree) + the lowest j holding it -> candidate index j T + tid
+//   row     a 16-lane DPP max (four steps); the lanes holding their row's maximum -- one per row unless distances tie -- fold
+//           {max bits : ~index} into ONE 64-bit LDS word with ds_max_u64 (larger distance wins, then the smaller index)
+//   group   one barrier, one broadcast read of the word.  Three words rotate: the word of iteration it + 2 is cleared after the
+//           barrier of iteration it, when its last readers (iteration it - 1) are behind that barrier and its next writers two
+//           barriers away.
+//   (a single-wave group skips LDS: a 64-lane DPP max, a ballot of the lanes holding it -- almost always one lane, whose candidate
+//   is one v_readlane away; several lanes: a DPP min over their candidates)
 // =====================================================================================================
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int T, int PPT, bool LDS_XYZ>
 __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                 int N, int npoint, const int64_t *__restrict__ start,
@@ -30,35 +40,39 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
                                                 float *__restrict__ out_new_xyz)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint2 *keys2 = reinterpret_cast<uint2 *>(smem);  // [2][16] {max distance bits, index} per wave
+    u64 *key = reinterpret_cast<u64 *>(smem);        // [3] {max distance bits : ~index}
     float *sx = reinterpret_cast<float *>(smem + 256);
     float *sy = sx + N;
     float *sz = sy + N;
 
     constexpr int NW = T / 64;
+    constexpr int NP = (PPT + 1) / 2, PP = 2 * NP;   // pairs of points per lane (PPT = 1: the second element is padding)
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
     const int b = blockIdx.x;
     const float *p = xyz + (int64_t)b * sb;
 
-    float x[PPT], y[PPT], z[PPT], d[PPT];
+    f32x2 x[NP], y[NP], z[NP];
+    u32 d[PP];
 #pragma unroll
-    for (int j = 0; j < PPT; ++j) {
+    for (int j = 0; j < PP; ++j) {
         const int i = j * T + tid;
-        if (i < N) {
-            x[j] = p[(int64_t)i * sn];
-            y[j] = p[(int64_t)i * sn + sc];
-            z[j] = p[(int64_t)i * sn + 2 * sc];
-            d[j] = init_dist;
-            if (LDS_XYZ) { sx[i] = x[j]; sy[i] = y[j]; sz[i] = z[j]; }
-        } else {  // padding lanes: distance pinned at +0 and index >= N, so they never win a max
-            x[j] = 0.f; y[j] = 0.f; z[j] = 0.f; d[j] = 0.f;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        d[j] = 0u;    // padding: distance pinned at +0 and index >= N, so it never wins a max against a real point
+        if (j < PPT && i < N) {
+            px = p[(int64_t)i * sn];
+            py = p[(int64_t)i * sn + sc];
+            pz = p[(int64_t)i * sn + 2 * sc];
+            d[j] = __float_as_uint(init_dist);
+            if (LDS_XYZ) { sx[i] = px; sy[i] = py; sz[i] = pz; }
         }
+        x[j >> 1][j & 1] = px; y[j >> 1][j & 1] = py; z[j >> 1][j & 1] = pz;
     }
+    if (tid < 3) key[tid] = 0ull;
     int far = (int)start[b];
-    if (LDS_XYZ) __syncthreads();
+    __syncthreads();
 
+    int s0 = 0, s2 = 2;      // it % 3, (it + 2) % 3
+    const u32 key_lds = (u32)(uintptr_t)key;
     for (int it = 0; it < npoint; ++it) {
         float cx, cy, cz;
         if (LDS_XYZ) { cx = sx[far]; cy = sy[far]; cz = sz[far]; }
@@ -70,46 +84,45 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
                 o[0] = cx; o[1] = cy; o[2] = cz;
             }
         }
-        // Running distances live as the BIT PATTERNS of non-negative floats: unsigned min / max / compare then equal the float
-        // ones and need neither canonicalisation (v_max_f32 x,x,x before every fminf) nor a serial compare-select chain.
-        u32 du[PPT];
+        const f32x2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const float dx = x[j] - cx, dy = y[j] - cy, dz = z[j] - cz;
-            const float dd = (dx * dx + dy * dy) + dz * dz;  // sum((xyz - centroid) ** 2, -1)  (:86)
-            const u32 a = __float_as_uint(dd), bq = __float_as_uint(d[j]);
-            du[j] = a < bq ? a : bq;                          // where(dist < distance, dist, distance) (:87-92)
-            d[j] = __uint_as_float(du[j]);
+        for (int q = 0; q < NP; ++q) {
+            const f32x2 dx = x[q] - c2x, dy = y[q] - c2y, dz = z[q] - c2z;
+            const f32x2 dd = (dx * dx + dy * dy) + dz * dz;          // sum((xyz - centroid) ** 2, -1)  (:86)
+            const u32 a0 = __float_as_uint(dd[0]), a1 = __float_as_uint(dd[1]);
+            d[2 * q] = a0 < d[2 * q] ? a0 : d[2 * q];                // where(dist < distance, dist, distance) (:87-92)
+            d[2 * q + 1] = a1 < d[2 * q + 1] ? a1 : d[2 * q + 1];
         }
-        // per-thread argmax as a max tree + "lowest j holding the max" (strict first-maximum rule, :93)
-        u32 bmax = du[0];
+        // per-thread argmax: max tree + the lowest j holding the max (strict first-maximum rule, :93)
+        u32 bmax = d[0];
 #pragma unroll
-        for (int j = 1; j < PPT; ++j) bmax = du[j] > bmax ? du[j] : bmax;
-        int bestj = PPT - 1;
+        for (int j = 1; j < PP; ++j) bmax = d[j] > bmax ? d[j] : bmax;
+        int bestj = PP - 1;
 #pragma unroll
-        for (int j = PPT - 2; j >= 0; --j) bestj = du[j] == bmax ? j : bestj;
-        const float bestd = __uint_as_float(bmax);
-        // wave argmax in two 32-bit DPP passes (64-bit compares are quarter rate): max distance, then the
-        // LOWEST index among the lanes holding it -- argmax(distance, -1) returns the first maximum (:93)
-        // (bestd >= 0 here: its bit pattern orders like the float, so the reductions run on unsigned integers)
-        const u32 bd = __float_as_uint(bestd);
-        const u32 mwb = readlane63_u32(wave_max_u32_fused_to_lane63(bd));
-        const float mw = __uint_as_float(mwb);
-        const u32 iw = readlane63_u32(wave_min_u32_fused_to_lane63(bd == mwb ? (u32)(bestj * T + tid) : 0xFFFFFFFFu));
+        for (int j = PP - 2; j >= 0; --j) bestj = d[j] == bmax ? j : bestj;
+        const u32 cand = (u32)(bestj * T + tid);
         if (NW == 1) {
+            // one wave: max distance, then the lowest candidate among the lanes holding it (almost always a single lane)
+            const u32 mwb = readlane63_u32(wave_max_u32_fused_to_lane63(bmax));
+            const u64 holders = __ballot(bmax == mwb);
+            u32 iw;
+            if (__builtin_popcountll(holders) == 1) iw = (u32)__builtin_amdgcn_readlane((int)cand, __builtin_ctzll(holders));
+            else iw = readlane63_u32(wave_min_u32_fused_to_lane63(bmax == mwb ? cand : 0xFFFFFFFFu));
             far = (int)iw;
         } else {
-            if (lane == 0) keys2[(it & 1) * 16 + wave] = make_uint2(__float_as_uint(mw), iw);
-            __syncthreads();
-            // every wave combines the <=16 per-wave results with a 16-lane row reduce (same two passes)
-            uint2 kv = make_uint2(0u /* +0.0f: below every real maximum's bit pattern or tied with index 0xFFFFFFFF */, 0xFFFFFFFFu);
-            if (lane < NW) kv = keys2[(it & 1) * 16 + lane];
-            u32 bm = row_max_u32_fused(kv.x);
-            asm volatile("s_nop 1" ::"v"(bm));
-            bm = readlane0_u32(bm);
-            u32 fi = row_min_u32_fused(kv.x == bm ? kv.y : 0xFFFFFFFFu);
-            asm volatile("s_nop 1" ::"v"(fi));
-            far = (int)readlane0_u32(fi);
+            // 16-lane row maximum (four DPP steps, every lane of the row ends with it); the lanes holding it -- one per row unless
+            // distances tie -- fold {distance bits : ~candidate} into the iteration's LDS word
+            const u32 rmax = row_max_u32_fused(bmax);
+            if (bmax == rmax) {
+                const u64 kv = ((u64)bmax << 32) | (u64)(~cand);
+                asm volatile("ds_max_u64 %0, %1" ::"v"(key_lds + 8u * (u32)s0), "v"(kv) : "memory");
+            }
+            lds_barrier();
+            const u64 k = key[s0];
+            far = (int)~(u32)__builtin_amdgcn_readfirstlane((int)(u32)k);
+            if (tid == 0) key[s2] = 0ull;
+            s2 = s0;                       // (it + 3) % 3
+            s0 = s0 == 2 ? 0 : s0 + 1;
         }
     }
 }
@@ -355,10 +368,10 @@ int papc_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, in
     PAPC_REQUIRE(N <= 16384, PAPC_E_UNSUPPORTED, "papc_fps_f32: N=%d > 16384 not supported", N);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_FPS, st);
-    // geometry (measured on MI355X, N=4096: 512 threads x 8 points beats 256x16 and 1024x4): 8 points per lane
-    // up to 512 threads (two waves per SIMD hide each other's DPP/LDS latency; more waves only add barrier cost)
-    int T = 64;
-    while (T < 512 && T * 8 < N) T *= 2;
+    // geometry (measured on MI355X, tools/probe/fps_time.py; us per iteration): up to 512 points ONE wave with 8 points per lane (0.32; no
+    // barrier, no LDS word); from 1024 points 512 threads (N = 1024: 0.32 against 0.35 at 256 threads; N = 2048: 0.40 / 0.42; N = 4096:
+    // 0.53, two waves per SIMD hide each other's DPP / LDS latency -- 1024 threads measure the same, 256 are 12 % slower)
+    int T = N <= 512 ? 64 : (N < 1024 ? 256 : 512);
     { const int t = knob(N <= 1024 ? KNOB_FPS_THREADS_SMALL : KNOB_FPS_THREADS);   // tuning knobs (small / large clouds)
       if (t == 64 || t == 128 || t == 256 || t == 512 || t == 1024) T = t; }
     int ppt = 1;

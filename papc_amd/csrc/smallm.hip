@@ -482,7 +482,8 @@ __global__ __launch_bounds__(256) void pg_final_kernel(const float *__restrict__
                                                        const float *__restrict__ beta, float eps, float momentum, float *mean, float *invstd,
                                                        float *scale, float *shift, float *rmean, float *rvar, float *__restrict__ gmax,
                                                        const float *__restrict__ gmin, const int32_t *__restrict__ amax,
-                                                       const int32_t *__restrict__ amin, int64_t G, float *__restrict__ out, int32_t *__restrict__ argmax)
+                                                       const int32_t *__restrict__ amin, int64_t G, float *__restrict__ out, int32_t *__restrict__ argmax,
+                                                       int tpg, float *__restrict__ ysel)
 {
     __shared__ double rd[2][4][64];
     __shared__ float cs[2][64];
@@ -515,6 +516,23 @@ __global__ __launch_bounds__(256) void pg_final_kernel(const float *__restrict__
     if (!cok) return;
     const float sc = cs[0][cl], sh = cs[1][cl];
     const bool up = sc >= 0.f;      // relu(sc*y+sh) is non-decreasing in y for sc >= 0 (bn_select_max_kernel)
+    if (tpg > 1) {
+        // a group spans tpg consecutive 128-row tiles (nsample = 128 tpg: PointNet-Basic's max over the N points of a cloud, pointnet_base.py:44):
+        // the extreme of the tiles' extrema, the first tile winning ties (= the first row of the group); ysel goes to its own [G, C] array
+        for (int64_t g = gl; g < G; g += 4) {
+            float best = up ? -INFINITY : INFINITY;
+            int arg = 0;
+            for (int t = 0; t < tpg; ++t) {
+                const int64_t e = (g * tpg + t) * C + c;
+                const float v = up ? gmax[e] : gmin[e];
+                if (up ? v > best : v < best) { best = v; arg = t * 128 + (up ? amax[e] : amin[e]); }
+            }
+            out[g * C + c] = fmaxf(fmaf(sc, best, sh), 0.f);
+            ysel[g * C + c] = best;
+            argmax[g * C + c] = arg;
+        }
+        return;
+    }
     for (int64_t g = gl; g < G; g += 4) {
         const int64_t e = g * C + c;
         const float sel = up ? gmax[e] : gmin[e];
@@ -704,8 +722,22 @@ int papc_pg_final_f32(const float *stats, int parts, int64_t M, int C, const flo
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BN_RELU_MAX, st);
     hipLaunchKernelGGL(pg_final_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, stats, parts, M, C, gamma, beta, eps, momentum, mean, invstd,
-                       scale, shift, running_mean, running_var, gmax, gmin, amax, amin, G, out, argmax);
+                       scale, shift, running_mean, running_var, gmax, gmin, amax, amin, G, out, argmax, 1, (float *)nullptr);
     return check_launch("papc_pg_final_f32");
+}
+
+int papc_pg_final_groups_f32(const float *stats, int parts, int64_t M, int C, const float *gamma, const float *beta, float eps, float momentum,
+                             float *mean, float *invstd, float *scale, float *shift, float *running_mean, float *running_var, const float *gmax,
+                             const float *gmin, const int32_t *amax, const int32_t *amin, int64_t G, int tiles_per_group, float *out, int32_t *argmax,
+                             float *ysel, papc_stream_t stream)
+{
+    PAPC_REQUIRE(stats && mean && invstd && scale && shift && gmax && gmin && amax && amin && out && argmax && ysel, PAPC_E_INVALID, "papc_pg_final_groups_f32: null pointer");
+    PAPC_REQUIRE(parts >= 1 && M >= 1 && C >= 1 && G >= 1 && tiles_per_group >= 2, PAPC_E_INVALID, "papc_pg_final_groups_f32: bad sizes (tiles_per_group >= 2; 1 is papc_pg_final_f32)");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BN_RELU_MAX, st);
+    hipLaunchKernelGGL(pg_final_kernel, dim3((unsigned)cdiv(C, 64)), dim3(256), 0, st, stats, parts, M, C, gamma, beta, eps, momentum, mean, invstd,
+                       scale, shift, running_mean, running_var, const_cast<float *>(gmax), gmin, amax, amin, G, out, argmax, tiles_per_group, ysel);
+    return check_launch("papc_pg_final_groups_f32");
 }
 
 int papc_pg_fold_f32(const papc_pg_fold_job *jobs, int count, papc_stream_t stream)
