@@ -16,7 +16,8 @@ def _cloud(B, N, seed):
 
 
 @pytest.mark.parametrize("B,N,npoint", [(2, 1024, 128), (1, 4096, 512), (3, 1000, 77), (2, 64, 64), (2, 37, 5), (1, 8192, 64),
-                                        (1, 16384, 32), (4, 512, 128), (1, 1, 1)])
+                                        (1, 16384, 32), (4, 512, 128), (1, 1, 1), (2, 513, 40), (2, 1023, 64), (2, 1025, 64), (3, 300, 60),
+                                        (2, 100, 100), (16, 2048, 512), (1, 5000, 33)])
 @pytest.mark.parametrize("planar", [False, True])
 def test_fps_index_exact(dev, B, N, npoint, planar):
     x, xyz = _cloud(B, N, 11 + N)
@@ -43,6 +44,21 @@ def test_fps_ties_and_init(dev):
         assert np.array_equal(got.cpu().numpy(), ref.astype(np.int64)), init
     f = F.farthest_point_sample(torch.from_numpy(xyz).to(dev), 8, torch.from_numpy(st).to(dev), as_float=True)
     assert f.dtype == torch.float32                   # the source returns float32 centroids (:74)
+
+
+@pytest.mark.parametrize("side,B", [(16, 2), (8, 3), (10, 1), (13, 2)])
+def test_fps_lattice_ties(dev, side, B):
+    # a shuffled cubic lattice: the running distances tie exactly among MANY distinct points in every iteration (equal squared
+    # distances to the chosen set), across lanes, DPP rows and waves -- the first maximum in index order must win every time
+    rng = np.random.default_rng(side)
+    g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.125)
+    xyz = np.stack([g[rng.permutation(len(g))] for _ in range(B)])
+    st = rng.integers(0, len(g), size=B).astype(np.int64)
+    npoint = min(len(g), 200)
+    for init in (1e10, 1.0):
+        ref = R.farthest_point_sample(xyz, npoint, st, init)
+        got = F.farthest_point_sample(torch.from_numpy(xyz).to(dev), npoint, torch.from_numpy(st).to(dev), init_dist=init)
+        assert np.array_equal(got.cpu().numpy(), ref.astype(np.int64)), (side, init)
 
 
 def test_fps_all_duplicates(dev):
