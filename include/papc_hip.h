@@ -83,6 +83,12 @@ int papc_index_points_bwd_f32(const float *grad_out, const void *idx, int idx64,
 int papc_group_points_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
                           const float *feats, const int32_t *idx, int B, int N, int S, int K, int D,
                           int xyz_first, float *out, papc_stream_t stream);
+/* gradient of papc_group_points_f32 (SURVEY 8b's papc_group_gather_bwd; the reference's index_points is where ITS autograd stops,
+ * :57-60 -- this is for hosts that let the gradient through).  grad_out [B,S,K,3+D] in the same column order; each output may be
+ * NULL: grad_feats [B,N,D] and grad_xyz [B,N,3] are ACCUMULATED into (float atomics: zero them first),
+ * grad_new_xyz [B,S,3] = -sum_k of the coordinate columns is written. */
+int papc_group_points_bwd_f32(const float *grad_out, const int32_t *idx, int B, int N, int S, int K, int D, int xyz_first,
+                              float *grad_feats, float *grad_xyz, float *grad_new_xyz, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Feature propagation (PointNetFeaturePropagation, pointnet2_basic_layers.py:284-335) -- the interpolation half;

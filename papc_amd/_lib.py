@@ -70,6 +70,7 @@ SIGNATURES = {
     "papc_index_points_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "papc_index_points_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "papc_group_points_f32": (c_i, [c_p, c_l, c_l, c_l, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "papc_group_points_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_three_nn_f32": (c_i, [c_p, c_l, c_l, c_l, c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_three_interpolate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "papc_three_interpolate_bwd_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),

@@ -352,6 +352,39 @@ __global__ void group_points_kernel(const float *__restrict__ xyz, int64_t sb, i
     }
 }
 
+// gradient of the gather / centre / concat: every (b, s, k) row scatters its feature columns to the point it gathered (float
+// atomics: a point sits in many neighbourhoods), its coordinate columns to that point's xyz and, negated, to its centre
+__global__ void group_points_bwd_kernel(const float *__restrict__ gout, const int32_t *__restrict__ idx, int N, int S, int K, int D,
+                                        int xyz_first, int64_t total, float *__restrict__ gfeats, float *__restrict__ gxyz)
+{
+    const int C = 3 + D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / C;
+        const int c = (int)(e - row * C);
+        const int64_t b = row / ((int64_t)S * K);
+        const int j = idx[row];
+        if (j < 0 || j >= N) continue;
+        const bool is_xyz = xyz_first ? (c < 3) : (c >= D);
+        if (is_xyz) {
+            if (gxyz) atomicAdd(&gxyz[(b * N + j) * 3 + (xyz_first ? c : c - D)], gout[e]);
+        } else if (gfeats) {
+            atomicAdd(&gfeats[(b * N + j) * D + (xyz_first ? c - 3 : c)], gout[e]);
+        }
+    }
+}
+__global__ void group_centre_bwd_kernel(const float *__restrict__ gout, int K, int D, int xyz_first, int64_t total, float *__restrict__ gnew)
+{
+    const int C = 3 + D;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (b, s, coordinate)
+    if (e >= total) return;
+    const int64_t bs = e / 3;
+    const int x = (int)(e - bs * 3);
+    const float *g = gout + bs * K * C + (xyz_first ? x : D + x);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc += g[(int64_t)k * C];
+    gnew[e] = -acc;
+}
+
 }  // namespace papc
 
 using namespace papc;
@@ -462,6 +495,28 @@ int papc_group_points_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, 
     const int64_t total = (int64_t)B * S * K * (3 + D);
     hipLaunchKernelGGL(group_points_kernel, dim3(ew_grid(total)), dim3(256), 0, st, xyz, sb, sn, sc, new_xyz, feats, idx, N, S, K, D, xyz_first, total, out);
     return check_launch("papc_group_points_f32");
+}
+
+int papc_group_points_bwd_f32(const float *grad_out, const int32_t *idx, int B, int N, int S, int K, int D, int xyz_first,
+                              float *grad_feats, float *grad_xyz, float *grad_new_xyz, papc_stream_t stream)
+{
+    PAPC_REQUIRE(grad_out && idx, PAPC_E_INVALID, "papc_group_points_bwd_f32: null pointer");
+    PAPC_REQUIRE(B >= 1 && N >= 1 && S >= 1 && K >= 1 && D >= 0, PAPC_E_INVALID, "papc_group_points_bwd_f32: bad sizes");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_GROUP, st);
+    if ((grad_feats && D > 0) || grad_xyz) {
+        const int64_t total = (int64_t)B * S * K * (3 + D);
+        hipLaunchKernelGGL(group_points_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, st, grad_out, idx, N, S, K, D, xyz_first, total,
+                           D > 0 ? grad_feats : nullptr, grad_xyz);
+        const int rc = check_launch("papc_group_points_bwd_f32");
+        if (rc) return rc;
+    }
+    if (grad_new_xyz) {
+        const int64_t total = (int64_t)B * S * 3;
+        hipLaunchKernelGGL(group_centre_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, grad_out, K, D, xyz_first, total, grad_new_xyz);
+        return check_launch("papc_group_points_bwd_f32 (centres)");
+    }
+    return PAPC_OK;
 }
 
 }  // extern "C"

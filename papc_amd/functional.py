@@ -150,6 +150,39 @@ def _group_raw(xyz, new_xyz, feats, idx, xyz_first=True):
     return out
 
 
+class _GroupPoints(torch.autograd.Function):
+    """_group_raw with the gradient let through (the reference's index_points cuts it, :57-60): to the gathered features, the gathered
+    coordinates and the centres."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats, idx, xyz_first):
+        ctx.save_for_backward(idx)
+        ctx.shape = (xyz.shape[0], xyz.shape[1], 0 if feats is None else feats.shape[2], bool(xyz_first))
+        return _group_raw(xyz, new_xyz, feats, idx, xyz_first)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        B, N, D, xyz_first = ctx.shape
+        S, K = idx.shape[1], idx.shape[2]
+        g = _f32c(g)
+        need_x, need_c, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and D > 0
+        gx = torch.zeros(B, N, 3, device=g.device, dtype=torch.float32) if need_x else None
+        gc = torch.empty(B, S, 3, device=g.device, dtype=torch.float32) if need_c else None
+        gf = torch.zeros(B, N, D, device=g.device, dtype=torch.float32) if need_f else None
+        check(_lib.load().papc_group_points_bwd_f32(ptr(g), ptr(idx), B, N, S, K, D, int(xyz_first), ptr(gf), ptr(gx), ptr(gc), stream_ptr()),
+              "papc_group_points_bwd_f32")
+        return gx, gc, gf, None, None
+
+
+def group_points(xyz, new_xyz, feats, idx, xyz_first=True):
+    """[B,S,K,3+D] = concat(xyz[idx] - new_xyz, feats[idx]) (SSG order, :146-153; ``xyz_first=False``: the MSG order :263-269), idx int32
+    [B,S,K].  Differentiable where an input asks for it; without that it is the plain gather."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (xyz, new_xyz, feats)):
+        return _GroupPoints.apply(xyz, new_xyz, feats, idx, xyz_first)
+    return _group_raw(xyz, new_xyz, feats, idx, xyz_first)
+
+
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, start_idx=None, init_dist=1.0):
     """:129-157.  xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,npoint,3], new_points [B,npoint,nsample,3+D]
     (xyz-normalised coordinates first, :151)."""
@@ -158,7 +191,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, star
         xyz = xyz.float()
     fps_idx, new_xyz = _fps_raw(xyz, npoint, start_idx, init_dist)                 # :143-144
     idx = _ball_query_raw([radius], [nsample], xyz, new_xyz)[0]                    # :145
-    new_points = _group_raw(xyz, new_xyz, points, idx, xyz_first=True)             # :146-153
+    new_points = group_points(xyz, new_xyz, points, idx, xyz_first=True)           # :146-153
     if returnfps:
         grouped_xyz = index_points(xyz.contiguous(), idx)
         return new_xyz, new_points, grouped_xyz, fps_idx.long()

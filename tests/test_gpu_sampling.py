@@ -180,3 +180,29 @@ def test_full_size_properties(dev):
             row = g[b, s]
             n_unique = len(np.unique(row))
             assert (np.diff(row[:n_unique]) > 0).all() and (row[n_unique:] == row[0]).all()
+
+
+@pytest.mark.parametrize("xyz_first", [True, False])
+@pytest.mark.parametrize("D", [0, 5, 16])
+def test_group_points_backward(dev, xyz_first, D):
+    # papc_group_points_bwd_f32 (SURVEY 8b's group_gather backward) against torch's own gather autograd in float64
+    rng = np.random.default_rng(3 + D)
+    B, N, S, K = 2, 200, 24, 9
+    xyz = torch.from_numpy(rng.normal(size=(B, N, 3)).astype(np.float32)).to(dev).requires_grad_()
+    new_xyz = torch.from_numpy(rng.normal(size=(B, S, 3)).astype(np.float32)).to(dev).requires_grad_()
+    feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev).requires_grad_() if D else None
+    idx = torch.from_numpy(rng.integers(0, N, size=(B, S, K)).astype(np.int32)).to(dev)
+    idx[0, 0, :] = 7                                      # one neighbourhood made of copies of a single point
+    w = torch.from_numpy(rng.normal(size=(B, S, K, 3 + D)).astype(np.float32)).to(dev)
+    out = F.group_points(xyz, new_xyz, feats, idx, xyz_first=xyz_first)
+    (out * w).sum().backward()
+    x64, c64 = xyz.detach().double().requires_grad_(), new_xyz.detach().double().requires_grad_()
+    f64 = feats.detach().double().requires_grad_() if D else None
+    bi = torch.arange(B, device=dev).view(B, 1, 1)
+    gx = x64[bi, idx.long()] - c64[:, :, None, :]
+    parts = [gx] + ([f64[bi, idx.long()]] if D else [])
+    ref = torch.cat(parts if xyz_first else parts[::-1], -1)
+    assert torch.equal(out.detach(), ref.float())
+    (ref * w.double()).sum().backward()
+    for got, want in ((xyz.grad, x64.grad), (new_xyz.grad, c64.grad)) + (((feats.grad, f64.grad),) if D else ()):
+        assert (got.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
