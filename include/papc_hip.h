@@ -428,6 +428,11 @@ int papc_pfn_bwd(const papc_pfn_desc *desc, const papc_pfn_io *io, const float *
 int papc_pfn_decorate_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
                           float vx, float vy, float x_offset, float y_offset, int with_distance, float *out,
                           papc_stream_t stream);
+/* the same decoration for points of ANY width F >= 3 ([x, y, z, ...]: pillars.py:79-102 only reads the first three / two columns) and
+ * any T: features [P,T,F] -> out [P,T,F+5(+1 with_distance)] = [F raw | xyz - cluster mean | x, y - pillar centre | (norm)], masked.
+ * PillarFeatureNet(num_input_features != 4) decorates here and runs its PFNLayers on the shared-MLP entry points. */
+int papc_pfn_decorate_nf_f32(const float *features, int F, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                             float vx, float vy, float x_offset, float y_offset, int with_distance, float *out, papc_stream_t stream);
 int papc_pfn_stats_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
                        float vx, float vy, float x_offset, float y_offset, const float *w, int C,
                        float *stats_partial, int *n_blocks_out, papc_stream_t stream);

@@ -106,6 +106,7 @@ SIGNATURES = {
     "papc_mlp_bwd_dw_chunk_hint": (c_i, [c_l, c_i, c_i, c_i, c_i, c_i]),
     "papc_reduce_partials_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p]),
     "papc_pfn_decorate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_p, c_p]),
+    "papc_pfn_decorate_nf_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_p, c_p]),
     "papc_pfn_stats_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p]),
     "papc_pfn_apply_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "papc_pfn_num_blocks": (c_i, [c_i]),

@@ -532,11 +532,57 @@ static int launch_pfn(const PfnArgs &a, hipStream_t st, const char *who)
     return check_launch(who);
 }
 
+// The decoration for ANY point width F >= 3 and any T (pillars.py:79-102 is written on features[:, :, :3] and features[:, :, :2]; the
+// extra columns ride along): one wave per pillar, lanes = points.  Row = [F raw | xyz - cluster mean | x, y - pillar centre | (norm)].
+// The cluster sums add this lane's points in t order, then across the wave -- for T <= 128 the same order as the F = 4 kernels above.
+__global__ __launch_bounds__(256) void pfn_decorate_nf_kernel(const float *__restrict__ feat, const int32_t *__restrict__ nvox,
+                                                               const int32_t *__restrict__ coors, int P, int T, int F, float vx, float vy,
+                                                               float xo, float yo, int with_dist, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const float *f = feat + (int64_t)p * T * F;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int t = lane; t < T; t += 64) { sx += f[(int64_t)t * F]; sy += f[(int64_t)t * F + 1]; sz += f[(int64_t)t * F + 2]; }
+    sx = readlane63_f32(wave_sum_f32_to_lane63(sx));
+    sy = readlane63_f32(wave_sum_f32_to_lane63(sy));
+    sz = readlane63_f32(wave_sum_f32_to_lane63(sz));
+    const int nv = nvox[p];
+    const float fn = (float)nv;
+    const float mx = sx / fn, my = sy / fn, mz = sz / fn;                                  // (:82)
+    const float pcx = (float)coors[(int64_t)p * 4 + 3] * vx + xo;                          // (:87)
+    const float pcy = (float)coors[(int64_t)p * 4 + 2] * vy + yo;                          // (:88)
+    const int nc = F + 5 + (with_dist ? 1 : 0);
+    for (int t = lane; t < T; t += 64) {
+        const float mk = t < nv ? 1.f : 0.f;
+        const float *r = f + (int64_t)t * F;
+        float *o = out + ((int64_t)p * T + t) * nc;
+        const float x = r[0], y = r[1], z = r[2];
+        for (int c = 0; c < F; ++c) o[c] = r[c] * mk;
+        o[F] = (x - mx) * mk; o[F + 1] = (y - my) * mk; o[F + 2] = (z - mz) * mk;
+        o[F + 3] = (x - pcx) * mk; o[F + 4] = (y - pcy) * mk;
+        if (with_dist) o[F + 5] = sqrtf((x * x + y * y) + z * z) * mk;                      // (:92-94)
+    }
+}
+
 }  // namespace papc
 
 using namespace papc;
 
 extern "C" {
+
+int papc_pfn_decorate_nf_f32(const float *features, int F, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                             float vx, float vy, float x_offset, float y_offset, int with_distance, float *out, papc_stream_t stream)
+{
+    PAPC_REQUIRE(features && num_voxels && coors && out, PAPC_E_INVALID, "papc_pfn_decorate_nf_f32: null pointer");
+    PAPC_REQUIRE(P >= 1 && T >= 1 && F >= 3, PAPC_E_INVALID, "papc_pfn_decorate_nf_f32: P=%d T=%d F=%d (F >= 3: x, y, z lead every point)", P, T, F);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_PFN, st);
+    hipLaunchKernelGGL(pfn_decorate_nf_kernel, dim3((unsigned)cdiv(P, 4)), dim3(256), 0, st, features, num_voxels, coors, P, T, F, vx, vy, x_offset,
+                       y_offset, with_distance ? 1 : 0, out);
+    return check_launch("papc_pfn_decorate_nf_f32");
+}
 
 int papc_pfn_num_blocks(int P) { return P >= 1 ? pfn_blocks(P) : 0; }
 

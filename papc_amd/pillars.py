@@ -241,9 +241,9 @@ class PillarFeatureNet(nn.Module):
         super().__init__()
         self.name = 'PillarFeatureNet'
         assert len(num_filters) > 0
-        if num_input_features != 4:
-            raise NotImplementedError("PillarFeatureNet: the decoration kernel reads [x, y, z, r] points (num_input_features=4, the "
-                                      "only layout the reference's voxeliser produces, yaml NUM_POINT_FEATURES: 4)")
+        if num_input_features < 3:
+            raise ValueError("PillarFeatureNet: points are [x, y, z, ...] (num_input_features >= 3; :82-88 read the first three columns)")
+        self._nf = int(num_input_features)          # (4 = the reference's voxeliser, yaml NUM_POINT_FEATURES: 4 -- the fused kernels' layout)
         num_input_features += 5                                                                # :55
         if with_distance:
             num_input_features += 1                                                            # :57-58
@@ -263,27 +263,34 @@ class PillarFeatureNet(nn.Module):
         return (float(self.vx), float(self.vy), float(self.x_offset), float(self.y_offset))
 
     def decorate(self, features, num_voxels, coors):
-        """:82-102 only -> masked rows [P,T,9] (+ the point norm as a 10th channel with_distance, :92-94).  The inputs are data
+        """:82-102 only -> masked rows [P,T,F+5] (+ the point norm as one more channel with_distance, :92-94).  The inputs are data
         (no gradient flows into the point cloud)."""
         lib = _lib.load()
         features = features.contiguous().float()
-        P, T, _ = features.shape
-        nc = 10 if self._with_distance else 9
+        P, T, F = features.shape
+        if F != self._nf:
+            raise ValueError("PillarFeatureNet: points of width %d, built for num_input_features=%d" % (F, self._nf))
+        nc = F + 5 + (1 if self._with_distance else 0)
         out = torch.empty(P, T, nc, device=features.device, dtype=torch.float32)
         vx, vy, xo, yo = self._geom()
+        if F != 4 or T > 128:      # (the F = 4 kernel keeps a pillar's <= 128 points in two float4 registers per lane)
+            check(lib.papc_pfn_decorate_nf_f32(ptr(features), F, ptr(num_voxels.int().contiguous()), ptr(coors.int().contiguous()), P, T,
+                                               vx, vy, xo, yo, int(self._with_distance), ptr(out), stream_ptr()), "papc_pfn_decorate_nf_f32")
+            return out
         check(lib.papc_pfn_decorate_f32(ptr(features), ptr(num_voxels.int().contiguous()), ptr(coors.int().contiguous()), P, T,
                                         vx, vy, xo, yo, int(self._with_distance), ptr(out), stream_ptr()), "papc_pfn_decorate_f32")
         return out
 
     def forward(self, features, num_voxels, coors):
-        """features [P,T,4] f32, num_voxels [P] int, coors [P,4] int (batch,z,y,x) -> [P,C]."""
+        """features [P,T,F] f32 (F = num_input_features, 4 in the reference's configs), num_voxels [P] int, coors [P,4] int
+        (batch,z,y,x) -> [P,C]."""
         if not features.is_cuda:
             raise _lib.PapcError("PillarFeatureNet needs CUDA(ROCm) tensors (no CPU fallback)")
         features = features.contiguous().float()
         num_voxels = num_voxels.int().contiguous()
         coors = coors.int().contiguous()
         pfn = self.pfn_layers[0]
-        if len(self.pfn_layers) == 1 and self._use_norm and not self._with_distance and pfn.units <= 64:
+        if self._nf == 4 and features.shape[1] <= 128 and len(self.pfn_layers) == 1 and self._use_norm and not self._with_distance and pfn.units <= 64:
             out = _PFNFused.apply(self._geom(), features, num_voxels, coors, pfn.linear.weight, pfn.norm.weight, pfn.norm.bias,
                                   pfn.norm.running_mean, pfn.norm.running_var, pfn.norm.eps, pfn.norm.momentum, self.training)
             return out.squeeze()                                                               # :108

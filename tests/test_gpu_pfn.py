@@ -49,6 +49,43 @@ def test_pfn_forward_vs_oracle(dev, vs, pr, P, T):
     assert np.allclose(dec.cpu().numpy()[..., 4:7], refd[..., 4:7], rtol=0, atol=2e-5)   # cluster mean: summation order
 
 
+@pytest.mark.parametrize("F,T,filters,with_distance", [(5, 100, (64,), False), (3, 40, (32, 64), False), (6, 150, (64,), False), (4, 150, (64,), False),
+                                                       (5, 20, (16,), True)])
+def test_pfn_other_point_widths(dev, F, T, filters, with_distance):
+    # num_input_features != 4 (e.g. [x, y, z, r, t] sweeps) and T > 128: the general decoration + the PFNLayer stack, vs the oracle
+    P = 97
+    voxels4, nump, coors = make_pillars(P=P, T=T, seed=5 + F)
+    rng = np.random.default_rng(F)
+    extra = rng.normal(size=(P, T, max(F - 3, 0))).astype(np.float32)
+    voxels = np.concatenate([voxels4[..., :3], extra], -1)
+    voxels *= (np.arange(T)[None, :] < nump[:, None])[:, :, None]
+    vs, pr = (0.16, 0.16, 4), (0, -39.68, -3, 69.12, 39.68, 1)
+    net = PillarFeatureNet(num_input_features=F, num_filters=filters, with_distance=with_distance, voxel_size=vs, pc_range=pr).to(dev)
+    ws, cin = [], F + 5 + (1 if with_distance else 0)
+    for i, pfn in enumerate(net.pfn_layers):
+        w, g, b = _weights(pfn.units, cin, 7 + i)
+        _load(pfn, w, g, b)
+        ws.append((w, g, b))
+        cin = 2 * pfn.units
+    tv, tn, tc = torch.from_numpy(voxels).to(dev), torch.from_numpy(nump).to(dev), torch.from_numpy(coors).to(dev)
+    dec = net.decorate(tv, tn, tc).cpu().numpy()
+    refd = R.pillar_decorate(voxels, nump, coors, vs[0], vs[1], vs[0] / 2 + pr[0], vs[1] / 2 + pr[1], with_distance=with_distance)
+    assert dec.shape == refd.shape
+    assert np.array_equal(dec[..., :F], refd[..., :F]) and np.array_equal(dec[..., F + 3:F + 5], refd[..., F + 3:F + 5])
+    # cluster mean: two fp32 summation orders (numpy's pairwise blocks, the kernel's lane-then-wave tree), each within
+    # ~log2(T) eps max|x| of the exact mean
+    tol = 2 * np.finfo(np.float32).eps * np.log2(T) * np.abs(voxels[..., :3]).max()
+    assert np.abs(dec[..., F:F + 3] - refd[..., F:F + 3]).max() <= max(tol, 2e-5)
+    if with_distance:
+        assert np.allclose(dec[..., F + 5], refd[..., F + 5], rtol=1e-6, atol=0)
+        return                                                                                 # (the oracle's net has no with_distance switch)
+    got = net(tv, tn, tc)
+    ref = R.pillar_feature_net(voxels, nump, coors, ws, vs, pr, f64=True)
+    assert_close(got.detach().cpu().numpy(), ref, 1e-5, "PFN F=%d vs f64 oracle" % F)
+    got.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
 def test_pfn_golden(dev):
     g = np.load(os.path.join(GOLD, "pfn_p64.npz"))
     for tag, vs, pr in [("ref_wiring", (1, 2, 3), (0, -40, -3, 70.4, 40, 1)), ("voxel_wiring", (0.16, 0.16, 4), (0, -39.68, -3, 69.12, 39.68, 1))]:
