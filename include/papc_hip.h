@@ -334,6 +334,7 @@ int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, in
 #define PAPC_SA_NO_COMPACT 32u
 #define PAPC_SA_NO_PLANES 64u            /* few-row stacks (sample_and_group_all, M <= 16 384) on the row kernels instead of the planes kernels */
 #define PAPC_SA_NO_PLANES_POINTWISE 128u /* ... only the un-pooled point-wise stacks */
+#define PAPC_SA_NO_XYZ_FUSE 256u        /* the dX above a coordinates-only first layer stored + papc_xyz_l1_bwd_f32 instead of papc_mlp_bwd_dx_xyz_f32 */
 typedef struct papc_sa_desc {
     int32_t B, N, S, K, D;
     int32_t n_layers;
@@ -598,6 +599,15 @@ int papc_bn_relu_max_seg_f32(const float *y, int C, const int32_t *start, const 
 int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, const float *w, int ldw, int xcol0, const float *bias, int C,
                            float *y, float *stats_partial, papc_stream_t stream);
 int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream);
+
+/* dX of the layer ABOVE a coordinates-only first layer (papc_mlp_xyz_ok), folded into that first layer's backward: dX [M, Cin] is never
+ * stored -- per channel c the four sums of p = dX[m, c] [wf_c . x_m + t_c > 0] against (x, y, z, 1) of the row's centred coordinates are all
+ * papc_xyz_l1_bwd_finalize_f32 needs.  xc [M,4], wf [Cin,4] (papc_xyz_l1_finalize_f32), partial [papc_mlp_gemm_parts(M)][Cin][4] = what
+ * papc_xyz_l1_bwd_f32 writes (pass papc_mlp_gemm_parts(M) as `parts` to the finalize).  Replaces papc_mlp_bwd_dx_f32 + papc_xyz_l1_bwd_f32
+ * (one [M, Cin] store and one read less).  papc_mlp_bwd_dx_xyz_ok: where it is built (else PAPC_E_UNSUPPORTED). */
+int papc_mlp_bwd_dx_xyz_ok(int64_t M, int Cin, int Cout);
+int papc_mlp_bwd_dx_xyz_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, const float *xc, const float *wf,
+                            float *partial, papc_stream_t stream);
 
 /* Backward of a max-pooled LAST layer without reading its dense output y [M,Cout] (the largest tensor of a stack).  With the BN+ReLU
  * backward expanded, dy = s*p - e*y + f (s = scale, e = s*c2*invstd, f = e*mean - s*c1; c1, c2 from papc_bn_bwd_finalize_f32) and

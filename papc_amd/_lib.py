@@ -134,6 +134,8 @@ SIGNATURES = {
     "papc_mlp_max_nostore_ok": (c_i, [c_l, c_i, c_i, c_i]),
     "papc_mlp_bwd_dw_max_ws_floats": (c_l, [c_l, c_i, c_i]),
     "papc_mlp_bwd_dw_max_f32": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "papc_mlp_bwd_dx_xyz_ok": (c_i, [c_l, c_i, c_i]),
+    "papc_mlp_bwd_dx_xyz_f32": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_mlp_bwd_dx_max_f32": (c_i, [c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p]),
     "papc_mlp_xyz_ok": (c_i, [c_l, c_i, c_i]),
     "papc_xyz_parts": (c_i, [c_l]),

@@ -7,11 +7,14 @@ namespace papc {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2, EPI_STORE_GMAX = 3, EPI_GMAX = 4 };   // (EPI_GMAX: EPI_STORE_GMAX without the output itself; row-streaming kernel only)
+enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2, EPI_STORE_GMAX = 3, EPI_GMAX = 4, EPI_XYZ_RED = 5 };   // (EPI_GMAX: EPI_STORE_GMAX without the output itself; row-streaming kernel only)
 
 // EPI_STORE_RED (dX only): besides storing dz_prev = dX, accumulate the BN-backward reductions of the PREVIOUS layer
 // (p = dz_prev * [scale*y_prev + shift > 0]; sum p and sum p*xhat per channel) into the stats partials, so no separate
 // pass has to re-read dz_prev.
+// EPI_XYZ_RED (dX of the layer above a coordinates-only first layer, row-streaming kernel only): dX is never stored -- the first layer's
+// whole backward needs four sums per channel of p = dX [wf . x + t > 0] against the row's centred coordinates (xyz1.hip), accumulated here:
+// RedSrc::y = xc [M][4], RedSrc::scale = the folded layer wf [Nout][4]; GemmArgs::stats = partial [parts][Nout][4] (T0, T1, T2, S).
 struct RedSrc {
     const float *y; const float *mean, *invstd, *scale, *shift;  // previous layer: pre-BN output [M,Nout] and BN constants
 };

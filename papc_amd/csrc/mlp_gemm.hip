@@ -1155,6 +1155,38 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
     return dy->dz_mode == PAPC_DZ_DENSE ? launch_gemm<A_DY_DENSE, EPI_STORE>(p, vec, st) : launch_gemm<A_DY_MAX, EPI_STORE>(p, vec, st);
 }
 
+int papc_mlp_bwd_dx_xyz_ok(int64_t M, int Cin, int Cout)
+{
+    // the row-streaming kernel's (Kin = Cout in {64, 128}) x (Nout = Cin = 64) dX flavours, whole 32-row tiles, enough of them
+    return knob(KNOB_STREAM) && knob(KNOB_STREAM_ASM) && !knob(KNOB_GEMM_F32) && Cin == 64 && (Cout == 64 || Cout == 128) && M % 32 == 0 &&
+           M / 32 >= knob(KNOB_STREAM_MINTILES);
+}
+
+int papc_mlp_bwd_dx_xyz_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, const float *xc, const float *wf,
+                            float *partial, papc_stream_t stream)
+{
+    PAPC_REQUIRE(wt && xc && wf && partial, PAPC_E_INVALID, "papc_mlp_bwd_dx_xyz_f32: null pointer");
+    PAPC_REQUIRE(M >= 1 && M < (1ll << 31) && Cin >= 1 && Cout >= 1, PAPC_E_INVALID, "papc_mlp_bwd_dx_xyz_f32: bad sizes");
+    PAPC_REQUIRE(dy && dy->dz_mode == PAPC_DZ_DENSE, PAPC_E_UNSUPPORTED, "papc_mlp_bwd_dx_xyz_f32: a dense dY source only (the layer above the first is never the pooled one)");
+    PAPC_REQUIRE(papc_mlp_bwd_dx_xyz_ok(M, Cin, Cout), PAPC_E_UNSUPPORTED, "papc_mlp_bwd_dx_xyz_f32: not built for M=%lld Cin=%d Cout=%d (papc_mlp_bwd_dx_xyz_ok)", (long long)M, Cin, Cout);
+    PAPC_REQUIRE(aligned16(xc) && aligned16(wf) && aligned16(wt), PAPC_E_INVALID, "papc_mlp_bwd_dx_xyz_f32: 16-byte alignment");
+    bool vec = false;
+    int rc = check_dy(dy, M, Cout, &vec, "papc_mlp_bwd_dx_xyz_f32");
+    if (rc) return rc;
+    GemmArgs p;
+    memset(&p, 0, sizeof(p));
+    fill_dy(p.a.d, dy);
+    p.a.d.C = Cout;
+    p.w = wt; p.ldw = Cout; p.M = M; p.Kin = Cout; p.Nout = Cin; p.y = nullptr; p.ldy = Cin;
+    p.rd.y = xc; p.rd.scale = wf; p.stats = partial; p.parts = gemm_parts(M);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_DX, st);
+    rc = stream_gemm_try(p, A_DY_DENSE, EPI_XYZ_RED, vec, st);
+    if (rc < 0) return rc;
+    if (rc == 0) { set_error("papc_mlp_bwd_dx_xyz_f32: the row-streaming kernel declined M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout); return PAPC_E_UNSUPPORTED; }
+    return PAPC_OK;
+}
+
 int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, const float *x, int64_t ldx, const float *bn_scale,
                             const float *bn_shift, const float *wcat, const float *hbias, int64_t M, int Cin, int Cout, float *dx,
                             const papc_bwd_red *next_red, papc_stream_t stream)

@@ -124,7 +124,9 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     constexpr int NCST = (AMODE == A_BNRELU || MC) ? 2 : (DY ? 5 : (XYZ ? 4 : 0));
     constexpr int W_BYTES = NT * ROWB;
     constexpr int CST_BYTES = NCST * K * 4;
-    constexpr int RED_BYTES = 2 * NW * NT * 4;
+    constexpr bool XR = (EPI == EPI_XYZ_RED);   // dX folded straight into the four sums of a coordinates-only first layer's backward: nothing stored
+    constexpr int NSUM = XR ? 4 : 2;
+    constexpr int RED_BYTES = NSUM * NW * NT * 4;
     constexpr int SMEM = (W_BYTES + CST_BYTES) > RED_BYTES ? (W_BYTES + CST_BYTES) : RED_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
     char *cstb = smem + W_BYTES;
@@ -450,10 +452,13 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     float rsc[WN], rsh[WN], rmu[WN], ris[WN];
     float gmx[WN], gmn[WN];
     int gix[WN], gin[WN];
+    float s3[WN], s4[WN];          // XR: (s1, s2, s3, s4) = sums of p x, p y, p z, p
+    float4 kq[WN];                 // XR: the folded first layer of this lane's column
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
         const int col = n0 + wn * 32 + l31;
-        s1[wn] = 0.f; s2[wn] = 0.f;
+        s1[wn] = 0.f; s2[wn] = 0.f; s3[wn] = 0.f; s4[wn] = 0.f;
+        kq[wn] = XR ? ld4(p.rd.scale + 4 * col) : make_float4(0.f, 0.f, 0.f, 0.f);
         biasv[wn] = (!CP && p.bias) ? p.bias[col] : 0.f;     // (CP: dX flavours only -- no bias; a compile-time zero frees WN registers at the limit)
         rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
         if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[col]; rsh[wn] = p.rd.shift[col]; rmu[wn] = p.rd.mean[col]; ris[wn] = p.rd.invstd[col]; }
@@ -463,6 +468,31 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     // epilogue of the tile starting at row0 (sub = its index inside the unit).  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 hi.
     auto epilogue = [&](int row0, int sub) {
         const int64_t ldy = p.ldy;
+        if constexpr (XR) {
+            // the rows' centred coordinates: one float4 per row, the same address for the 32 lanes of a half-wave (one broadcast line each)
+            const float4 *xq = reinterpret_cast<const float4 *>(p.rd.y) + row0 + 4 * hi;
+            // (four rows at a time, fenced: with all 16 coordinate loads hoisted to the top the flavour needs 256 registers and spills)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 xv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[i] = xq[8 * g + i];
+#pragma unroll
+                for (int wn = 0; wn < WN; ++wn) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * g + i;       // C/D layout: row = (r & 3) + 8 (r >> 2) + 4 hi
+                        const float z = fmaf(kq[wn].z, xv[i].z, fmaf(kq[wn].y, xv[i].y, fmaf(kq[wn].x, xv[i].x, kq[wn].w)));   // (as xyz_l1_bwd_kernel)
+                        const float pp = z > 0.f ? acc[wn][r] : 0.f;
+                        s1[wn] = fmaf(pp, xv[i].x, s1[wn]); s2[wn] = fmaf(pp, xv[i].y, s2[wn]); s3[wn] = fmaf(pp, xv[i].z, s3[wn]);
+                        s4[wn] += pp;
+                        acc[wn][r] = 0.f;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             const int col = n0 + wn * 32 + l31;
@@ -564,7 +594,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
 #ifdef PAPC_STREAM_NO_LATE1
             constexpr bool LATE1 = false;    // (diagnostic build: reproduces the hazard described above; tools/probe/late1_isa.py)
 #else
-            constexpr bool LATE1 = (EPI == EPI_STORE_RED);
+            constexpr bool LATE1 = (EPI == EPI_STORE_RED || EPI == EPI_XYZ_RED);   // (both epilogues issue compiler-visible loads)
 #endif
             sfor<0, NCH>([&](auto c_) {
                 constexpr int c = decltype(c_)::value;
@@ -613,19 +643,27 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         for (int wn = 0; wn < WN; ++wn) {
             s1[wn] += __shfl_xor(s1[wn], 32);
             s2[wn] += __shfl_xor(s2[wn], 32);
+            if (XR) { s3[wn] += __shfl_xor(s3[wn], 32); s4[wn] += __shfl_xor(s4[wn], 32); }
             if (hi == 0) {
                 red[(0 * NW + wave) * NT + wn * 32 + l31] = s1[wn];
                 red[(1 * NW + wave) * NT + wn * 32 + l31] = s2[wn];
+                if (XR) {
+                    red[(2 * NW + wave) * NT + wn * 32 + l31] = s3[wn];
+                    red[(3 * NW + wave) * NT + wn * 32 + l31] = s4[wn];
+                }
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * NT; i += NW * 64) {
+        for (int i = tid; i < NSUM * NT; i += NW * 64) {
             const int which = i / NT, c = i - which * NT;
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += red[(which * NW + w) * NT + c];
-            p.stats[((int64_t)blockIdx.x * 2 + which) * p.Nout + n0 + c] = t;
-            for (int r = blockIdx.x + gridDim.x; r < p.parts; r += gridDim.x) p.stats[((int64_t)r * 2 + which) * p.Nout + n0 + c] = 0.f;
+            // statistics: [part][which][Nout]; XR: [part][Nout][4], the layout papc_xyz_l1_bwd_finalize_f32 reads
+            const int64_t col_off = XR ? (int64_t)(n0 + c) * 4 + which : (int64_t)which * p.Nout + n0 + c;
+            const int64_t row_ld = (int64_t)NSUM * p.Nout;
+            p.stats[(int64_t)blockIdx.x * row_ld + col_off] = t;
+            for (int r = blockIdx.x + gridDim.x; r < p.parts; r += gridDim.x) p.stats[(int64_t)r * row_ld + col_off] = 0.f;
         }
     }
 }
@@ -664,7 +702,7 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     }
     if constexpr (AMODE == A_XYZ) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);   // (no streamed operand: no asm ring)
     else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true>), grid, dim3(512), 0, st, p, geo);
-    else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX) return 0;   // (the compiler-scheduled ring of these flavours spills: the caller falls back)
+    else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX || EPI == EPI_XYZ_RED) return 0;   // (the compiler-scheduled ring of these flavours spills / is not built: the caller falls back)
     else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);
     const int rc = check_launch("mlp stream gemm");
     return rc ? rc : 1;
@@ -694,7 +732,7 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     } else if constexpr (AMODE == A_XYZ) {
         // the layer above a coordinates-only first layer (xyz1.hip, papc_mlp_xyz_ok): 64 channels below, 64 or 128 above
         STREAM_CASE(4, 2); STREAM_CASE(4, 4);
-    } else if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE) {
+    } else if constexpr (AMODE == A_DY_DENSE && (EPI == EPI_STORE || EPI == EPI_XYZ_RED)) {
         STREAM_CASE(4, 2); STREAM_CASE(8, 2);
     } else {
         STREAM_CASE(2, 2); STREAM_CASE(2, 4);
@@ -747,6 +785,7 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
     if (amode == A_PLAIN && epi == EPI_STORE) return stream_pick<A_PLAIN, EPI_STORE>(p, geo, st);
     if (amode == A_DY_DENSE && epi == EPI_STORE_RED) return stream_pick<A_DY_DENSE, EPI_STORE_RED>(p, geo, st);
     if (amode == A_DY_DENSE && epi == EPI_STORE) return stream_pick<A_DY_DENSE, EPI_STORE>(p, geo, st);   // (layer above a Gram-path first layer: no BN-backward sums)
+    if (amode == A_DY_DENSE && epi == EPI_XYZ_RED) return (knob(KNOB_STREAM_ASM) && !geo.rows_dev) ? stream_pick<A_DY_DENSE, EPI_XYZ_RED>(p, geo, st) : 0;   // (the same layer, its dX folded into the first layer's sums)
     if (amode == A_XYZ && epi == EPI_STORE) return stream_pick<A_XYZ, EPI_STORE>(p, geo, st);
     if (amode == A_MAXCAT && epi == EPI_STORE_RED) return stream_pick<A_MAXCAT, EPI_STORE_RED>(p, geo, st);
     if (amode == A_DY_MAX && epi == EPI_STORE_RED) return stream_pick<A_DY_MAX, EPI_STORE_RED>(p, geo, st);

@@ -164,7 +164,7 @@ static size_t layout_bwd(const papc_sa_plan &p, void *base, BwdPtrs &b)
         b.eq = c.take<float>(2 * (size_t)cL);
         if (p.nostore) b.dwmax_ws = c.take<float>((size_t)papc_mlp_bwd_dw_max_ws_floats(M, cLi, cL) + 4);
     }
-    if (p.xyz1) b.bpart = c.take<float>((size_t)papc_xyz_bwd_parts(M) * p.d.cout[0] * 4);
+    if (p.xyz1) b.bpart = c.take<float>((size_t)std::max(papc_xyz_bwd_parts(M), papc_mlp_gemm_parts(M)) * p.d.cout[0] * 4);
     if (p.lin0) {
         const int c0 = p.d.cout[0];
         const int64_t BN = (int64_t)p.d.B * p.d.N;
@@ -635,6 +635,7 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
 
     papc_reduce_job jobs[PAPC_SA_MAX_LAYERS];
     int n_jobs = 0;
+    bool xyz_fused = false;
     const float *dz = nullptr;
     const float *fused_red = nullptr;
     int flip = 0;
@@ -656,8 +657,9 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             // the whole backward of the coordinates-only layer from one pass over dz and the inputs' moments
             PAPC_REQUIRE(!gr->dgamma[l] || (gr->acc_gb[l] != 0) == (gr->acc_w[l] != 0), PAPC_E_UNSUPPORTED,
                          "papc_sa_mlp_bwd: the coordinates-only first layer takes ONE accumulate flag for dw / dgamma / dbeta");
-            const int nbp = papc_xyz_bwd_parts(M);
-            SA_CALL(papc_xyz_l1_bwd_f32(dz, xc, s.wf, M, cout, b.bpart, st));
+            int nbp = papc_xyz_bwd_parts(M);
+            if (xyz_fused) nbp = papc_mlp_gemm_parts(M);      // (the partial sums came out of the layer above's dX kernel)
+            else SA_CALL(papc_xyz_l1_bwd_f32(dz, xc, s.wf, M, cout, b.bpart, st));
             SA_CALL(papc_xyz_l1_bwd_finalize_f32(b.bpart, nbp, M, cout, s.gram, ly.w, cin, 0, ly.b, cst, cst + cout, cst + 2 * cout, dgamma, dbeta, gr->dw[l],
                                                  acc_w ? 1 : 0, st));
             if (gr->db[l] && !acc_w) SA_CALL(papc_fill_f32(gr->db[l], cout, 0.f, st));
@@ -761,6 +763,10 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             if (p.sparse_max && l == L - 1) {
                 const float *pc = s.cst[l - 1];
                 SA_CALL(papc_mlp_bwd_dx_max_f32(b.psel, s.argmax, d.K, s.y[l - 1], cin, pc + 2 * cin, pc + 3 * cin, b.wcat, b.hb, M, cin, cout, dz_prev, nr_ref, st));
+            } else if (x1 && !(d.disable & PAPC_SA_NO_XYZ_FUSE) && dy.dz_mode == PAPC_DZ_DENSE && !dy.wrow && papc_mlp_bwd_dx_xyz_ok(M, cin, cout)) {
+                // the coordinates-only layer below needs four sums per channel of this dX, not dX: the kernel folds them, nothing is stored
+                SA_CALL(papc_mlp_bwd_dx_xyz_f32(&dy, wts[l], M, cin, cout, xc, s.wf, b.bpart, st));
+                xyz_fused = true;
             } else {
                 SA_CALL(papc_mlp_bwd_dx_f32(&dy, wts[l], M, cin, cout, dz_prev, nullptr, nr_ref, st));
             }

@@ -69,6 +69,7 @@ _SPARSE_MAX = os.environ.get("PAPC_SPARSE_MAX", "0") == "1"   # dX of the max-po
 _DW_WGS = int(os.environ.get("PAPC_DW_WGS", "512"))         # workgroups of one dW launch (row chunks x output tiles)
 _PY_ORCH = os.environ.get("PAPC_PY_ORCH", "0") == "1"      # this module's own launch sequence instead of the library's papc_sa_mlp_fwd / _bwd (stack.py)
 _XYZ1 = os.environ.get("PAPC_XYZ1", "1") == "1"             # coordinates-only first layer through its input moments, never materialised (xyz1.hip)
+_XYZ_FUSE = os.environ.get("PAPC_XYZ_FUSE", "1") == "1"   # A/B switch (library orchestration only): 0 = the dX above a coordinates-only first layer is stored and read back by papc_xyz_l1_bwd_f32
 
 
 def _dw_rows_per_chunk(M, cout, cin):

@@ -160,10 +160,16 @@ def test_group_all_stack_through_raw_c_entry_points_vs_oracle(dev):
     assert_close(out.cpu().numpy().reshape(B, 1024), ref64.reshape(B, 1024), 1e-5, "group_all via the C entry points vs f64 oracle")
 
 
-@pytest.mark.parametrize("shape", ["sa1", "sa2", "sa2_compact", "plain_nopool", "small"])
-def test_library_orchestration_equals_the_python_launch_sequence(dev, shape):
-    """papc_sa_mlp_fwd / _bwd issue the launches papc_amd.mlp.SharedMLPMax spells out in Python: bit-identical results"""
+@pytest.mark.parametrize("shape", ["sa1", "sa1_fused", "sa2", "sa2_compact", "plain_nopool", "small"])
+def test_library_orchestration_equals_the_python_launch_sequence(dev, shape, monkeypatch):
+    """papc_sa_mlp_fwd / _bwd issue the launches papc_amd.mlp.SharedMLPMax spells out in Python: bit-identical results.  (sa1_fused: the
+    library's own extra step -- the dX above the coordinates-only first layer folded into that layer's four sums instead of stored and
+    read back, papc_mlp_bwd_dx_xyz_f32 -- changes the summation order of the first layer's three gradients only.)"""
     rng = np.random.default_rng(9)
+    fused = shape == "sa1_fused"
+    monkeypatch.setattr(M_, "_XYZ_FUSE", fused)
+    if fused:
+        shape = "sa1"
     feats = idx = x_rows = xyz = new_xyz = None
     if shape == "plain_nopool":
         Mr, chans = 70000, [40, 64, 32]
@@ -197,7 +203,10 @@ def test_library_orchestration_equals_the_python_launch_sequence(dev, shape):
         assert (a is None) == (b is None)
         if a is None:
             continue
-        if i == 0 and feats is not None and chans[1] % 4 == 0 and feats.shape[2] >= 16:
+        if fused and i in (0, 2, 3):     # dW, dgamma, dbeta of the coordinates-only layer (its bias gradient is an exact zero)
+            assert not torch.equal(a, b) or i != 0, "the fused dX did not run"
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), "gradient %d of the first layer differs beyond summation order" % i
+        elif i == 0 and feats is not None and chans[1] % 4 == 0 and feats.shape[2] >= 16:
             # the gather-add first layer's dW_f = G^T feats reads G, the float-atomic row sums: same terms, run-dependent order
             assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), "gradient 0 differs beyond atomic-order noise"
         else:
