@@ -83,7 +83,7 @@ def run(args):
         tgt = torch.randint(0, 50, (B * N,), device=dev)
         st = (torch.from_numpy(make_start_idx(B, N, 3)).to(dev), torch.from_numpy(make_start_idx(B, 512, 4)).to(dev))
         from papc_amd.head import softmax_cross_entropy
-        loss_fn = lambda plan=None: softmax_cross_entropy(model((x, cls), st, plan=plan).reshape(B * N, 50), tgt)
+        loss_fn = lambda plan=None, hook=None: softmax_cross_entropy(model((x, cls), st, plan=plan, after_encode=hook).reshape(B * N, 50), tgt)
         # everything that depends on the coordinates only (FPS, the multi-radius ball queries, compact plans, the 3-NN searches of the
         # feature-propagation levels) is weight-independent: the NEXT batch's runs as a second branch of this batch's graph (side stream)
         plan_fn = lambda out=None: model.plan_sampling((x, cls), st, out=out)
@@ -134,11 +134,17 @@ def run(args):
             out = model(tv, tn, tc)
             out.backward(gout)
             return out
-        if plan_out is not None:                   # fork: the next batch's sampling branch fills the other graph's plan buffers in place
+        def fork():                                # the next batch's sampling branch fills the other graph's plan buffers in place
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 plan_fn(plan_out)
-        loss = loss_fn(plan_in) if plan_in is not None else loss_fn()
+        fork_at = getattr(args, "fork", "sa2")      # (bench.py's flag; here: "start" = with the step, anything else = behind the encoder)
+        if plan_out is not None and fork_at == "start":
+            fork()
+        if plan_out is not None and fork_at != "start":
+            loss = loss_fn(plan_in, fork)          # behind SA3: the decoder's kernels are small, the branch runs beside them instead of beside SA1 / SA2
+        else:
+            loss = loss_fn(plan_in) if plan_in is not None else loss_fn()
         loss.backward(one)
         if plan_out is not None:
             main.wait_stream(side)                 # join: the branch is part of this step

@@ -249,7 +249,9 @@ class _PartSegBase(nn.Module):
             n1 = self.fp1.plan(l0_xyz, l1_xyz, out=o[3])
         return p1, p2, n2, n1
 
-    def forward(self, inputs, start_idx=None, plan=None):
+    def forward(self, inputs, start_idx=None, plan=None, after_encode=None):
+        """``after_encode``: called once the three set-abstraction levels are enqueued, before the feature-propagation levels (a training
+        loop forks the next batch's sampling branch here: the decoder's kernels are small and leave most of the chip idle)."""
         xyz = torch.as_tensor(inputs[0])
         dev = xyz.device
         cls_label = Categorical(inputs[1], self.num_classes).to(dev)                               # :28
@@ -258,6 +260,8 @@ class _PartSegBase(nn.Module):
         l0_xyz = xyz[:, :3, :] if self.normal_channel else xyz
         pl = plan if plan is not None else (None, None, None, None)
         (l1_xyz, l1_points), (l2_xyz, l2_points), (l3_xyz, l3_points) = self._encode(l0_xyz, l0_points, start_idx, pl)
+        if after_encode is not None:
+            after_encode()
         l2_points = self.fp3(l2_xyz, l3_xyz, l2_points, l3_points)                                 # :42
         l1_points = self.fp2(l1_xyz, l2_xyz, l1_points, l2_points, planned=pl[2])                  # :43
         cls_label_one_hot = cls_label.reshape(B, self.num_classes, 1).expand(B, self.num_classes, N)   # :44
