@@ -763,12 +763,14 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             if (p.sparse_max && l == L - 1) {
                 const float *pc = s.cst[l - 1];
                 SA_CALL(papc_mlp_bwd_dx_max_f32(b.psel, s.argmax, d.K, s.y[l - 1], cin, pc + 2 * cin, pc + 3 * cin, b.wcat, b.hb, M, cin, cout, dz_prev, nr_ref, st));
-            } else if (x1 && !(d.disable & PAPC_SA_NO_XYZ_FUSE) && dy.dz_mode == PAPC_DZ_DENSE && !dy.wrow && papc_mlp_bwd_dx_xyz_ok(M, cin, cout)) {
-                // the coordinates-only layer below needs four sums per channel of this dX, not dX: the kernel folds them, nothing is stored
-                SA_CALL(papc_mlp_bwd_dx_xyz_f32(&dy, wts[l], M, cin, cout, xc, s.wf, b.bpart, st));
-                xyz_fused = true;
             } else {
-                SA_CALL(papc_mlp_bwd_dx_f32(&dy, wts[l], M, cin, cout, dz_prev, nullptr, nr_ref, st));
+                if (x1 && !(d.disable & PAPC_SA_NO_XYZ_FUSE) && dy.dz_mode == PAPC_DZ_DENSE && !dy.wrow && papc_mlp_bwd_dx_xyz_ok(M, cin, cout)) {
+                    // the coordinates-only layer below needs four sums per channel of this dX, not dX: the kernel folds them, nothing is stored
+                    const int rc = papc_mlp_bwd_dx_xyz_f32(&dy, wts[l], M, cin, cout, xc, s.wf, b.bpart, st);
+                    if (rc == PAPC_OK) xyz_fused = true;
+                    else if (rc != PAPC_E_UNSUPPORTED) return rc;      // (declined, e.g. an operand off a 16-byte boundary: the stored form below)
+                }
+                if (!xyz_fused) SA_CALL(papc_mlp_bwd_dx_f32(&dy, wts[l], M, cin, cout, dz_prev, nullptr, nr_ref, st));
             }
             dz = dz_prev;
         } else if (x_needs) {
