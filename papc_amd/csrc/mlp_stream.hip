@@ -100,15 +100,23 @@ __device__ __forceinline__ void split3_pair(f32x2 x, unsigned &p0, unsigned &p1,
 // CP (dX of a compacted stack: DY operands, STORE_RED epilogue): per-row weight w in the BatchNorm-backward term, dy = sc p - w (A + B' (y - mean));
 // DY_MAX: the row's group comes from seg_grp (ragged groups), argmax holds absolute rows.  The weight of tile j + 1 and the group of tile
 // j + 2 are fetched between the full drain that precedes tile j's epilogue (LATE1 flavours) and the epilogue itself: no new wait in the loop.
-template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false>
+// KV (ragged k: the MSG segmenter's 196-channel layer, pointnet2.py:63): the operand rows hold KV = 16 (KB16 - 1) + 4 channels.  The LDS image of the
+// weights and the constants are zero beyond KV; the last k block is a PARTIAL block of one 16-byte load per streamed array (channels KV - 4 ..
+// KV - 1, read by BOTH half-waves -- the upper half's copy meets zero weights) that rides on the last chunk of full blocks.
+// NR (ragged n): Nout is not a multiple of the column block; weight rows beyond it are zero in LDS, their stores and statistics are masked.
+template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false>
 __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo geo)
 {
     static_assert(!CP || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && EPI == EPI_STORE_RED && ASM && PAPC_STREAM_PK), "CP: dX flavours of the asm ring only");
     constexpr int NW = 8;
     constexpr int K = KB16 * 16;
     constexpr int NT = WN * 32;
-    constexpr int NCH = KB16 / CK;
-    static_assert(KB16 % CK == 0 && NCH >= 2 && NCH % 2 == 0, "an even number of chunks per tile");
+    constexpr bool KR = (KV != K);
+    constexpr int KBF = KR ? KB16 - 1 : KB16;      // full k blocks
+    static_assert(!KR || (KV == K - 12 && !CP && PAPC_STREAM_PK && (AMODE == A_BNRELU || AMODE == A_DY_DENSE || AMODE == A_PLAIN)), "ragged k: four channels in the last block");
+    static_assert(!NR || (EPI == EPI_STORE || EPI == EPI_STORE_RED), "ragged n: storing epilogues without the group max");
+    constexpr int NCH = KBF / CK;
+    static_assert(KBF % CK == 0 && NCH >= 2 && NCH % 2 == 0, "an even number of chunks per tile");
     constexpr bool DY = (AMODE == A_DY_DENSE || AMODE == A_DY_MAX);
     constexpr bool GM = (EPI == EPI_STORE_GMAX || EPI == EPI_GMAX);   // per-group max / min of the raw output in the epilogue
     constexpr bool XYZ = (AMODE == A_XYZ);   // operand computed from the row's centred coordinates: no streamed operand, no asm ring
@@ -118,7 +126,9 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     constexpr int KS = MC ? KB16 * 2 / 3 : 0;
     static_assert(!MC || (KB16 % 3 == 0 && CK == 1), "MAXCAT: Cout = 2 Cin, one k block per chunk");
     constexpr int NLD = (AMODE == A_DY_MAX) ? 6 : ((AMODE == A_DY_DENSE || MC) ? 4 : 2);   // 16-byte loads per lane and k block (MAXCAT: at most)
-    constexpr int CL = CK * NLD;                                                      // ... per chunk
+    constexpr int NLDP = KR ? NLD / 2 : 0;                                            // ... of the partial block (one per streamed array)
+    constexpr int CLB = CK * NLD;                                                     // ... per chunk of full blocks = registers of a ring buffer
+    constexpr int CL = CLB + NLDP;                                                    // ... per chunk at most
     static_assert(CL <= 60, "vmcnt is a 6-bit field");
     constexpr int ROWB = 6 * K + 16;          // LDS bytes of one weight row: [plane 0 | plane 1 | plane 2] bf16 + 16 (odd number of 16-B slots)
     constexpr int NCST = (AMODE == A_BNRELU || MC) ? 2 : (DY ? 5 : (XYZ ? 4 : 0));
@@ -137,20 +147,26 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     const int n0 = blockIdx.y * NT;
     const int ldx = (int)(DY ? p.a.d.C : p.a.ldx);     // row stride (floats) of the streamed operand(s)
     // loads of chunk ci (compile time): uniform except MAXCAT, whose sparse blocks take 4 and dense blocks 2
-    auto nld_of = [](int ci) constexpr -> int { return MC ? ((ci % NCH) < KS ? 4 : 2) : CL; };
+    auto nld_of = [](int ci) constexpr -> int { return MC ? ((ci % NCH) < KS ? 4 : 2) : (CK * NLD + ((ci % NCH) == NCH - 1 ? NLDP : 0)); };
 
     // ---- prologue: weights -> three bf16 planes in LDS (once per workgroup); folded per-channel constants
     {
         const float *wb = p.w + (int64_t)n0 * p.ldw;
         // all of the thread's pieces are loaded before the first is used: one exposed L2 round trip, not NI of them
-        constexpr int NI = NT * (K / 4) / (NW * 64);
-        static_assert(NT * (K / 4) % (NW * 64) == 0, "whole float4 pieces per thread");
+        constexpr int NP = NT * (K / 4);                  // float4 pieces of the block's weights
+        constexpr int NI = (NP + NW * 64 - 1) / (NW * 64);
+        constexpr bool PG = (NP % (NW * 64) != 0);        // (guarded last round)
+        static_assert(KR || !PG, "whole float4 pieces per thread");
         float4 wv[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
             const int i = tid + q * NW * 64;
             const int n = i / (K / 4), k4 = (i - n * (K / 4)) * 4;
-            wv[q] = ld4(wb + (int64_t)n * p.ldw + k4);
+            bool ok = true;
+            if constexpr (KR) ok = ok && k4 < KV;
+            if constexpr (PG) ok = ok && i < NP;
+            if constexpr (NR) ok = ok && n0 + n < p.Nout;
+            wv[q] = ok ? ld4(wb + (int64_t)n * p.ldw + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
@@ -159,13 +175,18 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             uint2 q0, q1, q2;
             split3(wv[q], q0, q1, q2);
             char *d = smem + n * ROWB + k4 * 2;
-            *reinterpret_cast<uint2 *>(d) = q0;
-            *reinterpret_cast<uint2 *>(d + 2 * K) = q1;
-            *reinterpret_cast<uint2 *>(d + 4 * K) = q2;
+            if (!PG || i < NP) {
+                *reinterpret_cast<uint2 *>(d) = q0;
+                *reinterpret_cast<uint2 *>(d + 2 * K) = q1;
+                *reinterpret_cast<uint2 *>(d + 4 * K) = q2;
+            }
         }
         float *cf = reinterpret_cast<float *>(cstb);
         for (int k = tid; k < K; k += NW * 64) {
-            if (AMODE == A_BNRELU) {
+            if (KR && k >= KV) {     // (zero constants: the transform of whatever a lane holds there is 0)
+#pragma unroll
+                for (int q = 0; q < NCST; ++q) cf[q * K + k] = 0.f;
+            } else if (AMODE == A_BNRELU) {
                 cf[k] = p.a.sc[k]; cf[K + k] = p.a.sh[k];
             } else if (MC) {         // BN+ReLU constants of the dense region, stored at the concatenated k
                 const bool dn = k >= KS * 16;
@@ -227,15 +248,22 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     };
     const unsigned voff_row = (unsigned)((l31 * ldx + 8 * hi) * 4);   // this lane's row and k half inside a tile
     const unsigned voff_grp = voff_grp0;                               // ... inside a per-group row (DY_MAX: gout / argmax)
+    const unsigned voff_lo = (unsigned)(l31 * ldx * 4);                // KR: the partial k block, channels KV - 4 .. KV - 1 of the lane's row for both halves
 
-    f32x4 buf[2][CL];
+    f32x4 buf[2][CLB];
+    f32x4 pbuf[NLDP > 0 ? NLDP : 1];       // KR: the partial block's registers (loaded with the last chunk only)
+#pragma unroll
+    for (int i = 0; i < (NLDP > 0 ? NLDP : 1); ++i) {
+        if constexpr (KR) asm volatile("" : "=v"(pbuf[i]));
+        else pbuf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int i = 0; i < CL; ++i) {
+        for (int i = 0; i < CLB; ++i) {
             // (CP flavours sit at the register limit: their ring registers are DEFINED here, behind the prologue's barrier, by an empty volatile asm
             // instead of a zero the compiler hoists above the weight split and then spills across it)
-            if constexpr (CP) asm volatile("" : "=v"(buf[b][i]));
+            if constexpr (CP || KR) asm volatile("" : "=v"(buf[b][i]));
             else buf[b][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 
@@ -271,10 +299,17 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 gload4<ASM, off + 16, false>(buf[bi][blk * NLD + 5], vg, s.p2);
             }
         });
+        if constexpr (KR && ci == NCH - 1) {       // the partial block rides on the last chunk
+            gload4<ASM, KBF * 64, false>(pbuf[0], voff_lo, s.p0);
+            if constexpr (AMODE == A_DY_DENSE) gload4<ASM, KBF * 64, false>(pbuf[1], voff_lo, s.p1);
+        }
     };
     auto touch_buf = [&](auto bi_) {
         constexpr int bi = decltype(bi_)::value;
-        sfor<0, CL>([&](auto i_) { touch<ASM>(buf[bi][decltype(i_)::value]); });
+        sfor<0, CLB>([&](auto i_) { touch<ASM>(buf[bi][decltype(i_)::value]); });
+    };
+    auto touch_p = [&]() {
+        if constexpr (KR) sfor<0, NLDP>([&](auto i_) { touch<ASM>(pbuf[decltype(i_)::value]); });
     };
 
     floatx16 acc[WN];
@@ -328,19 +363,17 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     };
 
     // MFMAs of chunk `ci` from buffer `bi`
-    auto compute = [&](auto bi_, auto ci_) {
-        constexpr int bi = decltype(bi_)::value, ci = decltype(ci_)::value;
-        sfor<0, CK>([&](auto blk_) {
-            constexpr int blk = decltype(blk_)::value;
-            constexpr int kb = ci * CK + blk;
-            const f32x4 *r = &buf[bi][blk * NLD];
+    auto compute_block = [&](auto kb_, const f32x4 *r) {
+        {
+            constexpr int kb = decltype(kb_)::value;
+            constexpr int NJ = (KR && kb == KBF) ? 2 : 4;      // value pairs of the lane that exist (partial block: channels KV - 4 .. KV - 1)
             bf16x8 af[3];
 #if PAPC_STREAM_PK
             {
                 f32x2 v2[4];   // pairs (k, k+1): r[0] = k 0..3, r[1] = k 4..7 of this lane's half block
                 if constexpr (AMODE == A_PLAIN) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v2[j] = f32x2{r[j >> 1][2 * (j & 1)], r[j >> 1][2 * (j & 1) + 1]};
+                    for (int j = 0; j < NJ; ++j) v2[j] = f32x2{r[j >> 1][2 * (j & 1)], r[j >> 1][2 * (j & 1) + 1]};
                 } else if constexpr (MC && kb < KS) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -351,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                     const f32x4 s0 = *reinterpret_cast<const f32x4 *>(cl + kb * 64), s1 = *reinterpret_cast<const f32x4 *>(cl + kb * 64 + 16);
                     const f32x4 h0 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64), h1 = *reinterpret_cast<const f32x4 *>(cl + K * 4 + kb * 64 + 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         const int h = j >> 1, i = 2 * (j & 1);
                         const f32x4 sc = h ? s1 : s0, sh = h ? h1 : h0;
                         const f32x2 t = pk_fma(f32x2{sc[i], sc[i + 1]}, f32x2{r[h][i], r[h][i + 1]}, f32x2{sh[i], sh[i + 1]});
@@ -365,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                         c[q][1] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64 + 16);
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         const int h = j >> 1, i = 2 * (j & 1);
                         const f32x2 y = f32x2{r[h][i], r[h][i + 1]};
                         f32x2 dz = f32x2{r[2 + h][i], r[2 + h][i + 1]};
@@ -387,7 +420,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 }
                 unsigned q0[4], q1[4], q2[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) split3_pair(v2[j], q0[j], q1[j], q2[j]);
+                for (int j = 0; j < 4; ++j) {
+                    if (j < NJ) split3_pair(v2[j], q0[j], q1[j], q2[j]);
+                    else { q0[j] = 0u; q1[j] = 0u; q2[j] = 0u; }      // (partial block: k beyond KV)
+                }
                 af[0] = __builtin_bit_cast(bf16x8, make_uint4(q0[0], q0[1], q0[2], q0[3]));
                 af[1] = __builtin_bit_cast(bf16x8, make_uint4(q1[0], q1[1], q1[2], q1[3]));
                 af[2] = __builtin_bit_cast(bf16x8, make_uint4(q2[0], q2[1], q2[2], q2[3]));
@@ -444,7 +480,22 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
 #pragma unroll
                 for (int wn = 0; wn < WN; ++wn)
                     acc[wn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]], bq[wn][PB[t]], acc[wn], 0, 0, 0);
+        }
+    };
+    auto compute = [&](auto bi_, auto ci_) {
+        constexpr int bi = decltype(bi_)::value, ci = decltype(ci_)::value;
+        sfor<0, CK>([&](auto blk_) {
+            constexpr int blk = decltype(blk_)::value;
+            compute_block(std::integral_constant<int, ci * CK + blk>{}, &buf[bi][blk * NLD]);
         });
+        if constexpr (KR && ci == NCH - 1) {
+            // the partial block: the lane's first four values are channels KV - 4 .. KV - 1 (upper half-wave: a copy that meets zero weights), the rest zeros
+            const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 rr[4];
+            rr[0] = pbuf[0]; rr[1] = z4;
+            rr[2] = (AMODE == A_DY_DENSE) ? pbuf[NLDP - 1] : z4; rr[3] = z4;
+            compute_block(std::integral_constant<int, KBF>{}, rr);
+        }
     };
 
     // ---- per-lane epilogue state: this lane's columns are n0 + 32 wn + l31 for every tile
@@ -456,10 +507,11 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     float4 kq[WN];                 // XR: the folded first layer of this lane's column
 #pragma unroll
     for (int wn = 0; wn < WN; ++wn) {
-        const int col = n0 + wn * 32 + l31;
+        const int colr = n0 + wn * 32 + l31;
+        const int col = NR ? min(colr, p.Nout - 1) : colr;       // (NR: masked lanes read a valid column's constants and never store)
         s1[wn] = 0.f; s2[wn] = 0.f; s3[wn] = 0.f; s4[wn] = 0.f;
         kq[wn] = XR ? ld4(p.rd.scale + 4 * col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        biasv[wn] = (!CP && p.bias) ? p.bias[col] : 0.f;     // (CP: dX flavours only -- no bias; a compile-time zero frees WN registers at the limit)
+        biasv[wn] = (!CP && !(KR && DY) && p.bias && colr == col) ? p.bias[col] : 0.f;     // (CP, ragged-k dX: no bias in a dX product; a compile-time zero frees WN registers at the limit)
         rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
         if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[col]; rsh[wn] = p.rd.shift[col]; rmu[wn] = p.rd.mean[col]; ris[wn] = p.rd.invstd[col]; }
         gmx[wn] = -INFINITY; gmn[wn] = INFINITY; gix[wn] = 0; gin[wn] = 0;
@@ -496,8 +548,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             const int col = n0 + wn * 32 + l31;
+            const bool cok = !NR || col < p.Nout;
             float *yp = p.y + (int64_t)(row0 + 4 * hi) * ldy + col;
             if (EPI == EPI_STORE_RED) {
+                if (cok) {
                 const float *qp = p.rd.y + (int64_t)(row0 + 4 * hi) * ldy + col;
                 float yv[16];
 #pragma unroll
@@ -510,12 +564,13 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                     s1[wn] += pp;
                     s2[wn] = fmaf(pp, (yv[r] - rmu[wn]) * ris[wn], s2[wn]);
                 }
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2);
                     const float v = acc[wn][r] + biasv[wn];
-                    if (EPI != EPI_GMAX) yp[(int64_t)ro * ldy] = v;   // (EPI_GMAX: under the max the output itself stays unwritten)
+                    if (EPI != EPI_GMAX && cok) yp[(int64_t)ro * ldy] = v;   // (EPI_GMAX: under the max the output itself stays unwritten)
                     s1[wn] += v;
                     s2[wn] = fmaf(v, v, s2[wn]);
                     if (GM) {
@@ -602,6 +657,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 if constexpr (c > 0) {   // (chunk 0 was waited for before the previous tile's stores went out)
                     wait_vm<ASM, nld_of(c + 1)>();   // (LATE1: chunk 1 was issued behind the epilogue's stores; chunk c + 1's loads are still the only younger ones)
                     touch_buf(std::integral_constant<int, bi>{});
+                    if constexpr (c == NCH - 1) touch_p();
                 }
                 compute(std::integral_constant<int, bi>{}, c_);
                 if constexpr (c + 2 < NCH) issue(std::integral_constant<int, bi>{}, std::integral_constant<int, c + 2>{}, sa);
@@ -633,6 +689,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         wait_vm<ASM, 0>();
         touch_buf(std::integral_constant<int, 0>{});
         touch_buf(std::integral_constant<int, 1>{});
+        touch_p();
     }
 
     // ---- BN statistics (or BN-backward sums): one deterministic partial row per row-workgroup
@@ -662,6 +719,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             // statistics: [part][which][Nout]; XR: [part][Nout][4], the layout papc_xyz_l1_bwd_finalize_f32 reads
             const int64_t col_off = XR ? (int64_t)(n0 + c) * 4 + which : (int64_t)which * p.Nout + n0 + c;
             const int64_t row_ld = (int64_t)NSUM * p.Nout;
+            if (NR && n0 + c >= p.Nout) continue;
             p.stats[(int64_t)blockIdx.x * row_ld + col_off] = t;
             for (int r = blockIdx.x + gridDim.x; r < p.parts; r += gridDim.x) p.stats[(int64_t)r * row_ld + col_off] = 0.f;
         }
@@ -681,13 +739,15 @@ static int stream_ncu()
     return ncu;
 }
 
-template <int AMODE, int EPI, int KB16, int WN, bool CP = false>
+template <int AMODE, int EPI, int KB16, int WN, bool CP = false, int KV = KB16 * 16, bool NR = false>
 static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
-    constexpr int CK2 = (KB16 == 6) ? 1 : 2;   // (six k blocks: an even chunk count needs 1 or 3 per chunk, and 3 spills the asm-loaded ring)
-    constexpr int CK = (KB16 < 4 || AMODE == A_DY_MAX || AMODE == A_MAXCAT || (AMODE == A_DY_DENSE && WN == 4) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : CK2;
-    const int ncb = p.Nout / (32 * WN);
+    constexpr bool KR = (KV != KB16 * 16);
+    constexpr int KBF = KR ? KB16 - 1 : KB16;
+    constexpr int CK2 = (KBF == 6) ? 1 : 2;   // (six k blocks: an even chunk count needs 1 or 3 per chunk, and 3 spills the asm-loaded ring)
+    constexpr int CK = (KBF < 4 || AMODE == A_DY_MAX || AMODE == A_MAXCAT || (AMODE == A_DY_DENSE && (WN == 4 || KR)) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : CK2;
+    const int ncb = (p.Nout + 32 * WN - 1) / (32 * WN);
     // one workgroup per CU in total (weights + 8 waves of up to 256 registers fill it); column blocks of the same rows are
     // gridDim.x apart in the flat id, i.e. on the same XCD when gridDim.x % 8 == 0: the second reader of a row finds it in L2
     int gx = std::max(8, (stream_ncu() / ncb) & ~7);
@@ -701,8 +761,8 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
         return rc ? rc : 1;
     }
     if constexpr (AMODE == A_XYZ) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);   // (no streamed operand: no asm ring)
-    else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true>), grid, dim3(512), 0, st, p, geo);
-    else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX || EPI == EPI_XYZ_RED) return 0;   // (the compiler-scheduled ring of these flavours spills / is not built: the caller falls back)
+    else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR>), grid, dim3(512), 0, st, p, geo);
+    else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX || EPI == EPI_XYZ_RED || KR || NR) return 0;   // (the compiler-scheduled ring of these flavours spills / is not built: the caller falls back)
     else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);
     const int rc = check_launch("mlp stream gemm");
     return rc ? rc : 1;
@@ -715,6 +775,15 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     if (geo.wrow) {      // dX of a compacted stack: the two flavours SA2-shaped stacks need (128 -> 128 dense, 256 -> 128 under the max)
         if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE_RED) { if (kb == 8 && p.Nout == 128) return stream_go<AMODE, EPI, 8, 4, true>(p, geo, st); }
         if constexpr (AMODE == A_DY_MAX && EPI == EPI_STORE_RED) { if (kb == 16 && p.Nout == 128) return stream_go<AMODE, EPI, 16, 2, true>(p, geo, st); }
+        return 0;
+    }
+    // the MSG segmenter's 196-channel layer pair (segment/pointnet2/pointnet2.py:63, [128, 196, 256]): ragged k (196 = 12 k blocks + 4 channels) and
+    // ragged n (196 of the last column block's columns exist); the column blocks are as wide as the weights' LDS image allows (<= 160 KB here)
+    if (p.Kin == 196 || p.Nout == 196) {
+        if constexpr (AMODE == A_BNRELU && EPI == EPI_STORE) { if (p.Kin == 128 && p.Nout == 196) return stream_go<AMODE, EPI, 8, 4, false, 128, true>(p, geo, st); }
+        if constexpr (AMODE == A_BNRELU && (EPI == EPI_STORE_GMAX || EPI == EPI_STORE)) { if (p.Kin == 196 && p.Nout % 128 == 0) return stream_go<AMODE, EPI, 13, 4, false, 196>(p, geo, st); }
+        if constexpr (AMODE == A_DY_MAX && EPI == EPI_STORE_RED) { if (p.Kin == 256 && p.Nout == 196) return stream_go<AMODE, EPI, 16, 3, false, 256, true>(p, geo, st); }
+        if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE_RED) { if (p.Kin == 196 && p.Nout % 64 == 0) return stream_go<AMODE, EPI, 13, 2, false, 196>(p, geo, st); }
         return 0;
     }
     // N tile: as many columns as the weights' LDS image allows (6 K + 16 bytes per column, <= ~100 KB), at most 128
@@ -758,7 +827,7 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
     auto why = [&](int site) -> int { if (getenv("PAPC_STREAM_WHY")) fprintf(stderr, "[stream_gemm_try] declined at site %d: amode %d epi %d M %lld Kin %d Nout %d vec %d\n", site, amode, epi, (long long)p.M, p.Kin, p.Nout, (int)vec); return 0; };
     if (!knob(KNOB_STREAM) || knob(KNOB_GEMM_F32) || !vec) return why(1);
     if (p.M % 32 != 0 || p.M / 32 < knob(KNOB_STREAM_MINTILES)) return why(2);
-    if (p.Kin % 32 != 0 || p.Kin < 32 || p.Kin > (amode == A_MAXCAT ? 384 : 256) || p.Nout % 32 != 0 || p.Nout < 64) return why(3);
+    if (((p.Kin % 32 != 0 || p.Nout % 32 != 0) && p.Kin != 196 && p.Nout != 196) || p.Kin % 4 != 0 || p.Kin < 32 || p.Kin > (amode == A_MAXCAT ? 384 : 256) || p.Nout < 64) return why(3);
     if (amode == A_MAXCAT && (p.a.d.C != 2 * p.Nout || p.Kin != 3 * p.Nout || p.a.ldx != p.Nout)) return why(4);   // Cout = 2 Cin, dense input rows
     if (p.wmap || p.nmap || p.ldy != p.Nout) return why(5);
     if (!(p.stats || epi == EPI_STORE)) return why(6);

@@ -53,6 +53,8 @@ def _run(dev, G, K, chans, seed, stream, need_x_grad=False):
     (24, 128, [32, 64, 128]),          # group = four tiles, 32-wide first layer, ragged number of units per wave
     (100, 32, [64, 128, 64]),          # unit count not a multiple of the wave count
     (96, 64, [64, 64, 96, 128]),       # the MSG branches' 96-channel layers: three column tiles (64 -> 96), six k blocks (96 -> 128)
+    (32, 128, [128, 128, 196, 256]),   # the MSG segmenter's 196-channel pair (pointnet2.py:63): ragged n (128 -> 196, dX 256 -> 196), ragged k (196 -> 256 + max, dX 196 -> 128)
+    (25, 128, [128, 128, 196, 256]),   # ... with a unit count that does not divide over the waves
 ])
 @pytest.mark.parametrize("asm", [1, 0])
 def test_stream_matches_tiled_and_f64(dev, stream_knobs, G, K, chans, asm):
