@@ -811,9 +811,13 @@ __global__ __launch_bounds__(512, 2) void dw_rows_kernel(DwArgs p)
 // CP (compacted stack, compact.hip): the row count comes from device memory (the chunk size is derived from it here), dY carries the row's
 // multiplicity weight in its BatchNorm-backward term, groups are ragged multiples of 8 rows (a lane's 8 rows share a group: seg_grp) and
 // argmax holds absolute rows.
-template <int DYMODE, int NW, bool CP = false>      // NW waves = NW 32-channel groups of Cout per workgroup: 8 (256-channel blocks) or 4 (128-channel blocks, two workgroups per CU)
+// RG (ragged widths: the MSG segmenter's 196-channel pair, pointnet2.py:63): Cout need not fill the workgroup's channel block (lanes beyond it read
+// its last channel and store nothing), and the input may be wider than 128 channels -- blockIdx.z walks 128-channel blocks of it, row stride
+// p.x.ldx, lanes beyond Cin read its last channel and their columns of the partial are not stored.
+template <int DYMODE, int NW, bool CP = false, bool RG = false>      // NW waves = NW 32-channel groups of Cout per workgroup: 8 (256-channel blocks) or 4 (128-channel blocks, two workgroups per CU)
 __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
 {
+    static_assert(!(CP && RG), "ragged widths: padded stacks only");
     constexpr int NTI = 4, CI = 128, CHS = 48, PLB = CI * CHS, STG = 3 * PLB;   // bytes: channel stride, plane, stage
     constexpr int CB = 32 * NW;              // channels of Cout per workgroup
     constexpr int RPT = 32 / NW;             // x rows per thread and block (the 64 NW threads share 16 rows x 128 channels): 4 or 8
@@ -821,8 +825,10 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
     __shared__ __attribute__((aligned(16))) char xs_lds[2 * STG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int co = blockIdx.y * CB + wave * 32 + l31;        // this lane's dY channel
+    const int co = RG ? min((int)blockIdx.y * CB + wave * 32 + l31, p.Cout - 1) : blockIdx.y * CB + wave * 32 + l31;        // this lane's dY channel
     const DySrc &d = p.dy.d;
+    const int i0 = RG ? (int)blockIdx.z * CI : 0;            // first input channel of this workgroup
+    const uint32_t LDX = RG ? (uint32_t)p.x.ldx : (uint32_t)CI;   // row stride of x (floats)
     int64_t rows_all = p.M, rpc = p.rows_per_chunk;
     if constexpr (CP) {      // one chunk per workgroup column of the grid, sized from the device-side row count (a multiple of 128)
         rows_all = __builtin_amdgcn_readfirstlane(*d.rows_dev);
@@ -837,7 +843,8 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
     const float kA = ksc * d.c1[co], kB = ksc * d.c2[co] * d.invstd[co];
     // x producer role: channel xc, rows RPT xq .. RPT xq + RPT - 1 of the block
     const int xc = tid & 127, xq = tid >> 7;
-    const float xsc = p.x.sc[xc], xsh = p.x.sh[xc];
+    const int xg = RG ? min(i0 + xc, p.Cin - 1) : xc;        // ... as a channel of the input
+    const float xsc = p.x.sc[xg], xsh = p.x.sh[xg];
 
     floatx16 acc[NTI];
 #pragma unroll
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
     auto ldgi = [](const int *base, uint32_t byte_off) { return *reinterpret_cast<const int *>(reinterpret_cast<const char *>(base) + byte_off); };
     const uint32_t ystride = (uint32_t)Cout * 4u;
     const uint32_t oy_lane = (uint32_t)((mbeg + 8 * hi) * Cout + co) * 4u;        // row (mbeg + 8 hi) of this lane's channel
-    const uint32_t ox_lane = (uint32_t)((mbeg + RPT * xq) * CI + xc) * 4u;
+    const uint32_t ox_lane = (uint32_t)((mbeg + RPT * xq) * LDX + xg) * 4u;
     const uint32_t ow_lane = (uint32_t)(mbeg + 8 * hi) * 4u;                      // CP: weights of this lane's 8 rows
     const uint32_t og_lane = (uint32_t)(((mbeg >> 3) + hi)) * 4u;                 // CP: group of this lane's 8-row segment
     // CP, DY_MAX: the group of block kb's segment, fetched one ring round ahead of the block itself (its gout / argmax addresses depend on it)
@@ -886,9 +893,9 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
         return a[j];
     };
     auto fetch_x = [&](int kb, RawX &w) {
-        const uint32_t o0 = ox_lane + (uint32_t)kb * (16u * CI * 4u);
+        const uint32_t o0 = ox_lane + (uint32_t)kb * (16u * LDX * 4u);
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) w.x[j] = ldg(p.x.x, o0 + (uint32_t)j * (CI * 4u));
+        for (int j = 0; j < RPT; ++j) w.x[j] = ldg(p.x.x, o0 + (uint32_t)j * (LDX * 4u));
     };
     auto stage_x = [&](int kb, const RawX &w, char *stg) {   // this thread's RPT rows of channel xc -> three (2 RPT)-byte plane pieces
         (void)kb;
@@ -1086,9 +1093,12 @@ __global__ __launch_bounds__(64 * NW, 2) void dw_rowsx_kernel(DwArgs p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = cbase + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if constexpr (RG) {
+                if (c < p.Cout && i0 + 32 * b + l31 < p.Cin) out[(int64_t)c * p.Cin + i0 + 32 * b + l31] = acc[b][r];
+            } else
             out[(int64_t)c * CI + 32 * b + l31] = acc[b][r];
         }
-    if (p.db_partial && tid < CB) p.db_partial[(int64_t)blockIdx.x * p.part_ld + blockIdx.y * CB + tid] = 0.f;
+    if (p.db_partial && tid < CB && (!RG || (blockIdx.z == 0 && (int)blockIdx.y * CB + tid < p.Cout))) p.db_partial[(int64_t)blockIdx.x * p.part_ld + blockIdx.y * CB + tid] = 0.f;
 }
 
 static unsigned long long *g_dw_dbg = nullptr;
@@ -1336,9 +1346,13 @@ static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 // row-streaming kernel (dw_rows_kernel): which layers take it (PAPC_DW_ROWS=0: none).  Measured on config 2's SA1 with one workgroup
 // per CU (papc_mlp_bwd_dw_chunk_hint): 64 -> 64 dense 99.5 -> 81 us; 64 -> 128 under the max 119 -> ~110 us although its two 64-channel
 // blocks of Cout transform the input twice; dW family 0.85 -> 0.82 ms/step.
+static bool dw_rowsx_ragged(int Cin, int Cout)      // the ragged flavours (RG): the 196-channel layer pair [128, 196, 256]
+{
+    return (Cin == 128 && Cout == 196) || (Cin == 196 && Cout == 256);
+}
 static bool dw_rowsx_eligible(int Cin, int Cout, bool dense, int K)   // dw_rowsx_kernel: 128-channel input, 256-channel blocks of Cout
 {
-    return knob(KNOB_DW_ROWSX) != 0 && Cin == 128 && Cout % 128 == 0 && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));   // (+ rowsx_rows_ok at the launch)
+    return knob(KNOB_DW_ROWSX) != 0 && ((Cin == 128 && Cout % 128 == 0) || dw_rowsx_ragged(Cin, Cout)) && !dw_f32_exact() && (dense || (K >= 16 && K % 16 == 0));   // (+ rowsx_rows_ok at the launch)
 }
 static bool dw_rows_eligible(int Cin, int Cout, bool dense, int K)
 {
@@ -1379,8 +1393,12 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
         }
         return check_launch("papc_mlp_bwd_dw_f32 (compacted)");
     }
-    if (VEC && XMODE == A_BNRELU && rowsx_rows_ok && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0) {
-        if (p.Cout % 256 == 0) {
+    if (VEC && XMODE == A_BNRELU && rowsx_rows_ok && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0 &&
+        (!dw_rowsx_ragged(p.Cin, p.Cout) || p.M * (int64_t)p.Cin * 4 < (1ll << 32))) {      // (ragged: 32-bit byte offsets into x as well)
+        if (dw_rowsx_ragged(p.Cin, p.Cout)) {
+            dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)cdiv(p.Cout, 256), (unsigned)cdiv(p.Cin, 128));
+            hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 8, false, true>), g2, dim3(512), 0, st, p);
+        } else if (p.Cout % 256 == 0) {
             dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)(p.Cout / 256));
             hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 8>), g2, dim3(512), 0, st, p);
         } else {        // 128-channel blocks: four waves per workgroup, two workgroups per CU
@@ -1446,7 +1464,8 @@ extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mo
     int dev = 0;
     static int ncu = 0;
     if (!ncu) { ncu = 256; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    const int64_t want = xk ? (Cout % 256 == 0 ? std::max<int64_t>(1, ncu / (Cout / 256)) : std::max<int64_t>(1, 2 * ncu / (Cout / 128)))
+    const int64_t want = xk ? (dw_rowsx_ragged(Cin, Cout) ? std::max<int64_t>(1, ncu / (cdiv(Cout, 256) * cdiv(Cin, 128)))
+                                  : Cout % 256 == 0 ? std::max<int64_t>(1, ncu / (Cout / 256)) : std::max<int64_t>(1, 2 * ncu / (Cout / 128)))
                             : std::max<int64_t>(1, ncu / ((Cout / 64) * (Cin / 64)));
     int64_t rpc = cdiv(M, want);
     rpc = std::max<int64_t>(64, cdiv(rpc, 64) * 64);
