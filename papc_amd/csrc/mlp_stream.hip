@@ -104,16 +104,21 @@ __device__ __forceinline__ void split3_pair(f32x2 x, unsigned &p0, unsigned &p1,
 // weights and the constants are zero beyond KV; the last k block is a PARTIAL block of one 16-byte load per streamed array (channels KV - 4 ..
 // KV - 1, read by BOTH half-waves -- the upper half's copy meets zero weights) that rides on the last chunk of full blocks.
 // NR (ragged n): Nout is not a multiple of the column block; weight rows beyond it are zero in LDS, their stores and statistics are masked.
-template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false>
+// CBW (with NR): a column block owns CBW < 32 WN columns and keeps CBW + 1 weight rows in LDS -- the last one zeros, which the lanes of the
+// boundary tile beyond column CBW read -- so that 196 columns are TWO blocks of 98 (four tiles each, two passes over the operand) where
+// whole tiles would need three passes (K = 256: 96 whole-tile rows are the most that fit beside the constants).
+template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32>
 __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo geo)
 {
     static_assert(!CP || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && EPI == EPI_STORE_RED && ASM && PAPC_STREAM_PK), "CP: dX flavours of the asm ring only");
     constexpr int NW = 8;
-    constexpr int K = KB16 * 16;
+    constexpr bool KR = (KV != KB16 * 16);
+    // K = extent of the LDS images (weight planes, constants).  Ragged k: KV + 4 -- the partial block's fragment reads of the UPPER half-wave
+    // (k = KV + 4 .. KV + 11) run into the next plane / the row's zeroed pad, and that half's operand is forced to zero in the transform
+    constexpr int K = KR ? KV + 4 : KB16 * 16;
     constexpr int NT = WN * 32;
-    constexpr bool KR = (KV != K);
     constexpr int KBF = KR ? KB16 - 1 : KB16;      // full k blocks
-    static_assert(!KR || (KV == K - 12 && !CP && PAPC_STREAM_PK && (AMODE == A_BNRELU || AMODE == A_DY_DENSE || AMODE == A_PLAIN)), "ragged k: four channels in the last block");
+    static_assert(!KR || (KV == KB16 * 16 - 12 && !CP && PAPC_STREAM_PK && (AMODE == A_BNRELU || AMODE == A_DY_DENSE || AMODE == A_PLAIN)), "ragged k: four channels in the last block");
     static_assert(!NR || (EPI == EPI_STORE || EPI == EPI_STORE_RED), "ragged n: storing epilogues without the group max");
     constexpr int NCH = KBF / CK;
     static_assert(KBF % CK == 0 && NCH >= 2 && NCH % 2 == 0, "an even number of chunks per tile");
@@ -130,10 +135,15 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     constexpr int CLB = CK * NLD;                                                     // ... per chunk of full blocks = registers of a ring buffer
     constexpr int CL = CLB + NLDP;                                                    // ... per chunk at most
     static_assert(CL <= 60, "vmcnt is a 6-bit field");
-    constexpr int ROWB = 6 * K + 16;          // LDS bytes of one weight row: [plane 0 | plane 1 | plane 2] bf16 + 16 (odd number of 16-B slots)
+    constexpr int ROWB = 6 * K + (KR ? 32 : 16);   // LDS bytes of one weight row: [plane 0 | plane 1 | plane 2] bf16 + pad (odd number of 16-B slots)
+    static_assert((ROWB / 16) % 2 == 1 && ROWB % 16 == 0, "conflict-free fragment reads");
     constexpr int NCST = (AMODE == A_BNRELU || MC) ? 2 : (DY ? 5 : (XYZ ? 4 : 0));
-    constexpr int W_BYTES = NT * ROWB;
-    constexpr int CST_BYTES = NCST * K * 4;
+    constexpr bool CB = (CBW != NT);
+    constexpr int TB = CBW / 32;                  // CB: the boundary tile
+    static_assert(!CB || (NR && TB == WN - 1 && CBW % 32 != 0), "a narrow column block ends inside its last tile");
+    constexpr int NROW = CB ? CBW + 1 : NT;       // weight rows in LDS
+    constexpr int W_BYTES = NROW * ROWB;
+    constexpr int CST_BYTES = NCST * K * 4 + (KR ? 32 : 0);      // (ragged k: the upper half-wave reads 8 constants past the last array; never used)
     constexpr bool XR = (EPI == EPI_XYZ_RED);   // dX folded straight into the four sums of a coordinates-only first layer's backward: nothing stored
     constexpr int NSUM = XR ? 4 : 2;
     constexpr int RED_BYTES = NSUM * NW * NT * 4;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int n0 = blockIdx.y * NT;
+    const int n0 = blockIdx.y * CBW;
     const int ldx = (int)(DY ? p.a.d.C : p.a.ldx);     // row stride (floats) of the streamed operand(s)
     // loads of chunk ci (compile time): uniform except MAXCAT, whose sparse blocks take 4 and dense blocks 2
     auto nld_of = [](int ci) constexpr -> int { return MC ? ((ci % NCH) < KS ? 4 : 2) : (CK * NLD + ((ci % NCH) == NCH - 1 ? NLDP : 0)); };
@@ -153,10 +163,10 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     {
         const float *wb = p.w + (int64_t)n0 * p.ldw;
         // all of the thread's pieces are loaded before the first is used: one exposed L2 round trip, not NI of them
-        constexpr int NP = NT * (K / 4);                  // float4 pieces of the block's weights
+        constexpr int NP = NROW * (K / 4);                // float4 pieces of the block's weights
         constexpr int NI = (NP + NW * 64 - 1) / (NW * 64);
         constexpr bool PG = (NP % (NW * 64) != 0);        // (guarded last round)
-        static_assert(KR || !PG, "whole float4 pieces per thread");
+        static_assert(KR || CB || !PG, "whole float4 pieces per thread");
         float4 wv[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
@@ -166,6 +176,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             if constexpr (KR) ok = ok && k4 < KV;
             if constexpr (PG) ok = ok && i < NP;
             if constexpr (NR) ok = ok && n0 + n < p.Nout;
+            if constexpr (CB) ok = ok && n < CBW;
             wv[q] = ok ? ld4(wb + (int64_t)n * p.ldw + k4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -179,6 +190,12 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 *reinterpret_cast<uint2 *>(d) = q0;
                 *reinterpret_cast<uint2 *>(d + 2 * K) = q1;
                 *reinterpret_cast<uint2 *>(d + 4 * K) = q2;
+            }
+        }
+        if constexpr (KR) {      // the rows' pads are READ (plane 2, upper half-wave of the partial block): zeros
+            for (int n = tid; n < NROW; n += NW * 64) {
+                *reinterpret_cast<uint4 *>(smem + n * ROWB + 6 * K) = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4 *>(smem + n * ROWB + 6 * K + 16) = make_uint4(0u, 0u, 0u, 0u);
             }
         }
         float *cf = reinterpret_cast<float *>(cstb);
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         for (int r = 0; r < 16; ++r) acc[wn][r] = 0.f;
 
     const char *wl = smem + l31 * ROWB + hi * 16;        // this lane's weight-fragment row (tile 0, plane 0, k block 0)
+    const char *wlb = smem + min(TB * 32 + l31, CBW) * ROWB + hi * 16;   // CB: ... in the boundary tile (the zero row beyond column CBW)
     const char *cl = cstb + hi * 32;                     // this lane's constants (k block 0)
     int kin = 0;                                         // DY_MAX: this lane's row offset inside its group (CP: its absolute row)
     float wcur = -1.f;                                   // CP: MINUS the multiplicity weight of this lane's row in the current tile
@@ -418,6 +436,9 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                         }
                     }
                 }
+                if constexpr (NJ == 2) {      // (partial block: the upper half-wave holds a copy of the same four channels -- its k does not exist)
+                    if (hi) { v2[0] = f32x2{0.f, 0.f}; v2[1] = f32x2{0.f, 0.f}; }
+                }
                 unsigned q0[4], q1[4], q2[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -472,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             for (int wn = 0; wn < WN; ++wn)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    bq[wn][pl] = *reinterpret_cast<const bf16x8 *>(wl + wn * 32 * ROWB + pl * 2 * K + kb * 32);
+                    bq[wn][pl] = *reinterpret_cast<const bf16x8 *>(((CB && wn == TB) ? wlb : wl + wn * 32 * ROWB) + pl * 2 * K + kb * 32);
             // smallest terms first; consecutive MFMAs go to different accumulators
             constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -511,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         const int col = NR ? min(colr, p.Nout - 1) : colr;       // (NR: masked lanes read a valid column's constants and never store)
         s1[wn] = 0.f; s2[wn] = 0.f; s3[wn] = 0.f; s4[wn] = 0.f;
         kq[wn] = XR ? ld4(p.rd.scale + 4 * col) : make_float4(0.f, 0.f, 0.f, 0.f);
-        biasv[wn] = (!CP && !(KR && DY) && p.bias && colr == col) ? p.bias[col] : 0.f;     // (CP, ragged-k dX: no bias in a dX product; a compile-time zero frees WN registers at the limit)
+        biasv[wn] = (!CP && !(KR && DY) && p.bias && colr == col && (!CB || wn * 32 + l31 < CBW)) ? p.bias[col] : 0.f;     // (CP, ragged-k dX: no bias in a dX product; a compile-time zero frees WN registers at the limit)
         rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
         if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[col]; rsh[wn] = p.rd.shift[col]; rmu[wn] = p.rd.mean[col]; ris[wn] = p.rd.invstd[col]; }
         gmx[wn] = -INFINITY; gmn[wn] = INFINITY; gix[wn] = 0; gin[wn] = 0;
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
 #pragma unroll
         for (int wn = 0; wn < WN; ++wn) {
             const int col = n0 + wn * 32 + l31;
-            const bool cok = !NR || col < p.Nout;
+            const bool cok = (!NR || col < p.Nout) && (!CB || wn * 32 + l31 < CBW);
             float *yp = p.y + (int64_t)(row0 + 4 * hi) * ldy + col;
             if (EPI == EPI_STORE_RED) {
                 if (cok) {
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
             // statistics: [part][which][Nout]; XR: [part][Nout][4], the layout papc_xyz_l1_bwd_finalize_f32 reads
             const int64_t col_off = XR ? (int64_t)(n0 + c) * 4 + which : (int64_t)which * p.Nout + n0 + c;
             const int64_t row_ld = (int64_t)NSUM * p.Nout;
-            if (NR && n0 + c >= p.Nout) continue;
+            if ((NR && n0 + c >= p.Nout) || (CB && c >= CBW)) continue;
             p.stats[(int64_t)blockIdx.x * row_ld + col_off] = t;
             for (int r = blockIdx.x + gridDim.x; r < p.parts; r += gridDim.x) p.stats[(int64_t)r * row_ld + col_off] = 0.f;
         }
@@ -739,7 +760,7 @@ static int stream_ncu()
     return ncu;
 }
 
-template <int AMODE, int EPI, int KB16, int WN, bool CP = false, int KV = KB16 * 16, bool NR = false>
+template <int AMODE, int EPI, int KB16, int WN, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32>
 static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
@@ -747,7 +768,7 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     constexpr int KBF = KR ? KB16 - 1 : KB16;
     constexpr int CK2 = (KBF == 6) ? 1 : 2;   // (six k blocks: an even chunk count needs 1 or 3 per chunk, and 3 spills the asm-loaded ring)
     constexpr int CK = (KBF < 4 || AMODE == A_DY_MAX || AMODE == A_MAXCAT || (AMODE == A_DY_DENSE && (WN == 4 || KR)) || (AMODE == A_PLAIN && KB16 == 8 && WN == 4)) ? 1 : CK2;
-    const int ncb = (p.Nout + 32 * WN - 1) / (32 * WN);
+    const int ncb = (p.Nout + CBW - 1) / CBW;
     // one workgroup per CU in total (weights + 8 waves of up to 256 registers fill it); column blocks of the same rows are
     // gridDim.x apart in the flat id, i.e. on the same XCD when gridDim.x % 8 == 0: the second reader of a row finds it in L2
     int gx = std::max(8, (stream_ncu() / ncb) & ~7);
@@ -761,7 +782,7 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
         return rc ? rc : 1;
     }
     if constexpr (AMODE == A_XYZ) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);   // (no streamed operand: no asm ring)
-    else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR>), grid, dim3(512), 0, st, p, geo);
+    else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);
     else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX || EPI == EPI_XYZ_RED || KR || NR) return 0;   // (the compiler-scheduled ring of these flavours spills / is not built: the caller falls back)
     else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);
     const int rc = check_launch("mlp stream gemm");
@@ -782,8 +803,8 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     if (p.Kin == 196 || p.Nout == 196) {
         if constexpr (AMODE == A_BNRELU && EPI == EPI_STORE) { if (p.Kin == 128 && p.Nout == 196) return stream_go<AMODE, EPI, 8, 4, false, 128, true>(p, geo, st); }
         if constexpr (AMODE == A_BNRELU && (EPI == EPI_STORE_GMAX || EPI == EPI_STORE)) { if (p.Kin == 196 && p.Nout % 128 == 0) return stream_go<AMODE, EPI, 13, 4, false, 196>(p, geo, st); }
-        if constexpr (AMODE == A_DY_MAX && EPI == EPI_STORE_RED) { if (p.Kin == 256 && p.Nout == 196) return stream_go<AMODE, EPI, 16, 3, false, 256, true>(p, geo, st); }
-        if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE_RED) { if (p.Kin == 196 && p.Nout % 64 == 0) return stream_go<AMODE, EPI, 13, 2, false, 196>(p, geo, st); }
+        if constexpr (AMODE == A_DY_MAX && EPI == EPI_STORE_RED) { if (p.Kin == 256 && p.Nout == 196) return stream_go<AMODE, EPI, 16, 4, false, 256, true, 98>(p, geo, st); }
+        if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE_RED) { if (p.Kin == 196 && p.Nout % 128 == 0) return stream_go<AMODE, EPI, 13, 4, false, 196>(p, geo, st); }
         return 0;
     }
     // N tile: as many columns as the weights' LDS image allows (6 K + 16 bytes per column, <= ~100 KB), at most 128
