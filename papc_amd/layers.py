@@ -12,6 +12,8 @@ Deliberate, flagged deviations from the source:
   ``reference_quirks=True`` restores both behaviours (SA parameters frozen, gather gradients cut).
   * as in the source, the SA BatchNorms always normalise with batch statistics (``.eval()`` never reaches them).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -178,6 +180,17 @@ class PointNetSetAbstraction(nn.Module):
         return new_xyz.transpose(1, 2), new_points                              # :220-221
 
 
+MSG_BRANCH_STREAMS = os.environ.get("PAPC_MSG_STREAMS", "1") != "0"     # the MSG layers' radius branches on parallel streams
+_BRANCH_STREAMS = {}
+
+
+def _branch_streams(dev, n):
+    lst = _BRANCH_STREAMS.setdefault(str(dev), [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:n]
+
+
 class PointNetSetAbstractionMsg(nn.Module):
     def __init__(self, npoint, radius_list, nsample_list, in_channel, mlp_list, reference_quirks=False, init_dist=1.0):
         super().__init__()
@@ -274,22 +287,41 @@ class PointNetSetAbstractionMsg(nn.Module):
             idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz)   # :260-262, one scan
             if feats is not None:
                 cplans = [self._branch_plan(i, idxs[i]) for i in range(R)]
-        outs = []
         feats_in = feats
         padded = None
         if feats_in is not None and D % 4 != 0:          # (one padded copy of the features for all branches)
             padded = (pad_cols(feats_in, D, (-D) % 4), D)
-        for i, K in enumerate(self.nsample_list):
+        # The radius branches are independent until the concatenation (:264-280): branch i > 0 runs on its own stream (forked from / joined
+        # into the caller's -- inside a hipGraph capture these become parallel graph branches), so one branch's launch-sized kernels
+        # (BatchNorm finalizes, partial folds, the dependency gaps around them) run beside another branch's GEMMs.  Autograd replays each
+        # branch's backward on the stream its forward ran on.
+        par = MSG_BRANCH_STREAMS and xyz.is_cuda and R > 1
+        side = _branch_streams(xyz.device, R - 1) if par else None
+        main = torch.cuda.current_stream(xyz.device) if par else None
+
+        def branch(i, K):
             params = _stack_params(self.conv_blocks[i], self.bn_blocks[i])
-            Dp = D
+            Dp, feats_i = D, feats
             if feats_in is not None:
-                feats, params, Dp = _pad_features(feats_in, params, False, padded)
+                feats_i, params, Dp = _pad_features(feats_in, params, False, padded)
             spec = StackSpec(B, N, S, K, Dp, xyz_first=False, eps=self.bn_blocks[i][0].eps, momentum=0.9,
                              cut_gather_grad=self.reference_quirks)             # feats first, then xyz (:267)
             if feats_in is not None:
                 spec.compact = cplans[i]
-            o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats, idxs[i], params)   # :271-276
-            outs.append(o.view(B, S, -1))
+            o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats_i, idxs[i], params)   # :271-276
+            return o.view(B, S, -1)
+
+        outs = [None] * R
+        for i, K in enumerate(self.nsample_list):
+            if par and i > 0:
+                side[i - 1].wait_stream(main)
+                with torch.cuda.stream(side[i - 1]):
+                    outs[i] = branch(i, K)
+            else:
+                outs[i] = branch(i, K)
+        if par:
+            for s_ in side:
+                main.wait_stream(s_)
         new_points_concat = cat_copy(outs, 2).transpose(1, 2)                   # :280  [B,D',S]
         return new_xyz.transpose(1, 2), new_points_concat
 
