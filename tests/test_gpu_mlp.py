@@ -297,6 +297,53 @@ def test_full_size_config3_msg_sa1(dev):
     assert_close(out[:, :64].detach().cpu().numpy(), ref, REL, "config-3 branch r=0.1 vs f64 oracle")
 
 
+def test_full_size_config3_msg_sa2_196_branch(dev):
+    """BASELINE config 3, the second SA2 branch at full size (B=16, 512 -> 128 centroids, r = 0.8, K = 128, 320 + 3 -> 128 -> 196 -> 256,
+    M = 262 144 rows; segment/pointnet2/pointnet2.py:63): the ragged flavours of the row-streaming kernels (196 = 12 k blocks + 4
+    channels / 6 column tiles + 4 columns) against the float64 oracle at the size the bench runs, and their gradients against the tiled
+    kernels' (PAPC_STREAM=0, PAPC_DW_ROWSX=0: other kernels, same exact-split products)."""
+    B, N, S, K, D = 16, 512, 128, 128, 320
+    mlp = [128, 196, 256]
+    rng = np.random.default_rng(77)
+    x = make_clouds(B, N, 77)[:, :3]
+    feats = rng.normal(size=(B, D, N)).astype(np.float32)
+    st = make_start_idx(B, N, 77)
+    ws = [seeded_weights([D + 3] + mlp, 91)]
+    gout = torch.from_numpy(rng.normal(size=(B, mlp[-1], S)).astype(np.float32)).to(dev)
+
+    def run(knobs):
+        lib = _lib.load()
+        old = {}
+        for n, v in knobs.items():
+            o = _lib.ctypes.c_int(0)
+            _lib.check(lib.papc_knob_get(n.encode(), _lib.ctypes.byref(o)), "papc_knob_get")
+            old[n] = o.value
+            _lib.check(lib.papc_knob_set(n.encode(), v), "papc_knob_set")
+        try:
+            layer = PointNetSetAbstractionMsg(S, [0.8], [K], D, [mlp]).to(dev)
+            _load_stack(layer.conv_blocks[0], layer.bn_blocks[0], ws[0], dev)
+            tf = torch.from_numpy(feats).to(dev).requires_grad_(True)
+            _, out = layer(torch.from_numpy(x).to(dev), tf, torch.from_numpy(st).to(dev))
+            out.backward(gout)
+            torch.cuda.synchronize()
+            grads = [p.grad.detach().cpu().numpy() for n_, p in layer.named_parameters() if not n_.endswith("bias") or "bn_blocks" in n_]
+            return out.detach().cpu().numpy(), grads, tf.grad.cpu().numpy()
+        finally:
+            for n, v in old.items():
+                _lib.check(lib.papc_knob_set(n.encode(), v), "papc_knob_set")
+
+    out, grads, gf = run({})
+    assert out.shape == (B, mlp[-1], S) and np.isfinite(out).all()
+    ora = R.PointNetSetAbstractionMsg(S, [0.8], [K], D, [mlp], ws)
+    _, ref = ora.forward(x, feats, st, f64=True)
+    assert_close(out, ref, REL, "config-3 SA2 branch [128, 196, 256] vs f64 oracle (full size)")
+    out_t, grads_t, gf_t = run({"PAPC_STREAM": 0, "PAPC_DW_ROWSX": 0})
+    assert_close(out, out_t, 2e-6, "ragged stream kernels vs tiled, forward")
+    for a_, b_ in zip(grads, grads_t):
+        assert_close(a_, b_, 1e-4, "ragged stream / row-streaming dW vs tiled, parameter gradients")
+    assert_close(gf, gf_t, 1e-4, "ragged stream vs tiled, feature gradient")
+
+
 @pytest.mark.parametrize("env", [
     {"PAPC_GEMM_F32": "1", "PAPC_DW_F32": "1"},   # the exact-fp32 MFMA flavour (v_mfma_f32_32x32x2_f32) of every GEMM
     {"PAPC_GEMM_WS": "3"},                        # the opt-in wave-specialised forward / dX GEMM
