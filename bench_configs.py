@@ -199,9 +199,12 @@ def run(args):
     torch.cuda.synchronize()
     lib.papc_prof_enable(0x3FF)
     lib.papc_prof_reset()
+    from papc_amd import layers as _layers0
+    _par0, _layers0.MSG_BRANCH_STREAMS = _layers0.MSG_BRANCH_STREAMS, False     # (family times: one kernel on the device at a time, see below)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    _layers0.MSG_BRANCH_STREAMS = _par0
     fam = _prof_read(lib)
     lib.papc_prof_enable(0)
     cand = [k for k in fam if k in work and fam[k][0] > 0]
@@ -230,9 +233,14 @@ def run(args):
         n_roof = min(args.steps, 20)
         lib.papc_prof_enable(1 << dominant)
         lib.papc_prof_reset()
+        # kernel quality is measured with the kernels ALONE on the device: the MSG layers' parallel branch streams (layers.py) are a
+        # throughput device of the timed region -- beside another branch's kernels a launch's begin-to-end time says nothing about it
+        from papc_amd import layers as _layers
+        _par, _layers.MSG_BRANCH_STREAMS = _layers.MSG_BRANCH_STREAMS, False
         for _ in range(n_roof):
             step_eager()
         torch.cuda.synchronize()
+        _layers.MSG_BRANCH_STREAMS = _par
     dom_ms, dom_n = _prof_read(lib)[dominant]
     lib.papc_prof_enable(0)
     final_loss = float(loss.item()) if loss.dim() == 0 else float(loss.float().mean().item())
@@ -253,7 +261,7 @@ def run(args):
                            "hbm_floor_ms": round(t_hbm * 1e3, 4)}
     roof["launches_per_step"] = dom_n // n_roof
     roof["ms_per_step"] = round(dom_ms / n_roof, 4)
-    roof["timing"] = ("HIP event pairs around every launch of the family, %d eager steps right after the graph-replayed timed region" % n_roof) if use_graph \
+    roof["timing"] = ("HIP event pairs around every launch of the family, %d eager steps right after the graph-replayed timed region (branches in series: one kernel on the device at a time)" % n_roof) if use_graph \
         else "HIP event pairs around every launch of the family over the timed region (eager launches)"
     # HBM traffic of the family from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/refresh_profiles.sh),
     # read back from the committed per-family summary of the latest round

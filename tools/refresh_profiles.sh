@@ -16,6 +16,8 @@ for c in msg_seg pfn basic; do
   timeout 400 python bench.py --config $c > $O/bench_line_$c.json 2> $O/bench_line_$c.err
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_$c -o run -- python bench.py --config $c --no-cpu-baseline --steps 20 --warmup 5 > $O/prof_stats_$c.log 2>&1
 done
+# config 3 again with its radius branches in series (PAPC_MSG_STREAMS=0): per-kernel durations with one kernel on the device at a time
+PAPC_MSG_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_msg_seg_serial -o run -- python bench.py --config msg_seg --no-cpu-baseline --steps 20 --warmup 5 > $O/prof_stats_msg_seg_serial.log 2>&1
 for cfg in pfn msg_seg basic; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${cfg}_$c -o run -- python bench.py --config $cfg --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_${cfg}_$c.log 2>&1

@@ -25,6 +25,7 @@ for c in msg_seg pfn basic; do
   cp $O/prof_stats_$c/run_kernel_stats.csv $P/${R}_cfg_${c}_kernel_stats.csv
   grep "^{" $O/bench_line_$c.json > $P/${R}_cfg_${c}_bench_line.json
 done
+[ -f $O/prof_stats_msg_seg_serial/run_kernel_stats.csv ] && cp $O/prof_stats_msg_seg_serial/run_kernel_stats.csv $P/${R}_cfg_msg_seg_serial_kernel_stats.csv
 {
   echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of: python bench.py --config pfn --no-cpu-baseline --steps 6 --warmup 2  (KB per dispatch; FETCH_SIZE x2 on gfx950)"
   python tools/pmc_summary.py $O/pmc_pfn_FETCH_SIZE 8
