@@ -124,12 +124,16 @@ def run(args):
         work = {8: (2.0 * P * T * 9 * 64 + 2.0 * P * T * 11 * 11, 3 * feat + P * 64 * 4.0 * 4)}
     flat = FlatParams(model)
     opt = FlatAdam(flat, lr=1e-3, weight_decay=1e-3)
+    # the flat gradient bucket starts as zeros and every backward here is followed by an optimiser step, so the step kernel clears it
+    # (papc_adam_step_zero_f32) instead of a clear_grad launch at the head of the next step (PAPC_ZERO_IN_ADAM=0: the separate fill)
+    ZERO_IN_ADAM = os.environ.get("PAPC_ZERO_IN_ADAM", "1") != "0"
     overlap = args.config == "msg_seg" and getattr(args, "overlap", True)
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream() if overlap else None
 
     def fwd_bwd(plan_in=None, plan_out=None):
-        flat.zero_grad()
+        if not ZERO_IN_ADAM:
+            flat.zero_grad()
         if loss_fn is None:                        # PFN: forward + backward of the layer under a given upstream gradient
             out = model(tv, tn, tc)
             out.backward(gout)
@@ -152,7 +156,7 @@ def run(args):
 
     def step_eager():
         loss = fwd_bwd()
-        opt.step(flat.allreduce_grads())
+        opt.step(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
         return loss
 
     # zero_grad + forward + loss + backward captured once into a hipGraph and replayed (as in bench.py); Adam stays an eager launch
@@ -191,7 +195,7 @@ def run(args):
         i = graph["i"] % len(graph["g"])
         graph["i"] += 1
         graph["g"][i].replay()
-        opt.step(flat.allreduce_grads())
+        opt.step(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
         return graph["loss"][i]
 
     for _ in range(max(1, args.warmup)):
@@ -291,7 +295,7 @@ def run(args):
     out = {"metric": metric, "value": round(units * args.steps / elapsed, 2), "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": workload, "final_loss": round(final_loss, 4), "launch": "hipGraph replay of zero_grad+fwd+loss+bwd, eager Adam" if use_graph else "eager",
+           "config": {"workload": workload, "final_loss": round(final_loss, 4), "launch": ("hipGraph replay of fwd+loss+bwd, eager Adam (which also clears the gradient bucket)" if ZERO_IN_ADAM else "hipGraph replay of zero_grad+fwd+loss+bwd, eager Adam") if use_graph else "eager",
                       "sampling": ("software-pipelined: batch i+1's FPS / ball queries / compact plans / 3-NN searches run as a second branch (side stream) of "
                                    "batch i's graph, two alternating graphs; every timed step computes one full set") if (overlap and use_graph) else "in-line",
                       "families_ms_per_step": {K_NAMES[k]: round(v[0] / 3, 4) for k, v in fam.items() if v[0] > 0}},

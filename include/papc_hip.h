@@ -798,6 +798,11 @@ int papc_scale_by_f32(const float *x, const float *scalar, int64_t n, float *out
 int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                        float lr, double beta1, double beta2, float eps, float weight_decay, int step,
                        float grad_scale, papc_stream_t stream);
+/* the same step, and grad[i] = 0 behind it: the next step's in-place gradient accumulation starts from zeros without an
+ * optimizer.clear_grad() launch of its own (PAPC/train.py:87) */
+int papc_adam_step_zero_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                            float lr, double beta1, double beta2, float eps, float weight_decay, int step,
+                            float grad_scale, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Event profiler (bench.py's live per-kernel durations).  Off by default.

@@ -163,6 +163,7 @@ SIGNATURES = {
     "papc_reduce_partials_strided_f32": (c_i, [c_p, c_i, c_l, c_i, c_i, c_p, c_l, c_i, c_p]),
     "papc_scale_by_f32": (c_i, [c_p, c_p, c_l, c_p, c_p]),
     "papc_adam_step_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, ctypes.c_double, ctypes.c_double, c_f, c_f, c_i, c_f, c_p]),
+    "papc_adam_step_zero_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, ctypes.c_double, ctypes.c_double, c_f, c_f, c_i, c_f, c_p]),
     "papc_knob_set": (c_i, [ctypes.c_char_p, c_i]),
     "papc_knob_get": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),
     "papc_prof_enable": (c_i, [ctypes.c_uint]),

@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void reduce_partials_wide_kernel(const float *
     }
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, int64_t n, float lr, float b1, float b2, float omb1, float omb2,
                                                    float eps, float wd, float bc1, float bc2, float gscale)
 {
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         const float vi = b2 * v[i] + omb2 * gi * gi;
         m[i] = mi; v[i] = vi;
         p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        if (ZERO) g[i] = 0.f;
     }
 }
 
@@ -929,19 +931,36 @@ int papc_transpose_batch_f32(const float *const *src, float *const *dst, const i
     return check_launch("papc_transpose_batch_f32");
 }
 
-int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
-                       float lr, double beta1, double beta2, float eps, float weight_decay, int step,
-                       float grad_scale, papc_stream_t stream)
+static int adam_step(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2, float eps,
+                     float weight_decay, int step, float grad_scale, bool zero, papc_stream_t stream, const char *who)
 {
-    PAPC_REQUIRE(param && grad && exp_avg && exp_avg_sq, PAPC_E_INVALID, "papc_adam_step_f32: null pointer");
-    PAPC_REQUIRE(n >= 1 && step >= 1, PAPC_E_INVALID, "papc_adam_step_f32: bad n/step");
+    PAPC_REQUIRE(param && grad && exp_avg && exp_avg_sq, PAPC_E_INVALID, "%s: null pointer", who);
+    PAPC_REQUIRE(n >= 1 && step >= 1, PAPC_E_INVALID, "%s: bad n/step", who);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
     // everything that depends on the betas only is formed in double here (the optimiser's hyper-parameters are doubles on the host)
     const float bc1 = (float)(1.0 - pow(beta1, (double)step)), bc2 = (float)(1.0 - pow(beta2, (double)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, (float)beta1, (float)beta2,
-                       (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc1, bc2, grad_scale);
-    return check_launch("papc_adam_step_f32");
+    if (zero)
+        hipLaunchKernelGGL(adam_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, (float)beta1, (float)beta2,
+                           (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc1, bc2, grad_scale);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, (float)beta1, (float)beta2,
+                           (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc1, bc2, grad_scale);
+    return check_launch(who);
+}
+
+int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                       float lr, double beta1, double beta2, float eps, float weight_decay, int step,
+                       float grad_scale, papc_stream_t stream)
+{
+    return adam_step(param, const_cast<float *>(grad), exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, false, stream, "papc_adam_step_f32");
+}
+
+int papc_adam_step_zero_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
+                            float lr, double beta1, double beta2, float eps, float weight_decay, int step,
+                            float grad_scale, papc_stream_t stream)
+{
+    return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, true, stream, "papc_adam_step_zero_f32");
 }
 
 }  // extern "C"

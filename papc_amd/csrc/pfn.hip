@@ -40,7 +40,40 @@ struct PfnArgs {
     float *red; float *dwp;
     double *gram;    // PFN_GRAM: [gridDim.x][256] partial Gram matrices
     int with_dist;   // PFN_DECORATE only: also write ||xyz|| as a 10th channel (pillars.py:92-94)
+    // PFN_GRAM with ticket != NULL: the workgroup that finishes last folds the partials and writes the BatchNorm constants (pfn_gram_finalize_body)
+    unsigned *ticket; const float *gamma, *beta; float eps, momentum; double Mrows; int Cfin;
+    float *o_mean, *o_invstd, *o_scale, *o_shift, *rmean, *rvar; double *gram_out;
 };
+
+// ---- last-arriving workgroup ------------------------------------------------------------------------------------------
+// The Gram pass and the backward fold end in a one-workgroup tail (BatchNorm constants / dW from folded sums).  As launches of their own
+// these tails are 5-9 us of launch + dependency latency around ~3 us of work; here the workgroup that finishes LAST runs them: every
+// workgroup publishes its partial row, takes a ticket, and the holder of the last ticket does the tail.  No device-scope fence: a release
+// fence writes back EVERYTHING dirty in the XCD's L2 (the previous kernels' outputs -- measured here: +60 us per frame), so the partial rows
+// are written and read with agent-scope accesses instead (pfn_st / pfn_ld: they bypass the per-XCD L2), ordered against the ticket by
+// waiting for the stores' acknowledgements (workgroup-scope release = s_waitcnt vmcnt(0)).  The ticket word returns to zero for the next
+// launch.
+template <class T>
+__device__ __forceinline__ void pfn_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ T pfn_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool pfn_last_block(unsigned *ticket)
+{
+    __shared__ unsigned s_last;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's agent-scope stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (s_last) pfn_st(ticket, 0u);
+    }
+    __syncthreads();
+    return s_last != 0u;
+}
+template <bool COH>
+__device__ void pfn_gram_finalize_body(const double *part, int n_blocks, double M, const float *w, int C, const float *gamma, const float *beta,
+                                       float eps, float momentum, float *mean, float *invstd, float *scale, float *shift, float *rmean, float *rvar,
+                                       double *gram);
 
 enum { PFN_STATS = 0, PFN_APPLY = 1, PFN_BWD_RED = 2, PFN_BWD_DW = 3, PFN_DECORATE = 4, PFN_GRAM = 5, PFN_BWD_SPARSE = 6 };
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -254,8 +287,15 @@ __global__ __launch_bounds__(64 * WAVES) void pfn_kernel(PfnArgs a)
                 double sum = 0.0;
 #pragma unroll
                 for (int g = 0; g < PFN_WAVES; ++g) sum += dred[(g * 4 + r) * 64 + lane];
-                a.gram[(int64_t)blockIdx.x * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15)] = sum;
+                double *dst = a.gram + (int64_t)blockIdx.x * 256 + ((lane >> 4) + 4 * r) * 16 + (lane & 15);
+                if (a.ticket) pfn_st(dst, sum);
+                else *dst = sum;
             }
+        }
+        if constexpr (WAVES == 16) {      // (the fold wants 1024 threads)
+            if (a.ticket && pfn_last_block(a.ticket))
+                pfn_gram_finalize_body<true>(a.gram, (int)gridDim.x, a.Mrows, a.w, a.Cfin, a.gamma, a.beta, a.eps, a.momentum, a.o_mean, a.o_invstd, a.o_scale,
+                                       a.o_shift, a.rmean, a.rvar, a.gram_out);
         }
         return;
     }
@@ -422,10 +462,10 @@ constexpr int PFN_GN = 11;             // channels of G that are used: 9 decorat
 
 // gram_partial [n_blocks][256] -> G [16][16] (f64, fixed summation tree), then the train-mode BatchNorm constants of the
 // 9 -> C linear layer straight from G (see the file header).  One workgroup of 1024 threads: 128 entry lanes x 8 block slices.
-__global__ __launch_bounds__(1024) void pfn_gram_finalize_kernel(const double *__restrict__ part, int n_blocks, double M, const float *__restrict__ w,
-                                                                int C, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                                float eps, float momentum, float *mean, float *invstd, float *scale,
-                                                                float *shift, float *rmean, float *rvar, double *gram)
+template <bool COH>     // COH: the partial rows were written by other workgroups of THIS launch (agent-scope loads)
+__device__ void pfn_gram_finalize_body(const double *part, int n_blocks, double M, const float *w, int C, const float *gamma, const float *beta,
+                                       float eps, float momentum, float *mean, float *invstd, float *scale, float *shift, float *rmean, float *rvar,
+                                       double *gram)
 {
     __shared__ double red[8][128];
     __shared__ double G[PFN_GN][PFN_GN];
@@ -436,7 +476,10 @@ __global__ __launch_bounds__(1024) void pfn_gram_finalize_kernel(const double *_
         for (int b = sl; b < n_blocks; b += 8 * 16) {   // 16 loads in flight per thread: the kernel is a latency chain
             double v[16];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = (b + 8 * q < n_blocks) ? part[(int64_t)(b + 8 * q) * 256 + gi * 16 + gj] : 0.0;
+            for (int q = 0; q < 16; ++q) {
+                const double *src = part + (int64_t)(b + 8 * q) * 256 + gi * 16 + gj;
+                v[q] = (b + 8 * q < n_blocks) ? (COH ? pfn_ld(src) : *src) : 0.0;
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) s += v[q];
         }
@@ -480,16 +523,24 @@ __global__ __launch_bounds__(1024) void pfn_gram_finalize_kernel(const double *_
     }
 }
 
+__global__ __launch_bounds__(1024) void pfn_gram_finalize_kernel(const double *__restrict__ part, int n_blocks, double M, const float *__restrict__ w,
+                                                                int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                float eps, float momentum, float *mean, float *invstd, float *scale,
+                                                                float *shift, float *rmean, float *rvar, double *gram)
+{
+    pfn_gram_finalize_body<false>(part, n_blocks, M, w, C, gamma, beta, eps, momentum, mean, invstd, scale, shift, rmean, rvar, gram);
+}
+
 // sums [11][C] (sum p, sum p*xhat, T[c][0..8]; reduced over the workgroups by papc_reduce_partials_f32) + G -> dgamma, dbeta, dW [C][9]
-__global__ __launch_bounds__(64) void pfn_bwd_finalize_kernel(const float *__restrict__ sums, double M, const float *__restrict__ w, int C,
-                                                             const double *__restrict__ gram, const float *__restrict__ mean,
-                                                             const float *__restrict__ invstd, const float *__restrict__ scale,
-                                                             float *dgamma, float *dbeta, float *dw, int flags)
+template <bool COH>
+__device__ __forceinline__ void pfn_bwd_finalize_body(const float *sums, double M, const float *w, int C, const double *gram, const float *mean,
+                                                      const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int flags)
 {
     const int eval_bn = flags & 1, accumulate = flags & 2;   // bit 1: add into dgamma / dbeta / dw (a parameter's .grad)
     const int c = threadIdx.x;
     if (c >= C) return;
-    const double s1 = (double)sums[0 * C + c], s2 = (double)sums[1 * C + c];
+    auto ld = [&](int i) -> float { return COH ? pfn_ld(sums + i) : sums[i]; };
+    const double s1 = (double)ld(0 * C + c), s2 = (double)ld(1 * C + c);
     dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
     dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     const double sc = (double)scale[c];
@@ -505,10 +556,50 @@ __global__ __launch_bounds__(64) void pfn_bwd_finalize_kernel(const float *__res
 #pragma unroll
         for (int l = 0; l < 9; ++l) wg += wc[l] * gram[l * 16 + k];
         const double colsum = gram[k * 16 + 10];
-        const double t = (double)sums[(2 + k) * C + c];
+        const double t = (double)ld((2 + k) * C + c);
         const float g = (float)(sc * (t - c1 * colsum - c2 * is * (wg - mu * colsum)));
         dw[c * 9 + k] = accumulate ? dw[c * 9 + k] + g : g;
     }
+}
+
+__global__ __launch_bounds__(64) void pfn_bwd_finalize_kernel(const float *__restrict__ sums, double M, const float *__restrict__ w, int C,
+                                                             const double *__restrict__ gram, const float *__restrict__ mean,
+                                                             const float *__restrict__ invstd, const float *__restrict__ scale,
+                                                             float *dgamma, float *dbeta, float *dw, int flags)
+{
+    pfn_bwd_finalize_body<false>(sums, M, w, C, gram, mean, invstd, scale, dgamma, dbeta, dw, flags);
+}
+
+// The fold of the sparse pass's partial rows (the summation order of reduce_partials_kernel, bn_ops.hip: 64 elements x 16 chunk lanes, 8 loads
+// in flight) with the finalize above as the last-arriving workgroup's tail: one launch instead of two.
+__global__ __launch_bounds__(1024) void pfn_bwd_fold_finalize_kernel(const float *__restrict__ part, int n_chunks, int64_t n, float *sums, unsigned *ticket,
+                                                                    double M, const float *w, int C, const double *gram, const float *mean,
+                                                                    const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int flags)
+{
+    __shared__ float red[16][64];
+    const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + el;
+    float s = 0.f;
+    if (i < n) {
+        for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + 16 * j;
+                v[j] = part[(int64_t)(t < n_chunks ? t : t0) * n + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (t0 + 16 * j < n_chunks) ? v[j] : 0.f;
+        }
+    }
+    red[cl][el] = s;
+    __syncthreads();
+    if (cl == 0 && i < n) {
+#pragma unroll
+        for (int g = 1; g < 16; ++g) s += red[g][el];
+        pfn_st(sums + i, s);
+    }
+    if (pfn_last_block(ticket)) pfn_bwd_finalize_body<true>(sums, M, w, C, gram, mean, invstd, scale, dgamma, dbeta, dw, flags);
 }
 
 static int pfn_blocks(int P) { return (int)std::min<int64_t>(cdiv(P, PFN_WAVES), 1024); }
@@ -564,6 +655,55 @@ __global__ __launch_bounds__(256) void pfn_decorate_nf_kernel(const float *__res
         o[F + 3] = (x - pcx) * mk; o[F + 4] = (y - pcy) * mk;
         if (with_dist) o[F + 5] = sqrtf((x * x + y * y) + z * z) * mk;                      // (:92-94)
     }
+}
+
+// ---- the fused launches papc_pfn_fwd / papc_pfn_bwd (sa_mlp.hip) use -------------------------------------------------------------
+static unsigned *g_pfn_tickets = nullptr;      // two ticket words (Gram pass, backward fold), zero between launches
+unsigned *pfn_tickets()
+{
+    // (first use must be outside a stream capture, like every lazily created constant of this library; on failure the callers keep
+    // the separate finalize launches)
+    if (!g_pfn_tickets) {
+        unsigned *t = nullptr;
+        if (hipMalloc(&t, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(t, 0, 64) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t); return nullptr; }
+        g_pfn_tickets = t;
+    }
+    return g_pfn_tickets;
+}
+
+// papc_pfn_gram_f32 + papc_pfn_gram_finalize_f32 in one launch
+int pfn_gram_stats(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset,
+                   double *gram_partial, const float *w, int C, const float *gamma, const float *beta, float eps, float momentum, float *mean, float *invstd,
+                   float *scale, float *shift, float *running_mean, float *running_var, double *gram, unsigned *ticket, hipStream_t st)
+{
+    const float dummy = 0.f;
+    int rc = pfn_check("papc_pfn_fwd (gram)", features, num_voxels, coors, P, T, &dummy, 1);
+    if (rc) return rc;
+    PAPC_REQUIRE(gram_partial && gram && ticket && w && mean && invstd && scale && shift, PAPC_E_INVALID, "papc_pfn_fwd (gram): null pointer");
+    PAPC_REQUIRE(C >= 1 && C <= 64, PAPC_E_UNSUPPORTED, "papc_pfn_fwd (gram): C=%d not in [1,64]", C);
+    PfnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
+    a.C = 1; a.gram = gram_partial;
+    a.ticket = ticket; a.w = w; a.Cfin = C; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.Mrows = (double)((int64_t)P * T);
+    a.o_mean = mean; a.o_invstd = invstd; a.o_scale = scale; a.o_shift = shift; a.rmean = running_mean; a.rvar = running_var; a.gram_out = gram;
+    ProfScope prof(PAPC_K_PFN, st);
+    hipLaunchKernelGGL((pfn_kernel<PFN_GRAM, PFN_GRAM_WAVES>), dim3(papc_pfn_gram_blocks(P)), dim3(64 * PFN_GRAM_WAVES), 0, st, a);
+    return check_launch("papc_pfn_fwd (gram + statistics)");
+}
+
+// papc_reduce_partials_f32 + papc_pfn_bwd_finalize_f32 in one launch
+int pfn_bwd_fold_finalize(const float *partial, int n_chunks, float *sums, int64_t M, const float *w, int C, const double *gram, const float *mean,
+                          const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int flags, unsigned *ticket, hipStream_t st)
+{
+    PAPC_REQUIRE(partial && sums && w && gram && mean && invstd && scale && dgamma && dbeta && dw && ticket, PAPC_E_INVALID, "papc_pfn_bwd (fold): null pointer");
+    PAPC_REQUIRE(C >= 1 && C <= 64 && M >= 1 && n_chunks >= 1, PAPC_E_UNSUPPORTED, "papc_pfn_bwd (fold): C=%d not in [1,64]", C);
+    const int64_t n = (int64_t)PFN_NACC * C;
+    ProfScope prof(PAPC_K_PFN, st);
+    hipLaunchKernelGGL(pfn_bwd_fold_finalize_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, sums, ticket, (double)M, w, C, gram, mean,
+                       invstd, scale, dgamma, dbeta, dw, flags);
+    return check_launch("papc_pfn_bwd (fold + finalize)");
 }
 
 }  // namespace papc

@@ -22,6 +22,13 @@
     } while (0)
 
 namespace papc {
+// (pfn.hip: the fused launches of the PillarFeatureNet entry points below)
+unsigned *pfn_tickets();
+int pfn_gram_stats(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset,
+                   double *gram_partial, const float *w, int C, const float *gamma, const float *beta, float eps, float momentum, float *mean, float *invstd,
+                   float *scale, float *shift, float *running_mean, float *running_var, double *gram, unsigned *ticket, hipStream_t st);
+int pfn_bwd_fold_finalize(const float *partial, int n_chunks, float *sums, int64_t M, const float *w, int C, const double *gram, const float *mean,
+                          const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int flags, unsigned *ticket, hipStream_t st);
 
 constexpr int A_PLAIN_ = PAPC_A_PLAIN, A_BNRELU_ = PAPC_A_BNRELU, A_GROUP_ = PAPC_A_GROUP, A_XYZ_ = PAPC_A_XYZ;
 
@@ -821,9 +828,15 @@ int papc_pfn_fwd(const papc_pfn_desc *desc, const papc_pfn_io *io, papc_stream_t
     if (d.training) {
         // batch statistics from the inputs' Gram matrix: one float64-MFMA pass over the points instead of a C-channel pass over [P*T, C]
         const int ng = papc_pfn_gram_blocks(d.P);
-        SA_CALL(papc_pfn_gram_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, gpart, st));
-        SA_CALL(papc_pfn_gram_finalize_f32(gpart, ng, (int64_t)d.P * d.T, io->w, C, io->gamma, io->beta, d.eps, d.momentum, cst, cst + C, cst + 2 * C, cst + 3 * C,
-                                           io->running_mean, io->running_var, gram, st));
+        unsigned *tk = knob(KNOB_PFN_FUSED_TAILS) ? papc::pfn_tickets() : nullptr;
+        if (tk) {    // the Gram pass's last-arriving workgroup writes the BatchNorm constants (pfn.hip): one launch
+            SA_CALL(papc::pfn_gram_stats(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, gpart, io->w, C, io->gamma, io->beta,
+                                         d.eps, d.momentum, cst, cst + C, cst + 2 * C, cst + 3 * C, io->running_mean, io->running_var, gram, tk, as_stream(st)));
+        } else {
+            SA_CALL(papc_pfn_gram_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, gpart, st));
+            SA_CALL(papc_pfn_gram_finalize_f32(gpart, ng, (int64_t)d.P * d.T, io->w, C, io->gamma, io->beta, d.eps, d.momentum, cst, cst + C, cst + 2 * C, cst + 3 * C,
+                                               io->running_mean, io->running_var, gram, st));
+        }
     } else {
         PAPC_REQUIRE(io->running_mean && io->running_var, PAPC_E_INVALID, "papc_pfn_fwd: eval mode needs the running statistics");
         SA_CALL(papc_bn_eval_consts_f32(io->running_mean, io->running_var, io->gamma, io->beta, d.eps, C, cst, cst + C, cst + 2 * C, cst + 3 * C, st));
@@ -843,6 +856,10 @@ int papc_pfn_bwd(const papc_pfn_desc *desc, const papc_pfn_io *io, const float *
     // sparse pass (one argmax row per (pillar, channel)): sum p, sum p*xhat, sum p*x_k; the dense part of dW comes from the Gram matrix
     SA_CALL(papc_pfn_bwd_sparse_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, io->w, C, gout, argmax, cst, cst + C,
                                     cst + 2 * C, cst + 3 * C, part, st));
+    unsigned *tk = knob(KNOB_PFN_FUSED_TAILS) ? papc::pfn_tickets() : nullptr;
+    if (tk)      // the fold of the partial rows and the finalize in one launch (last-arriving workgroup, pfn.hip)
+        return papc::pfn_bwd_fold_finalize(part, nb, sums, (int64_t)d.P * d.T, io->w, C, gram, cst, cst + C, cst + 2 * C, dgamma, dbeta, dw,
+                                           (d.training ? 0 : 1) | (accumulate ? 2 : 0), tk + 1, as_stream(st));
     SA_CALL(papc_reduce_partials_f32(part, nb, 11 * (int64_t)C, sums, 0, st));
     return papc_pfn_bwd_finalize_f32(sums, (int64_t)d.P * d.T, io->w, C, gram, cst, cst + C, cst + 2 * C, dgamma, dbeta, dw, (d.training ? 0 : 1) | (accumulate ? 2 : 0), st);
 }

@@ -111,10 +111,13 @@ class FlatAdam:
         self.v = torch.zeros_like(flat.data)
         self.t = 0
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, zero_grad=False):
+        """``zero_grad=True``: the kernel also clears the flat gradient bucket behind the update (papc_adam_step_zero_f32), so a
+        training loop whose every backward is followed by a step needs no ``FlatParams.zero_grad()`` launch."""
         from . import _lib
         self.t += 1
         f = self.flat
-        _lib.check(_lib.load().papc_adam_step_f32(f.data.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                                  f.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
-                                                  float(grad_scale), _lib.stream_ptr()), "papc_adam_step_f32")
+        fn = _lib.load().papc_adam_step_zero_f32 if zero_grad else _lib.load().papc_adam_step_f32
+        _lib.check(fn(f.data.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                      f.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                      float(grad_scale), _lib.stream_ptr()), "papc_adam_step_f32")

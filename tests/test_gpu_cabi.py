@@ -292,3 +292,56 @@ def test_library_planes_orchestration_equals_the_python_one(dev, pool):
     assert torch.equal(o0, o1) and torch.equal(i0, i1)
     for a, b in zip(g0, g1):
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+
+
+def test_pfn_fused_tails_equal_the_separate_launches(dev):
+    """papc_pfn_fwd / _bwd with the BatchNorm constants and the dW finalize as the last-arriving workgroup's tail of the Gram pass / the fold
+    (PAPC_PFN_FUSED_TAILS=1, the default: 4 launches per frame) against the separate finalize launches (=0: 6): the same sums in the same
+    order, so every output is bit-identical -- over several frames in a row (the ticket words must return to zero) and at the full KITTI
+    frame size of BASELINE configs[4]."""
+    from papc_amd.pillars import PfnDesc, PfnIo
+    from papc_amd.synthetic import make_pillars
+    lib = _lib.load()
+
+    def run(P, T, Cc, seed, fused, reps):
+        old = ctypes.c_int(0)
+        _lib.check(lib.papc_knob_get(b"PAPC_PFN_FUSED_TAILS", ctypes.byref(old)), "papc_knob_get")
+        _lib.check(lib.papc_knob_set(b"PAPC_PFN_FUSED_TAILS", int(fused)), "papc_knob_set")
+        try:
+            voxels, nump, coors = make_pillars(P, T, seed=seed)
+            rng = np.random.default_rng(seed)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            feat, nv, co = t(voxels), t(nump), t(coors)
+            wt = t((rng.normal(size=(Cc, 9)) * 0.3).astype(np.float32))
+            gt = t(rng.uniform(0.5, 1.5, Cc).astype(np.float32))
+            bt = t((rng.normal(size=Cc) * 0.2).astype(np.float32))
+            gout = t(rng.normal(size=(P, Cc)).astype(np.float32))
+            d = PfnDesc(P, T, Cc, 0.16, 0.16, 0.08, -39.6, 1e-3, 0.01, 1)
+            sb, wb = ctypes.c_int64(0), ctypes.c_int64(0)
+            _lib.check(lib.papc_pfn_workspace(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(wb)), "papc_pfn_workspace")
+            saved = torch.empty(sb.value, device=dev, dtype=torch.uint8)
+            scr = torch.empty(wb.value, device=dev, dtype=torch.uint8)
+            out = torch.empty(P, Cc, device=dev)
+            rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+            io = PfnIo(feat.data_ptr(), nv.data_ptr(), co.data_ptr(), wt.data_ptr(), gt.data_ptr(), bt.data_ptr(), rm.data_ptr(), rv.data_ptr(), out.data_ptr(),
+                       saved.data_ptr(), scr.data_ptr())
+            st = torch.cuda.current_stream().cuda_stream
+            res = []
+            for r in range(reps):
+                dw, dg, db = torch.empty(Cc, 9, device=dev), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+                _lib.check(lib.papc_pfn_fwd(ctypes.byref(d), ctypes.byref(io), st), "papc_pfn_fwd")
+                _lib.check(lib.papc_pfn_bwd(ctypes.byref(d), ctypes.byref(io), gout.data_ptr(), dw.data_ptr(), dg.data_ptr(), db.data_ptr(), 0, st), "papc_pfn_bwd")
+                torch.cuda.synchronize()
+                res.append([x.clone() for x in (out, dw, dg, db, rm, rv)])
+                wt.mul_(1.01)          # (another frame's weights: the statistics must be recomputed, not remembered)
+            return res
+        finally:
+            _lib.check(lib.papc_knob_set(b"PAPC_PFN_FUSED_TAILS", old.value), "papc_knob_set")
+
+    for P, T, Cc, reps in ((1500, 100, 64, 4), (12000, 100, 64, 2), (37, 20, 16, 3)):
+        a = run(P, T, Cc, 11, 1, reps)
+        b = run(P, T, Cc, 11, 0, reps)
+        for ra, rb in zip(a, b):
+            for xa, xb, nm in zip(ra, rb, ("out", "dw", "dgamma", "dbeta", "running_mean", "running_var")):
+                assert torch.isfinite(xa).all(), nm
+                assert torch.equal(xa, xb), "fused tails: %s differs (P=%d)" % (nm, P)

@@ -116,6 +116,24 @@ def test_adam_kernel_vs_float64(dev):
     assert np.allclose(v.cpu().numpy(), V, rtol=2e-5, atol=1e-30)
     assert np.abs(p.cpu().numpy() - P).max() <= 1e-6
 
+def test_adam_step_zero_equals_step_then_clear(dev):
+    """papc_adam_step_zero_f32 == papc_adam_step_f32 followed by clearing the gradient: bit-identical parameters and moments, gradient all zeros"""
+    lib = _lib.load()
+    n = 100003
+    rng = np.random.default_rng(5)
+    p0 = torch.from_numpy(rng.normal(size=n).astype(np.float32)).to(dev)
+    pa, pb = p0.clone(), p0.clone()
+    ma, va, mb, vb = (torch.zeros(n, device=dev) for _ in range(4))
+    for t in range(1, 4):
+        g = torch.from_numpy((rng.normal(size=n) * 10.0 ** rng.uniform(-6, 1, size=n)).astype(np.float32)).to(dev)
+        ga, gb = g.clone(), g.clone()
+        _lib.check(lib.papc_adam_step_f32(pa.data_ptr(), ga.data_ptr(), ma.data_ptr(), va.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 1e-3, t, 0.5, _lib.stream_ptr()), "adam")
+        _lib.check(lib.papc_adam_step_zero_f32(pb.data_ptr(), gb.data_ptr(), mb.data_ptr(), vb.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 1e-3, t, 0.5, _lib.stream_ptr()), "adam")
+        torch.cuda.synchronize()
+        assert torch.equal(ga, g) and not gb.any()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
 
 def _stack_node(t):
     """the autograd node of the MLP stack behind a set-abstraction output [B, D', S] (transpose <- view <- stack)"""
