@@ -476,15 +476,9 @@ def main():
         n_roof = min(args.steps, 20)
         lib.papc_prof_enable(1 << dominant)
         lib.papc_prof_reset()
-        # (kernel quality = a launch's duration with the device to itself: for these steps the stacks' dW kernels stay on the main stream
-        # instead of beside the dX chain, PAPC_SA_BWD_FORK)
-        _fork = ctypes.c_int(0)
-        lib.papc_knob_get(b"PAPC_SA_BWD_FORK", ctypes.byref(_fork))
-        lib.papc_knob_set(b"PAPC_SA_BWD_FORK", 0)
         for _ in range(n_roof):
             step_eager()
         torch.cuda.synchronize()
-        lib.papc_knob_set(b"PAPC_SA_BWD_FORK", _fork.value)
     dom_ms, dom_n = prof_read(lib)[dominant]
     lib.papc_prof_enable(0)
     assert final_loss == final_loss, "loss is NaN"

@@ -205,15 +205,10 @@ def run(args):
     lib.papc_prof_reset()
     from papc_amd import layers as _layers0
     _par0, _layers0.MSG_BRANCH_STREAMS = _layers0.MSG_BRANCH_STREAMS, False     # (family times: one kernel on the device at a time, see below)
-    import ctypes as _ct
-    _fork0 = _ct.c_int(0)
-    lib.papc_knob_get(b"PAPC_SA_BWD_FORK", _ct.byref(_fork0))
-    lib.papc_knob_set(b"PAPC_SA_BWD_FORK", 0)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
     _layers0.MSG_BRANCH_STREAMS = _par0
-    lib.papc_knob_set(b"PAPC_SA_BWD_FORK", _fork0.value)
     fam = _prof_read(lib)
     lib.papc_prof_enable(0)
     cand = [k for k in fam if k in work and fam[k][0] > 0]
@@ -246,12 +241,10 @@ def run(args):
         # throughput device of the timed region -- beside another branch's kernels a launch's begin-to-end time says nothing about it
         from papc_amd import layers as _layers
         _par, _layers.MSG_BRANCH_STREAMS = _layers.MSG_BRANCH_STREAMS, False
-        lib.papc_knob_set(b"PAPC_SA_BWD_FORK", 0)      # (likewise the stacks' dW kernels: main stream, not beside the dX chain)
         for _ in range(n_roof):
             step_eager()
         torch.cuda.synchronize()
         _layers.MSG_BRANCH_STREAMS = _par
-        lib.papc_knob_set(b"PAPC_SA_BWD_FORK", _fork0.value)
     dom_ms, dom_n = _prof_read(lib)[dominant]
     lib.papc_prof_enable(0)
     final_loss = float(loss.item()) if loss.dim() == 0 else float(loss.float().mean().item())

@@ -432,31 +432,6 @@ __global__ void mul_vec_kernel(const float *__restrict__ a, const float *__restr
 
 using namespace papc;
 
-// ---- the dW kernels of a stack beside its dX chain ------------------------------------------------------------------------------
-// dW_l and dX_l read the same (dY_l, y_l, y_{l-1}); only dX_l feeds the layer below, dW_l feeds nothing before the partial fold at the end
-// of the call.  With PAPC_SA_BWD_FORK the dW launches go to a second stream forked behind the layer's BatchNorm-backward finalize and joined
-// ahead of the fold (inside a hipGraph capture: a parallel branch), so the dX chain's launch-sized kernels (finalizes, the dependency gaps
-// around them) and kernel tails run beside dW work instead of beside nothing.  One side stream + two events per caller stream (a small table:
-// the MSG layers call from several streams); created on first use, which must not be inside a capture.
-struct BwdFork { hipStream_t main, side; hipEvent_t ev_fork, ev_join; };
-static BwdFork g_forks[16];
-static int g_n_forks = 0;
-static BwdFork *fork_for(hipStream_t main)
-{
-    for (int i = 0; i < g_n_forks; ++i)
-        if (g_forks[i].main == main) return &g_forks[i];
-    if (g_n_forks == 16) return nullptr;
-    BwdFork f;
-    f.main = main;
-    if (hipStreamCreateWithFlags(&f.side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    g_forks[g_n_forks] = f;
-    return &g_forks[g_n_forks++];
-}
-
 extern "C" {
 
 int papc_sa_mlp_plan(const papc_sa_desc *desc, const papc_sa_io *io, papc_sa_plan *plan)
@@ -667,9 +642,6 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
 
     papc_reduce_job jobs[PAPC_SA_MAX_LAYERS];
     int n_jobs = 0;
-    // (three layers at most: deeper stacks alternate two dz buffers, and a dW still reading one must not meet the dX that refills it)
-    BwdFork *fk = (knob(KNOB_SA_BWD_FORK) && L <= 3 && M >= 32768) ? fork_for(as_stream(st)) : nullptr;
-    bool forked = false;
     bool xyz_fused = false;
     const float *dz = nullptr;
     const float *fused_red = nullptr;
@@ -751,33 +723,24 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
                                          b.wcat, b.hb, b.eq, b.eq + cout, st));     // (psel: written by the reduction above)
         }
         const bool x1 = p.xyz1 && l == 1;     // the input of this layer is the recomputed activation of the coordinates-only first layer
-        // ---- dW, db (on the side stream when forked: everything it reads exists behind this point of the main stream)
-        papc_stream_t sw = st;
-        if (fk) {
-            if (hipEventRecord(fk->ev_fork, as_stream(st)) != hipSuccess || hipStreamWaitEvent(fk->side, fk->ev_fork, 0) != hipSuccess) {
-                set_error("papc_sa_mlp_bwd: forking the dW stream failed: %s", hipGetErrorString(hipGetLastError()));
-                return PAPC_E_LAUNCH;
-            }
-            sw = reinterpret_cast<papc_stream_t>(fk->side);
-            forked = true;
-        }
+        // ---- dW, db
         if (p.nostore && l == L - 1) {
             const float *pc = s.cst[l - 1];
             SA_CALL(papc_mlp_bwd_dw_max_f32(b.psel, s.argmax, d.K, s.y[l - 1], pc + 2 * cin, pc + 3 * cin, ly.w, b.eq, cst + 2 * cout, c12, M, cin, cout, b.dwmax_ws,
-                                            gr->dw[l], acc_w ? 1 : 0, sw));
-            if (gr->db[l] && !acc_w) SA_CALL(papc_fill_f32(gr->db[l], cout, 0.f, sw));
+                                            gr->dw[l], acc_w ? 1 : 0, st));
+            if (gr->db[l] && !acc_w) SA_CALL(papc_fill_f32(gr->db[l], cout, 0.f, st));
         } else {
             const int am = l == 0 ? (plain ? A_PLAIN_ : A_GROUP_) : (x1 ? A_XYZ_ : A_BNRELU_);
             const int rpc = dw_chunk(p, l, am, dy.dz_mode);
             const int n_chunks = (int)((M + rpc - 1) / rpc);
             const int64_t pld = (int64_t)cout * cin + cout;
             float *dwp = b.part[l], *dbp = b.part[l] + (int64_t)cout * cin;
-            if (l == 0 && plain) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_PLAIN_, io->x_rows, cin, nullptr, nullptr, nullptr, M, cin, cout, rpc, dwp, dbp, pld, sw));
-            else if (l == 0) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_GROUP_, nullptr, 0, &grp, nullptr, nullptr, M, cin, cout, rpc, dwp, dbp, pld, sw));
-            else if (x1) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_XYZ_, xc, 4, nullptr, s.wf, nullptr, M, cin, cout, rpc, dwp, dbp, pld, sw));
+            if (l == 0 && plain) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_PLAIN_, io->x_rows, cin, nullptr, nullptr, nullptr, M, cin, cout, rpc, dwp, dbp, pld, st));
+            else if (l == 0) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_GROUP_, nullptr, 0, &grp, nullptr, nullptr, M, cin, cout, rpc, dwp, dbp, pld, st));
+            else if (x1) SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_XYZ_, xc, 4, nullptr, s.wf, nullptr, M, cin, cout, rpc, dwp, dbp, pld, st));
             else {
                 const float *pc = s.cst[l - 1];
-                SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_BNRELU_, s.y[l - 1], cin, nullptr, pc + 2 * cin, pc + 3 * cin, M, cin, cout, rpc, dwp, dbp, pld, sw));
+                SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_BNRELU_, s.y[l - 1], cin, nullptr, pc + 2 * cin, pc + 3 * cin, M, cin, cout, rpc, dwp, dbp, pld, st));
             }
             // the partials of all layers are folded in ONE launch once the stack's last dW kernel is enqueued
             papc_reduce_job &j = jobs[n_jobs++];
@@ -825,12 +788,6 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             memset(&sc, 0, sizeof(sc));
             sc.grad_feats = gr->grad_feats; sc.idx = io->idx; sc.N = d.N; sc.S = d.S; sc.K = d.K; sc.D = d.D; sc.col0 = d.xyz_first ? 3 : 0;
             SA_CALL(papc_mlp_bwd_dx_f32(&dy, wts[l], M, cin, cout, nullptr, &sc, nullptr, st));
-        }
-    }
-    if (forked) {      // join: the fold below (and whatever the caller enqueues next) comes behind the last dW kernel
-        if (hipEventRecord(fk->ev_join, fk->side) != hipSuccess || hipStreamWaitEvent(as_stream(st), fk->ev_join, 0) != hipSuccess) {
-            set_error("papc_sa_mlp_bwd: joining the dW stream failed: %s", hipGetErrorString(hipGetLastError()));
-            return PAPC_E_LAUNCH;
         }
     }
     if (n_jobs) SA_CALL(papc_reduce_partials_batch_f32(jobs, n_jobs, st));
