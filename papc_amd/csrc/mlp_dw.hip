@@ -1346,9 +1346,9 @@ static void dw_dbg_report(const DwArgs &p, int xm, int dm)
 // row-streaming kernel (dw_rows_kernel): which layers take it (PAPC_DW_ROWS=0: none).  Measured on config 2's SA1 with one workgroup
 // per CU (papc_mlp_bwd_dw_chunk_hint): 64 -> 64 dense 99.5 -> 81 us; 64 -> 128 under the max 119 -> ~110 us although its two 64-channel
 // blocks of Cout transform the input twice; dW family 0.85 -> 0.82 ms/step.
-static bool dw_rowsx_ragged(int Cin, int Cout)      // the ragged flavours (RG): the 196-channel layer pair [128, 196, 256]
+static bool dw_rowsx_ragged(int Cin, int Cout)      // the ragged flavours (RG): the 196-channel layer pair [128, 196, 256], the 96-channel pair [64, 96, 128]
 {
-    return (Cin == 128 && Cout == 196) || (Cin == 196 && Cout == 256);
+    return (Cin == 128 && Cout == 196) || (Cin == 196 && Cout == 256) || (Cin == 96 && Cout == 128) || (Cin == 64 && Cout == 96);
 }
 static bool dw_rowsx_eligible(int Cin, int Cout, bool dense, int K)   // dw_rowsx_kernel: 128-channel input, 256-channel blocks of Cout
 {
@@ -1395,7 +1395,10 @@ static int launch_dw_v(const DwArgs &p_in, hipStream_t st)
     }
     if (VEC && XMODE == A_BNRELU && rowsx_rows_ok && dw_rowsx_eligible(p.Cin, p.Cout, DYMODE == A_DY_DENSE, p.dy.d.K) && p.x.ldx == p.Cin && p.rows_per_chunk % 16 == 0 &&
         (!dw_rowsx_ragged(p.Cin, p.Cout) || p.M * (int64_t)p.Cin * 4 < (1ll << 32))) {      // (ragged: 32-bit byte offsets into x as well)
-        if (dw_rowsx_ragged(p.Cin, p.Cout)) {
+        if (dw_rowsx_ragged(p.Cin, p.Cout) && p.Cout <= 128) {     // one 128-channel block of Cout: four waves, two workgroups per CU
+            dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), 1u, (unsigned)cdiv(p.Cin, 128));
+            hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 4, false, true>), g2, dim3(256), 0, st, p);
+        } else if (dw_rowsx_ragged(p.Cin, p.Cout)) {
             dim3 g2((unsigned)cdiv(p.M, p.rows_per_chunk), (unsigned)cdiv(p.Cout, 256), (unsigned)cdiv(p.Cin, 128));
             hipLaunchKernelGGL((dw_rowsx_kernel<DYMODE, 8, false, true>), g2, dim3(512), 0, st, p);
         } else if (p.Cout % 256 == 0) {
@@ -1464,7 +1467,7 @@ extern "C" int papc_mlp_bwd_dw_chunk_hint(int64_t M, int Cin, int Cout, int a_mo
     int dev = 0;
     static int ncu = 0;
     if (!ncu) { ncu = 256; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
-    const int64_t want = xk ? (dw_rowsx_ragged(Cin, Cout) ? std::max<int64_t>(1, ncu / (cdiv(Cout, 256) * cdiv(Cin, 128)))
+    const int64_t want = xk ? (dw_rowsx_ragged(Cin, Cout) ? std::max<int64_t>(1, (Cout <= 128 ? 2 : 1) * ncu / (cdiv(Cout, 256) * cdiv(Cin, 128)))
                                   : Cout % 256 == 0 ? std::max<int64_t>(1, ncu / (Cout / 256)) : std::max<int64_t>(1, 2 * ncu / (Cout / 128)))
                             : std::max<int64_t>(1, ncu / ((Cout / 64) * (Cin / 64)));
     int64_t rpc = cdiv(M, want);
