@@ -473,15 +473,18 @@ __device__ void pfn_gram_finalize_body(const double *part, int n_blocks, double 
     const int gi = e / PFN_GN, gj = e - gi * PFN_GN;
     double s = 0.0;
     if (e < PFN_GN * PFN_GN) {
-        for (int b = sl; b < n_blocks; b += 8 * 16) {   // 16 loads in flight per thread: the kernel is a latency chain
-            double v[16];
+        // NF loads in flight per thread: the kernel is a latency chain (the last-arriving workgroup's loads go past its L2: one round of 32;
+        // the summation order -- blocks sl, sl + 8, ... -- does not depend on NF)
+        constexpr int NF = COH ? 32 : 16;
+        for (int b = sl; b < n_blocks; b += 8 * NF) {
+            double v[NF];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NF; ++q) {
                 const double *src = part + (int64_t)(b + 8 * q) * 256 + gi * 16 + gj;
                 v[q] = (b + 8 * q < n_blocks) ? (COH ? pfn_ld(src) : *src) : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) s += v[q];
+            for (int q = 0; q < NF; ++q) s += v[q];
         }
     }
     red[sl][e] = s;
@@ -581,15 +584,15 @@ __global__ __launch_bounds__(1024) void pfn_bwd_fold_finalize_kernel(const float
     const int64_t i = (int64_t)blockIdx.x * 64 + el;
     float s = 0.f;
     if (i < n) {
-        for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {
-            float v[8];
+        for (int t0 = cl; t0 < n_chunks; t0 += 16 * 32) {     // (32 loads in flight; the same summation order as with 8)
+            float v[32];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 32; ++j) {
                 const int t = t0 + 16 * j;
                 v[j] = part[(int64_t)(t < n_chunks ? t : t0) * n + i];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (t0 + 16 * j < n_chunks) ? v[j] : 0.f;
+            for (int j = 0; j < 32; ++j) s += (t0 + 16 * j < n_chunks) ? v[j] : 0.f;
         }
     }
     red[cl][el] = s;
