@@ -330,3 +330,55 @@ def test_full_size_config2_sa_vs_oracle(dev):
         l2_xyz, l2 = sa2(torch.from_numpy(ref_xyz1).to(dev), torch.from_numpy(l1_ref).to(dev), torch.from_numpy(s2).to(dev))
     assert np.array_equal(l2_xyz.cpu().numpy(), ref_xyz2)
     assert_close(l2.cpu().numpy(), ref2, 1e-5, "config-2 SA2 (M = 262144) vs f64 oracle")
+
+
+def test_msg_branch_streams_equal_serial_branches(dev):
+    """PointNetSetAbstractionMsg (pointnet2_basic_layers.py:264-280) with its radius branches on parallel streams (layers.MSG_BRANCH_STREAMS,
+    the default) against the serial branch order: the branches are independent until the concatenation, so outputs and parameter gradients
+    are bit-identical (the feature gradient is a float-atomic sum inside each branch and an autograd sum over the branches: tolerance) --
+    eagerly and inside a captured hipGraph, where the branch streams become parallel graph branches."""
+    from papc_amd import layers
+    B, N, S = 4, 1024, 256
+    radii, ks, mlps = [0.1, 0.2, 0.4], [16, 32, 64], [[32, 32, 64], [64, 64, 128], [64, 96, 128]]
+    x = torch.from_numpy(make_clouds(B, N, 21)).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 21)).to(dev)
+    gout = torch.randn(B, 320, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+
+    def run(par, graph):
+        old = layers.MSG_BRANCH_STREAMS
+        layers.MSG_BRANCH_STREAMS = par
+        try:
+            torch.manual_seed(5)
+            layer = PointNetSetAbstractionMsg(S, radii, ks, 3, mlps).to(dev)
+            pts = x.clone().requires_grad_(True)
+
+            def fwd_bwd():
+                _, out = layer(x, pts, st)
+                out.backward(gout)
+                return out
+
+            if graph:
+                fwd_bwd()                                        # (lazily created streams / constants outside the capture)
+                for p in list(layer.parameters()) + [pts]:
+                    p.grad = None
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                    out = fwd_bwd()
+                for p in list(layer.parameters()) + [pts]:
+                    p.grad.zero_()
+                g.replay()
+            else:
+                out = fwd_bwd()
+            torch.cuda.synchronize()
+            return out.detach().clone(), [p.grad.clone() for p in layer.parameters()], pts.grad.clone()
+        finally:
+            layers.MSG_BRANCH_STREAMS = old
+
+    o0, g0, f0 = run(False, False)
+    for par, graph in ((True, False), (True, True)):
+        o1, g1, f1 = run(par, graph)
+        assert torch.equal(o0, o1), "outputs differ (graph=%s)" % graph
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b), "a parameter gradient differs (graph=%s)" % graph
+        assert float((f0 - f1).abs().max()) <= 1e-5 * float(f0.abs().max())
