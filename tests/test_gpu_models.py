@@ -358,12 +358,16 @@ def test_msg_branch_streams_equal_serial_branches(dev):
                 return out
 
             if graph:
-                fwd_bwd()                                        # (lazily created streams / constants outside the capture)
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    fwd_bwd()                                    # (lazily created streams / constants outside the capture)
+                torch.cuda.current_stream().wait_stream(s)
                 for p in list(layer.parameters()) + [pts]:
                     p.grad = None
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                with torch.cuda.graph(g):
                     out = fwd_bwd()
                 for p in list(layer.parameters()) + [pts]:
                     p.grad.zero_()
