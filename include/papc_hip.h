@@ -49,7 +49,7 @@ const char *papc_last_error_string(void);
  * start_idx[b] replaces paddle.randint (:76); init_dist is 1.0f for reference parity (:75).
  * out_idx [B,npoint] int32; out_new_xyz [B,npoint,3] (may be NULL) = index_points(xyz, out_idx) (:144).
  * Bit-exact contract: dist = (dx*dx+dy*dy)+dz*dz, strict-< update, lowest index on ties.
- * Supports N <= 16384. */
+ * N <= 16384 runs the register-resident kernel; up to N = 131072 a slower kernel that re-reads the cloud from L2. */
 int papc_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                  const int64_t *start_idx, float init_dist, int32_t *out_idx, float *out_new_xyz,
                  papc_stream_t stream);

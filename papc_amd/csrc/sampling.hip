@@ -127,6 +127,59 @@ __global__ __launch_bounds__(T) void fps_kernel(const float *__restrict__ xyz, i
     }
 }
 
+// ---- clouds beyond the register-resident kernel (N > 16 384, up to 131 072: a KITTI sweep) -----------------------------------------
+// Same arithmetic, same first-maximum rule; what changes is where things live: 1024 threads per cloud, the running distances of a thread's PPT
+// points in its registers (as bit patterns), the coordinates re-read every iteration (the cloud is L2-resident: 12 N bytes), the candidate
+// {distance bits : ~index} keys folded by six 64-bit shuffle steps per wave and one LDS row per iteration parity (one barrier per iteration).
+// A capability path, not a tuned one: ~PPT x 3 loads per thread and iteration.
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sc, int N, int npoint,
+                                                       const int64_t *__restrict__ start, float init_dist, int32_t *__restrict__ out_idx,
+                                                       float *__restrict__ out_new_xyz)
+{
+    __shared__ u64 wkey[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    const float *p = xyz + (int64_t)b * sb;
+    u32 d[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) d[j] = (j * 1024 + tid < N) ? __float_as_uint(init_dist) : 0u;
+    int far = (int)start[b];
+    for (int it = 0; it < npoint; ++it) {
+        const float cx = p[(int64_t)far * sn], cy = p[(int64_t)far * sn + sc], cz = p[(int64_t)far * sn + 2 * sc];
+        if (tid == 0) {
+            out_idx[(int64_t)b * npoint + it] = far;
+            if (out_new_xyz) {
+                float *o = out_new_xyz + ((int64_t)b * npoint + it) * 3;
+                o[0] = cx; o[1] = cy; o[2] = cz;
+            }
+        }
+        u64 best = 0ull;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = j * 1024 + tid;
+            if (i < N) {
+                const float dx = p[(int64_t)i * sn] - cx, dy = p[(int64_t)i * sn + sc] - cy, dz = p[(int64_t)i * sn + 2 * sc] - cz;
+                const u32 a = __float_as_uint((dx * dx + dy * dy) + dz * dz);
+                d[j] = a < d[j] ? a : d[j];
+                const u64 k = ((u64)d[j] << 32) | (u64)(u32)~(u32)i;       // larger distance wins, then the smaller index
+                best = k > best ? k : best;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const u32 lo = (u32)__shfl_xor((int)(u32)best, m), hi = (u32)__shfl_xor((int)(u32)(best >> 32), m);
+            const u64 o = ((u64)hi << 32) | lo;
+            best = o > best ? o : best;
+        }
+        if (lane == 0) wkey[it & 1][wave] = best;
+        __syncthreads();
+        u64 k = wkey[it & 1][0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) { const u64 o = wkey[it & 1][w]; k = o > k ? o : k; }
+        far = (int)~(u32)k;
+    }
+}
+
 template <int T, int PPT>
 static int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                       const int64_t *start, float init_dist, int32_t *out_idx, float *out_new_xyz, hipStream_t st)
@@ -398,9 +451,15 @@ int papc_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, in
     PAPC_REQUIRE(xyz && start_idx && out_idx, PAPC_E_INVALID, "papc_fps_f32: null pointer");
     PAPC_REQUIRE(B >= 1 && N >= 1 && npoint >= 1, PAPC_E_INVALID, "papc_fps_f32: B=%d N=%d npoint=%d must be >= 1", B, N, npoint);
     PAPC_REQUIRE(init_dist >= 0.f, PAPC_E_INVALID, "papc_fps_f32: init_dist must be >= 0");
-    PAPC_REQUIRE(N <= 16384, PAPC_E_UNSUPPORTED, "papc_fps_f32: N=%d > 16384 not supported", N);
+    PAPC_REQUIRE(N <= 131072, PAPC_E_UNSUPPORTED, "papc_fps_f32: N=%d > 131072 points per cloud not supported", N);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_FPS, st);
+    if (N > 16384) {     // beyond the register-resident kernel: distances in registers, coordinates from L2 (fps_big_kernel)
+        if (N <= 32768) hipLaunchKernelGGL(fps_big_kernel<32>, dim3(B), dim3(1024), 0, st, xyz, sb, sn, sc, N, npoint, start_idx, init_dist, out_idx, out_new_xyz);
+        else if (N <= 65536) hipLaunchKernelGGL(fps_big_kernel<64>, dim3(B), dim3(1024), 0, st, xyz, sb, sn, sc, N, npoint, start_idx, init_dist, out_idx, out_new_xyz);
+        else hipLaunchKernelGGL(fps_big_kernel<128>, dim3(B), dim3(1024), 0, st, xyz, sb, sn, sc, N, npoint, start_idx, init_dist, out_idx, out_new_xyz);
+        return check_launch("papc_fps_f32 (large cloud)");
+    }
     // geometry (measured on MI355X, tools/probe/fps_time.py; us per iteration): up to 512 points ONE wave with 8 points per lane (0.32; no
     // barrier, no LDS word); from 1024 points 512 threads (N = 1024: 0.32 against 0.35 at 256 threads; N = 2048: 0.40 / 0.42; N = 4096:
     // 0.53, two waves per SIMD hide each other's DPP / LDS latency -- 1024 threads measure the same, 256 are 12 % slower)

@@ -17,7 +17,9 @@ def _cloud(B, N, seed):
 
 @pytest.mark.parametrize("B,N,npoint", [(2, 1024, 128), (1, 4096, 512), (3, 1000, 77), (2, 64, 64), (2, 37, 5), (1, 8192, 64),
                                         (1, 16384, 32), (4, 512, 128), (1, 1, 1), (2, 513, 40), (2, 1023, 64), (2, 1025, 64), (3, 300, 60),
-                                        (2, 100, 100), (16, 2048, 512), (1, 5000, 33)])
+                                        (2, 100, 100), (16, 2048, 512), (1, 5000, 33),
+                                        # beyond the register-resident kernel (fps_big_kernel: 32 / 64 / 128 points per thread)
+                                        (2, 16385, 16), (1, 30000, 40), (2, 50000, 24), (1, 131072, 12)])
 @pytest.mark.parametrize("planar", [False, True])
 def test_fps_index_exact(dev, B, N, npoint, planar):
     x, xyz = _cloud(B, N, 11 + N)
