@@ -204,11 +204,12 @@ def run(args):
     lib.papc_prof_enable(0x3FF)
     lib.papc_prof_reset()
     from papc_amd import layers as _layers0
-    _par0, _layers0.MSG_BRANCH_STREAMS = _layers0.MSG_BRANCH_STREAMS, False     # (family times: one kernel on the device at a time, see below)
+    _par0 = _layers0.set_branch_streams(model, False)     # (family times: one kernel on the device at a time, see below)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    _layers0.MSG_BRANCH_STREAMS = _par0
+    for _m, _v in _par0:
+        _m.branch_streams = _v
     fam = _prof_read(lib)
     lib.papc_prof_enable(0)
     cand = [k for k in fam if k in work and fam[k][0] > 0]
@@ -240,11 +241,12 @@ def run(args):
         # kernel quality is measured with the kernels ALONE on the device: the MSG layers' parallel branch streams (layers.py) are a
         # throughput device of the timed region -- beside another branch's kernels a launch's begin-to-end time says nothing about it
         from papc_amd import layers as _layers
-        _par, _layers.MSG_BRANCH_STREAMS = _layers.MSG_BRANCH_STREAMS, False
+        _par = _layers.set_branch_streams(model, False)
         for _ in range(n_roof):
             step_eager()
         torch.cuda.synchronize()
-        _layers.MSG_BRANCH_STREAMS = _par
+        for _m, _v in _par:
+            _m.branch_streams = _v
     dom_ms, dom_n = _prof_read(lib)[dominant]
     lib.papc_prof_enable(0)
     final_loss = float(loss.item()) if loss.dim() == 0 else float(loss.float().mean().item())

@@ -243,7 +243,9 @@ def const_zeros(shape, device):
 def const_idx3(B, N, device):
     """read-only int32 [B, N, 3] = (0, 1, 2) per row: the neighbour indices the reference's sort-then-argsort yields
     (pointnet2_basic_layers.py:316-317, see layers.PointNetFeaturePropagation).  ONE buffer per device, grown to the largest B*N seen
-    and handed out as a narrowed contiguous view (segmentation over varying batch / point counts does not accumulate one tensor per shape)."""
+    and handed out as a narrowed contiguous view (segmentation over varying batch / point counts does not accumulate one tensor per shape).
+    A buffer that has been handed out is NEVER freed: a captured hipGraph may have baked its address into a three_interpolate launch, so a
+    superseded buffer moves to a keep-alive list (growth is geometric: at most ~log2 of them, together below 2x the largest)."""
     import torch
     key = ("idx3", str(device))
     rows = int(B) * int(N)
@@ -252,7 +254,12 @@ def const_idx3(B, N, device):
         mk = lambda n: torch.arange(3, device=device, dtype=torch.int32).expand(n, 3).contiguous()
         if _capturing():
             return mk(rows).view(B, N, 3)
-        t = _CONSTS[key] = mk(rows)
+        if t is not None:
+            _CONSTS.setdefault(("idx3-retired", str(device)), []).append(t)
+            rows_alloc = max(rows, 2 * int(t.shape[0]))
+        else:
+            rows_alloc = rows
+        t = _CONSTS[key] = mk(rows_alloc)
     return t[:rows].view(B, N, 3)
 
 

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void bn_relu_max_kernel(const float *__restric
             const Vec<V> v = Vec<V>::load(yp + (int64_t)k * C);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
-                const float z = fmaxf(fmaf(sc[i], v[i], sh[i]), 0.f);
-                if (z > best[i]) { best[i] = z; bi[i] = k; }
+                const float z = relu_np(fmaf(sc[i], v[i], sh[i]));
+                if (z > best[i] || z != z) { best[i] = z; bi[i] = k; }      // (a NaN wins and stays: torch.max / paddle.max propagate it)
             }
         }
         best.store(out + g * C + c);
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void bn_select_max_kernel(float *__restrict__ 
         const float sc = scale[c], sh = shift[c];
         const bool up = sc >= 0.f;   // relu(sc*y+sh) is non-decreasing in y for sc >= 0, non-increasing otherwise
         const float sel = up ? gmax[e] : gmin[e];
-        out[e] = fmaxf(fmaf(sc, sel, sh), 0.f);
+        out[e] = relu_np(fmaf(sc, sel, sh));
         gmax[e] = sel;               // the raw pre-BN value behind out[e]: the backward reductions read it instead of gathering y
         if (argmax) argmax[e] = up ? amax[e] : amin[e];
     }
@@ -504,10 +504,10 @@ __global__ __launch_bounds__(1024) void bn_relu_max_split_kernel(const float *__
         for (int k = k0; k < k1; ++k) {
             const float4 v = ld4f(yp + (int64_t)k * C);
             float z;
-            z = fmaxf(fmaf(sc.x, v.x, sh.x), 0.f); if (z > best.x) { best.x = z; bi.x = k; }
-            z = fmaxf(fmaf(sc.y, v.y, sh.y), 0.f); if (z > best.y) { best.y = z; bi.y = k; }
-            z = fmaxf(fmaf(sc.z, v.z, sh.z), 0.f); if (z > best.z) { best.z = z; bi.z = k; }
-            z = fmaxf(fmaf(sc.w, v.w, sh.w), 0.f); if (z > best.w) { best.w = z; bi.w = k; }
+            z = relu_np(fmaf(sc.x, v.x, sh.x)); if (z > best.x || z != z) { best.x = z; bi.x = k; }
+            z = relu_np(fmaf(sc.y, v.y, sh.y)); if (z > best.y || z != z) { best.y = z; bi.y = k; }
+            z = relu_np(fmaf(sc.z, v.z, sh.z)); if (z > best.z || z != z) { best.z = z; bi.z = k; }
+            z = relu_np(fmaf(sc.w, v.w, sh.w)); if (z > best.w || z != z) { best.w = z; bi.w = k; }
         }
     }
     sv[sl][cq][0] = best.x; sv[sl][cq][1] = best.y; sv[sl][cq][2] = best.z; sv[sl][cq][3] = best.w;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(1024) void bn_relu_max_split_kernel(const float *__
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {       // slices in row order, strict >: the first row attaining the max wins
             const float v = sv[s2][q][i];
-            if (v > b) { b = v; bk = si[s2][q][i]; }
+            if (v > b || v != v) { b = v; bk = si[s2][q][i]; }
         }
         if (cc < C) {
             out[g * C + cc] = b;

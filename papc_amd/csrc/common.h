@@ -170,6 +170,10 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ReLU that lets a NaN through (v_max_f32 / fmaxf return the non-NaN operand): used where a pooled layer writes its OUTPUT, so that a
+// diverged stack (NaN weights -> NaN statistics -> NaN scale / shift) shows up as NaN downstream in the padded and the compacted form alike,
+// the way the reference's relu(max(.)) does (pointnet2_basic_layers.py:217-219)
+__device__ __forceinline__ float relu_np(float t) { return !(t <= 0.f) ? t : 0.f; }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace papc

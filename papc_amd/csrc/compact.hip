@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void seg_max_kernel(const float *__restrict__ 
         const bool up = s4[i] >= 0.f;
         ys[i] = up ? mx[i] : mn[i];
         am[i] = up ? ix[i] : in_[i];
-        o[i] = fmaxf(fmaf(s4[i], ys[i], h4[i]), 0.f);
+        o[i] = relu_np(fmaf(s4[i], ys[i], h4[i]));      // (NaN statistics -> NaN out, like the padded form: bn_select_max)
     }
     const int64_t q = (int64_t)g * C + c;
     *reinterpret_cast<float4 *>(out + q) = make_float4(o[0], o[1], o[2], o[3]);

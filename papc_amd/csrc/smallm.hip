@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void pg_final_kernel(const float *__restrict__
                 const float v = up ? gmax[e] : gmin[e];
                 if (up ? v > best : v < best) { best = v; arg = t * 128 + (up ? amax[e] : amin[e]); }
             }
-            out[g * C + c] = fmaxf(fmaf(sc, best, sh), 0.f);
+            out[g * C + c] = relu_np(fmaf(sc, best, sh));
             ysel[g * C + c] = best;
             argmax[g * C + c] = arg;
         }
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void pg_final_kernel(const float *__restrict__
     for (int64_t g = gl; g < G; g += 4) {
         const int64_t e = g * C + c;
         const float sel = up ? gmax[e] : gmin[e];
-        out[e] = fmaxf(fmaf(sc, sel, sh), 0.f);
+        out[e] = relu_np(fmaf(sc, sel, sh));
         gmax[e] = sel;               // ysel: the raw value behind out[e]
         argmax[e] = up ? amax[e] : amin[e];
     }

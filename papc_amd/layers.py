@@ -184,6 +184,16 @@ MSG_BRANCH_STREAMS = os.environ.get("PAPC_MSG_STREAMS", "1") != "0"     # the MS
 _BRANCH_STREAMS = {}
 
 
+def set_branch_streams(model, on):
+    """per-model switch for the MSG layers' parallel branch streams (None restores the process default); returns the previous settings"""
+    old = []
+    for m in model.modules():
+        if isinstance(m, PointNetSetAbstractionMsg):
+            old.append((m, m.branch_streams))
+            m.branch_streams = on
+    return old
+
+
 def _branch_streams(dev, n):
     lst = _BRANCH_STREAMS.setdefault(str(dev), [])
     while len(lst) < n:
@@ -210,6 +220,7 @@ class PointNetSetAbstractionMsg(nn.Module):
         self.init_dist = init_dist
         self.compact = None            # compacted branches (compact.py): None = decide once per branch from the data, True / False = forced
         self._compact_on = {}
+        self.branch_streams = None     # radius branches on parallel streams: None = the process default (PAPC_MSG_STREAMS), True / False = this layer
         if reference_quirks:
             for p in self.parameters():
                 p.requires_grad_(False)
@@ -240,6 +251,7 @@ class PointNetSetAbstractionMsg(nn.Module):
             cp = C.plan(idx, out)
             self._compact_on[i] = cp.fraction() <= C.AUTO_MAX_FRACTION
             return cp if self._compact_on[i] else None
+        self._compact_on[i] = True      # forced (compact=True / PAPC_COMPACT=1): sample() and forward() read the branch's layout from this one flag
         return C.plan(idx, out)
 
     def sample(self, xyz, start_idx=None, out=None):
@@ -255,7 +267,8 @@ class PointNetSetAbstractionMsg(nn.Module):
         res = [new_xyz] + list(idxs)
         pos = 1 + R
         for i in range(R):
-            have = out is not None and self._compact_on.get(i) is True and len(out) >= pos + 7
+            forced = self._branch_compact_mode(i, xyz.shape[0]) is True
+            have = out is not None and (forced or self._compact_on.get(i) is True) and len(out) >= pos + 7
             cp = self._branch_plan(i, idxs[i], out=tuple(out[pos:pos + 7]) if have else None)
             if cp is not None:
                 res += list(cp.tensors())
@@ -295,7 +308,7 @@ class PointNetSetAbstractionMsg(nn.Module):
         # into the caller's -- inside a hipGraph capture these become parallel graph branches), so one branch's launch-sized kernels
         # (BatchNorm finalizes, partial folds, the dependency gaps around them) run beside another branch's GEMMs.  Autograd replays each
         # branch's backward on the stream its forward ran on.
-        par = MSG_BRANCH_STREAMS and xyz.is_cuda and R > 1
+        par = (MSG_BRANCH_STREAMS if self.branch_streams is None else self.branch_streams) and xyz.is_cuda and R > 1
         side = _branch_streams(xyz.device, R - 1) if par else None
         main = torch.cuda.current_stream(xyz.device) if par else None
 
@@ -315,8 +328,18 @@ class PointNetSetAbstractionMsg(nn.Module):
         for i, K in enumerate(self.nsample_list):
             if par and i > 0:
                 side[i - 1].wait_stream(main)
+                # every tensor the branch reads was allocated on the caller's stream: tell the allocator the side stream uses it too, in the
+                # forward here and in the backward autograd replays on the same stream (a freed block is otherwise handed to the next
+                # main-stream allocation while a side-stream kernel may still be reading it)
+                shared = [xyz, new_xyz, idxs[i], feats_in, None if padded is None else padded[0]]
+                if cplans[i] is not None:
+                    shared += list(cplans[i].tensors())
+                for t in shared:
+                    if t is not None:
+                        t.record_stream(side[i - 1])
                 with torch.cuda.stream(side[i - 1]):
                     outs[i] = branch(i, K)
+                outs[i].record_stream(main)     # (consumed by the concatenation on the caller's stream)
             else:
                 outs[i] = branch(i, K)
         if par:

@@ -333,8 +333,8 @@ def test_full_size_config2_sa_vs_oracle(dev):
 
 
 def test_msg_branch_streams_equal_serial_branches(dev):
-    """PointNetSetAbstractionMsg (pointnet2_basic_layers.py:264-280) with its radius branches on parallel streams (layers.MSG_BRANCH_STREAMS,
-    the default) against the serial branch order: the branches are independent until the concatenation, so outputs and parameter gradients
+    """PointNetSetAbstractionMsg (pointnet2_basic_layers.py:264-280) with its radius branches on parallel streams (`layer.branch_streams`,
+    on by default) against the serial branch order: the branches are independent until the concatenation, so outputs and parameter gradients
     are bit-identical (the feature gradient is a float-atomic sum inside each branch and an autograd sum over the branches: tolerance) --
     eagerly and inside a captured hipGraph, where the branch streams become parallel graph branches."""
     from papc_amd import layers
@@ -345,11 +345,10 @@ def test_msg_branch_streams_equal_serial_branches(dev):
     gout = torch.randn(B, 320, S, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
 
     def run(par, graph):
-        old = layers.MSG_BRANCH_STREAMS
-        layers.MSG_BRANCH_STREAMS = par
-        try:
+        if True:
             torch.manual_seed(5)
             layer = PointNetSetAbstractionMsg(S, radii, ks, 3, mlps).to(dev)
+            layer.branch_streams = par          # (per-layer switch: no module-level state is touched)
             pts = x.clone().requires_grad_(True)
 
             def fwd_bwd():
@@ -376,8 +375,6 @@ def test_msg_branch_streams_equal_serial_branches(dev):
                 out = fwd_bwd()
             torch.cuda.synchronize()
             return out.detach().clone(), [p.grad.clone() for p in layer.parameters()], pts.grad.clone()
-        finally:
-            layers.MSG_BRANCH_STREAMS = old
 
     o0, g0, f0 = run(False, False)
     for par, graph in ((True, False), (True, True)):
