@@ -37,8 +37,8 @@ K_MLP_GEMM, K_BN_RELU_MAX, K_BWD_REDUCE, K_BWD_DX, K_BWD_DW, K_FPS, K_BQ = 3, 4,
 
 
 def ssg_layers(B, N):
-    """(M rows, [channel widths]) of the three SA stacks of PointNet2_SSG_Clas for one per-GPU batch."""
-    return [(B * 512 * 32, [3, 64, 64, 128], 0), (B * 128 * 64, [131, 128, 128, 256], 128), (B * 1 * 128, [259, 256, 512, 1024], 256)]
+    """(M rows, [channel widths], D feature channels, source points) of the three SA stacks of PointNet2_SSG_Clas for one per-GPU batch."""
+    return [(B * 512 * 32, [3, 64, 64, 128], 0, B * N), (B * 128 * 64, [131, 128, 128, 256], 128, B * 512), (B * 1 * 128, [259, 256, 512, 1024], 256, B * 128)]
 
 
 def algorithmic_work(B, N):
@@ -49,7 +49,7 @@ def algorithmic_work(B, N):
       dW   layer: read y_l (+ dz_l when dense) + read the input rows (M x Cin)"""
     w = {}
     f_fwd = f_dx = b_fwd = b_dx = b_dw = 0.0
-    for M, ch, D in ssg_layers(B, N):
+    for M, ch, D, _ in ssg_layers(B, N):
         for l in range(3):
             cin, cout = ch[l], ch[l + 1]
             dense = l < 2                                   # the last layer's dz comes from the small max-pooled gradient
@@ -68,9 +68,68 @@ def algorithmic_work(B, N):
     w[K_BWD_DX] = (f_dx, b_dx)
     w[K_FPS] = (0.0, (B * 512 * N + B * 128 * 512) * 20.0)
     w[K_BQ] = (0.0, (B * 512 * N + B * 128 * 512) * 12.0)
-    w[K_BN_RELU_MAX] = (0.0, sum(M * ch[3] * 4.0 for M, ch, _ in ssg_layers(B, N)))
-    w[K_BWD_REDUCE] = (0.0, sum(2.0 * M * (ch[1] + ch[2]) * 4.0 for M, ch, _ in ssg_layers(B, N)))
+    w[K_BN_RELU_MAX] = (0.0, sum(M * ch[3] * 4.0 for M, ch, _, _ in ssg_layers(B, N)))
+    w[K_BWD_REDUCE] = (0.0, sum(2.0 * M * (ch[1] + ch[2]) * 4.0 for M, ch, _, _ in ssg_layers(B, N)))
     return w
+
+
+def moved_work(B, N, plans, rows_sa2=None):
+    """Bytes (and FLOP) the launches of each GEMM family REALLY process per step: `algorithmic_work` with the tensors dropped that the
+    round-3/4 paths no longer move and the compacted stack priced on its device-side row count.  ``plans`` = papc_amd.stack.LAST_PLANS (the
+    path the library chose per stack: csrc/sa_mlp.hip), ``rows_sa2`` = physical rows of the compacted SA2 stack (rows[0] of its plan).
+      xyz1     coordinates-only first layer through its input moments: y_1 is never stored, the second layer reads the grouped centred
+               coordinates (16 B / row) instead of 4 c_1 B / row, its dX is folded into four sums per channel instead of stored (xyz_fuse),
+               there is no first-layer dW pass
+      nostore  the max-pooled last layer never writes its [M, c_3] output; its dX / dW read the layer's INPUT instead
+      lin0     gather-add first layer: the D-wide product runs on the B*N source points; the row-sum backward is a dW-family launch
+      compact  distinct neighbours only: every row count below is the physical one
+      planes   few-row stacks on the planes path: operands are three bf16 planes (6 B / element), outputs fp32
+    Fused epilogue operands (the BN-backward sums' second read of y_(l-1)) are counted, L2-resident weights are not."""
+    fam = {K_MLP_GEMM: [0.0, 0.0], K_BWD_DX: [0.0, 0.0], K_BWD_DW: [0.0, 0.0]}
+    for M, ch, D, src_pts in ssg_layers(B, N):
+        fl = plans.get((M, tuple(ch[1:])), {})
+        R = float(rows_sa2) if (fl.get("compact") and rows_sa2) else float(M)
+        for l in range(3):
+            cin, cout = ch[l], ch[l + 1]
+            last, dense = l == 2, l < 2
+            if fl.get("planes"):
+                fam[K_MLP_GEMM][0] += 2.0 * M * cin * cout
+                fam[K_MLP_GEMM][1] += 6.0 * M * cin + 6.0 * cin * cout + 4.0 * M * cout
+                n_in = cin if l > 0 else D
+                if n_in:
+                    fam[K_BWD_DX][0] += 2.0 * M * n_in * cout
+                    fam[K_BWD_DX][1] += 6.0 * M * cout + 6.0 * n_in * cout + 4.0 * M * n_in * (2 if l > 0 else 1)
+                fam[K_BWD_DW][0] += 2.0 * M * cin * cout
+                fam[K_BWD_DW][1] += 6.0 * M * (cin + cout) + 8.0 * cin * cout
+                continue
+            stored = not (last and fl.get("nostore"))
+            x1 = l == 1 and fl.get("xyz1")
+            in_bytes = R * 16.0 if x1 else R * cin * 4.0
+            dy_bytes = (R * cout * 4.0 * (2 if dense else 1)) if stored else R * cin * 4.0     # nostore: dX / dW read the layer's input instead of y
+            if l == 0 and fl.get("xyz1"):
+                continue                                   # moments: no forward GEMM, no dX, no dW pass over rows
+            if l == 0 and fl.get("lin0"):
+                fam[K_MLP_GEMM][0] += 2.0 * src_pts * D * cout + 6.0 * R * cout
+                fam[K_MLP_GEMM][1] += 4.0 * src_pts * (D + 2 * cout) + 4.0 * R * cout
+                fam[K_BWD_DX][0] += 2.0 * src_pts * D * cout
+                fam[K_BWD_DX][1] += 4.0 * src_pts * (D + cout)
+                fam[K_BWD_DW][0] += 2.0 * src_pts * D * cout + 6.0 * R * cout
+                fam[K_BWD_DW][1] += 8.0 * R * cout + 12.0 * src_pts * cout + 4.0 * src_pts * (D + cout)
+                continue
+            fam[K_MLP_GEMM][0] += 2.0 * R * cin * cout
+            fam[K_MLP_GEMM][1] += in_bytes + (R * cout * 4.0 if stored else 0.0)
+            if l > 0:
+                k_dx = cout + (cin if not stored else 0)   # A_MAXCAT: [P | A] against [W^T ; -W^T E W]
+                fam[K_BWD_DX][0] += 2.0 * R * cin * k_dx
+                wr = 0.0 if (x1 and fl.get("xyz_fuse")) else R * cin * 4.0
+                red = in_bytes if not x1 else R * 16.0
+                fam[K_BWD_DX][1] += dy_bytes + wr + (red if stored else 0.0)
+            elif D:
+                fam[K_BWD_DX][0] += 2.0 * R * D * cout
+                fam[K_BWD_DX][1] += dy_bytes + 4.0 * R * D
+            fam[K_BWD_DW][0] += 2.0 * R * cin * cout + (0.0 if stored else 2.0 * R * cin * cin)
+            fam[K_BWD_DW][1] += (dy_bytes if stored else 0.0) + in_bytes
+    return {k: (v[0], v[1]) for k, v in fam.items()}
 
 
 def prof_read(lib):
@@ -119,6 +178,8 @@ def main():
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
     ap.add_argument("--diag-fixed-plan", action="store_true", help="DIAGNOSTIC ONLY (the printed value is NOT the benchmark): reuse one "
                     "precomputed sampling plan in every step, i.e. time the MLP branch alone, to measure what the sampling overlap costs")
+    ap.add_argument("--no-padded-leg", action="store_true", help="skip the second timed region with the compacted SA2 stack forced padded "
+                    "(`value_padded` in the JSON line)")
     ap.add_argument("--require-graph", action="store_true", help="fail instead of falling back to eager launches when the hipGraph capture "
                     "does not succeed (a multi-GPU run must not quietly measure the slow path)")
     ap.add_argument("--dry-run", action="store_true", help="capture, run the warm-up steps, print the launch structure as JSON and exit")
@@ -191,7 +252,10 @@ def main():
     # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
     side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else 0)
     ONE = torch.ones((), device=dev)            # d(loss)/d(loss), allocated once (loss.backward() would fill a fresh one every step)
-    state = {"plan": None, "ev": None}
+    state = {"plan": None, "ev": None, "last_grad": None}
+    # every backward here is followed by an optimiser step: the Adam kernel clears the flat gradient bucket behind its update
+    # (papc_adam_step_zero_f32), so the step has no clear_grad launch at its head (PAPC_ZERO_IN_ADAM=0: the separate fill)
+    ZERO_IN_ADAM = os.environ.get("PAPC_ZERO_IN_ADAM", "1") != "0"
 
     def launch_plan():
         side.wait_stream(main)                     # the inputs (and the allocator) are ordered behind the main stream
@@ -215,7 +279,8 @@ def main():
             main.wait_event(ev)
         # the next batch's pyramid is enqueued on the side stream beside this batch's MLP kernels (--fork sa2: only once the
         # main stream reaches SA3 -- the group_all layer, the FC head and their backward are small-grid kernels)
-        flat.zero_grad()
+        if not ZERO_IN_ADAM or not exchange:
+            flat.zero_grad()                       # (exchange=False: no optimiser step follows to clear the bucket)
         if args.overlap and args.fork == "start":
             launch_plan()
         tap = {} if use_dist else None
@@ -261,7 +326,8 @@ def main():
         assert 2 <= B <= 256, "two-stage backward needs the fused classifier head (2 <= B <= 256)"
 
     def stage1(plan_in=None, plan_out=None, cut=None):
-        flat.zero_grad()
+        if not ZERO_IN_ADAM:
+            flat.zero_grad()
 
         def fork():
             side.wait_stream(main)
@@ -300,6 +366,8 @@ def main():
 
     def capture():
         """Returns True when the graph(s) were captured; on any capture failure the bench falls back to eager launches."""
+        if ZERO_IN_ADAM:
+            flat.zero_grad()                       # (the passes ahead of a capture may have ended without an optimiser step)
         torch.cuda.synchronize()
         try:
             if args.diag_fixed_plan:
@@ -373,7 +441,9 @@ def main():
             scale = flat.allreduce_grads(0, split)
         else:
             scale = flat.allreduce_grads()
-        opt.step(scale)
+        if args.dump_trajectory:
+            state["last_grad"] = flat.grad.detach().clone()     # (tests: the optimiser clears the bucket)
+        opt.step(scale, zero_grad=ZERO_IN_ADAM)
 
     def sample_into(plan_out):
         """the next batch's pyramid, enqueued on the side stream beside the graph that is being replayed (N > 1)"""
@@ -452,22 +522,28 @@ def main():
 
     # ---- timed region
     traj = []
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-        if args.dump_trajectory:
-            traj.append(loss.detach().clone())    # (the replayed graphs overwrite their loss tensor)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_region():
+        sync()
+        t0 = time.perf_counter()
+        ls = None
+        for _ in range(args.steps):
+            ls = step()
+            if args.dump_trajectory:
+                traj.append(ls.detach().clone())  # (the replayed graphs overwrite their loss tensor)
+        sync()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, ls
+
+    elapsed, loss = timed_region()
     final_loss = float(loss.item())
     if args.dump_trajectory and rank == 0:
         import numpy as np
-        np.savez(args.dump_trajectory, loss=torch.stack(traj).cpu().numpy(), params=flat.data.detach().cpu().numpy(), params0=params0, grad=flat.grad.detach().cpu().numpy(),
+        np.savez(args.dump_trajectory, loss=torch.stack(traj).cpu().numpy(), params=flat.data.detach().cpu().numpy(), params0=params0, grad=(state["last_grad"] if state["last_grad"] is not None else flat.grad).detach().cpu().numpy(),
                  graph=np.array(int(use_graph)), overlap=np.array(int(args.overlap)))
     n_roof = args.steps
     if use_graph:
@@ -483,10 +559,49 @@ def main():
     lib.papc_prof_enable(0)
     assert final_loss == final_loss, "loss is NaN"
 
+    # ---- how much of the headline depends on the generator: the compacted SA2 stack (distinct neighbours only, papc_amd/compact.py) pays
+    # where the ball query's padding copies are plentiful (pointnet2_basic_layers.py:118-124) -- 0.56 of SA2's rows are kept on the SURVEY 8d
+    # clouds, 0.91-0.99 on ShapeNet-like surfaces, where the auto policy stays padded.  Same process, same box, same weights trajectory
+    # continued: the timed region once more with the stack forced padded (`value_padded`), and the measured row fraction.
+    from papc_amd import stack as _stack
+    plans_used = dict(_stack.LAST_PLANS)
+    rows_sa2, row_fraction = None, 1.0
+    sa2_key = (B * 128 * 64, (128, 128, 256))
+    compact_on = bool(plans_used.get(sa2_key, {}).get("compact"))
+    if compact_on:
+        pl2 = (graph_state["bufs"][0][1] if (use_graph and args.overlap) else state["plan"][1]) if args.overlap else None
+        if pl2 is None:
+            pl2 = model.plan_sampling(x, (s1, s2))[1]
+        if len(pl2) == 9:
+            rows_sa2 = int(pl2[4][0].item())
+            row_fraction = rows_sa2 / float(B * 128 * 64)
+    padded = None
+    if compact_on and world == 1 and not args.diag_fixed_plan and not args.dump_trajectory and not args.no_padded_leg:
+        model.sa2.compact = False                 # forced padded (layers.PointNetSetAbstraction._compact_mode)
+        state["plan"], state["ev"] = None, None
+        graph_state.update({"g": None, "loss": None, "i": 0})
+        for _ in range(3):
+            loss_p = step()                       # eager: allocations of the padded shapes
+        torch.cuda.synchronize()
+        loss_p = None
+        if not args.no_graph:
+            capture()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        el_p, loss_p = timed_region()
+        assert not _stack.LAST_PLANS.get(sa2_key, {}).get("compact"), "the padded leg still ran the compacted stack"
+        padded = {"value": round(B * args.steps / el_p, 2), "ms_per_step": round(1e3 * el_p / args.steps, 3),
+                  "graph": graph_state["g"] is not None}
+        model.sa2.compact = None
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
-        flop, byts = algorithmic_work(B, N).get(dominant, (0.0, 0.0))
+        flop_fixed, byts_fixed = algorithmic_work(B, N).get(dominant, (0.0, 0.0))
+        # priced on what the launches process: the path each stack took (papc_sa_mlp_plan) and the compacted stack's device-side row count;
+        # the SURVEY 8d figure, fixed across rounds, stays beside it as `frac_fixed_bytes`
+        flop, byts = moved_work(B, N, plans_used, rows_sa2).get(dominant, (flop_fixed, byts_fixed))
         per_step_s = (dom_ms / 1e3) / n_roof if dom_ms > 0 else float("nan")
         # which roof bounds the family: its matrix time at the rate the instruction mix allows (exact 3-way bf16 split =
         # 6 bf16 MFMA products per fp32 product -> 2500 / 6 TFLOP/s of algorithmic fp32 work) against its HBM time at 8 TB/s
@@ -528,7 +643,12 @@ def main():
             except (OSError, ValueError, KeyError) as e:
                 roof["traffic_note"] = "could not read %s: %s" % (fams[-1], e)
         roof["algorithmic"] = {"GFLOP_per_step": round(flop / 1e9, 2), "MB_per_step": round(byts / 1e6, 1),
-                               "mfma_floor_ms": round(t_mfma * 1e3, 3), "hbm_floor_ms": round(t_hbm * 1e3, 3)}
+                               "mfma_floor_ms": round(t_mfma * 1e3, 3), "hbm_floor_ms": round(t_hbm * 1e3, 3),
+                               "basis": "operands the family's launches process on the paths taken (bench.py::moved_work): moment first layer, "
+                                        "no-store max layer, gather-add first layer, compacted rows = %s" % (rows_sa2 if rows_sa2 else "padded"),
+                               "fixed_MB_per_step": round(byts_fixed / 1e6, 1), "fixed_GFLOP_per_step": round(flop_fixed / 1e9, 2)}
+        if roof["bound"] == "hbm" and per_step_s == per_step_s:
+            roof["frac_fixed_bytes"] = round(byts_fixed / per_step_s / (PEAK_HBM_GBS * 1e9), 4)
         roof["launches_per_step"] = dom_n // n_roof
         roof["avg_launch_ms"] = round(dom_ms / max(1, dom_n), 4)
         roof["ms_per_step"] = round(dom_ms / n_roof, 3)
@@ -545,12 +665,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
+                       "compact_row_fraction": round(row_fraction, 4),
+                       "compact": ("SA2 on its distinct neighbours (auto policy: kept rows %.3f of the padded count on this generator; ShapeNet-like "
+                                   "surfaces keep 0.91-0.99 and stay padded -> `value_padded` is their rate)" % row_fraction) if compact_on else "padded (policy)",
                        "sampling": ("software-pipelined: batch i+1's FPS + ball-query pyramid runs as a second branch (side stream) of "
                                     "batch i's step, %s; every timed step computes one full pyramid"
                                     % ("enqueued on the side stream beside the graph replay" if ext_sampling else "fork at " + args.fork)) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
-                       "launch": ("hipGraph replay of zero_grad+fwd+loss+bwd (%d graph(s) per step, two alternating sets), eager all-reduce + Adam"
+                       "launch": ("hipGraph replay of fwd+loss+bwd (%d graph(s) per step, two alternating sets), eager all-reduce + Adam (which also clears the gradient bucket)"
                                   % len([g for g in graph_state["g"][0] if g is not None])) if use_graph
                                  else ("eager" + (" (hipGraph capture FAILED: %s)" % graph_state["why"] if graph_state["why"] else "")),
                        "collectives": ("world %d, backend %s (RCCL %s); two-stage backward: all-reduce of the [SA3 | FC head] tail of the flat bucket "
@@ -558,6 +681,8 @@ def main():
                                        "per-GPU BatchNorm statistics"
                                        % (world, dist.get_backend(), ".".join(str(v) for v in torch.cuda.nccl.version()), flat.numel - split, split))
                                       if use_dist else "none (one process)"},
+            "value_padded": padded["value"] if padded else None,
+            "ms_per_step_padded": padded["ms_per_step"] if padded else None,
             "roofline": roof,
             "cpu_baseline": cpu,
         }

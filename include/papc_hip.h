@@ -306,6 +306,24 @@ int papc_reduce_partials_batch_f32(const papc_reduce_job *jobs, int count, papc_
 int papc_reduce_partials2_f32(const float *partial, int n_chunks, int64_t ld, int64_t n1, float *out1, int64_t n2,
                               float *out2, int accumulate, papc_stream_t stream);
 
+/* Deferred folds: up to PAPC_FOLD_MAX partial reductions of ANY of the kinds above (a stack's dW / db partials, the strided xyz / feature
+ * column blocks of the gather-add first layer, the split-K partials of the planes path) in ONE launch:
+ *     out[r * out_ld + c] (+)= sum_{t < n_chunks} partial[t * ld + r * cols + c]      r < rows, c < cols      (fixed order)
+ * A training step folds the partials of ALL its stacks once, behind the last backward kernel, instead of 5-6 launch-latency-sized
+ * kernels spread over the backward: papc_sa_mlp_bwd appends its jobs to papc_sa_grads.defer (a HOST list owned by the caller, who keeps
+ * the backward scratch buffers alive until papc_fold_jobs_f32 has been enqueued) instead of launching them.  `jobs` is a HOST array. */
+#define PAPC_FOLD_MAX 24
+typedef struct papc_fold_job {
+    const float *partial;   /* [n_chunks][ld] */
+    int32_t n_chunks;
+    int32_t accumulate;     /* != 0: add into out */
+    int64_t ld;             /* chunk stride (floats) */
+    int32_t rows, cols;     /* the folded block: rows x cols contiguous in a chunk */
+    float *out; int64_t out_ld;
+} papc_fold_job;
+typedef struct papc_fold_list { papc_fold_job *jobs; int32_t capacity, count; } papc_fold_list;
+int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * A whole shared-MLP stack in ONE call per direction (csrc/sa_mlp.hip) -- the boundary SURVEY 8b names `papc_sa_mlp_{fwd,bwd}`.
  * Replaces, after the grouping, the body of PointNetSetAbstraction.forward (PAPC/models/layers/pointnet2_basic_layers.py:214-219:
@@ -386,6 +404,9 @@ typedef struct papc_sa_grads {
     int32_t acc_w[PAPC_SA_MAX_LAYERS], acc_gb[PAPC_SA_MAX_LAYERS];
     const float *wt[PAPC_SA_MAX_LAYERS];
     float *grad_feats, *grad_x;
+    struct papc_fold_list *defer;         /* optional: the partial folds of this backward are appended here instead of launched (papc_fold_jobs_f32);
+                                             the parameter gradients are complete only after the caller has run the list, and `scratch` must
+                                             stay alive until then */
 } papc_sa_grads;
 int papc_sa_mlp_plan(const papc_sa_desc *desc, const papc_sa_io *io, papc_sa_plan *plan);
 int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_t stream);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "papc_mlp_bwd_dw_f32": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_l, c_p]),
     "papc_reduce_partials2_f32": (c_i, [c_p, c_i, c_l, c_l, c_p, c_l, c_p, c_i, c_p]),
     "papc_reduce_partials_batch_f32": (c_i, [c_p, c_i, c_p]),
+    "papc_fold_jobs_f32": (c_i, [c_p, c_i, c_p]),
     "papc_mlp_bwd_dw_chunk_hint": (c_i, [c_l, c_i, c_i, c_i, c_i, c_i]),
     "papc_reduce_partials_f32": (c_i, [c_p, c_i, c_l, c_p, c_i, c_p]),
     "papc_pfn_decorate_f32": (c_i, [c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_f, c_f, c_i, c_p, c_p]),

@@ -657,6 +657,74 @@ __global__ __launch_bounds__(1024) void reduce_partials_batch_kernel(ReduceBatch
     }
 }
 
+// ---- deferred folds: every partial reduction of a training step's backward in ONE launch (papc_fold_jobs_f32) ---------------------------
+// Flat grid: workgroup b belongs to the job whose [wg0, wg0 + nwg) range holds it.  Two shapes, uniform per workgroup:
+//   many chunks (kind 0): 64 elements x 16 chunk lanes, 8 loads in flight per lane, chunk lanes folded in lane order -- the summation
+//                         order of reduce_partials_batch_kernel, so a deferred fold equals the stack's own launch bit for bit;
+//   few chunks  (kind 1): a thread owns a float4 of 4096 consecutive elements per workgroup and walks the chunks in order -- the order of
+//                         pg_fold_kernel (smallm.hip): the split-K partials of the planes path (<= 8 chunks of up to 512 K elements).
+struct FoldBatch {
+    const float *part[PAPC_FOLD_MAX]; float *out[PAPC_FOLD_MAX];
+    int64_t ld[PAPC_FOLD_MAX], out_ld[PAPC_FOLD_MAX];
+    int n_chunks[PAPC_FOLD_MAX], rows[PAPC_FOLD_MAX], cols[PAPC_FOLD_MAX], wg0[PAPC_FOLD_MAX + 1];
+    unsigned acc_mask, wide_mask;
+    int count;
+};
+__global__ __launch_bounds__(1024) void fold_jobs_kernel(FoldBatch b)
+{
+    __shared__ float red[16][64];
+    int job = 0;
+    while (job + 1 < b.count && (int)blockIdx.x >= b.wg0[job + 1]) ++job;       // (<= 24 scalar compares)
+    const int wg = (int)blockIdx.x - b.wg0[job];
+    const float *__restrict__ part = b.part[job];
+    float *__restrict__ out = b.out[job];
+    const int64_t ld = b.ld[job], out_ld = b.out_ld[job];
+    const int n_chunks = b.n_chunks[job], cols = b.cols[job];
+    const int64_t n = (int64_t)b.rows[job] * cols;
+    const bool acc = (b.acc_mask >> job) & 1u;
+    if ((b.wide_mask >> job) & 1u) {        // few chunks, contiguous output (out_ld == cols), n % 4 == 0, 16-byte aligned
+        const int64_t e = ((int64_t)wg * 1024 + threadIdx.x) * 4;
+        if (e >= n) return;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t0 = 0; t0 < n_chunks; t0 += 8) {          // 8 loads in flight, summed in chunk order
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4 *>(part + (int64_t)(t0 + j < n_chunks ? t0 + j : t0) * ld + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (t0 + j < n_chunks) { if (t0 + j == 0) s = v[j]; else { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; } }
+        }
+        float4 *o = reinterpret_cast<float4 *>(out + e);
+        if (acc) { const float4 a = *o; s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w; }
+        *o = s;
+        return;
+    }
+    const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
+    const int64_t i = (int64_t)wg * 64 + el;
+    float s = 0.f;
+    if (i < n) {
+        for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {     // 8 loads in flight per lane; summed in chunk order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int t = t0 + 16 * j;
+                v[j] = part[(int64_t)(t < n_chunks ? t : t0) * ld + i];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (t0 + 16 * j < n_chunks) ? v[j] : 0.f;
+        }
+    }
+    red[cl][el] = s;
+    __syncthreads();
+    if (cl == 0 && i < n) {
+#pragma unroll
+        for (int g = 1; g < 16; ++g) s += red[g][el];
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        float *o = out + (int64_t)r * out_ld + c;
+        *o = acc ? *o + s : s;
+    }
+}
+
 }  // namespace papc
 
 
@@ -825,6 +893,40 @@ int papc_reduce_partials_batch_f32(const papc_reduce_job *jobs, int count, papc_
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(reduce_partials_batch_kernel, dim3((unsigned)cdiv(nmax, 64), (unsigned)count), dim3(1024), 0, st, b);
     return check_launch("papc_reduce_partials_batch_f32");
+}
+
+int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t stream)
+{
+    PAPC_REQUIRE(jobs, PAPC_E_INVALID, "papc_fold_jobs_f32: null jobs");
+    PAPC_REQUIRE(count >= 1, PAPC_E_INVALID, "papc_fold_jobs_f32: count=%d", count);
+    hipStream_t st = as_stream(stream);
+    for (int j0 = 0; j0 < count; j0 += PAPC_FOLD_MAX) {
+        const int nj = std::min(PAPC_FOLD_MAX, count - j0);
+        FoldBatch b;
+        memset(&b, 0, sizeof(b));
+        int64_t wgs = 0;
+        for (int i = 0; i < nj; ++i) {
+            const papc_fold_job &j = jobs[j0 + i];
+            PAPC_REQUIRE(j.partial && j.out, PAPC_E_INVALID, "papc_fold_jobs_f32: null pointer in job %d", j0 + i);
+            PAPC_REQUIRE(j.n_chunks >= 1 && j.rows >= 1 && j.cols >= 1 && j.ld >= (int64_t)j.rows * j.cols && j.out_ld >= j.cols, PAPC_E_INVALID,
+                         "papc_fold_jobs_f32: bad sizes in job %d", j0 + i);
+            const int64_t n = (int64_t)j.rows * j.cols;
+            const bool wide = j.n_chunks <= 16 && n >= 16384 && n % 4 == 0 && j.ld % 4 == 0 && (j.rows == 1 || j.out_ld == j.cols) && aligned16(j.partial) && aligned16(j.out);
+            b.part[i] = j.partial; b.out[i] = j.out; b.ld[i] = j.ld; b.out_ld[i] = j.out_ld; b.n_chunks[i] = j.n_chunks; b.rows[i] = j.rows; b.cols[i] = j.cols;
+            if (j.accumulate) b.acc_mask |= 1u << i;
+            if (wide) b.wide_mask |= 1u << i;
+            b.wg0[i] = (int)wgs;
+            wgs += wide ? cdiv(n, 4096) : cdiv(n, 64);
+            PAPC_REQUIRE(wgs < (1ll << 30), PAPC_E_UNSUPPORTED, "papc_fold_jobs_f32: too many elements");
+        }
+        b.wg0[nj] = (int)wgs;
+        b.count = nj;
+        ProfScope prof(PAPC_K_BWD_DW, st);
+        hipLaunchKernelGGL(fold_jobs_kernel, dim3((unsigned)wgs), dim3(1024), 0, st, b);
+        const int rc = check_launch("papc_fold_jobs_f32");
+        if (rc != PAPC_OK) return rc;
+    }
+    return PAPC_OK;
 }
 
 int papc_reduce_partials_f32(const float *partial, int n_chunks, int64_t n, float *out, int accumulate, papc_stream_t stream)

@@ -71,6 +71,18 @@ struct BwdPtrs {
 };
 
 static inline int64_t rows_of(const papc_sa_desc &d) { return (int64_t)d.B * d.S * d.K; }
+
+// deferred folds (papc_sa_grads.defer, include/papc_hip.h): append to the caller's list; false = no list or no room (the caller of this
+// helper then launches the fold itself, as without a list)
+static bool defer_fold(const papc_sa_grads &gr, const float *partial, int n_chunks, int64_t ld, int rows, int cols, float *out, int64_t out_ld, int accumulate)
+{
+    papc_fold_list *fl = gr.defer;
+    if (!fl || !fl->jobs || fl->count >= fl->capacity) return false;
+    papc_fold_job &j = fl->jobs[fl->count++];
+    j.partial = partial; j.n_chunks = n_chunks; j.accumulate = accumulate; j.ld = ld; j.rows = rows; j.cols = cols; j.out = out; j.out_ld = out_ld;
+    return true;
+}
+static bool defer_room(const papc_sa_grads &gr, int n) { return gr.defer && gr.defer->jobs && gr.defer->count + n <= gr.defer->capacity; }
 static inline int cin_of(const papc_sa_plan &p, int l) { return l == 0 ? p.cin0 : p.d.cout[l - 1]; }
 
 static int dw_rows_per_chunk(int64_t M, int cout, int cin)      // (mlp.py::_dw_rows_per_chunk: one residency wave of workgroups in total)
@@ -406,7 +418,8 @@ static int planes_bwd(const papc_sa_plan &p, const papc_sa_io &io, const papc_sa
         g.epi = PAPC_PG_STORE; g.a = b.dypt; g.b = s.PT[l]; g.R1 = cout; g.R2 = cin; g.K = (int)M;
         g.c = b.part[l]; g.ldc = cin; g.split = split; g.split_stride = (int64_t)cout * cin; g.family = PAPC_K_BWD_DW;
         SA_CALL(papc_pg_gemm_f32(&g, st));
-        fold[n_fold++] = papc_pg_fold_job{b.part[l], split, (int64_t)cout * cin, (int64_t)cout * cin, gr.dw[l], acc_w ? 1 : 0};
+        if (!defer_fold(gr, b.part[l], split, (int64_t)cout * cin, 1, cout * cin, gr.dw[l], (int64_t)cout * cin, acc_w ? 1 : 0))
+            fold[n_fold++] = papc_pg_fold_job{b.part[l], split, (int64_t)cout * cin, (int64_t)cout * cin, gr.dw[l], acc_w ? 1 : 0};
         if (gr.db[l] && !acc_w) SA_CALL(papc_fill_f32(gr.db[l], cout, 0.f, st));      // (a bias feeding a train-mode BN: gradient exactly 0)
         if (l > 0) { dz = dz_prev; red = red_prev; }
     }
@@ -695,7 +708,8 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             const int fcol0 = d.xyz_first ? 3 : 0, xcol0 = d.xyz_first ? 0 : d.D;
             float *dw = gr->dw[l];
             const int acc = acc_w ? 1 : 0;
-            SA_CALL(papc_reduce_partials_strided_f32(b.dwx_part, parts_l, (int64_t)cout * 3, cout, 3, dw + xcol0, cin, acc, st));
+            if (!defer_fold(*gr, b.dwx_part, parts_l, (int64_t)cout * 3, cout, 3, dw + xcol0, cin, acc))
+                SA_CALL(papc_reduce_partials_strided_f32(b.dwx_part, parts_l, (int64_t)cout * 3, cout, 3, dw + xcol0, cin, acc, st));
             // dW_f = G^T feats on the library's own dW kernel: G plays dY with BN constants that make dY = dz (scale 1, shift huge, c1 = c2 = 0)
             papc_bwd_dy dyg;
             memset(&dyg, 0, sizeof(dyg));
@@ -705,7 +719,8 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             const int n_chunks_g = (int)((BN + rpc_g - 1) / rpc_g);
             const int64_t pld_g = (int64_t)cout * d.D + cout;
             SA_CALL(papc_mlp_bwd_dw_f32(&dyg, A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, BN, d.D, cout, rpc_g, b.part_g, b.part_g + (int64_t)cout * d.D, pld_g, st));
-            SA_CALL(papc_reduce_partials_strided_f32(b.part_g, n_chunks_g, pld_g, cout, d.D, dw + fcol0, cin, acc, st));
+            if (!defer_fold(*gr, b.part_g, n_chunks_g, pld_g, cout, d.D, dw + fcol0, cin, acc))
+                SA_CALL(papc_reduce_partials_strided_f32(b.part_g, n_chunks_g, pld_g, cout, d.D, dw + fcol0, cin, acc, st));
             if (gr->db[l] && !acc_w) SA_CALL(papc_fill_f32(gr->db[l], cout, 0.f, st));      // (a bias feeding a train-mode BN: gradient exactly 0)
             if (f_needs) {
                 const float *wft;
@@ -743,10 +758,15 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
                 SA_CALL(papc_mlp_bwd_dw_f32(&dy, A_BNRELU_, s.y[l - 1], cin, nullptr, pc + 2 * cin, pc + 3 * cin, M, cin, cout, rpc, dwp, dbp, pld, st));
             }
             // the partials of all layers are folded in ONE launch once the stack's last dW kernel is enqueued
-            papc_reduce_job &j = jobs[n_jobs++];
-            j.partial = b.part[l]; j.n_chunks = n_chunks; j.accumulate = acc_w ? 1 : 0; j.ld = pld; j.n1 = (int64_t)cout * cin; j.out1 = gr->dw[l];
             const bool want_db = gr->db[l] && !ev;
-            j.n2 = want_db ? cout : 0; j.out2 = want_db ? gr->db[l] : nullptr;
+            if (defer_room(*gr, 2)) {
+                defer_fold(*gr, b.part[l], n_chunks, pld, 1, cout * cin, gr->dw[l], (int64_t)cout * cin, acc_w ? 1 : 0);
+                if (want_db) defer_fold(*gr, b.part[l] + (int64_t)cout * cin, n_chunks, pld, 1, cout, gr->db[l], cout, acc_w ? 1 : 0);
+            } else {
+                papc_reduce_job &j = jobs[n_jobs++];
+                j.partial = b.part[l]; j.n_chunks = n_chunks; j.accumulate = acc_w ? 1 : 0; j.ld = pld; j.n1 = (int64_t)cout * cin; j.out1 = gr->dw[l];
+                j.n2 = want_db ? cout : 0; j.out2 = want_db ? gr->db[l] : nullptr;
+            }
             if (ev && gr->db[l]) {     // no batch-mean term removes the bias direction: db = sum_m dy = scale * sum_m p
                 hipLaunchKernelGGL(mul_vec_kernel, dim3((unsigned)cdiv(cout, 256)), dim3(256), 0, as_stream(st), cst + 2 * cout, dbeta, cout, gr->db[l], acc_w ? 1 : 0);
                 SA_CALL(check_launch("papc_sa_mlp_bwd (eval-mode bias gradient)"));

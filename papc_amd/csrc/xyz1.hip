@@ -190,46 +190,60 @@ __global__ __launch_bounds__(XYZ_T) void xyz_l1_bwd_kernel(const float *__restri
 }
 
 // partial [parts][C][4] (T0, T1, T2, S) + the input moments -> dgamma, dbeta, dW [C][3]  (closed form, float64).
-// A workgroup owns 16 channels: 64 entries x 16 slices of the partial rows, summed in fixed order.
+// A workgroup owns 4 channels: 16 entries x 64 slices of the partial rows, summed in fixed order.  The kernel is one latency chain (it is the
+// LAST node of the backward): with 64 slices a thread's share of <= 768 partial rows is 12 loads, all in flight at once -- one memory round
+// trip instead of six (17.6 -> ~7 us in the replayed step).
 __global__ __launch_bounds__(1024) void xyz_l1_bwd_finalize_kernel(const float *__restrict__ partial, int parts, double M, int C, const double *__restrict__ gram,
                                                                    const float *__restrict__ w, int ldw, int xcol0, const float *__restrict__ bias,
                                                                    const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                    const float *__restrict__ scale, float *dgamma, float *dbeta, float *dw, int accumulate)
 {
-    __shared__ double red[16][64];
-    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e0 = blockIdx.x * 64;                  // first entry (channel * 4 + slot) of this workgroup
+    __shared__ double red[64][17], red2[8][17];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e0 = blockIdx.x * 16;                  // first entry (channel * 4 + slot) of this workgroup
+    const int c = blockIdx.x * 4 + threadIdx.x;
+    const bool fin = threadIdx.x < 4 && c < C;       // (the finalizing threads fetch their constants with the partial rows, not behind the barriers)
+    const int cc = fin ? c : 0;
+    const double w0 = w[(int64_t)cc * ldw + xcol0], w1 = w[(int64_t)cc * ldw + xcol0 + 1], w2 = w[(int64_t)cc * ldw + xcol0 + 2];
+    const double b = bias ? (double)bias[cc] : 0.0;
+    const double mu = mean[cc], is = invstd[cc], sc = scale[cc];
+    double gq[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gq[i] = gram[i];
     double s = 0.0;
     if (e0 + e < C * 4) {
-        for (int t0 = sl; t0 < parts; t0 += 16 * 8) {   // 8 loads in flight per thread
-            float v[8];
+        for (int t0 = sl; t0 < parts; t0 += 64 * 12) {   // 12 loads in flight per thread
+            float v[12];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (t0 + 16 * q < parts) ? partial[(int64_t)(t0 + 16 * q) * C * 4 + e0 + e] : 0.f;
+            for (int q = 0; q < 12; ++q) v[q] = (t0 + 64 * q < parts) ? partial[(int64_t)(t0 + 64 * q) * C * 4 + e0 + e] : 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) s += (double)v[q];
+            for (int q = 0; q < 12; ++q) s += (double)v[q];
         }
     }
     red[sl][e] = s;
     __syncthreads();
+    if (sl < 8) {                                    // 64 slices -> 8 -> 1, fixed order
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[sl * 8 + q][e];
+        red2[sl][e] = t;
+    }
+    __syncthreads();
     if (sl == 0) {
         double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t += red[q][e];
+        for (int q = 0; q < 8; ++q) t += red2[q][e];
         red[0][e] = t;
     }
     __syncthreads();
-    const int c = blockIdx.x * 16 + threadIdx.x;
-    if (threadIdx.x < 16 && c < C) {
+    if (fin) {
         const double T0 = red[0][threadIdx.x * 4 + 0], T1 = red[0][threadIdx.x * 4 + 1], T2 = red[0][threadIdx.x * 4 + 2], S = red[0][threadIdx.x * 4 + 3];
-        const double w0 = w[(int64_t)c * ldw + xcol0], w1 = w[(int64_t)c * ldw + xcol0 + 1], w2 = w[(int64_t)c * ldw + xcol0 + 2];
-        const double b = bias ? (double)bias[c] : 0.0;
-        const double mu = mean[c], is = invstd[c], sc = scale[c];
         const double dg = is * (w0 * T0 + w1 * T1 + w2 * T2 + (b - mu) * S);     // sum p xhat
         dbeta[c] = accumulate ? dbeta[c] + (float)S : (float)S;
         dgamma[c] = accumulate ? dgamma[c] + (float)dg : (float)dg;
         const double c1 = S / M, c2 = dg / M;
-        const double Sx[3] = {gram[0], gram[1], gram[2]};
-        const double Sxx[3][3] = {{gram[3], gram[4], gram[5]}, {gram[4], gram[6], gram[7]}, {gram[5], gram[7], gram[8]}};
+        const double Sx[3] = {gq[0], gq[1], gq[2]};
+        const double Sxx[3][3] = {{gq[3], gq[4], gq[5]}, {gq[4], gq[6], gq[7]}, {gq[5], gq[7], gq[8]}};
         const double T[3] = {T0, T1, T2};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -310,7 +324,7 @@ int papc_xyz_l1_bwd_finalize_f32(const float *partial, int parts, int64_t M, int
     PAPC_REQUIRE(parts >= 1 && M >= 1 && C >= 1 && C <= 256 && ldw >= xcol0 + 3 && xcol0 >= 0, PAPC_E_INVALID, "papc_xyz_l1_bwd_finalize_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);
-    hipLaunchKernelGGL(xyz_l1_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, partial, parts, (double)M, C, gram, w, ldw, xcol0, bias, mean, invstd,
+    hipLaunchKernelGGL(xyz_l1_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 4)), dim3(1024), 0, st, partial, parts, (double)M, C, gram, w, ldw, xcol0, bias, mean, invstd,
                        scale, dgamma, dbeta, dw, accumulate);
     return check_launch("papc_xyz_l1_bwd_finalize_f32");
 }

@@ -53,10 +53,11 @@ class SaPlan(ctypes.Structure):
 class SaGrads(ctypes.Structure):
     """papc_sa_grads"""
     _fields_ = [("gout", c_p), ("dw", c_p * MAXL), ("db", c_p * MAXL), ("dgamma", c_p * MAXL), ("dbeta", c_p * MAXL), ("acc_w", c_i * MAXL),
-                ("acc_gb", c_i * MAXL), ("wt", c_p * MAXL), ("grad_feats", c_p), ("grad_x", c_p)]
+                ("acc_gb", c_i * MAXL), ("wt", c_p * MAXL), ("grad_feats", c_p), ("grad_x", c_p), ("defer", c_p)]
 
 
 _CONSTS3 = {}
+LAST_PLANS = {}
 
 
 def _consts3(dev):
@@ -154,6 +155,11 @@ class SharedMLPStack(torch.autograd.Function):
         io.out, io.saved, io.scratch = out.data_ptr(), saved.data_ptr(), scratch.data_ptr()
         check(lib.papc_sa_mlp_fwd(ctypes.byref(plan), ctypes.byref(io), stream_ptr()), "papc_sa_mlp_fwd")
         ctx.spec, ctx.L, ctx.plan, ctx.saved = spec, L, plan, saved
+        # (diagnostics: which path the library chose for a stack of this shape -- bench.py prices its roofline line on the tensors these
+        # paths really move)
+        LAST_PLANS[(int(M), tuple(int(d.cout[l]) for l in range(L)))] = dict(
+            lin0=bool(plan.lin0), xyz1=bool(plan.xyz1), gmax=bool(plan.gmax), nostore=bool(plan.nostore), compact=bool(plan.compact), planes=bool(plan.planes),
+            xyz_fuse=bool(plan.xyz1) and not (d.disable & NO_XYZ_FUSE))
         ctx.compact = spec.compact if plan.compact else None
         ctx.nostore, ctx.xyz1, ctx.lin0, ctx.planes = bool(plan.nostore), bool(plan.xyz1), bool(plan.lin0), bool(plan.planes)     # (which paths the library took)
         ctx.bn_buffers = bn_buffers
@@ -194,6 +200,7 @@ class SharedMLPStack(torch.autograd.Function):
         g = SaGrads()
         g.gout = gout.data_ptr()
         grads = [None] * (4 * L)
+        all_inplace = True
         for l in range(L):
             w = params[4 * l]
             cout = w.shape[0]
@@ -201,6 +208,7 @@ class SharedMLPStack(torch.autograd.Function):
             tgt = spec.grad_targets[4 * l: 4 * l + 4] if spec.grad_targets is not None else None
             inplace = tgt is not None and all(t is not None for t in tgt)
             gb_inplace = tgt is not None and tgt[2] is not None and tgt[3] is not None and not spec.eval_bn
+            all_inplace = all_inplace and inplace
             if inplace:          # accumulate straight into the parameters' .grad (flat-bucket views): no autograd add kernels
                 g.dw[l], g.db[l], g.acc_w[l] = tgt[0].data_ptr(), tgt[1].data_ptr(), 1
             else:
@@ -230,5 +238,11 @@ class SharedMLPStack(torch.autograd.Function):
         if ctx.x_needs_grad:
             grad_x = torch.empty(spec.M, x_rows.shape[1], device=dev, dtype=torch.float32)
             g.grad_x = grad_x.data_ptr()
+        # the partial folds of this stack join the running backward pass's list (folds.py: one launch behind the last backward kernel)
+        # (only when every weight gradient lands in place in its .grad: a tensor handed back to autograd must be complete on return)
+        from . import folds
+        fl = folds.pending([scratch, ctx.saved]) if all_inplace else None
+        if fl is not None:
+            g.defer = ctypes.cast(fl, c_p)
         check(lib.papc_sa_mlp_bwd(ctypes.byref(plan), ctypes.byref(io), ctypes.byref(g), stream_ptr()), "papc_sa_mlp_bwd")
         return (None, None, None, None, grad_feats, None, grad_x) + tuple(grads)
