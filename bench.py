@@ -576,7 +576,7 @@ def main():
             rows_sa2 = int(pl2[4][0].item())
             row_fraction = rows_sa2 / float(B * 128 * 64)
     padded = None
-    if compact_on and world == 1 and not args.diag_fixed_plan and not args.dump_trajectory and not args.no_padded_leg:
+    if compact_on and not use_dist and not args.diag_fixed_plan and not args.dump_trajectory and not args.no_padded_leg:     # (one process: a second capture behind collectives would trip RCCL's watchdog, see `comm` above)
         model.sa2.compact = False                 # forced padded (layers.PointNetSetAbstraction._compact_mode)
         state["plan"], state["ev"] = None, None
         graph_state.update({"g": None, "loss": None, "i": 0})

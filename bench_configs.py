@@ -110,12 +110,16 @@ def run(args):
         from papc_amd.pillars import PillarFeatureNet
         v, n, c = make_pillars()
         model = PillarFeatureNet(num_filters=(64,), voxel_size=(0.16, 0.16, 4), pc_range=(0, -39.68, -3, 69.12, 39.68, 1)).to(dev).train()
+        # the frame comes zero-padded behind num_points, as the reference's voxeliser produces it (point_cloud_ops.py:148 zero-initialises the
+        # buffers; synthetic.make_pillars masks likewise): the kernels may load the real rows only (PAPC_PFN_ZERO_PADDED=0: every row)
+        model.assume_zero_padding = os.environ.get("PAPC_PFN_ZERO_PADDED", "1") != "0"
+        workload_note = "rows behind num_points are zero (voxeliser contract): real rows loaded only" if model.assume_zero_padding else "all T rows loaded"
         tv, tn, tc = torch.from_numpy(v).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev)
         # the layer feeds PointPillarsScatter + the 2-D backbone (out of scope): its upstream gradient is a fixed [P, 64] tensor
         gout = torch.randn(12000, 64, device=dev) * 1e-3
         loss_fn = None
         units, unit, metric = 1, "frames/s", "pillar frames/sec (fwd+bwd) PillarFeatureNet 12000 pillars x 100 points"
-        workload = "PointPillars PillarFeatureNet fwd+bwd+Adam, 12000 pillars x 100 points, one KITTI-shaped frame (BASELINE configs[4])"
+        workload = "PointPillars PillarFeatureNet fwd+bwd+Adam, 12000 pillars x 100 points, one KITTI-shaped frame (BASELINE configs[4]); " + workload_note
         P, T = 12000, 100
         feat = P * T * 4 * 4.0
         # three passes over the 19.2 MB of points: the Gram pass (train-mode BN statistics AND the dense part of dW from the inputs' 10x10

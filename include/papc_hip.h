@@ -422,6 +422,10 @@ typedef struct papc_pfn_desc {
     float vx, vy, x_offset, y_offset;     /* pillars.py:74-77 */
     float eps, momentum;
     int32_t training;
+    int32_t zero_padded;                  /* != 0: the caller states that rows t >= num_voxels[p] of `features` are zero -- what the reference's
+                                             voxeliser hands over (its buffers are zero-initialised, libs/ops/point_cloud/point_cloud_ops.py:148).
+                                             The passes then load only the real rows (a KITTI pillar holds ~12 of its 100 slots); with non-zero
+                                             padding the result would differ from pillars.py:82 (the cluster mean sums ALL T rows), hence opt-in */
 } papc_pfn_desc;
 typedef struct papc_pfn_io {
     const float *features; const int32_t *num_voxels, *coors;
@@ -429,6 +433,11 @@ typedef struct papc_pfn_io {
     float *running_mean, *running_var;    /* [C] or NULL (training) */
     float *out;
     void *saved, *scratch;
+    uint32_t *tickets;                    /* optional: 2 words of device memory owned by the caller, ZERO at first use; the library leaves them zero
+                                             behind every launch.  With them the statistics ride as the last-arriving workgroup's tail of the Gram
+                                             pass and the dW / dgamma / dbeta finalize as the tail of the backward fold (5 launches per frame
+                                             instead of 8).  One pair per stream on which PFN calls may be in flight at the same time; NULL = the
+                                             separate finalize launches */
 } papc_pfn_io;
 int papc_pfn_workspace(const papc_pfn_desc *desc, int64_t *saved_bytes, int64_t *scratch_bytes);
 int papc_pfn_fwd(const papc_pfn_desc *desc, const papc_pfn_io *io, papc_stream_t stream);
@@ -569,6 +578,11 @@ int papc_nms_f32(const float *dets, int N, float nms_overlap_thresh, int32_t *ke
  * the source's fp32 corners :366-389) -- not by the source's candidate list + angular sort; results agree with it to rounding wherever
  * the source's strict edge tests are not ties (coincident edges, e.g. identical boxes at a general angle, are rounding noise there and
  * exact here).
+ * NOT OFFERED, deliberately: a `reference_quirks` mode for that coincident-edge case.  The source's value for two boxes that share an edge
+ * line is whatever its fp32 candidate list / angular sort leaves after ties between strict `>` tests (:235-278, :323-339) -- anything between 0
+ * and the true IoU for the SAME pair depending on the angle's last bit (oracle/reference_np.py::quad_inter reproduces it) -- so rotated NMS
+ * there cannot suppress an exact duplicate.  Matching it would mean shipping the source's routine instruction for instruction; the value has
+ * no geometric meaning to preserve, callers get the geometric one (identical boxes -> 1) and tests/test_gpu_nms.py states the divergence.
  * papc_rotate_nms_f32: rotate_nms_gpu (:453-488), dets [N,6] = (x, y, x_d, y_d, angle, score); outputs and workspace as papc_nms_f32.
  * papc_rotate_iou_f32: rotate_iou_gpu / rotate_iou_gpu_eval (:524-653), boxes [N,5], query_boxes [K,5] = (x, y, x_d, y_d, angle) ->
  * iou [N,K]; criterion -1: intersection over union, 0: over area(query), 1: over area(box), 2: the intersection area. */

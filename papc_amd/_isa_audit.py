@@ -68,6 +68,33 @@ def audit(asm_text, want="stream_kernel"):
     return {"kernels": seen, "loads": nload, "violations": bad}
 
 
+def audit_ticket(asm_text):
+    """csrc/pfn.hip's last-arriving-workgroup protocol (pfn_last_block): every ticket atomic (global_atomic_add) must sit behind an
+    ``s_waitcnt vmcnt(0)`` with no global store between the wait and the atomic -- the partial rows a workgroup publishes have then been
+    acknowledged before its ticket is taken (a workgroup-scope release fence alone does not emit that wait on gfx950).
+    Returns {"atomics": n, "violations": [(line, text)]}."""
+    lines = asm_text.splitlines()
+    n, bad = 0, []
+    for i, line in enumerate(lines):
+        t = line.strip()
+        if not t.startswith("global_atomic_add"):
+            continue
+        n += 1
+        ok = False
+        for j in range(i - 1, -1, -1):
+            u = lines[j].strip()
+            if re.match(r"^(_ZN|\.Lfunc_begin)", u) or u.startswith("s_endpgm"):
+                break
+            if u.startswith(("global_store", "buffer_store", "flat_store", "scratch_store")):
+                break
+            if u.startswith("s_waitcnt") and "vmcnt(0)" in u:
+                ok = True
+                break
+        if not ok:
+            bad.append((i + 1, t))
+    return {"atomics": n, "violations": bad}
+
+
 def report(res):
     lines = ["scanned %d hidden loads in %d kernels" % (res["loads"], len(res["kernels"]))]
     for k, v in res["violations"].items():

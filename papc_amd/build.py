@@ -64,6 +64,23 @@ def _audit_asm_ring(asm_path):
                            % (len(res["kernels"]), res["loads"], report(res)[-2000:]))
 
 
+def _audit_pfn_tickets(cmd):
+    """pfn.hip's fused tails: the ISA must wait for the published partial rows' acknowledgements before a ticket is taken
+    (papc_amd/_isa_audit.py::audit_ticket).  Fails closed."""
+    from ._isa_audit import audit_ticket
+    asm = os.path.join(OBJ, "pfn.s")
+    cmd_s = list(cmd)
+    cmd_s[cmd_s.index("-c")] = "-S"
+    cmd_s[cmd_s.index("-o") + 1] = asm
+    r2 = subprocess.run(cmd_s + ["--cuda-device-only"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r2.returncode != 0:
+        raise RuntimeError("hipcc -S failed on pfn.hip\n" + r2.stdout[-2000:])
+    res = audit_ticket(open(asm).read())
+    os.remove(asm)
+    if res["violations"] or res["atomics"] == 0:
+        raise RuntimeError("pfn.hip: the ticket audit failed (%d ticket atomics scanned): %s" % (res["atomics"], res["violations"][:4]))
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -104,6 +121,8 @@ def build(force=False, verbose=True):
                     _audit_asm_ring(asm)
                     os.remove(asm)
                     out = "\n".join(l for l in out.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l)
+                if os.path.basename(s) == "pfn.hip" and rc == 0:
+                    _audit_pfn_tickets(jobs_by_src[s])
                 if verbose and out.strip():
                     print(out)
                 if rc != 0:

@@ -667,7 +667,7 @@ struct FoldBatch {
     const float *part[PAPC_FOLD_MAX]; float *out[PAPC_FOLD_MAX];
     int64_t ld[PAPC_FOLD_MAX], out_ld[PAPC_FOLD_MAX];
     int n_chunks[PAPC_FOLD_MAX], rows[PAPC_FOLD_MAX], cols[PAPC_FOLD_MAX], wg0[PAPC_FOLD_MAX + 1];
-    unsigned acc_mask, wide_mask;
+    unsigned acc_mask, wide_mask, vec_mask;
     int count;
 };
 __global__ __launch_bounds__(1024) void fold_jobs_kernel(FoldBatch b)
@@ -700,6 +700,34 @@ __global__ __launch_bounds__(1024) void fold_jobs_kernel(FoldBatch b)
         return;
     }
     const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
+    if ((b.vec_mask >> job) & 1u) {         // many chunks, float4 lanes (n % 4 == 0, contiguous output): the same order per element, 1 KB per wave and chunk
+        __shared__ float4 red4[16][64];
+        const int64_t i4 = ((int64_t)wg * 64 + el) * 4;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < n) {
+            for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = t0 + 16 * j;
+                    v[j] = *reinterpret_cast<const float4 *>(part + (int64_t)(t < n_chunks ? t : t0) * ld + i4);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (t0 + 16 * j < n_chunks) { s4.x += v[j].x; s4.y += v[j].y; s4.z += v[j].z; s4.w += v[j].w; }
+            }
+        }
+        red4[cl][el] = s4;
+        __syncthreads();
+        if (cl == 0 && i4 < n) {
+#pragma unroll
+            for (int g = 1; g < 16; ++g) { const float4 r = red4[g][el]; s4.x += r.x; s4.y += r.y; s4.z += r.z; s4.w += r.w; }
+            float4 *o = reinterpret_cast<float4 *>(out + i4);
+            if (acc) { const float4 a = *o; s4.x += a.x; s4.y += a.y; s4.z += a.z; s4.w += a.w; }
+            *o = s4;
+        }
+        return;
+    }
     const int64_t i = (int64_t)wg * 64 + el;
     float s = 0.f;
     if (i < n) {
@@ -914,9 +942,11 @@ int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t strea
             const bool wide = j.n_chunks <= 16 && n >= 16384 && n % 4 == 0 && j.ld % 4 == 0 && (j.rows == 1 || j.out_ld == j.cols) && aligned16(j.partial) && aligned16(j.out);
             b.part[i] = j.partial; b.out[i] = j.out; b.ld[i] = j.ld; b.out_ld[i] = j.out_ld; b.n_chunks[i] = j.n_chunks; b.rows[i] = j.rows; b.cols[i] = j.cols;
             if (j.accumulate) b.acc_mask |= 1u << i;
+            const bool vec = !wide && n >= 1024 && n % 4 == 0 && j.ld % 4 == 0 && (j.rows == 1 || j.out_ld == j.cols) && aligned16(j.partial) && aligned16(j.out);
             if (wide) b.wide_mask |= 1u << i;
+            if (vec) b.vec_mask |= 1u << i;
             b.wg0[i] = (int)wgs;
-            wgs += wide ? cdiv(n, 4096) : cdiv(n, 64);
+            wgs += wide ? cdiv(n, 4096) : (vec ? cdiv(n, 256) : cdiv(n, 64));
             PAPC_REQUIRE(wgs < (1ll << 30), PAPC_E_UNSUPPORTED, "papc_fold_jobs_f32: too many elements");
         }
         b.wg0[nj] = (int)wgs;

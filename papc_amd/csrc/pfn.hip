@@ -40,6 +40,8 @@ struct PfnArgs {
     float *red; float *dwp;
     double *gram;    // PFN_GRAM: [gridDim.x][256] partial Gram matrices
     int with_dist;   // PFN_DECORATE only: also write ||xyz|| as a 10th channel (pillars.py:92-94)
+    int zero_padded; // the caller states that rows t >= num_voxels of `features` are zero (the reference's voxeliser zero-initialises its buffers,
+                     // libs/ops/point_cloud/point_cloud_ops.py:148): only the real rows are loaded
     // PFN_GRAM with ticket != NULL: the workgroup that finishes last folds the partials and writes the BatchNorm constants (pfn_gram_finalize_body)
     unsigned *ticket; const float *gamma, *beta; float eps, momentum; double Mrows; int Cfin;
     float *o_mean, *o_invstd, *o_scale, *o_shift, *rmean, *rvar; double *gram_out;
@@ -60,7 +62,11 @@ __device__ __forceinline__ T pfn_ld(const T *p) { return __hip_atomic_load(p, __
 __device__ __forceinline__ bool pfn_last_block(unsigned *ticket)
 {
     __shared__ unsigned s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this thread's agent-scope stores have been acknowledged
+    // every agent-scope store of this thread has been acknowledged before the workgroup takes its ticket.  A workgroup-scope release fence
+    // does NOT emit this wait on gfx950 (round-4 advisor: the ISA went store -> s_barrier -> atomic), so it is spelled out; the build's ISA
+    // audit (papc_amd/_isa_audit.py::audit_ticket) checks that every ticket atomic of this file sits behind one.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -83,16 +89,18 @@ constexpr int PFN_NACC = 11;   // accumulator slots per channel (BWD_SPARSE: sum
 // (pfn_stage_from) so that a mode whose per-pillar work is short can put the next pillar's loads in flight first.
 struct PfnRaw { float4 f[2]; int nv, cx, cy; };
 
-__device__ __forceinline__ PfnRaw pfn_fetch(const PfnArgs &a, int p, int lane)
+// `nv_known` >= 0: the pillar's point count, fetched an iteration earlier (zero_padded: the row loads are sized by it)
+__device__ __forceinline__ PfnRaw pfn_fetch(const PfnArgs &a, int p, int lane, int nv_known = -1)
 {
     PfnRaw r;
+    r.nv = nv_known >= 0 ? nv_known : a.nvox[p];
+    const int lim = a.zero_padded ? (r.nv < a.T ? r.nv : a.T) : a.T;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int t = lane + 64 * h;
         r.f[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < a.T) r.f[h] = *reinterpret_cast<const float4 *>(a.feat + ((int64_t)p * a.T + t) * 4);
+        if (t < lim) r.f[h] = *reinterpret_cast<const float4 *>(a.feat + ((int64_t)p * a.T + t) * 4);
     }
-    r.nv = a.nvox[p];
     r.cx = a.coors[(int64_t)p * 4 + 3];
     r.cy = a.coors[(int64_t)p * 4 + 2];
     return r;
@@ -174,14 +182,21 @@ __global__ __launch_bounds__(64 * WAVES) void pfn_kernel(PfnArgs a)
 #pragma unroll
     for (int q = 0; q < 4; ++q) gacc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
 
+    constexpr bool PF = MODE == PFN_GRAM || MODE == PFN_BWD_SPARSE;      // modes whose per-pillar work is short: software-pipelined loads
     PfnRaw nxt = {};
-    if (MODE == PFN_GRAM && (int)(blockIdx.x * PFN_WAVES + wave) < a.P) nxt = pfn_fetch(a, blockIdx.x * PFN_WAVES + wave, lane);
+    int nv2 = 0;              // point count of the pillar AFTER the prefetched one (so that a count-sized fetch never waits for its count)
+    if (PF && (int)(blockIdx.x * PFN_WAVES + wave) < a.P) {
+        const int p0 = blockIdx.x * PFN_WAVES + wave, p1 = p0 + gridDim.x * PFN_WAVES;
+        nxt = pfn_fetch(a, p0, lane);
+        if (p1 < a.P) nv2 = a.nvox[p1];
+    }
     for (int p = blockIdx.x * PFN_WAVES + wave; p < a.P; p += gridDim.x * PFN_WAVES) {
         PfnRaw cur = {};
-        if (MODE == PFN_GRAM) {   // the next pillar's loads fly under this pillar's MFMAs
+        if (PF) {   // the next pillar's loads fly under this pillar's work
             cur = nxt;
-            const int pn = p + gridDim.x * PFN_WAVES;
-            if (pn < a.P) nxt = pfn_fetch(a, pn, lane);
+            const int pn = p + gridDim.x * PFN_WAVES, pnn = pn + gridDim.x * PFN_WAVES;
+            if (pn < a.P) nxt = pfn_fetch(a, pn, lane, nv2);
+            if (pnn < a.P) nv2 = a.nvox[pnn];
             pfn_stage_from<false>(a, cur, rows, lane);
         } else {
             pfn_stage<MODE == PFN_DECORATE>(a, p, rows, lane);
@@ -380,11 +395,17 @@ __global__ __launch_bounds__(64 * PFN_WAVES) void pfn_apply_mfma_kernel(PfnArgs 
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest terms first
 
     PfnRaw nxt = {};
-    if ((int)(blockIdx.x * PFN_WAVES + wave) < a.P) nxt = pfn_fetch(a, blockIdx.x * PFN_WAVES + wave, lane);
+    int nv2 = 0;
+    if ((int)(blockIdx.x * PFN_WAVES + wave) < a.P) {
+        const int p0 = blockIdx.x * PFN_WAVES + wave, p1 = p0 + gridDim.x * PFN_WAVES;
+        nxt = pfn_fetch(a, p0, lane);
+        if (p1 < a.P) nv2 = a.nvox[p1];
+    }
     for (int p = blockIdx.x * PFN_WAVES + wave; p < a.P; p += gridDim.x * PFN_WAVES) {
         const PfnRaw cur = nxt;
-        const int pn = p + gridDim.x * PFN_WAVES;
-        if (pn < a.P) nxt = pfn_fetch(a, pn, lane);      // the next pillar's points fly under this pillar's tiles
+        const int pn = p + gridDim.x * PFN_WAVES, pnn = pn + gridDim.x * PFN_WAVES;
+        if (pn < a.P) nxt = pfn_fetch(a, pn, lane, nv2);      // the next pillar's points fly under this pillar's tiles
+        if (pnn < a.P) nv2 = a.nvox[pnn];
         pfn_stage_from<false>(a, cur, rows, lane);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -661,22 +682,8 @@ __global__ __launch_bounds__(256) void pfn_decorate_nf_kernel(const float *__res
 }
 
 // ---- the fused launches papc_pfn_fwd / papc_pfn_bwd (sa_mlp.hip) use -------------------------------------------------------------
-static unsigned *g_pfn_tickets = nullptr;      // two ticket words (Gram pass, backward fold), zero between launches
-unsigned *pfn_tickets()
-{
-    // (first use must be outside a stream capture, like every lazily created constant of this library; on failure the callers keep
-    // the separate finalize launches)
-    if (!g_pfn_tickets) {
-        unsigned *t = nullptr;
-        if (hipMalloc(&t, 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        if (hipMemset(t, 0, 64) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t); return nullptr; }
-        g_pfn_tickets = t;
-    }
-    return g_pfn_tickets;
-}
-
 // papc_pfn_gram_f32 + papc_pfn_gram_finalize_f32 in one launch
-int pfn_gram_stats(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset,
+int pfn_gram_stats(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset, int zero_padded,
                    double *gram_partial, const float *w, int C, const float *gamma, const float *beta, float eps, float momentum, float *mean, float *invstd,
                    float *scale, float *shift, float *running_mean, float *running_var, double *gram, unsigned *ticket, hipStream_t st)
 {
@@ -688,7 +695,7 @@ int pfn_gram_stats(const float *features, const int32_t *num_voxels, const int32
     PfnArgs a;
     memset(&a, 0, sizeof(a));
     a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
-    a.C = 1; a.gram = gram_partial;
+    a.C = 1; a.gram = gram_partial; a.zero_padded = zero_padded;
     a.ticket = ticket; a.w = w; a.Cfin = C; a.gamma = gamma; a.beta = beta; a.eps = eps; a.momentum = momentum; a.Mrows = (double)((int64_t)P * T);
     a.o_mean = mean; a.o_invstd = invstd; a.o_scale = scale; a.o_shift = shift; a.rmean = running_mean; a.rvar = running_var; a.gram_out = gram;
     ProfScope prof(PAPC_K_PFN, st);
@@ -707,6 +714,60 @@ int pfn_bwd_fold_finalize(const float *partial, int n_chunks, float *sums, int64
     hipLaunchKernelGGL(pfn_bwd_fold_finalize_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, partial, n_chunks, n, sums, ticket, (double)M, w, C, gram, mean,
                        invstd, scale, dgamma, dbeta, dw, flags);
     return check_launch("papc_pfn_bwd (fold + finalize)");
+}
+
+extern "C" int papc_pfn_gram_blocks(int P);
+
+int pfn_apply_impl(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                       float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                       const float *scale, const float *shift, float *out, int32_t *argmax, int zero_padded, papc_stream_t stream)
+{
+    int rc = pfn_check("papc_pfn_apply_f32", features, num_voxels, coors, P, T, w, C);
+    if (rc) return rc;
+    PAPC_REQUIRE(scale && shift && out, PAPC_E_INVALID, "papc_pfn_apply_f32: null pointer");
+    PfnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset; a.zero_padded = zero_padded;
+    a.w = w; a.C = C; a.scale = scale; a.shift = shift; a.out = out; a.argmax = argmax;
+    if (knob(KNOB_PFN_MFMA)) {   // default: the matrix-pipe flavour (PAPC_PFN_MFMA=0: lanes-are-channels VALU flavour)
+        hipStream_t st = as_stream(stream);
+        ProfScope prof(PAPC_K_PFN, st);
+        hipLaunchKernelGGL(pfn_apply_mfma_kernel, dim3(pfn_blocks(P)), dim3(64 * PFN_WAVES), 0, st, a);   // (512 .. 3000 workgroups: same time)
+        return check_launch("papc_pfn_apply_f32");
+    }
+    return launch_pfn<PFN_APPLY>(a, as_stream(stream), "papc_pfn_apply_f32");
+}
+
+int pfn_gram_impl(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
+                      float vx, float vy, float x_offset, float y_offset, double *gram_partial, int zero_padded, papc_stream_t stream)
+{
+    const float dummy = 0.f;
+    int rc = pfn_check("papc_pfn_gram_f32", features, num_voxels, coors, P, T, &dummy, 1);
+    if (rc) return rc;
+    PAPC_REQUIRE(gram_partial, PAPC_E_INVALID, "papc_pfn_gram_f32: null gram_partial");
+    PfnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset; a.zero_padded = zero_padded;
+    a.C = 1; a.gram = gram_partial;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_PFN, st);
+    hipLaunchKernelGGL((pfn_kernel<PFN_GRAM, PFN_GRAM_WAVES>), dim3(papc_pfn_gram_blocks(P)), dim3(64 * PFN_GRAM_WAVES), 0, st, a);
+    return check_launch("papc_pfn_gram_f32");
+}
+
+int pfn_bwd_sparse_impl(const float *features, const int32_t *num_voxels, const int32_t *coors, int P,
+                            int T, float vx, float vy, float x_offset, float y_offset, const float *w, int C,
+                            const float *gout, const int32_t *argmax, const float *mean, const float *invstd,
+                            const float *scale, const float *shift, float *partial, int zero_padded, papc_stream_t stream)
+{
+    int rc = pfn_check("papc_pfn_bwd_sparse_f32", features, num_voxels, coors, P, T, w, C);
+    if (rc) return rc;
+    PAPC_REQUIRE(gout && argmax && mean && invstd && scale && shift && partial, PAPC_E_INVALID, "papc_pfn_bwd_sparse_f32: null pointer");
+    PfnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset; a.zero_padded = zero_padded;
+    a.w = w; a.C = C; a.gout = gout; a.amax = argmax; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.red = partial;
+    return launch_pfn<PFN_BWD_SPARSE>(a, as_stream(stream), "papc_pfn_bwd_sparse_f32");
 }
 
 }  // namespace papc
@@ -763,20 +824,7 @@ int papc_pfn_apply_f32(const float *features, const int32_t *num_voxels, const i
                        float vx, float vy, float x_offset, float y_offset, const float *w, int C,
                        const float *scale, const float *shift, float *out, int32_t *argmax, papc_stream_t stream)
 {
-    int rc = pfn_check("papc_pfn_apply_f32", features, num_voxels, coors, P, T, w, C);
-    if (rc) return rc;
-    PAPC_REQUIRE(scale && shift && out, PAPC_E_INVALID, "papc_pfn_apply_f32: null pointer");
-    PfnArgs a;
-    memset(&a, 0, sizeof(a));
-    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
-    a.w = w; a.C = C; a.scale = scale; a.shift = shift; a.out = out; a.argmax = argmax;
-    if (knob(KNOB_PFN_MFMA)) {   // default: the matrix-pipe flavour (PAPC_PFN_MFMA=0: lanes-are-channels VALU flavour)
-        hipStream_t st = as_stream(stream);
-        ProfScope prof(PAPC_K_PFN, st);
-        hipLaunchKernelGGL(pfn_apply_mfma_kernel, dim3(pfn_blocks(P)), dim3(64 * PFN_WAVES), 0, st, a);   // (512 .. 3000 workgroups: same time)
-        return check_launch("papc_pfn_apply_f32");
-    }
-    return launch_pfn<PFN_APPLY>(a, as_stream(stream), "papc_pfn_apply_f32");
+    return papc::pfn_apply_impl(features, num_voxels, coors, P, T, vx, vy, x_offset, y_offset, w, C, scale, shift, out, argmax, 0, stream);
 }
 
 int papc_pfn_bwd_reduce_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P,
@@ -817,18 +865,7 @@ int papc_pfn_gram_blocks(int P) { return P >= 1 ? (int)std::min<int64_t>(cdiv(P,
 int papc_pfn_gram_f32(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T,
                       float vx, float vy, float x_offset, float y_offset, double *gram_partial, papc_stream_t stream)
 {
-    const float dummy = 0.f;
-    int rc = pfn_check("papc_pfn_gram_f32", features, num_voxels, coors, P, T, &dummy, 1);
-    if (rc) return rc;
-    PAPC_REQUIRE(gram_partial, PAPC_E_INVALID, "papc_pfn_gram_f32: null gram_partial");
-    PfnArgs a;
-    memset(&a, 0, sizeof(a));
-    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
-    a.C = 1; a.gram = gram_partial;
-    hipStream_t st = as_stream(stream);
-    ProfScope prof(PAPC_K_PFN, st);
-    hipLaunchKernelGGL((pfn_kernel<PFN_GRAM, PFN_GRAM_WAVES>), dim3(papc_pfn_gram_blocks(P)), dim3(64 * PFN_GRAM_WAVES), 0, st, a);
-    return check_launch("papc_pfn_gram_f32");
+    return papc::pfn_gram_impl(features, num_voxels, coors, P, T, vx, vy, x_offset, y_offset, gram_partial, 0, stream);
 }
 
 int papc_pfn_gram_finalize_f32(const double *gram_partial, int n_blocks, int64_t M, const float *w, int C, const float *gamma,
@@ -853,14 +890,7 @@ int papc_pfn_bwd_sparse_f32(const float *features, const int32_t *num_voxels, co
                             const float *gout, const int32_t *argmax, const float *mean, const float *invstd,
                             const float *scale, const float *shift, float *partial, papc_stream_t stream)
 {
-    int rc = pfn_check("papc_pfn_bwd_sparse_f32", features, num_voxels, coors, P, T, w, C);
-    if (rc) return rc;
-    PAPC_REQUIRE(gout && argmax && mean && invstd && scale && shift && partial, PAPC_E_INVALID, "papc_pfn_bwd_sparse_f32: null pointer");
-    PfnArgs a;
-    memset(&a, 0, sizeof(a));
-    a.feat = features; a.nvox = num_voxels; a.coors = coors; a.P = P; a.T = T; a.vx = vx; a.vy = vy; a.xo = x_offset; a.yo = y_offset;
-    a.w = w; a.C = C; a.gout = gout; a.amax = argmax; a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.red = partial;
-    return launch_pfn<PFN_BWD_SPARSE>(a, as_stream(stream), "papc_pfn_bwd_sparse_f32");
+    return papc::pfn_bwd_sparse_impl(features, num_voxels, coors, P, T, vx, vy, x_offset, y_offset, w, C, gout, argmax, mean, invstd, scale, shift, partial, 0, stream);
 }
 
 int papc_pfn_bwd_finalize_f32(const float *sums, int64_t M, const float *w, int C, const double *gram, const float *mean,

@@ -23,10 +23,16 @@
 
 namespace papc {
 // (pfn.hip: the fused launches of the PillarFeatureNet entry points below)
-unsigned *pfn_tickets();
-int pfn_gram_stats(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset,
+int pfn_gram_stats(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset, int zero_padded,
                    double *gram_partial, const float *w, int C, const float *gamma, const float *beta, float eps, float momentum, float *mean, float *invstd,
                    float *scale, float *shift, float *running_mean, float *running_var, double *gram, unsigned *ticket, hipStream_t st);
+int pfn_gram_impl(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset,
+                  double *gram_partial, int zero_padded, papc_stream_t stream);
+int pfn_apply_impl(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset,
+                   const float *w, int C, const float *scale, const float *shift, float *out, int32_t *argmax, int zero_padded, papc_stream_t stream);
+int pfn_bwd_sparse_impl(const float *features, const int32_t *num_voxels, const int32_t *coors, int P, int T, float vx, float vy, float x_offset, float y_offset,
+                        const float *w, int C, const float *gout, const int32_t *argmax, const float *mean, const float *invstd, const float *scale,
+                        const float *shift, float *partial, int zero_padded, papc_stream_t stream);
 int pfn_bwd_fold_finalize(const float *partial, int n_chunks, float *sums, int64_t M, const float *w, int C, const double *gram, const float *mean,
                           const float *invstd, const float *scale, float *dgamma, float *dbeta, float *dw, int flags, unsigned *ticket, hipStream_t st);
 
@@ -848,12 +854,12 @@ int papc_pfn_fwd(const papc_pfn_desc *desc, const papc_pfn_io *io, papc_stream_t
     if (d.training) {
         // batch statistics from the inputs' Gram matrix: one float64-MFMA pass over the points instead of a C-channel pass over [P*T, C]
         const int ng = papc_pfn_gram_blocks(d.P);
-        unsigned *tk = knob(KNOB_PFN_FUSED_TAILS) ? papc::pfn_tickets() : nullptr;
+        unsigned *tk = knob(KNOB_PFN_FUSED_TAILS) ? io->tickets : nullptr;      // (caller-owned ticket words: no process-global state)
         if (tk) {    // the Gram pass's last-arriving workgroup writes the BatchNorm constants (pfn.hip): one launch
-            SA_CALL(papc::pfn_gram_stats(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, gpart, io->w, C, io->gamma, io->beta,
+            SA_CALL(papc::pfn_gram_stats(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, d.zero_padded, gpart, io->w, C, io->gamma, io->beta,
                                          d.eps, d.momentum, cst, cst + C, cst + 2 * C, cst + 3 * C, io->running_mean, io->running_var, gram, tk, as_stream(st)));
         } else {
-            SA_CALL(papc_pfn_gram_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, gpart, st));
+            SA_CALL(papc::pfn_gram_impl(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, gpart, d.zero_padded, st));
             SA_CALL(papc_pfn_gram_finalize_f32(gpart, ng, (int64_t)d.P * d.T, io->w, C, io->gamma, io->beta, d.eps, d.momentum, cst, cst + C, cst + 2 * C, cst + 3 * C,
                                                io->running_mean, io->running_var, gram, st));
         }
@@ -861,7 +867,7 @@ int papc_pfn_fwd(const papc_pfn_desc *desc, const papc_pfn_io *io, papc_stream_t
         PAPC_REQUIRE(io->running_mean && io->running_var, PAPC_E_INVALID, "papc_pfn_fwd: eval mode needs the running statistics");
         SA_CALL(papc_bn_eval_consts_f32(io->running_mean, io->running_var, io->gamma, io->beta, d.eps, C, cst, cst + C, cst + 2 * C, cst + 3 * C, st));
     }
-    return papc_pfn_apply_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, io->w, C, cst + 2 * C, cst + 3 * C, io->out, argmax, st);
+    return papc::pfn_apply_impl(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, io->w, C, cst + 2 * C, cst + 3 * C, io->out, argmax, d.zero_padded, st);
 }
 
 int papc_pfn_bwd(const papc_pfn_desc *desc, const papc_pfn_io *io, const float *gout, float *dw, float *dgamma, float *dbeta, int accumulate, papc_stream_t st)
@@ -874,9 +880,9 @@ int papc_pfn_bwd(const papc_pfn_desc *desc, const papc_pfn_io *io, const float *
     const int C = d.C, nb = papc_pfn_num_blocks(d.P);
     if (!d.training) SA_CALL(papc_fill_f32(reinterpret_cast<float *>(gram), 512, 0.f, st));     // eval-mode BN: the Gram terms carry zero weight
     // sparse pass (one argmax row per (pillar, channel)): sum p, sum p*xhat, sum p*x_k; the dense part of dW comes from the Gram matrix
-    SA_CALL(papc_pfn_bwd_sparse_f32(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, io->w, C, gout, argmax, cst, cst + C,
-                                    cst + 2 * C, cst + 3 * C, part, st));
-    unsigned *tk = knob(KNOB_PFN_FUSED_TAILS) ? papc::pfn_tickets() : nullptr;
+    SA_CALL(papc::pfn_bwd_sparse_impl(io->features, io->num_voxels, io->coors, d.P, d.T, d.vx, d.vy, d.x_offset, d.y_offset, io->w, C, gout, argmax, cst, cst + C,
+                                      cst + 2 * C, cst + 3 * C, part, d.zero_padded, st));
+    unsigned *tk = knob(KNOB_PFN_FUSED_TAILS) ? io->tickets : nullptr;
     if (tk)      // the fold of the partial rows and the finalize in one launch (last-arriving workgroup, pfn.hip)
         return papc::pfn_bwd_fold_finalize(part, nb, sums, (int64_t)d.P * d.T, io->w, C, gram, cst, cst + C, cst + 2 * C, dgamma, dbeta, dw,
                                            (d.training ? 0 : 1) | (accumulate ? 2 : 0), tk + 1, as_stream(st));

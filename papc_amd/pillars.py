@@ -28,34 +28,35 @@ class PfnDesc(ctypes.Structure):
     """papc_pfn_desc"""
     _fields_ = [("P", ctypes.c_int32), ("T", ctypes.c_int32), ("C", ctypes.c_int32), ("vx", ctypes.c_float), ("vy", ctypes.c_float),
                 ("x_offset", ctypes.c_float), ("y_offset", ctypes.c_float), ("eps", ctypes.c_float), ("momentum", ctypes.c_float),
-                ("training", ctypes.c_int32)]
+                ("training", ctypes.c_int32), ("zero_padded", ctypes.c_int32)]
 
 
 class PfnIo(ctypes.Structure):
     """papc_pfn_io"""
     _fields_ = [(n, ctypes.c_void_p) for n in ("features", "num_voxels", "coors", "w", "gamma", "beta", "running_mean", "running_var", "out",
-                                               "saved", "scratch")]
+                                               "saved", "scratch", "tickets")]
 
 
 class _PFNFused(torch.autograd.Function):
     """the single-layer PillarFeatureNet (pillars.py:79-108) through the library's coarse entry points: papc_pfn_fwd / papc_pfn_bwd"""
 
     @staticmethod
-    def forward(ctx, geom, features, num_voxels, coors, w, gamma, beta, rmean, rvar, eps, momentum, training=True):
+    def forward(ctx, geom, features, num_voxels, coors, w, gamma, beta, rmean, rvar, eps, momentum, training=True, tickets=None, zero_padded=False):
         lib = _lib.load()
         P, T, _ = features.shape
         C = w.shape[0]
         dev = features.device
-        d = PfnDesc(P, T, C, geom[0], geom[1], geom[2], geom[3], eps, momentum, int(bool(training)))
+        d = PfnDesc(P, T, C, geom[0], geom[1], geom[2], geom[3], eps, momentum, int(bool(training)), int(bool(zero_padded)))
         sb, wb = ctypes.c_int64(0), ctypes.c_int64(0)
         check(lib.papc_pfn_workspace(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(wb)), "papc_pfn_workspace")
         saved = torch.empty(sb.value, device=dev, dtype=torch.uint8)
         scratch = torch.empty(wb.value, device=dev, dtype=torch.uint8)
         out = torch.empty(P, C, device=dev, dtype=torch.float32)
-        io = PfnIo(ptr(features), ptr(num_voxels), ptr(coors), ptr(w), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(out), ptr(saved), ptr(scratch))
+        io = PfnIo(ptr(features), ptr(num_voxels), ptr(coors), ptr(w), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(out), ptr(saved), ptr(scratch),
+                   ptr(tickets))
         check(lib.papc_pfn_fwd(ctypes.byref(d), ctypes.byref(io), stream_ptr()), "papc_pfn_fwd")
         ctx.desc, ctx.saved = d, saved
-        ctx.bufs = (rmean, rvar)
+        ctx.bufs = (rmean, rvar, tickets)
         from .mlp import grad_targets_of
         ctx.grad_targets = grad_targets_of([w, gamma, beta]) if torch.is_grad_enabled() or w.requires_grad else None
         ctx.save_for_backward(features, num_voxels, coors, w, gamma, beta)
@@ -72,18 +73,18 @@ class _PFNFused(torch.autograd.Function):
         check(lib.papc_pfn_workspace(ctypes.byref(d), ctypes.byref(sb), ctypes.byref(wb)), "papc_pfn_workspace")
         scratch = torch.empty(wb.value, device=dev, dtype=torch.uint8)
         io = PfnIo(ptr(features), ptr(num_voxels), ptr(coors), ptr(w), ptr(gamma), ptr(beta), ptr(ctx.bufs[0]), ptr(ctx.bufs[1]), None, ptr(ctx.saved),
-                   ptr(scratch))
+                   ptr(scratch), ptr(ctx.bufs[2]))
         tg = ctx.grad_targets            # (w.grad, gamma.grad, beta.grad) of parameters that opted in to in-place accumulation, or None
         if tg is not None and any(t is None for t in tg):
             tg = None
         if tg is not None:
             check(lib.papc_pfn_bwd(ctypes.byref(d), ctypes.byref(io), ptr(gout), tg[0].data_ptr(), tg[1].data_ptr(), tg[2].data_ptr(), 1, stream_ptr()),
                   "papc_pfn_bwd")
-            return (None,) * 12
+            return (None,) * 14
         dgb = torch.empty(2, d.C, device=dev, dtype=torch.float32)
         dw = torch.empty(d.C, 9, device=dev, dtype=torch.float32)
         check(lib.papc_pfn_bwd(ctypes.byref(d), ctypes.byref(io), ptr(gout), ptr(dw), dgb[0].data_ptr(), dgb[1].data_ptr(), 0, stream_ptr()), "papc_pfn_bwd")
-        return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None, None
+        return None, None, None, None, dw, dgb[0], dgb[1], None, None, None, None, None, None, None
 
 
 class _GroupMax(torch.autograd.Function):
@@ -254,6 +255,12 @@ class PillarFeatureNet(nn.Module):
         for i in range(len(num_filters) - 1):
             layers.append(PFNLayer(num_filters[i], num_filters[i + 1], use_norm, last_layer=(i >= len(num_filters) - 2)))
         self.pfn_layers = nn.ModuleList(layers)                                                # :71
+        # the fused path's two ticket words (include/papc_hip.h: papc_pfn_io.tickets): owned by this module, zero between launches; a module
+        # runs on one stream at a time, so this is the per-stream pair the header asks for (no process-global state in the library)
+        self.register_buffer("_tickets", torch.zeros(16, dtype=torch.int32), persistent=False)
+        # True: the caller guarantees zero rows behind num_voxels (what the reference's voxeliser produces, point_cloud_ops.py:148) ->
+        # the kernels load only the real rows.  Off by default: with other padding the cluster mean (:82) would differ
+        self.assume_zero_padding = False
         self.vx = voxel_size[0]
         self.vy = voxel_size[1]
         self.x_offset = self.vx / 2 + pc_range[0]                                              # :76
@@ -292,7 +299,8 @@ class PillarFeatureNet(nn.Module):
         pfn = self.pfn_layers[0]
         if self._nf == 4 and features.shape[1] <= 128 and len(self.pfn_layers) == 1 and self._use_norm and not self._with_distance and pfn.units <= 64:
             out = _PFNFused.apply(self._geom(), features, num_voxels, coors, pfn.linear.weight, pfn.norm.weight, pfn.norm.bias,
-                                  pfn.norm.running_mean, pfn.norm.running_var, pfn.norm.eps, pfn.norm.momentum, self.training)
+                                  pfn.norm.running_mean, pfn.norm.running_var, pfn.norm.eps, pfn.norm.momentum, self.training,
+                                  self._tickets, self.assume_zero_padding)
             return out.squeeze()                                                               # :108
         with torch.no_grad():
             x = self.decorate(features, num_voxels, coors)

@@ -196,3 +196,86 @@ def test_seg_planned_sampling_equals_in_line(dev, cls_):
     assert torch.equal(l0, l1), "logits differ between the planned and the in-line sampling"
     for a, b in zip(g0, g1):      # (float atomics in the gather-add backward: same terms, run-dependent order)
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-6      # (+ 1e-6: conv biases under a train-mode BN hold rounding noise around their exact 0)
+
+
+@pytest.mark.parametrize("neighbours", ["reference", "nearest"])
+def test_full_size_config3_fp_levels_vs_oracle(dev, neighbours):
+    """BASELINE configs[2] at its own size (PointNet2_MSG_Seg, B=16, N=2048): the decoder -- fp3 (1536 -> 256 -> 256 on 128 points, S = 1:
+    tile), fp2 (576 -> 256 -> 128 on 512 points, 3-NN over 128), fp1 (150 -> 128 -> 128 on 2048 points, 3-NN over 512) and the per-point head
+    conv1 / bn1 / relu / conv2 -- each level against the float64 oracle on the ORACLE's inputs (the previous level's oracle output, so every
+    level is held on its own, as test_full_size_config2_sa_vs_oracle does for the encoder): 3-NN distances / indices / weights bit-exact,
+    activations 1e-5, both `neighbours` modes.  pointnet2_basic_layers.py:284-335, segment/pointnet2/pointnet2.py:65-67, 88-98."""
+    from papc_amd import functional as F
+    from papc_amd.linear import linear_rows
+    from papc_amd.mlp import StackSpec, shared_mlp_max
+    from papc_amd.layers import _bn_buffers, _stack_params
+    from tests.util import seeded_weights
+    B, N = 16, 2048
+    rng = np.random.default_rng(77)
+    x = make_clouds(B, N, 41)                                                 # [B,3,N]
+    cls = (np.arange(B).reshape(B, 1) % 16).astype(np.int64)
+    xyz0 = np.ascontiguousarray(x.transpose(0, 2, 1))
+    i1 = R.farthest_point_sample(xyz0, 512, make_start_idx(B, N, 41))
+    xyz1 = R.index_points(xyz0, i1.astype(np.int64))                          # [B,512,3]
+    i2 = R.farthest_point_sample(xyz1, 128, make_start_idx(B, 512, 42))
+    xyz2 = R.index_points(xyz1, i2.astype(np.int64))                          # [B,128,3]
+    l1_xyz, l2_xyz = (np.ascontiguousarray(a.transpose(0, 2, 1)) for a in (xyz1, xyz2))
+    l3_xyz = np.zeros((B, 3, 1), np.float32)                                  # sample_and_group_all's centre (:170)
+    feat = lambda c, n: rng.normal(size=(B, c, n)).astype(np.float32)
+    l1_points, l2_points, l3_points = feat(320, 512), feat(512, 128), feat(1024, 1)
+    torch.manual_seed(0)
+    m = PointNet2_MSG_Seg(fp_neighbours=neighbours).to(dev)
+    m.train()
+    specs = {"fp3": [1536, 256, 256], "fp2": [576, 256, 128], "fp1": [150, 128, 128]}
+    ws = {k: seeded_weights(v, 50 + i) for i, (k, v) in enumerate(specs.items())}
+    w_head = seeded_weights([128, 128], 60)
+    w2 = (rng.normal(size=(50, 128)) * 0.1).astype(np.float32)
+    b2 = (rng.normal(size=50) * 0.1).astype(np.float32)
+    with torch.no_grad():
+        for k in specs:
+            layer = getattr(m, k)
+            for conv, bn, (w, b, g, bt) in zip(layer.mlp_convs, layer.mlp_bns, ws[k]):
+                conv.weight.copy_(torch.from_numpy(w).reshape(conv.weight.shape)); conv.bias.copy_(torch.from_numpy(b))
+                bn.weight.copy_(torch.from_numpy(g)); bn.bias.copy_(torch.from_numpy(bt))
+        (w, b, g, bt), = w_head
+        m.conv1.weight.copy_(torch.from_numpy(w).reshape(m.conv1.weight.shape)); m.conv1.bias.copy_(torch.from_numpy(b))
+        m.bn1.weight.copy_(torch.from_numpy(g)); m.bn1.bias.copy_(torch.from_numpy(bt))
+        m.conv2.weight.copy_(torch.from_numpy(w2).reshape(m.conv2.weight.shape)); m.conv2.bias.copy_(torch.from_numpy(b2))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ora = lambda k: R.PointNetFeaturePropagation(specs[k][0], specs[k][1:], ws[k], neighbours)
+
+    # ---- 3-NN searches at the two sizes the decoder runs them: bit-exact against the literal restatement (:315-322)
+    for q, s_, nm in ((l1_xyz, l2_xyz, "fp2 (512 over 128)"), (x, l1_xyz, "fp1 (2048 over 512)")):
+        qn, sn = np.ascontiguousarray(q.transpose(0, 2, 1)), np.ascontiguousarray(s_.transpose(0, 2, 1))
+        d_ref, i_ref, w_ref = R.three_nn_true(qn, sn)
+        d, i, w = F.three_nn(t(qn), t(sn))
+        assert np.array_equal(d.cpu().numpy(), d_ref), nm + ": distances"
+        assert np.array_equal(i.cpu().numpy().astype(np.int64), i_ref), nm + ": neighbour indices"
+        assert np.array_equal(w.cpu().numpy(), w_ref), nm + ": weights"
+
+    with torch.no_grad():
+        # fp3 (:65 / :88): S = 1 -> the coarse feature is tiled
+        ref3 = ora("fp3").forward(l2_xyz, l3_xyz, l2_points, l3_points, f64=True)
+        got3 = m.fp3(t(l2_xyz), t(l3_xyz), t(l2_points), t(l3_points))
+        assert_close(got3.cpu().numpy(), ref3, 1e-5, "config-3 fp3 (2048 rows x 1536) vs f64 oracle")
+        l2p = ref3.astype(np.float32)
+        # fp2 (:66 / :89)
+        ref2 = ora("fp2").forward(l1_xyz, l2_xyz, l1_points, l2p, f64=True)
+        got2 = m.fp2(t(l1_xyz), t(l2_xyz), t(l1_points), t(l2p))
+        assert_close(got2.cpu().numpy(), ref2, 1e-5, "config-3 fp2 (8192 rows x 576) vs f64 oracle")
+        l1p = ref2.astype(np.float32)
+        # fp1 (:67 / :90-91): skip input = [one-hot class, xyz, points]
+        onehot = np.tile(np.eye(16, dtype=np.float32)[cls.reshape(-1)][:, :, None], (1, 1, N))
+        p1 = np.concatenate([onehot, x, x], axis=1)
+        ref1 = ora("fp1").forward(x, l1_xyz, p1, l1p, f64=True)
+        got1 = m.fp1(t(x), t(l1_xyz), t(p1), t(l1p))
+        assert_close(got1.cpu().numpy(), ref1, 1e-5, "config-3 fp1 (32768 rows x 150) vs f64 oracle")
+        # head (:47-49 / :93-95): relu(bn1(conv1(.))) then conv2, on the oracle's fp1 output
+        rows = np.ascontiguousarray(ref1.astype(np.float32).transpose(0, 2, 1)).reshape(B * N, 128)
+        feat_ref = R.mlp_stack_rows(rows, w_head, f64=True)
+        logits_ref = feat_ref @ w2.astype(np.float64).T + b2.astype(np.float64)
+        spec = StackSpec(B, N, N, 1, 128, True, eps=m.bn1.eps, momentum=0.9, pool=False)
+        f_got = shared_mlp_max(spec, _bn_buffers([m.bn1]), None, None, None, None, _stack_params([m.conv1], [m.bn1]), x_rows=t(rows))
+        assert_close(f_got.cpu().numpy(), feat_ref, 1e-5, "config-3 head conv1 / bn1 / relu vs f64 oracle")
+        lg = linear_rows(t(feat_ref.astype(np.float32)), m.conv2.weight, m.conv2.bias)
+        assert_close(lg.cpu().numpy(), logits_ref, 1e-5, "config-3 head conv2 vs f64")
