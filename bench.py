@@ -251,11 +251,16 @@ def main():
     # queue -- on a default-priority stream the sampling kernels queue up BEHIND the graphs already enqueued (2.81 ms vs 2.46 ms per step)
     # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
     side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else 0)
-    ONE = torch.ones((), device=dev)            # d(loss)/d(loss), allocated once (loss.backward() would fill a fresh one every step)
+    from papc_amd.head import unit_gradient
+    ONE = unit_gradient(dev)                    # d(loss)/d(loss), allocated once; seeding with this tensor skips the loss's multiply-by-one launch
     state = {"plan": None, "ev": None, "last_grad": None}
     # every backward here is followed by an optimiser step: the Adam kernel clears the flat gradient bucket behind its update
     # (papc_adam_step_zero_f32), so the step has no clear_grad launch at its head (PAPC_ZERO_IN_ADAM=0: the separate fill)
     ZERO_IN_ADAM = os.environ.get("PAPC_ZERO_IN_ADAM", "1") != "0"
+    # one process: the optimiser launch is the LAST NODE of the step's graph (FlatAdam.step_dev: step count in device memory, advanced by a
+    # one-thread tick on the sampling branch) -- an eager Adam behind the replay starts 8-20 us after the graph's last kernel.  N > 1 keeps the
+    # eager launch: the gradient all-reduce sits between the backward and the update.  PAPC_ADAM_IN_GRAPH=0: eager everywhere.
+    ADAM_IN_GRAPH = os.environ.get("PAPC_ADAM_IN_GRAPH", "1") != "0" and not dist.is_initialized()
 
     def launch_plan():
         side.wait_stream(main)                     # the inputs (and the allocator) are ordered behind the main stream
@@ -281,6 +286,8 @@ def main():
         # main stream reaches SA3 -- the group_all layer, the FC head and their backward are small-grid kernels)
         if not ZERO_IN_ADAM or not exchange:
             flat.zero_grad()                       # (exchange=False: no optimiser step follows to clear the bucket)
+        if ADAM_IN_GRAPH and exchange:
+            opt.tick()
         if args.overlap and args.fork == "start":
             launch_plan()
         tap = {} if use_dist else None
@@ -329,9 +336,14 @@ def main():
         if not ZERO_IN_ADAM:
             flat.zero_grad()
 
+        ticked = [not ADAM_IN_GRAPH]
+
         def fork():
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                if not ticked[0]:
+                    opt.tick()                                     # the optimiser's step count advances off the critical path
+                    ticked[0] = True
                 model.plan_sampling(x, (s1, s2), out=plan_out)     # the kernels write the other graph's plan buffers in place
 
         # (N > 1: the two stages are two graphs and a fork must be joined inside the graph that opened it, so the sampling
@@ -351,6 +363,10 @@ def main():
             loss.backward(ONE)
             if plan_out is not None:
                 main.wait_stream(side)             # join: the branch is part of this step
+            if ADAM_IN_GRAPH:
+                if not ticked[0]:
+                    opt.tick()
+                finish(None)                       # the update is the last node of the captured step
             return loss, None, None, None
         l2 = tap["l2_points"]
         (g_l2,) = torch.autograd.grad(loss, [l2], [ONE])  # the kernels write the head's and SA3's gradients straight into the flat views
@@ -442,8 +458,13 @@ def main():
         else:
             scale = flat.allreduce_grads()
         if args.dump_trajectory:
-            state["last_grad"] = flat.grad.detach().clone()     # (tests: the optimiser clears the bucket)
-        opt.step(scale, zero_grad=ZERO_IN_ADAM)
+            if state["last_grad"] is None:
+                state["last_grad"] = torch.empty_like(flat.grad)
+            state["last_grad"].copy_(flat.grad)                 # (tests: the optimiser clears the bucket)
+        if ADAM_IN_GRAPH:
+            opt.step_dev(scale, zero_grad=ZERO_IN_ADAM)
+        else:
+            opt.step(scale, zero_grad=ZERO_IN_ADAM)
 
     def sample_into(plan_out):
         """the next batch's pyramid, enqueued on the side stream beside the graph that is being replayed (N > 1)"""
@@ -467,7 +488,8 @@ def main():
         if g2 is not None:
             _, work = flat.allreduce_grads(split, None, async_op=True)
             g2.replay()
-        finish(work)
+        if not ADAM_IN_GRAPH:
+            finish(work)
         return graph_state["loss"][i]
 
 
@@ -673,8 +695,10 @@ def main():
                                     % ("enqueued on the side stream beside the graph replay" if ext_sampling else "fork at " + args.fork)) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
-                       "launch": ("hipGraph replay of fwd+loss+bwd (%d graph(s) per step, two alternating sets), eager all-reduce + Adam (which also clears the gradient bucket)"
-                                  % len([g for g in graph_state["g"][0] if g is not None])) if use_graph
+                       "launch": ("hipGraph replay of fwd+loss+bwd (%d graph(s) per step, two alternating sets), %s"
+                                  % (len([g for g in graph_state["g"][0] if g is not None]),
+                                     "Adam (which also clears the gradient bucket) as the graph's last node" if ADAM_IN_GRAPH
+                                     else "eager all-reduce + Adam (which also clears the gradient bucket)")) if use_graph
                                  else ("eager" + (" (hipGraph capture FAILED: %s)" % graph_state["why"] if graph_state["why"] else "")),
                        "collectives": ("world %d, backend %s (RCCL %s); two-stage backward: all-reduce of the [SA3 | FC head] tail of the flat bucket "
                                        "(%d floats) in flight during the SA2 + SA1 backward, then the %d-float head of the bucket; RCCL over xGMI, "

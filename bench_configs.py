@@ -73,7 +73,8 @@ def run(args):
     torch.cuda.set_stream(torch.cuda.Stream())
     lib = _lib.load()
     torch.manual_seed(1234)
-    one = torch.ones((), device=dev)
+    from papc_amd.head import unit_gradient
+    one = unit_gradient(dev)          # seeding the backward with this tensor skips the loss's multiply-by-one launch (head.py)
     if args.config == "msg_seg":
         from papc_amd.models import PointNet2_MSG_Seg
         B, N = 16, 2048
@@ -131,6 +132,9 @@ def run(args):
     # the flat gradient bucket starts as zeros and every backward here is followed by an optimiser step, so the step kernel clears it
     # (papc_adam_step_zero_f32) instead of a clear_grad launch at the head of the next step (PAPC_ZERO_IN_ADAM=0: the separate fill)
     ZERO_IN_ADAM = os.environ.get("PAPC_ZERO_IN_ADAM", "1") != "0"
+    # the optimiser launch is the last node of the captured step (FlatAdam.step_dev, step count in device memory advanced by a one-thread tick:
+    # on the sampling branch where the step forks one, else at its head): an eager Adam behind a replay starts 8-20 us late
+    ADAM_IN_GRAPH = os.environ.get("PAPC_ADAM_IN_GRAPH", "1") != "0"
     overlap = args.config == "msg_seg" and getattr(args, "overlap", True)
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream() if overlap else None
@@ -138,13 +142,25 @@ def run(args):
     def fwd_bwd(plan_in=None, plan_out=None):
         if not ZERO_IN_ADAM:
             flat.zero_grad()
+        ticked = [not ADAM_IN_GRAPH]
+
+        def update():
+            if ADAM_IN_GRAPH:
+                if not ticked[0]:
+                    opt.tick()
+                opt.step_dev(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
+
         if loss_fn is None:                        # PFN: forward + backward of the layer under a given upstream gradient
             out = model(tv, tn, tc)
             out.backward(gout)
+            update()
             return out
         def fork():                                # the next batch's sampling branch fills the other graph's plan buffers in place
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                if not ticked[0]:
+                    opt.tick()
+                    ticked[0] = True
                 plan_fn(plan_out)
         fork_at = getattr(args, "fork", "sa2")      # (bench.py's flag; here: "start" = with the step, anything else = behind the encoder)
         if plan_out is not None and fork_at == "start":
@@ -156,11 +172,13 @@ def run(args):
         loss.backward(one)
         if plan_out is not None:
             main.wait_stream(side)                 # join: the branch is part of this step
+        update()
         return loss
 
     def step_eager():
         loss = fwd_bwd()
-        opt.step(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
+        if not ADAM_IN_GRAPH:
+            opt.step(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
         return loss
 
     # zero_grad + forward + loss + backward captured once into a hipGraph and replayed (as in bench.py); Adam stays an eager launch
@@ -199,7 +217,8 @@ def run(args):
         i = graph["i"] % len(graph["g"])
         graph["i"] += 1
         graph["g"][i].replay()
-        opt.step(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
+        if not ADAM_IN_GRAPH:
+            opt.step(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
         return graph["loss"][i]
 
     for _ in range(max(1, args.warmup)):
@@ -301,7 +320,7 @@ def run(args):
     out = {"metric": metric, "value": round(units * args.steps / elapsed, 2), "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": {"workload": workload, "final_loss": round(final_loss, 4), "launch": ("hipGraph replay of fwd+loss+bwd, eager Adam (which also clears the gradient bucket)" if ZERO_IN_ADAM else "hipGraph replay of zero_grad+fwd+loss+bwd, eager Adam") if use_graph else "eager",
+           "config": {"workload": workload, "final_loss": round(final_loss, 4), "launch": (("hipGraph replay of fwd+loss+bwd+Adam (the update, which also clears the gradient bucket, is the graph's last node)" if ADAM_IN_GRAPH else "hipGraph replay of fwd+loss+bwd, eager Adam (which also clears the gradient bucket)") if ZERO_IN_ADAM else "hipGraph replay of zero_grad+fwd+loss+bwd, eager Adam") if use_graph else "eager",
                       "sampling": ("software-pipelined: batch i+1's FPS / ball queries / compact plans / 3-NN searches run as a second branch (side stream) of "
                                    "batch i's graph, two alternating graphs; every timed step computes one full set") if (overlap and use_graph) else "in-line",
                       "families_ms_per_step": {K_NAMES[k]: round(v[0] / 3, 4) for k, v in fam.items() if v[0] > 0}},

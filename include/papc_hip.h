@@ -838,6 +838,13 @@ int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *e
 int papc_adam_step_zero_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,
                             float lr, double beta1, double beta2, float eps, float weight_decay, int step,
                             float grad_scale, papc_stream_t stream);
+/* The same update with the step count in DEVICE memory, so that the launch can be part of a captured hipGraph (no host scalar changes from
+ * step to step; an eager launch behind a graph replay starts 8-20 us after the graph's last kernel).  step_dev: one int64, the number of the
+ * step being applied (1 for the first); papc_adam_tick adds 1 to it -- enqueue it anywhere EARLIER in the step (e.g. on the sampling branch),
+ * never concurrently with the update.  zero_grad != 0 also clears the gradient bucket (papc_adam_step_zero_f32). */
+int papc_adam_tick(int64_t *step_dev, papc_stream_t stream);
+int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,
+                           float eps, float weight_decay, const int64_t *step_dev, float grad_scale, int zero_grad, papc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Event profiler (bench.py's live per-kernel durations).  Off by default.

@@ -372,6 +372,35 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     }
 }
 
+// Adam with the step count in DEVICE memory (papc_adam_step_dev_f32): the launch takes no host scalar that changes from step to step, so it
+// can live inside a captured hipGraph (an eager launch behind a graph replay starts 8-20 us after the graph's last kernel).  step_dev[0] is
+// advanced by papc_adam_tick (one thread, anywhere earlier in the step -- e.g. on the sampling branch), never by this kernel: every block
+// reads the same value.  The bias corrections are formed in double from it, like the host form.
+template <bool ZERO>
+__global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                       float *__restrict__ v, int64_t n, float lr, double beta1, double beta2,
+                                                       float eps, float wd, const int64_t *__restrict__ step_dev, float gscale)
+{
+    __shared__ float s_bc[2];
+    if (threadIdx.x == 0) {
+        const double t = (double)step_dev[0];
+        s_bc[0] = (float)(1.0 - pow(beta1, t));
+        s_bc[1] = (float)(1.0 - pow(beta2, t));
+    }
+    __syncthreads();
+    const float bc1 = s_bc[0], bc2 = s_bc[1];
+    const float b1 = (float)beta1, b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale + wd * p[i];
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+        if (ZERO) g[i] = 0.f;
+    }
+}
+__global__ void adam_tick_kernel(int64_t *step_dev) { step_dev[0] += 1; }
+
 __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ p, int64_t n, float v)
 {
     const int64_t n4 = n >> 2;
@@ -1086,6 +1115,29 @@ int papc_adam_step_f32(float *param, const float *grad, float *exp_avg, float *e
                        float grad_scale, papc_stream_t stream)
 {
     return adam_step(param, const_cast<float *>(grad), exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, false, stream, "papc_adam_step_f32");
+}
+
+int papc_adam_tick(int64_t *step_dev, papc_stream_t stream)
+{
+    PAPC_REQUIRE(step_dev, PAPC_E_INVALID, "papc_adam_tick: null pointer");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    return check_launch("papc_adam_tick");
+}
+
+int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,
+                           float eps, float weight_decay, const int64_t *step_dev, float grad_scale, int zero_grad, papc_stream_t stream)
+{
+    PAPC_REQUIRE(param && grad && exp_avg && exp_avg_sq && step_dev, PAPC_E_INVALID, "papc_adam_step_dev_f32: null pointer");
+    PAPC_REQUIRE(n >= 1, PAPC_E_INVALID, "papc_adam_step_dev_f32: n=%lld", (long long)n);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    if (zero_grad)
+        hipLaunchKernelGGL(adam_dev_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
+    else
+        hipLaunchKernelGGL(adam_dev_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
+    return check_launch("papc_adam_step_dev_f32");
 }
 
 int papc_adam_step_zero_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n,

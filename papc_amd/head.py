@@ -200,6 +200,23 @@ def plain_head(spec, x, fc1, fc2, drop, fc3):
     return _HeadPlain.apply(spec, float(drop.p), x, *params)
 
 
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """The constant 1.0 to seed ``loss.backward(unit_gradient(dev))`` with: d(loss)/d(loss), allocated once per device.  Seeding with THIS
+    tensor lets the loss's backward hand its stored gradient on unscaled (no multiply-by-one launch on the step's serial chain); any other
+    upstream gradient -- including the ones tensor ``loss.backward()`` makes for itself -- is multiplied in as usual."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+    t = _UNIT.get(key)
+    if t is None:
+        if _lib._capturing():
+            return torch.ones((), device=dev)
+        t = _UNIT[key] = torch.ones((), device=dev)
+    return t
+
+
 class _SoftmaxXent(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels):
@@ -215,6 +232,8 @@ class _SoftmaxXent(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dz,) = ctx.saved_tensors
+        if any(g is u for u in _UNIT.values()) or (g.dim() == 0 and any(g.data_ptr() == u.data_ptr() for u in _UNIT.values())):
+            return dz, None                            # seeded with unit_gradient(): the stored gradient IS the answer
         g = g.contiguous().float()                     # upstream gradient of the scalar loss, on the device
         out = torch.empty_like(dz)
         check(_lib.load().papc_scale_by_f32(ptr(dz), ptr(g), dz.numel(), ptr(out), stream_ptr()), "papc_scale_by_f32")

@@ -239,3 +239,62 @@ def test_whole_model_gradients_with_pinned_routing(dev, B):   # the gather-add f
         if ours > max(2e-4, 3.0 * e32):
             bad.append("%s: %.2e of max|grad| (plain fp32 autograd %.2e)" % (n, ours, e32))
     assert not bad, bad
+
+
+def test_adam_device_step_count_equals_host_form(dev):
+    """FlatAdam.step_dev (papc_adam_step_dev_f32: step count in device memory, advanced by papc_adam_tick -- the graph-capturable form)
+    against FlatAdam.step (host scalar) over several steps on identical gradients, eagerly and replayed from a captured hipGraph.
+    PAPC/train.py:62-65."""
+    import torch.nn as nn
+    torch.manual_seed(3)
+    gens = [torch.randn(7, 1531, device=dev) for _ in range(2)]
+
+    def run(mode):
+        torch.manual_seed(5)
+        mod = nn.Linear(1531, 1, bias=False).to(dev)
+        flat = FlatParams(mod)
+        opt = FlatAdam(flat, lr=1e-3, weight_decay=1e-3)
+        if mode == "graph":
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    opt.tick()
+                    opt.step_dev(0.5, zero_grad=True)
+            torch.cuda.current_stream().wait_stream(s)
+        for k in range(7):
+            flat.grad.copy_(gens[0][k] if k % 2 == 0 else gens[1][k])
+            if mode == "host":
+                opt.step(0.5, zero_grad=True)
+            elif mode == "dev":
+                opt.tick()
+                opt.step_dev(0.5, zero_grad=True)
+            else:
+                g.replay()
+        torch.cuda.synchronize()
+        assert float(flat.grad.abs().max()) == 0.0
+        if mode != "host":
+            assert int(opt.t_dev.item()) == 7
+        return flat.data.detach().cpu().numpy().copy(), opt.m.cpu().numpy().copy(), opt.v.cpu().numpy().copy()
+
+    ref = run("host")
+    for mode in ("dev", "graph"):
+        got = run(mode)
+        for a, b, nm in zip(got, ref, ("param", "exp_avg", "exp_avg_sq")):
+            assert_close(a, b, 1e-6, "Adam %s, %s step count vs host scalar" % (nm, mode))
+
+
+def test_unit_gradient_seed_skips_the_scale_launch(dev):
+    """softmax_cross_entropy's backward seeded with head.unit_gradient() hands the stored gradient on as it is; any other seed is multiplied in"""
+    from papc_amd.head import unit_gradient
+    z = torch.randn(8, 16, device=dev, requires_grad=True)
+    y = torch.randint(0, 16, (8,), device=dev)
+    softmax_cross_entropy(z, y).backward(unit_gradient(dev))
+    g1 = z.grad.clone()
+    z.grad = None
+    softmax_cross_entropy(z, y).backward()
+    assert torch.equal(g1, z.grad)
+    z.grad = None
+    softmax_cross_entropy(z, y).backward(torch.full((), 2.0, device=dev))
+    assert torch.equal(2.0 * g1, z.grad)
