@@ -247,11 +247,11 @@ def test_adam_device_step_count_equals_host_form(dev):
     PAPC/train.py:62-65."""
     import torch.nn as nn
     torch.manual_seed(3)
-    gens = [torch.randn(7, 1531, device=dev) for _ in range(2)]
+    gens = [torch.randn(7, 1536, device=dev) for _ in range(2)]
 
     def run(mode):
         torch.manual_seed(5)
-        mod = nn.Linear(1531, 1, bias=False).to(dev)
+        mod = nn.Linear(1536, 1, bias=False).to(dev)
         flat = FlatParams(mod)
         opt = FlatAdam(flat, lr=1e-3, weight_decay=1e-3)
         if mode == "graph":
