@@ -140,6 +140,10 @@ typedef struct papc_group_src {
     /* compacted grouping (papc_compact_plan_f32; all NULL for the padded [B,S,K] lists): point index of every physical row, group of
      * every 8-row segment, physical row count in device memory.  Read by the gather-add first layer (papc_lingather_*) only. */
     const int32_t *cidx, *seg_grp, *rows_dev;
+    /* optional, compacted grouping only: the rows' multiplicity weights (papc_compact_plan_f32: wrow, 1 + the group's padding copies on its
+     * first row).  With it papc_lingather_fwd_f32 writes the statistics of the PADDED tensor (sum w y, sum w y^2) itself, without it the
+     * unweighted sums of the physical rows (the copies' share then comes from papc_bn_stats_corr_f32). */
+    const float *wstat;
 } papc_group_src;
 
 /* One conv1x1 layer on rows with fp32 MFMA: y[M,Cout] = A(x)[M,Cin] . w[Cout,Cin]^T + bias.
@@ -171,6 +175,14 @@ int papc_mlp_gemm_rows_f32(int a_mode, const float *x, int64_t ldx, const papc_g
                            const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
                            int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
                            const int32_t *rows_dev, papc_stream_t stream);
+/* ... with the rows' multiplicity weights `wrow` (papc_compact_plan_f32): stats_partial then holds the statistics of the PADDED tensor -- sum
+ * w y, sum w y^2 over the physical rows -- so a compacted stack needs no papc_bn_stats_corr_f32 launch per layer.  (The kernel adds the
+ * copies' share itself: only a group's first row has w != 1 and it starts an 8-row segment, so each wave re-reads rows 0 / 8 / 16 / 24 of the
+ * tiles it has just written.)  wrow == NULL: papc_mlp_gemm_rows_f32. */
+int papc_mlp_gemm_rows_w_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
+                             const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
+                             int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
+                             const int32_t *rows_dev, const float *wrow, papc_stream_t stream);
 /* out[g,c] = relu(scale*(scale >= 0 ? gmax : gmin) + shift), argmax[g,c] = the matching row offset.  On return gmax holds the
  * SELECTED raw value (ysel: y at the argmax) -- pass it to papc_bn_bwd_reduce_f32 (MAX) so the backward need not gather y. */
 int papc_bn_select_max_f32(float *gmax, const float *gmin, const int32_t *amax, const int32_t *amin,
@@ -352,7 +364,8 @@ int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t strea
 #define PAPC_SA_NO_COMPACT 32u
 #define PAPC_SA_NO_PLANES 64u            /* few-row stacks (sample_and_group_all, M <= 16 384) on the row kernels instead of the planes kernels */
 #define PAPC_SA_NO_PLANES_POINTWISE 128u /* ... only the un-pooled point-wise stacks */
-#define PAPC_SA_NO_XYZ_FUSE 256u        /* the dX above a coordinates-only first layer stored + papc_xyz_l1_bwd_f32 instead of papc_mlp_bwd_dx_xyz_f32 */
+#define PAPC_SA_NO_XYZ_FUSE 256u
+#define PAPC_SA_NO_WSTATS 512u          /* compacted stack: unweighted statistics + one papc_bn_stats_corr_f32 launch per layer instead of weighted ones */        /* the dX above a coordinates-only first layer stored + papc_xyz_l1_bwd_f32 instead of papc_mlp_bwd_dx_xyz_f32 */
 typedef struct papc_sa_desc {
     int32_t B, N, S, K, D;
     int32_t n_layers;

@@ -23,7 +23,7 @@ class GroupSrc(ctypes.Structure):
     """papc_group_src"""
     _fields_ = [("xyz", c_p), ("sb", c_l), ("sn", c_l), ("sc", c_l), ("new_xyz", c_p), ("feats", c_p),
                 ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("xyz_first", c_i),
-                ("cidx", c_p), ("seg_grp", c_p), ("rows_dev", c_p)]
+                ("cidx", c_p), ("seg_grp", c_p), ("rows_dev", c_p), ("wstat", c_p)]
 
 
 class BwdDy(ctypes.Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "papc_mlp_gemm_gmax_ok": (c_i, [c_l, c_i, c_i]),
     "papc_mlp_gemm_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_mlp_gemm_rows_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "papc_mlp_gemm_rows_w_f32": (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "papc_sa_mlp_plan": (c_i, [c_p, c_p, c_p]),
     "papc_sa_mlp_fwd": (c_i, [c_p, c_p, c_p]),
     "papc_sa_mlp_bwd": (c_i, [c_p, c_p, c_p, c_p]),

@@ -27,6 +27,7 @@ struct LinGatherArgs {
     // compacted stack (compact.hip; all NULL for a padded one): point index per physical row, group of every 8-row segment, the physical
     // row count in device memory (M then is the capacity); the backward's per-row multiplicity weight is d.wrow
     const int32_t *cidx, *seg_grp, *rows_dev;
+    const float *wstat;         // fwd, compacted: the rows' multiplicity weights -> statistics of the padded tensor (sum w y, sum w y^2)
     DySrc d;                    // bwd: dz, y, BN constants (DENSE)
     float *G;                   // bwd: [B*N, C], pre-zeroed, atomically accumulated
     float *dwx;                 // bwd: [gridDim.x][C][3]
@@ -65,6 +66,8 @@ __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
     __shared__ float red[LG_T * 8];
     __shared__ int s_p[LG_ROWS];                 // b * N + j, or -1 for a no-hit row
     __shared__ float s_dx[LG_ROWS], s_dy[LG_ROWS], s_dz[LG_ROWS];
+    __shared__ float s_wq[LG_ROWS];              // wstat: the row's multiplicity weight
+    const bool wq_on = a.wstat != nullptr;
     const int tid = threadIdx.x;
     const int CQ = a.C >> 2, RSL = LG_T / CQ;
     const int cq = tid % CQ, slot = tid / CQ;
@@ -90,6 +93,7 @@ __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
             const LgRow r = lg_row(a, base + rr);
             s_p[rr] = r.j < 0 ? -1 : r.b * a.N + r.j;
             s_dx[rr] = r.dx; s_dy[rr] = r.dy; s_dz[rr] = r.dz;
+            if (wq_on) s_wq[rr] = a.wstat[base + rr];
         }
         __syncthreads();
         if (!act) continue;
@@ -113,6 +117,12 @@ __global__ __launch_bounds__(LG_T) void lingather_fwd_kernel(LinGatherArgs a)
                 v.z = fmaf(dz, w2.z, fmaf(dy, w1.z, fmaf(dx, w0.z, v.z + bv.z)));
                 v.w = fmaf(dz, w2.w, fmaf(dy, w1.w, fmaf(dx, w0.w, v.w + bv.w)));
                 *reinterpret_cast<float4 *>(a.y + (base + rr) * a.C + c) = v;
+                if (wq_on) {          // (compacted stack: a group's first row stands for its padding copies too)
+                    const float wq = s_wq[rr];
+                    s1.x = fmaf(wq, v.x, s1.x); s1.y = fmaf(wq, v.y, s1.y); s1.z = fmaf(wq, v.z, s1.z); s1.w = fmaf(wq, v.w, s1.w);
+                    s2.x = fmaf(wq * v.x, v.x, s2.x); s2.y = fmaf(wq * v.y, v.y, s2.y); s2.z = fmaf(wq * v.z, v.z, s2.z); s2.w = fmaf(wq * v.w, v.w, s2.w);
+                    continue;
+                }
                 s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
                 s2.x = fmaf(v.x, v.x, s2.x); s2.y = fmaf(v.y, v.y, s2.y); s2.z = fmaf(v.z, v.z, s2.z); s2.w = fmaf(v.w, v.w, s2.w);
             }
@@ -264,6 +274,7 @@ int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, con
     memset(&a, 0, sizeof(a));
     lg_fill(a, grp, B, C);
     a.P = P; a.w = w; a.ldw = ldw; a.xcol0 = xcol0; a.bias = bias; a.y = y; a.stats = stats_partial;
+    a.wstat = grp->cidx ? grp->wstat : nullptr;
     const int parts = papc_lingather_parts(a.M);
     a.rows_per_wg = (int)((a.M + parts - 1) / parts);
     hipStream_t st = as_stream(stream);

@@ -46,6 +46,7 @@ struct GemmArgs {
     RedSrc rd;
     GmaxDst gm;
     const int32_t *rows_dev;       // compacted stack (compact.hip): the physical row count in device memory (<= M, a multiple of 128); row-streaming kernel only
+    const float *wstat;            // ... its rows' multiplicity weights: the forward statistics are those of the padded tensor (row-streaming kernel only)
     unsigned long long *dbg;       // PAPC_GEMM_DBG=1: per-workgroup cycle counters (development aid)
     int tl;                        // host: the transposed-accumulator epilogue is legal (16-byte aligned dense dX store)
 };

@@ -906,7 +906,7 @@ static int launch_gemm(const GemmArgs &p, bool vec, hipStream_t st)
         const int rc = stream_gemm_try(q, AMODE, EPI, vec, st);
         if (rc != 0) return rc < 0 ? rc : PAPC_OK;
     }
-    if (p.rows_dev || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (p.a.d.wrow || p.a.d.rows_dev))) {
+    if (p.wstat || p.rows_dev || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && (p.a.d.wrow || p.a.d.rows_dev))) {
         set_error("mlp gemm: a device-side row count / compacted dY source is only built for the row-streaming kernel's flavours (M=%lld Kin=%d Nout=%d)",
                   (long long)p.M, p.Kin, p.Nout);
         return PAPC_E_UNSUPPORTED;
@@ -1009,10 +1009,10 @@ int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_
     return papc_mlp_gemm_rows_f32(a_mode, x, ldx, grp, bn_scale, bn_shift, w, bias, M, Cin, Cout, y, stats_partial, gmax, nullptr, stream);
 }
 
-int papc_mlp_gemm_rows_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
+int papc_mlp_gemm_rows_w_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
                            const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
                            int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
-                           const int32_t *rows_dev, papc_stream_t stream)
+                           const int32_t *rows_dev, const float *wrow, papc_stream_t stream)
 {
     PAPC_REQUIRE(w && (y || gmax), PAPC_E_INVALID, "papc_mlp_gemm_f32: null w/y");
     PAPC_REQUIRE(!rows_dev || (!gmax && (a_mode == A_PLAIN || a_mode == A_BNRELU)), PAPC_E_UNSUPPORTED,
@@ -1025,6 +1025,7 @@ int papc_mlp_gemm_rows_f32(int a_mode, const float *x, int64_t ldx, const papc_g
     if (rc) return rc;
     p.w = w; p.ldw = Cin; p.bias = bias; p.M = M; p.Kin = Cin; p.Nout = Cout; p.y = y; p.ldy = Cout; p.stats = stats_partial;
     p.rows_dev = rows_dev;
+    p.wstat = rows_dev ? wrow : nullptr;
     p.wmap = (a_mode == A_GROUP) ? 1 : 0;  // GROUP: internal order [feats, xyz] -> caller's columns through gk()
     const bool vec = p.a.vec && (p.wmap || (aligned16(w) && Cin % 4 == 0));
     hipStream_t st = as_stream(stream);
@@ -1061,6 +1062,14 @@ int papc_mlp_gemm_rows_f32(int a_mode, const float *x, int64_t ldx, const papc_g
     case A_BNRELU: return launch_gemm<A_BNRELU, EPI_STORE>(p, vec, st);
     default: return launch_gemm<A_GROUP, EPI_STORE>(p, vec, st);
     }
+}
+
+int papc_mlp_gemm_rows_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
+                           const float *bn_scale, const float *bn_shift, const float *w, const float *bias,
+                           int64_t M, int Cin, int Cout, float *y, float *stats_partial, const papc_group_max *gmax,
+                           const int32_t *rows_dev, papc_stream_t stream)
+{
+    return papc_mlp_gemm_rows_w_f32(a_mode, x, ldx, grp, bn_scale, bn_shift, w, bias, M, Cin, Cout, y, stats_partial, gmax, rows_dev, nullptr, stream);
 }
 
 /* 1 when a stack whose first layer is fed by coordinates only (D = 0) can run that layer through its input moments (xyz1.hip): the

@@ -75,6 +75,7 @@ struct StreamGeo {
     const int *rows_dev;
     const float *wrow;       // [rows] (CP flavours)
     const int *seg_grp;      // [rows / 8] group of every 8-row segment (CP, DY_MAX)
+    const float *wstat;      // forward of a compacted stack: the rows' multiplicity weights -> statistics of the padded tensor (see the kernel's tail)
 };
 
 // AMODE: A_PLAIN, A_BNRELU, A_DY_DENSE, A_DY_MAX, A_MAXCAT, A_XYZ.  EPI: EPI_STORE, EPI_STORE_GMAX / EPI_GMAX (forward), EPI_STORE_RED (dX).
@@ -713,6 +714,35 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         touch_p();
     }
 
+    // ---- compacted stack, forward: the copies' share of the statistics.  The ball query's padding copies are not rows of a compacted stack;
+    // what is left of a group's nsample slots rides as a weight w = 1 + copies on the group's FIRST row (compact.hip), which starts an 8-row
+    // segment -- rows 0 / 8 / 16 / 24 of a tile.  This wave re-reads those four rows of every tile it has just written (its own stores,
+    // acknowledged: nothing hidden is in flight any more) and adds (w - 1) y, (w - 1) y^2: the partial row then carries sum w y, sum w y^2,
+    // the padded tensor's statistics, and the stack needs no correction launch per layer (bn_stats_corr_kernel: 6-11 us on the serial chain).
+    if constexpr (EPI == EPI_STORE && (AMODE == A_BNRELU || AMODE == A_PLAIN) && !NR && !KR) {
+        if (geo.wstat && p.stats && my_tiles > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int j = 0; j < my_tiles; ++j) {
+                const int row0 = tile_row0(j);
+                float cfq[2], vq[2][WN];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {           // this half-wave's two candidate rows: segments hi and hi + 2 of the tile
+                    const int64_t row = row0 + 8 * (2 * q + hi);
+                    cfq[q] = geo.wstat[row] - 1.f;
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn) vq[q][wn] = p.y[row * p.ldy + n0 + wn * 32 + l31];
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int wn = 0; wn < WN; ++wn) {
+                        s1[wn] = fmaf(cfq[q], vq[q][wn], s1[wn]);
+                        s2[wn] = fmaf(cfq[q] * vq[q][wn], vq[q][wn], s2[wn]);
+                    }
+            }
+        }
+    }
+
     // ---- BN statistics (or BN-backward sums): one deterministic partial row per row-workgroup
     if (p.stats) {
         __syncthreads();   // every wave has left the weights: the reduction scratch may overwrite them
@@ -800,6 +830,7 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     }
     // the MSG segmenter's 196-channel layer pair (segment/pointnet2/pointnet2.py:63, [128, 196, 256]): ragged k (196 = 12 k blocks + 4 channels) and
     // ragged n (196 of the last column block's columns exist); the column blocks are as wide as the weights' LDS image allows (<= 160 KB here)
+    if (geo.wstat && (p.Kin == 196 || p.Nout == 196)) return 0;     // (weighted statistics are not built for the ragged flavours)
     if (p.Kin == 196 || p.Nout == 196) {
         if constexpr (AMODE == A_BNRELU && EPI == EPI_STORE) { if (p.Kin == 128 && p.Nout == 196) return stream_go<AMODE, EPI, 8, 4, false, 128, true>(p, geo, st); }
         if constexpr (AMODE == A_BNRELU && (EPI == EPI_STORE_GMAX || EPI == EPI_STORE)) { if (p.Kin == 196 && p.Nout % 128 == 0) return stream_go<AMODE, EPI, 13, 4, false, 196>(p, geo, st); }
@@ -855,6 +886,8 @@ int stream_gemm_try(const GemmArgs &p, int amode, int epi, bool vec, hipStream_t
     StreamGeo geo;
     geo.ushift = 0; geo.kgshift = 5;
     geo.rows_dev = p.rows_dev; geo.wrow = nullptr; geo.seg_grp = nullptr;
+    geo.wstat = (p.rows_dev && epi == EPI_STORE && (amode == A_BNRELU || amode == A_PLAIN)) ? p.wstat : nullptr;
+    if (p.wstat && !geo.wstat) return why(12);      // (weighted statistics: the storing forward flavours under a device-side row count only)
     if (amode == A_DY_DENSE || amode == A_DY_MAX) { geo.wrow = p.a.d.wrow; geo.seg_grp = p.a.d.seg_grp; geo.rows_dev = p.a.d.rows_dev; }
     if (geo.rows_dev && (p.M % 128 != 0 || epi == EPI_STORE_GMAX || epi == EPI_GMAX)) return why(7);   // (ragged groups: no fused group max)
     if (geo.wrow && (!geo.rows_dev || (amode == A_DY_MAX && !geo.seg_grp))) return why(8);

@@ -535,9 +535,13 @@ int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_
     layout_saved(p, io->saved, s);
     layout_fwd(p, io->scratch, f);
     const int parts = papc_mlp_gemm_parts(M);
-    const int R_c = p.compact ? papc_compact_corr_parts() : 0;
+    // compacted stack: the producers weigh their statistics with the rows' multiplicities themselves (papc_mlp_gemm_rows_w_f32, papc_group_src.wstat);
+    // PAPC_SA_NO_WSTATS: unweighted sums + one papc_bn_stats_corr_f32 launch per layer
+    const bool wstats = p.compact && !(d.disable & PAPC_SA_NO_WSTATS);
+    const int R_c = (p.compact && !wstats) ? papc_compact_corr_parts() : 0;
     papc_group_src grp;
     if (!plain) fill_grp(grp, d, *io, p.compact);
+    if (!plain && wstats) grp.wstat = io->compact->wrow;
     int cmax = 0;
     for (int l = 0; l < L; ++l) cmax = std::max(cmax, d.cout[l]);
     const size_t stats_stride = (size_t)(std::max(parts, p.lin0 ? papc_lingather_parts(M) : 0) + R_c) * 2 * cmax;
@@ -590,11 +594,12 @@ int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_
         } else if (l == 0) {
             SA_CALL(papc_mlp_gemm_f32(A_GROUP_, nullptr, 0, &grp, nullptr, nullptr, ly.w, ly.b, M, cin, cout, y, stats, gm_ref, st));
         } else if (p.compact) {
-            SA_CALL(papc_mlp_gemm_rows_f32(A_BNRELU_, prev_y, cin, nullptr, prev_sc, prev_sh, ly.w, ly.b, M, cin, cout, y, stats, nullptr, io->compact->rows, st));
+            SA_CALL(papc_mlp_gemm_rows_w_f32(A_BNRELU_, prev_y, cin, nullptr, prev_sc, prev_sh, ly.w, ly.b, M, cin, cout, y, stats, nullptr, io->compact->rows,
+                                             wstats ? io->compact->wrow : nullptr, st));
         } else {
             SA_CALL(papc_mlp_gemm_f32(A_BNRELU_, prev_y, cin, nullptr, prev_sc, prev_sh, ly.w, ly.b, M, cin, cout, y, stats, gm_ref, st));
         }
-        if (p.compact) {      // what the copies add to this layer's statistics: extra partial rows behind the kernel's own
+        if (p.compact && !wstats) {      // what the copies add to this layer's statistics: extra partial rows behind the kernel's own
             SA_CALL(papc_bn_stats_corr_f32(y, cout, io->compact->start, io->compact->coef, io->compact->G, stats + (size_t)parts_l * 2 * cout, st));
             parts_l += R_c;
         }

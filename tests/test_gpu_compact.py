@@ -158,3 +158,23 @@ def test_auto_policy_measures_once(dev):
     assert len(full.sample(x, st)) == 2 and full._compact_on is False
     other = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 128], False).to(dev)     # widths without a compacted flavour
     assert len(other.sample(x, st)) == 2 and other._compact_on is None
+
+
+def test_weighted_statistics_equal_the_correction_launches(dev, monkeypatch):
+    """A compacted stack's train-mode BatchNorm statistics are those of the PADDED tensor (pointnet2_basic_layers.py:118-124 pads with copies,
+    :215-217 normalises over them): by default the producing kernels weigh their sums with the rows' multiplicities themselves
+    (papc_mlp_gemm_rows_w_f32, papc_group_src.wstat); PAPC_WSTATS=0 keeps the unweighted sums + papc_bn_stats_corr_f32.  Same numbers up to
+    the summation order."""
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PAPC_WSTATS", mode)
+        _, _, _, feats, params, _, out = _sa2_like(dev, 8, 3, True)
+        assert out.grad_fn.compact is not None
+        gout = torch.from_numpy(np.random.default_rng(9).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        res[mode] = (out.detach().cpu().numpy(), [p.grad.cpu().numpy() for p in params], feats.grad.cpu().numpy())
+    assert_close(res["1"][0], res["0"][0], 2e-6, "weighted statistics vs correction launches: forward")
+    for i, (a, b) in enumerate(zip(res["1"][1], res["0"][1])):
+        if i % 4 != 1:
+            assert_close(a, b, 2e-5, "weighted statistics vs correction launches: gradient %d" % i)
+    assert_close(res["1"][2], res["0"][2], 2e-5, "weighted statistics vs correction launches: dfeats")
