@@ -168,6 +168,9 @@ def test_library_orchestration_equals_the_python_launch_sequence(dev, shape, mon
     rng = np.random.default_rng(9)
     fused = shape == "sa1_fused"
     monkeypatch.setattr(M_, "_XYZ_FUSE", fused)
+    # (the Python sequence keeps the compacted stack's statistics as unweighted sums + papc_bn_stats_corr_f32: hold the library to the same
+    # form here; its default -- the producers weigh the sums themselves -- is held to this one in tests/test_gpu_compact.py)
+    monkeypatch.setenv("PAPC_WSTATS", "0")
     if fused:
         shape = "sa1"
     feats = idx = x_rows = xyz = new_xyz = None
