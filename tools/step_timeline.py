@@ -12,7 +12,7 @@ def short(n):
 
 db = sqlite3.connect(sys.argv[1])
 rows = db.cursor().execute("select name, start, end, grid_x, workgroup_x from kernels order by start").fetchall()
-idx = [i for i, r in enumerate(rows) if "adam_kernel" in r[0]]
+idx = [i for i, r in enumerate(rows) if "adam_kernel" in r[0] or "adam_dev_kernel" in r[0]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(idx) // 2
 a, b = idx[k], idx[k + 1]
 t0 = prev_end = rows[a][2]
