@@ -291,8 +291,7 @@ def main():
         if args.overlap and args.fork == "start":
             launch_plan()
         tap = {} if use_dist else None
-        logits = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap and args.fork == "sa2" else None), tap=tap)
-        loss = softmax_cross_entropy(logits, y)
+        loss, _ = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap and args.fork == "sa2" else None), tap=tap, labels=y)
         work = None
         if use_dist and exchange:
             l2 = tap["l2_points"]
@@ -353,10 +352,9 @@ def main():
         tap = {} if use_dist else None
         if args.diag_fixed_plan:
             plan_in, plan_out = graph_state["fixed_plan"], None
-        logits = model(x, (s1, s2), plan=plan_in, tap=tap,
-                       after_sa2=cut if cut is not None else (fork if plan_out is not None and args.fork == "sa2" and not use_dist else None),
-                       after_sa3=(fork if plan_out is not None and args.fork == "sa3" and not use_dist else None))
-        loss = softmax_cross_entropy(logits, y)
+        loss, _ = model(x, (s1, s2), plan=plan_in, tap=tap,
+                        after_sa2=cut if cut is not None else (fork if plan_out is not None and args.fork == "sa2" and not use_dist else None),
+                       after_sa3=(fork if plan_out is not None and args.fork == "sa3" and not use_dist else None), labels=y)
         if not use_dist:
             if plan_out is not None and args.fork == "loss":
                 fork()

@@ -579,6 +579,36 @@ int papc_head_bwd_f32(const float *gnext, const float *wnext, int Cn, const floa
                       float *dy, float *dw, float *db, float *dgamma, float *dbeta, int accumulate, papc_stream_t stream);
 int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int C, float *loss, float *dlogits, papc_stream_t stream);
 
+/* The same layers as PHASES OF ONE LAUNCH each way (csrc/head.hip, head_chain_*_kernel): inside a replayed graph a dependent launch costs
+ * about 5 us before its first instruction, and a head is eight of them around ~3 us of work each.  A grid barrier separates the phases;
+ * what one phase hands the next is written and read with agent-scope accesses (no fence).  Results are bit-identical to the per-layer calls.
+ *   papc_head_chain_fwd_f32   layers[i] = the arguments of papc_head_fc_f32 for layer i (layers[i].x must be layers[i-1].out); with `labels`
+ *                             the mean softmax cross-entropy of the last layer's output and its gradient are computed by the same launch
+ *                             (classify/pointnet2/pointnet2.py:37-39 + train.py:106-109 in one launch)
+ *   papc_head_chain_bwd_f32   jobs[i] = the arguments of papc_head_bwd_f32; jobs of one `phase` run side by side, a job that reads the dy of
+ *                             another one belongs to a later phase (phases non-decreasing over the list)
+ *   sync                      2 words of device memory owned by the caller, ZERO at first use; the library leaves them zero behind every
+ *                             launch.  One pair per stream on which chain launches may be in flight at the same time.
+ * At most 4 layers / jobs, 64 / 128 workgroups per phase (all resident at once: the barrier spins); wider heads take the per-layer calls. */
+typedef struct papc_head_fc_layer {
+    const float *x, *w, *bias, *gamma, *beta;
+    int32_t Cin, Cout, has_bn;
+    float eps, momentum;
+    float *running_mean, *running_var; int64_t *num_batches_tracked;
+    float drop_p; int32_t layer_tag;
+    float *y, *mean, *invstd; uint8_t *keep; float *out;
+} papc_head_fc_layer;
+typedef struct papc_head_bwd_job {
+    const float *gnext, *wnext; int32_t Cn;
+    const float *out, *y, *mean, *invstd, *gamma; float drop_p; int32_t has_bn;
+    const float *x; int32_t Cin, Cout;
+    float *dy, *dw, *db, *dgamma, *dbeta; int32_t accumulate;
+    int32_t phase;
+} papc_head_bwd_job;
+int papc_head_chain_fwd_f32(const papc_head_fc_layer *layers, int n_layers, int B, const int64_t *rng_state, int64_t *rng_bump,
+                            const int64_t *labels, float *loss, float *dlogits, uint32_t *sync, papc_stream_t stream);
+int papc_head_chain_bwd_f32(const papc_head_bwd_job *jobs, int n_jobs, int B, uint32_t *sync, papc_stream_t stream);
+
 /* Axis-aligned bitmask NMS: nms_gpu of pointpillars/libs/ops/non_max_suppression/nms_gpu.py:130-164 (CUDA twin
  * libs/ops/cc/nms/nms_kernel.cu.cc:38-157), all on the device.  dets [N,5] = (x1, y1, x2, y2, score) fp32, N <= 65536.
  * keep [N] int32 receives the ORIGINAL indices of the kept boxes in descending-score order (ties: higher index first, the

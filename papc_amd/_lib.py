@@ -127,6 +127,8 @@ SIGNATURES = {
                                c_p, c_p, c_p]),
     "papc_head_bwd_f32": (c_i, [c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_softmax_xent_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "papc_head_chain_fwd_f32": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_head_chain_bwd_f32": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "papc_nms_workspace": (ctypes.c_size_t, [c_i]),
     "papc_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_lingather_parts": (c_i, [c_l]),

@@ -21,6 +21,7 @@ constexpr int HT = 512;             // threads (8 waves)
 constexpr int HW = 8;               // waves: K split
 constexpr int HROWS_MAX = 256;      // batch rows a workgroup can hold in LDS
 constexpr int TP = 33;              // LDS tile pitch (floats)
+constexpr int HC_STAGE_FLOATS = 16384;   // chain kernels: a [B, C] operand handed over by the previous phase is staged in LDS up to this size (64 KB)
 
 __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t counter, uint32_t tag, uint32_t idx)
 {
@@ -31,8 +32,51 @@ __device__ __forceinline__ float hash_uniform(uint64_t seed, uint64_t counter, u
     return (float)(uint32_t)(z >> 40) * (1.0f / 16777216.0f);   // 24 bits -> [0,1)
 }
 
+// ---- one launch for a chain of layers (head_chain_fwd_kernel / head_chain_bwd_kernel below) ---------------------------------------------
+// Inside a replayed graph a dependent launch costs >= 4.7 us before its first instruction (profiles/r05_*: a one-workgroup kernel with
+// nothing to do), and the head is 8 of them around ~3 us of work each.  The chain kernels run the layers as PHASES of one launch with a
+// grid barrier between them.  No fence: a device-scope release writes back everything dirty in the XCD's L2 (pfn.hip measured +60 us), so
+// what one phase hands the next (activations, dY) is written and read with agent-scope accesses that bypass the per-XCD L2 (COH flavours
+// of the loaders below), ordered against the barrier's counter by waiting for the stores' acknowledgements.  The workgroups of a chain
+// launch (<= 64) are all resident at once on any part this library targets, so spinning on the counter cannot deadlock.
+template <class T>
+__device__ __forceinline__ void coh_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ T coh_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool COH>
+__device__ __forceinline__ float ld1(const float *p) { if constexpr (COH) return coh_ld(p); else return *p; }
+template <bool COH>
+__device__ __forceinline__ float4 ld4(const float *p)
+{
+    if constexpr (COH) return make_float4(coh_ld(p), coh_ld(p + 1), coh_ld(p + 2), coh_ld(p + 3));
+    else return *reinterpret_cast<const float4 *>(p);
+}
+template <bool COH>
+__device__ __forceinline__ void st1(float *p, float v) { if constexpr (COH) coh_st(p, v); else *p = v; }
+
+__device__ __forceinline__ void grid_barrier(unsigned *bar, unsigned target)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's agent-scope stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+// behind the last phase: the last workgroup to leave returns both words to zero for the next launch
+__device__ __forceinline__ void grid_exit(unsigned *bar)
+{
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) { coh_st(bar, 0u); coh_st(bar + 1, 0u); }
+    }
+}
+
 // acc[] += A[rows r0.., k] * Bm[cols c0.., k] over the wave's share of K; both operands K-contiguous (row-major [*, K]).
 // lane: row/col = lane & 31, k half = lane >> 5; float4 loads give 4 MFMA steps (any k pairing is valid: the sum is over k).
+// COH: A was written by another workgroup of this launch (chain kernels).
+template <bool COH>
 __device__ __forceinline__ void mfma_kcontig(f32x16 &acc, const float *__restrict__ A, int a_rows, int a_r0, const float *__restrict__ Bm,
                                              int b_rows, int b_r0, int K, int wave, int lane)
 {
@@ -53,7 +97,7 @@ __device__ __forceinline__ void mfma_kcontig(f32x16 &acc, const float *__restric
         for (int j = 0; j < NB; ++j) {
             const int k = (blk0 + j < blk_end ? blk0 + j : nblk) * 8 + 4 * h;        // K % 4 == 0
             const int kc = k < K ? k : 0;
-            a[j] = *reinterpret_cast<const float4 *>(ap + kc);
+            a[j] = ld4<COH>(ap + kc);
             b[j] = *reinterpret_cast<const float4 *>(bp + kc);
         }
 #pragma unroll
@@ -70,6 +114,7 @@ __device__ __forceinline__ void mfma_kcontig(f32x16 &acc, const float *__restric
 }
 
 // acc[] += G[rows r0.., n] * Wn[n, cols c0..] over the wave's share of n < Cn: G [rows, Cn] row-major (K-contiguous), Wn [Cn, ldw]
+template <bool COH>
 __device__ __forceinline__ void mfma_g_times_w(f32x16 &acc, const float *__restrict__ G, int g_rows, int g_r0, const float *__restrict__ Wn,
                                                int Cn, int ldw, int c0, int wave, int lane)
 {
@@ -87,7 +132,7 @@ __device__ __forceinline__ void mfma_g_times_w(f32x16 &acc, const float *__restr
         for (int j = 0; j < 2; ++j) {
             const int n = (blk0 + j < blk_end ? blk0 + j : nblk) * 8 + 4 * h;        // Cn % 4 == 0
             const int nc = n < Cn ? n : 0;
-            a[j] = *reinterpret_cast<const float4 *>(gp + nc);
+            a[j] = ld4<COH>(gp + nc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) b[j][i] = wp[(int64_t)(nc + i) * ldw];
         }
@@ -138,18 +183,37 @@ struct HeadFwd {
     uint8_t *keep;
 };
 
-__global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
+// one workgroup's share (output channels 32 bx ..) of a layer.  CIN: x comes from another workgroup of this launch; COUT: `out` goes to one
+template <bool CIN, bool COUT>
+__device__ __forceinline__ void head_fwd_body(const HeadFwd &a, const int bx)
 {
     extern __shared__ float smem[];
     float *red = smem;                          // [8*32][TP]
     float *tile = smem + HW * 32 * TP;          // [Bpad][TP]
     __shared__ float s_mean[32], s_scale[32], s_shift[32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int c0 = blockIdx.x * 32;
+    const int c0 = bx * 32;
     const int nrb = (a.B + 31) >> 5;
+    const float *xin = a.x;
+    bool staged = false;
+    if constexpr (CIN) {
+        // x was written by other workgroups of this launch: read past the L2 (agent scope).  Such a load is a ~2 us round trip, so the whole
+        // [B, Cin] operand is fetched at once into LDS (every thread's loads in flight together) when it fits, and the k loop then runs from
+        // LDS; a larger operand is read in place, coherently, block by block
+        const int Bpad0 = nrb * 32;
+        if ((int64_t)a.B * a.Cin <= HC_STAGE_FLOATS) {
+            float *xs = tile + Bpad0 * TP;
+            const int n = a.B * a.Cin;
+            for (int e = tid; e < n; e += HT) xs[e] = coh_ld(a.x + e);
+            __syncthreads();
+            xin = xs;
+            staged = true;
+        }
+    }
     for (int rb = 0; rb < nrb; ++rb) {
         f32x16 acc = {0};
-        mfma_kcontig(acc, a.x, a.B, rb * 32, a.w, a.Cout, c0, a.Cin, wave, lane);
+        if (CIN && !staged) mfma_kcontig<true>(acc, xin, a.B, rb * 32, a.w, a.Cout, c0, a.Cin, wave, lane);
+        else mfma_kcontig<false>(acc, xin, a.B, rb * 32, a.w, a.Cout, c0, a.Cin, wave, lane);
         reduce_waves_to_tile(acc, red, tile, rb * 32, wave, lane, tid);
     }
     const int ncol = min(32, a.Cout - c0);
@@ -190,7 +254,7 @@ __global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
             s_scale[tid] = invstd * a.gamma[c];
             s_shift[tid] = a.beta[c];
         }
-        if (tid == 0 && blockIdx.x == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
+        if (tid == 0 && bx == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
     }
     __syncthreads();
     uint64_t seed = 0, counter = 0;
@@ -212,10 +276,12 @@ __global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a)
             if (a.keep) a.keep[o] = k ? 1 : 0;
             v = k ? v * keep_scale : 0.f;
         }
-        a.out[o] = v;
+        st1<COUT>(a.out + o, v);
     }
-    if (a.rng_bump && blockIdx.x == 0 && tid == 0) a.rng_bump[1] += 1;   // stream order: every reader of this step is done or is this launch
+    if (a.rng_bump && bx == 0 && tid == 0) a.rng_bump[1] += 1;   // stream order: every reader of this step is done or is this launch
 }
+
+__global__ __launch_bounds__(HT) void head_fwd_kernel(HeadFwd a) { head_fwd_body<false, false>(a, (int)blockIdx.x); }
 
 struct HeadBwd {
     const float *gnext;           // [B, Cn]: dY of the next layer (or dlogits)
@@ -231,7 +297,10 @@ struct HeadBwd {
     int accumulate;
 };
 
-__global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
+// one workgroup's share of a layer's backward: channels 32 bx .., dW column blocks by, by + ny, ...  CIN: gnext comes from another workgroup
+// of this launch; COUT: dy goes to one
+template <bool CIN, bool COUT>
+__device__ __forceinline__ void head_bwd_body(const HeadBwd &a, const int bx, const int by, const int ny)
 {
     extern __shared__ float smem[];
     float *red = smem;                          // [8*32][TP]
@@ -239,20 +308,33 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
     float *xh = gt + ((a.B + 31) & ~31) * TP;   // [Bpad][TP]  x-hat
     __shared__ float s_k1[32], s_k2[32], s_k3[32];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int c0 = blockIdx.x * 32;
+    const int c0 = bx * 32;
     const int nrb = (a.B + 31) >> 5;
     const int Bpad = nrb * 32;
     const int ncol = min(32, a.Cout - c0);
     if (a.wnext) {
+        const float *gin = a.gnext;
+        bool staged = false;
+        if constexpr (CIN) {      // (as in the forward body: one round trip for the whole [B, Cn] operand)
+            if ((int64_t)a.B * a.Cn <= HC_STAGE_FLOATS) {
+                float *gs = xh + Bpad * TP;
+                const int n = a.B * a.Cn;
+                for (int e = tid; e < n; e += HT) gs[e] = coh_ld(a.gnext + e);
+                __syncthreads();
+                gin = gs;
+                staged = true;
+            }
+        }
         for (int rb = 0; rb < nrb; ++rb) {
             f32x16 acc = {0};
-            mfma_g_times_w(acc, a.gnext, a.B, rb * 32, a.wnext, a.Cn, a.Cout, c0, wave, lane);
+            if (CIN && !staged) mfma_g_times_w<true>(acc, gin, a.B, rb * 32, a.wnext, a.Cn, a.Cout, c0, wave, lane);
+            else mfma_g_times_w<false>(acc, gin, a.B, rb * 32, a.wnext, a.Cn, a.Cout, c0, wave, lane);
             reduce_waves_to_tile(acc, red, gt, rb * 32, wave, lane, tid);
         }
     } else {
         for (int e = tid; e < Bpad * 32; e += HT) {
             const int b = e >> 5, t = e & 31;
-            gt[b * TP + t] = (b < a.B && t < ncol) ? a.gnext[(int64_t)b * a.Cout + c0 + t] : 0.f;
+            gt[b * TP + t] = (b < a.B && t < ncol) ? ld1<CIN>(a.gnext + (int64_t)b * a.Cout + c0 + t) : 0.f;
         }
         __syncthreads();
     }
@@ -282,7 +364,7 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
             for (int b = 0; b < a.B; ++b) { sg += gt[b * TP + tid]; sgx += gt[b * TP + tid] * xh[b * TP + tid]; }
             if (tid < ncol) {
                 const int c = c0 + tid;
-                if (blockIdx.y == 0) {
+                if (by == 0) {
                     a.dbeta[c] = (a.accumulate ? a.dbeta[c] : 0.f) + sg;
                     a.dgamma[c] = (a.accumulate ? a.dgamma[c] : 0.f) + sgx;
                 }
@@ -302,11 +384,11 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
         }
         __syncthreads();
     }
-    const bool first = blockIdx.y == 0;          // the column-split workgroups recompute dY; only the first one publishes it
+    const bool first = by == 0;          // the column-split workgroups recompute dY; only the first one publishes it
     if (a.dy && first) {
         for (int e = tid; e < a.B * 32; e += HT) {
             const int b = e >> 5, t = e & 31;
-            if (t < ncol) a.dy[(int64_t)b * a.Cout + c0 + t] = gt[b * TP + t];
+            if (t < ncol) st1<COUT>(a.dy + (int64_t)b * a.Cout + c0 + t, gt[b * TP + t]);
         }
     }
     if (!a.x) return;
@@ -318,7 +400,7 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
     // dW[c0 + r, k] = sum_b dY[b, c0 + r] * X[b, k]: MFMA with the batch as K; one wave per 32-column block of Cin, the
     // column blocks dealt round-robin over (blockIdx.y, wave)
     const int r = lane & 31, h = lane >> 5;
-    for (int kb = blockIdx.y * HW + wave; kb * 32 < a.Cin; kb += HW * gridDim.y) {
+    for (int kb = by * HW + wave; kb * 32 < a.Cin; kb += HW * ny) {
         const int kcol = kb * 32 + r;
         const bool k_ok = kcol < a.Cin;
         const float *xp = a.x + (k_ok ? kcol : 0);
@@ -351,35 +433,48 @@ __global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a)
     }
 }
 
+__global__ __launch_bounds__(HT) void head_bwd_kernel(HeadBwd a) { head_bwd_body<false, false>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y); }
+
 // mean softmax cross-entropy + its gradient: loss = mean_b (logsumexp(z_b) - z_b[label_b]); dz = (softmax(z) - onehot) / B
-__global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restrict__ z, const int64_t *__restrict__ label, int B, int C,
-                                                           float *__restrict__ loss, float *__restrict__ dz)
+// rows at z + b * ldz: the logits in global memory (COH: written by another workgroup of this launch) or a layer body's LDS tile
+template <bool COH>
+__device__ __forceinline__ void softmax_xent_body(const float *z, int ldz, const int64_t *__restrict__ label, int B, int C, float *__restrict__ loss,
+                                                  float *__restrict__ dz, float *part /* [blockDim.x] LDS */)
 {
-    __shared__ float part[256];
+    const int nt = blockDim.x;
     float acc = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const float *row = z + (int64_t)b * C;
-        float m = row[0];
-        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+    for (int b = threadIdx.x; b < B; b += nt) {
+        const float *row = z + (int64_t)b * ldz;
+        float m = ld1<COH>(row);
+        for (int c = 1; c < C; ++c) m = fmaxf(m, ld1<COH>(row + c));
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(row[c] - m);
+        for (int c = 0; c < C; ++c) s += expf(ld1<COH>(row + c) - m);
         const float lse = m + logf(s);
         const int64_t y = label[b];
-        if (y >= 0 && y < C) acc += lse - row[y];
+        if (y >= 0 && y < C) acc += lse - ld1<COH>(row + y);
         const float inv = 1.0f / (s * (float)B);
         for (int c = 0; c < C; ++c) {
-            float g = expf(row[c] - m) * inv;
+            float g = expf(ld1<COH>(row + c) - m) * inv;
             if (c == y) g -= 1.0f / (float)B;
             dz[(int64_t)b * C + c] = g;
         }
     }
     part[threadIdx.x] = acc;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
-        __syncthreads();
+    // fixed order, independent of the workgroup size: thread 0 adds the B rows' terms in row order groups (rows b, b + nt, ... sit in one thread)
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        const int n = B < nt ? B : nt;
+        for (int i = 0; i < n; ++i) t += part[i];
+        loss[0] = t / (float)B;
     }
-    if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
+}
+
+__global__ __launch_bounds__(256) void softmax_xent_kernel(const float *__restrict__ z, const int64_t *__restrict__ label, int B, int C,
+                                                           float *__restrict__ loss, float *__restrict__ dz)
+{
+    __shared__ float part[256];
+    softmax_xent_body<false>(z, C, label, B, C, loss, dz, part);
 }
 
 // the same for many rows (per-point segmentation logits: B*N = 32768 rows): one row per thread, any number of workgroups; the
@@ -414,6 +509,65 @@ __global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float *__r
         __syncthreads();
     }
     if (threadIdx.x == 0) atomicAdd(loss, part[0] * invB);
+}
+
+// ---- chains: the layers of a head as phases of ONE launch (grid barrier in between, see the top of the file) --------------------------------
+constexpr int HC_MAX = 4;
+struct HeadChainFwd {
+    HeadFwd l[HC_MAX];
+    int n;
+    const int64_t *labels; float *loss, *dlogits;     // optional: mean softmax cross-entropy of the last layer's output, fused
+    unsigned *bar;
+};
+__global__ __launch_bounds__(HT) void head_chain_fwd_kernel(HeadChainFwd c)
+{
+    const int bid = (int)blockIdx.x;
+    for (int p = 0; p < c.n; ++p) {
+        const HeadFwd &a = c.l[p];
+        if (bid * 32 < a.Cout) {
+            if (p == 0) head_fwd_body<false, true>(a, bid);
+            else head_fwd_body<true, true>(a, bid);
+        }
+        if (p < c.n - 1) grid_barrier(c.bar, (unsigned)(p + 1) * gridDim.x);
+    }
+    if (c.labels) {
+        extern __shared__ float smem[];
+        const HeadFwd &a = c.l[c.n - 1];
+        if (a.Cout <= 32) {
+            // the one workgroup that made the logits still holds them (bias added, no norm on a last layer) in its LDS tile
+            if (bid == 0) {
+                __syncthreads();
+                softmax_xent_body<false>(smem + HW * 32 * TP, TP, c.labels, a.B, a.Cout, c.loss, c.dlogits, smem);
+            }
+        } else {
+            grid_barrier(c.bar, (unsigned)c.n * gridDim.x);
+            if (bid == 0) softmax_xent_body<true>(a.out, a.Cout, c.labels, a.B, a.Cout, c.loss, c.dlogits, smem);
+        }
+    }
+    grid_exit(c.bar);
+}
+
+struct HeadChainBwd {
+    HeadBwd j[HC_MAX];
+    int gx[HC_MAX], gy[HC_MAX], off[HC_MAX], phase[HC_MAX];
+    int n, n_phases;
+    unsigned *bar;
+};
+__global__ __launch_bounds__(HT) void head_chain_bwd_kernel(HeadChainBwd c)
+{
+    const int bid = (int)blockIdx.x;
+    for (int ph = 0; ph < c.n_phases; ++ph) {
+        for (int j = 0; j < c.n; ++j) {
+            if (c.phase[j] != ph) continue;
+            const int local = bid - c.off[j];
+            if (local >= 0 && local < c.gx[j] * c.gy[j]) {
+                if (ph == 0) head_bwd_body<false, true>(c.j[j], local % c.gx[j], local / c.gx[j], c.gy[j]);
+                else head_bwd_body<true, true>(c.j[j], local % c.gx[j], local / c.gx[j], c.gy[j]);
+            }
+        }
+        if (ph < c.n_phases - 1) grid_barrier(c.bar, (unsigned)(ph + 1) * gridDim.x);
+    }
+    grid_exit(c.bar);
 }
 
 }  // namespace papc
@@ -484,6 +638,89 @@ int papc_softmax_xent_f32(const float *logits, const int64_t *labels, int B, int
                            loss, dlogits);
     }
     return check_launch("papc_softmax_xent_f32");
+}
+
+int papc_head_chain_fwd_f32(const papc_head_fc_layer *layers, int n_layers, int B, const int64_t *rng_state, int64_t *rng_bump,
+                            const int64_t *labels, float *loss, float *dlogits, uint32_t *sync, papc_stream_t stream)
+{
+    PAPC_REQUIRE(layers && sync, PAPC_E_INVALID, "papc_head_chain_fwd_f32: null pointer");
+    PAPC_REQUIRE(n_layers >= 1 && n_layers <= HC_MAX, PAPC_E_UNSUPPORTED, "papc_head_chain_fwd_f32: %d layers (1..%d)", n_layers, HC_MAX);
+    PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_chain_fwd_f32: B=%d not in [1, %d]", B, HROWS_MAX);
+    PAPC_REQUIRE(!labels || (loss && dlogits), PAPC_E_INVALID, "papc_head_chain_fwd_f32: labels without loss / dlogits");
+    HeadChainFwd c;
+    memset(&c, 0, sizeof(c));
+    int grid = 1;
+    for (int i = 0; i < n_layers; ++i) {
+        const papc_head_fc_layer &l = layers[i];
+        PAPC_REQUIRE(l.x && l.w && l.out, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: null pointer", i);
+        PAPC_REQUIRE(l.Cin >= 4 && l.Cin % 4 == 0 && l.Cout >= 1, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: Cin=%d must be a multiple of 4", i, l.Cin);
+        PAPC_REQUIRE(l.has_bn >= 0 && l.has_bn <= 2, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: has_bn=%d", i, l.has_bn);
+        PAPC_REQUIRE(l.has_bn != 1 || (l.gamma && l.beta && l.mean && l.invstd && l.y), PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: BatchNorm needs gamma/beta/mean/invstd/y", i);
+        PAPC_REQUIRE(l.drop_p >= 0.f && l.drop_p < 1.f, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: drop_p=%f", i, (double)l.drop_p);
+        PAPC_REQUIRE(i == 0 || (l.x == layers[i - 1].out && l.Cin == layers[i - 1].Cout), PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d does not consume layer %d's output", i, i - 1);
+        c.l[i] = HeadFwd{l.x, l.w, l.bias, l.gamma, l.beta, B, l.Cin, l.Cout, l.has_bn, l.eps, l.momentum, l.running_mean, l.running_var, l.num_batches_tracked,
+                         l.drop_p, rng_state, l.layer_tag, (i == n_layers - 1) ? rng_bump : nullptr, l.y, l.mean, l.invstd, l.out, l.keep};
+        grid = std::max(grid, (int)cdiv(l.Cout, 32));
+    }
+    PAPC_REQUIRE(!labels || layers[n_layers - 1].has_bn == 0, PAPC_E_INVALID, "papc_head_chain_fwd_f32: the fused loss wants a plain last layer (has_bn = 0)");
+    PAPC_REQUIRE(grid <= 64, PAPC_E_UNSUPPORTED, "papc_head_chain_fwd_f32: %d workgroups (layers wider than 2048 channels take papc_head_fc_f32 per layer)", grid);
+    c.n = n_layers; c.labels = labels; c.loss = loss; c.dlogits = dlogits; c.bar = sync;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    const int Bpad = (B + 31) & ~31;
+    int stage = 0;
+    for (int i = 1; i < n_layers; ++i)
+        if ((int64_t)B * layers[i].Cin <= HC_STAGE_FLOATS) stage = std::max(stage, B * layers[i].Cin);
+    const size_t lds = ((size_t)(HW * 32 + Bpad) * TP + stage) * sizeof(float);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(head_chain_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("papc_head_chain_fwd_f32: hipFuncSetAttribute");
+    hipLaunchKernelGGL(head_chain_fwd_kernel, dim3((unsigned)grid), dim3(HT), lds, st, c);
+    return check_launch("papc_head_chain_fwd_f32");
+}
+
+int papc_head_chain_bwd_f32(const papc_head_bwd_job *jobs, int n_jobs, int B, uint32_t *sync, papc_stream_t stream)
+{
+    PAPC_REQUIRE(jobs && sync, PAPC_E_INVALID, "papc_head_chain_bwd_f32: null pointer");
+    PAPC_REQUIRE(n_jobs >= 1 && n_jobs <= HC_MAX, PAPC_E_UNSUPPORTED, "papc_head_chain_bwd_f32: %d jobs (1..%d)", n_jobs, HC_MAX);
+    PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_chain_bwd_f32: B=%d not in [1, %d]", B, HROWS_MAX);
+    HeadChainBwd c;
+    memset(&c, 0, sizeof(c));
+    int grid = 1, n_phases = 0;
+    int used[HC_MAX] = {0, 0, 0, 0};          // workgroups handed out per phase
+    for (int i = 0; i < n_jobs; ++i) {
+        const papc_head_bwd_job &j = jobs[i];
+        PAPC_REQUIRE(j.gnext, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: null gnext", i);
+        PAPC_REQUIRE(j.Cout >= 1 && (!j.wnext || (j.Cn >= 4 && j.Cn % 4 == 0)), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: Cn=%d must be a multiple of 4", i, j.Cn);
+        PAPC_REQUIRE(j.wnext || j.Cn == j.Cout, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: without wnext, gnext must be [B, Cout]", i);
+        PAPC_REQUIRE(j.has_bn >= 0 && j.has_bn <= 2, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: has_bn=%d", i, j.has_bn);
+        PAPC_REQUIRE(j.has_bn != 1 || (j.out && j.y && j.mean && j.invstd && j.gamma && j.dgamma && j.dbeta), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: BatchNorm backward needs the saved forward", i);
+        PAPC_REQUIRE(j.has_bn != 2 || j.out, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: ReLU backward needs the layer's output", i);
+        PAPC_REQUIRE(!j.x || (j.dw && j.Cin >= 1), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: x without dw", i);
+        PAPC_REQUIRE(j.drop_p >= 0.f && j.drop_p < 1.f, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: drop_p=%f", i, (double)j.drop_p);
+        PAPC_REQUIRE(j.phase >= 0 && j.phase < HC_MAX && (i == 0 || j.phase >= jobs[i - 1].phase), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: phases must be 0..%d, non-decreasing", i, HC_MAX - 1);
+        c.j[i] = HeadBwd{j.gnext, j.wnext, j.Cn, j.out, j.y, j.mean, j.invstd, j.gamma, 1.0f / (1.0f - j.drop_p), j.has_bn, j.x, B, j.Cin, j.Cout, j.dy, j.dw, j.db,
+                         j.dgamma, j.dbeta, j.accumulate};
+        c.gx[i] = (int)cdiv(j.Cout, 32);
+        c.gy[i] = j.x ? std::min(8, std::max(1, (int)cdiv(cdiv(j.Cin, 32), HW))) : 1;      // (papc_head_bwd_f32's own split)
+        c.phase[i] = j.phase;
+        c.off[i] = used[j.phase];
+        used[j.phase] += c.gx[i] * c.gy[i];
+        grid = std::max(grid, used[j.phase]);
+        n_phases = std::max(n_phases, j.phase + 1);
+    }
+    PAPC_REQUIRE(grid <= 128, PAPC_E_UNSUPPORTED, "papc_head_chain_bwd_f32: %d workgroups in one phase (wider layers take papc_head_bwd_f32 per layer)", grid);
+    c.n = n_jobs; c.n_phases = n_phases; c.bar = sync;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_MISC, st);
+    const int Bpad = (B + 31) & ~31;
+    int stage = 0;
+    for (int i = 0; i < n_jobs; ++i)
+        if (jobs[i].phase > 0 && jobs[i].wnext && (int64_t)B * jobs[i].Cn <= HC_STAGE_FLOATS) stage = std::max(stage, B * jobs[i].Cn);
+    const size_t lds = ((size_t)(HW * 32 + 2 * Bpad) * TP + stage) * sizeof(float);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(head_chain_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("papc_head_chain_bwd_f32: hipFuncSetAttribute");
+    hipLaunchKernelGGL(head_chain_bwd_kernel, dim3((unsigned)grid), dim3(HT), lds, st, c);
+    return check_launch("papc_head_chain_bwd_f32");
 }
 
 }  // extern "C"

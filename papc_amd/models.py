@@ -50,15 +50,22 @@ def _bn1d(bn, y):
 class _ClasHead:
     """fc1/bn1/drop1/fc2/bn2/drop2/fc3 (pointnet2.py:37-39): fused launches in train mode on the GPU (head.py), the modules otherwise."""
 
-    def _head(self, x):
+    def _head(self, x, labels=None):
+        """logits, or with ``labels`` (int64 [B]) the pair (mean softmax cross-entropy, logits): train.py:106-109's loss computed by the head's own
+        launch (head.classifier_head_loss); the logits then carry no gradient."""
         spec = self.__dict__.get("_head_spec")
         if spec is None:
             spec = self.__dict__["_head_spec"] = _head.HeadSpec()
         if _FUSED_HEAD and _head.usable(x, self.fc1, self.fc2, self.fc3, self.training):
+            if labels is not None:
+                return _head.classifier_head_loss(spec, x, labels, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3)
             return _head.classifier_head(spec, x, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3)
         x = self.drop1(F.relu(_bn1d(self.bn1, self.fc1(x))))
         x = self.drop2(F.relu(_bn1d(self.bn2, self.fc2(x))))
-        return self.fc3(x)
+        logits = self.fc3(x)
+        if labels is not None:
+            return (_head.softmax_cross_entropy(logits, labels) if logits.is_cuda else F.cross_entropy(logits, labels.reshape(-1))), logits.detach()
+        return logits
 
 
 class PointNet2_SSG_Clas(nn.Module, _ClasHead):
@@ -96,8 +103,9 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
             p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1], out=o[1])
         return p1, p2
 
-    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None, after_sa3=None):
-        """inputs [B,3,N]; ``start_idx`` = optional (s1 [B], s2 [B]) FPS start indices (the source draws them at random);
+    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None, after_sa3=None, labels=None):
+        """inputs [B,3,N]; ``labels`` = optional int64 [B]: return (loss, logits) instead of logits, the cross-entropy of train.py:106-109
+        computed by the head's own launch; ``start_idx`` = optional (s1 [B], s2 [B]) FPS start indices (the source draws them at random);
         ``plan`` = optional result of :meth:`plan_sampling` for these inputs; ``after_sa2`` = optional callable invoked
         once SA2's kernels are enqueued -- from there to the end of SA3's backward only small-grid kernels run (group_all
         layer, FC head), the window in which a side stream can sample the next batch on otherwise idle CUs;
@@ -131,7 +139,7 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
         if after_sa3 is not None:
             after_sa3()
         x = l3_points.reshape(B, 1024)
-        return self._head(x)
+        return self._head(x, labels)
 
 
 class PointNet2_MSG_Clas(nn.Module, _ClasHead):

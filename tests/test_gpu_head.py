@@ -299,3 +299,133 @@ def test_bn_relu_max_few_long_groups(dev, G, K, C):
     assert not bool(earlier.any())
     dead = ref == 0
     assert bool((am[dead] == 0).all())                        # all-dead channels: row 0, as the serial scan returns
+
+
+def _clone_mods(mods):
+    import copy
+    return [copy.deepcopy(m) for m in mods]
+
+
+def _run_head(mods, x0v, glog, chain, labels=None, seed_state=None, steps=1):
+    """`steps` forward + backward passes through the fused head; returns everything a caller can observe"""
+    from papc_amd import head
+    fc1, bn1, d1, fc2, bn2, d2, fc3 = mods
+    spec = head.HeadSpec()
+    spec.chain = chain
+    spec.export_masks = True
+    if seed_state is not None:
+        spec.rng_state = seed_state.clone()
+    outs = []
+    for _ in range(steps):
+        x0 = x0v.clone().requires_grad_(True)
+        for m in mods:
+            for p in m.parameters():
+                p.grad = None
+        if labels is None:
+            logits = head.classifier_head(spec, x0, fc1, bn1, d1, fc2, bn2, d2, fc3)
+            logits.backward(glog)
+            loss = None
+        else:
+            loss, logits = head.classifier_head_loss(spec, x0, labels, fc1, bn1, d1, fc2, bn2, d2, fc3)
+            (loss * 1.0).backward() if glog is None else loss.backward(glog)
+        torch.cuda.synchronize()
+        outs.append(dict(logits=logits.detach().clone(), loss=None if loss is None else loss.detach().clone(), dx=x0.grad.clone(),
+                         grads=[p.grad.clone() for m in mods for p in m.parameters()],
+                         stats=[t.clone() for bn in (bn1, bn2) for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked)],
+                         masks=[k.clone() for k in spec.masks]))
+    return outs, spec
+
+
+@pytest.mark.parametrize("B,c3,dims", [(32, 16, None), (32, 40, None), (7, 16, None), (256, 8, None), (5, 12, (132, 72, 40)), (33, 4, (36, 100, 68))])
+def test_head_chain_equals_per_layer_launches(B, c3, dims):
+    """papc_head_chain_fwd_f32 / _bwd_f32 (the layers as phases of one launch, grid barrier in between) vs one launch per layer:
+    bit-identical logits, gradients, running statistics and dropout masks, three steps in a row (the barrier words return to zero)."""
+    c0, c1, c2 = dims if dims else (1024, 512, 256)
+    mods = [m.cuda() for m in _modules(c0, c1, c2, c3, 17 + B)]
+    x0 = torch.randn(B, c0, device="cuda")
+    glog = torch.randn(B, c3, device="cuda")
+    st = torch.tensor([1234567, 0], dtype=torch.int64, device="cuda")
+    a, spec_a = _run_head(_clone_mods(mods), x0, glog, True, seed_state=st, steps=3)
+    b, _ = _run_head(_clone_mods(mods), x0, glog, False, seed_state=st, steps=3)
+    for sa, sb in zip(a, b):
+        assert torch.equal(sa["logits"], sb["logits"]) and torch.equal(sa["dx"], sb["dx"])
+        for ga, gb in zip(sa["grads"], sb["grads"]):
+            assert torch.equal(ga, gb)
+        for ta, tb in zip(sa["stats"] + sa["masks"], sb["stats"] + sb["masks"]):
+            assert torch.equal(ta, tb)
+    assert all(int(v) == 0 for t in spec_a._sync.values() for v in t.cpu())
+
+
+@pytest.mark.parametrize("B,c3", [(32, 16), (32, 40), (6, 36), (256, 16)])
+def test_head_with_fused_loss_equals_head_then_loss(B, c3):
+    """classifier_head_loss (cross-entropy computed by the head's own launch: from the logits' LDS tile for <= 32 classes, behind one more
+    barrier otherwise) vs classifier_head + softmax_cross_entropy: bit-identical loss, logits and gradients; also with an upstream scale
+    and with unit_gradient() as the seed."""
+    from papc_amd import head
+    mods = [m.cuda() for m in _modules(1024, 512, 256, c3, 5 + B)]
+    x0 = torch.randn(B, 1024, device="cuda")
+    y = torch.randint(0, c3, (B,), device="cuda")
+    st = torch.tensor([99, 0], dtype=torch.int64, device="cuda")
+    for seed in (None, torch.tensor(1.7, device="cuda"), head.unit_gradient("cuda")):
+        a, _ = _run_head(_clone_mods(mods), x0, seed, True, labels=y, seed_state=st, steps=2)
+        # reference: the per-layer head, then the separate loss
+        m2 = _clone_mods(mods)
+        spec = head.HeadSpec()
+        spec.chain = False
+        spec.rng_state = st.clone()
+        for step in range(2):
+            x = x0.clone().requires_grad_(True)
+            for m in m2:
+                for p in m.parameters():
+                    p.grad = None
+            logits = head.classifier_head(spec, x, *m2)
+            loss = head.softmax_cross_entropy(logits, y)
+            loss.backward() if seed is None else loss.backward(seed)
+            torch.cuda.synchronize()
+            assert torch.equal(a[step]["loss"], loss.detach()) and torch.equal(a[step]["logits"], logits.detach())
+            assert torch.equal(a[step]["dx"], x.grad)
+            for ga, p in zip(a[step]["grads"], [p for m in m2 for p in m.parameters()]):
+                assert torch.equal(ga, p.grad)
+        want = F.cross_entropy(a[0]["logits"].double().cpu(), y.cpu())
+        assert abs(a[0]["loss"].item() - want.item()) <= 1e-5 * abs(want.item())
+
+
+def test_head_chain_replays_in_a_graph():
+    """the chain launches (spinning grid barrier, self-resetting words) captured into a hipGraph and replayed: every replay equals the eager step"""
+    from papc_amd import head
+    mods = [m.cuda() for m in _modules(1024, 512, 256, 16, 4)]
+    fc1, bn1, d1, fc2, bn2, d2, fc3 = mods
+    for m in mods:
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+    x0 = torch.randn(32, 1024, device="cuda", requires_grad=True)
+    y = torch.randint(0, 16, (32,), device="cuda")
+    spec = head.HeadSpec()
+    one = head.unit_gradient("cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for _ in range(2):                       # eager first (allocations, the spec's barrier words)
+            loss, _ = head.classifier_head_loss(spec, x0, y, *mods)
+            loss.backward(one)
+        torch.cuda.synchronize()
+        for m in mods:
+            for p in m.parameters():
+                p.grad.zero_()
+        x0.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            loss, logits = head.classifier_head_loss(spec, x0, y, *mods)
+            loss.backward(one)
+        losses = []
+        for _ in range(5):
+            for m in mods:
+                for p in m.parameters():
+                    p.grad.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            losses.append(float(loss))
+            want = F.cross_entropy(logits.double().cpu(), y.cpu())
+            assert abs(losses[-1] - want.item()) <= 1e-5 * abs(want.item())
+            assert all(torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in (fc1.weight, fc2.weight, fc3.weight))
+        assert len(set(losses)) > 1              # fresh dropout masks on every replay
+    assert all(int(v) == 0 for t in spec._sync.values() for v in t.cpu())

@@ -6,7 +6,16 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 mkdir -p $O
 timeout 400 python bench.py > $O/bench_line.json 2> $O/bench_line.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o run -- python bench.py --no-cpu-baseline --steps 50 --warmup 10 > $O/prof_stats.log 2>&1
+# the N > 1 launch structure (three graphs + eager high-priority sampling stream + RCCL all-reduces) with a forced 1-rank group: the per-GPU
+# ceiling of the multi-GPU run
+PAPC_FORCE_DIST=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 50 --no-cpu-baseline > $O/bench_line_dist1.json 2> $O/bench_line_dist1.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o run -- python bench.py --no-cpu-baseline --no-padded-leg --steps 50 --warmup 10 > $O/prof_stats.log 2>&1
+# one step's dispatch timeline (start / gap / duration per launch) with and without the sampling branch
+timeout 400 rocprofv3 --kernel-trace -d $O/prof_tl -o run -- python bench.py --no-cpu-baseline --no-padded-leg --steps 50 > /dev/null 2>&1
+python tools/step_timeline.py $O/prof_tl/run_results.db 40 > $O/timeline.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace -d $O/prof_tlf -o run -- python bench.py --no-cpu-baseline --no-padded-leg --diag-fixed-plan --steps 50 > /dev/null 2>&1
+python tools/step_timeline.py $O/prof_tlf/run_results.db 40 > $O/timeline_fixed_plan.txt 2>&1
+rm -rf $O/prof_tl $O/prof_tlf
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_$c.log 2>&1
 done

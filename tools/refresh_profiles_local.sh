@@ -1,10 +1,13 @@
 #!/bin/bash
 # Turn gpurun_out/ of tools/refresh_profiles.sh into the committed summaries under profiles/ (round tag = $1, default r01).
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out
 P=profiles
 cp $O/prof_stats/run_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
 grep "^{" $O/bench_line.json > $P/${R}_bench_line.json
+[ -f $O/bench_line_dist1.json ] && grep "^{" $O/bench_line_dist1.json > $P/${R}_bench_line_dist1.json
+[ -f $O/timeline.txt ] && cp $O/timeline.txt $P/${R}_bench_step_timeline.txt
+[ -f $O/timeline_fixed_plan.txt ] && cp $O/timeline_fixed_plan.txt $P/${R}_bench_step_timeline_fixed_plan.txt
 {
   echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, with --kernel-trace only) of: python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2"
   echo "# values are KB per dispatch as reported; FETCH_SIZE must be DOUBLED on gfx950 (MI355X_MICROARCH.md, HBM section) -- calibrated in this repo on"
