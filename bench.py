@@ -250,7 +250,7 @@ def main():
     # N > 1 (sampling enqueued eagerly beside the graph replays, see ext_sampling below): a high-priority stream gets its own hardware
     # queue -- on a default-priority stream the sampling kernels queue up BEHIND the graphs already enqueued (2.81 ms vs 2.46 ms per step)
     # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
-    side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else 0)
+    side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else int(os.environ.get("PAPC_SIDE_PRIO", "0")))   # (PAPC_SIDE_PRIO: A/B)
     from papc_amd.head import unit_gradient
     ONE = unit_gradient(dev)                    # d(loss)/d(loss), allocated once; seeding with this tensor skips the loss's multiply-by-one launch
     state = {"plan": None, "ev": None, "last_grad": None}

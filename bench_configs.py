@@ -110,6 +110,11 @@ def run(args):
     else:
         from papc_amd.pillars import PillarFeatureNet
         v, n, c = make_pillars()
+        # DIAGNOSTIC (the printed value is then NOT the benchmark): PAPC_BENCH_PFN_P=<pillars> runs the same five launches on the first P pillars of
+        # the frame -- at a few hundred pillars what is left is the launches' fixed cost (boundaries, dependent round trips, one-workgroup tails)
+        P_diag = int(os.environ.get("PAPC_BENCH_PFN_P", "0"))
+        if P_diag:
+            v, n, c = v[:P_diag], n[:P_diag], c[:P_diag]
         model = PillarFeatureNet(num_filters=(64,), voxel_size=(0.16, 0.16, 4), pc_range=(0, -39.68, -3, 69.12, 39.68, 1)).to(dev).train()
         # the frame comes zero-padded behind num_points, as the reference's voxeliser produces it (point_cloud_ops.py:148 zero-initialises the
         # buffers; synthetic.make_pillars masks likewise): the kernels may load the real rows only (PAPC_PFN_ZERO_PADDED=0: every row)
@@ -117,11 +122,13 @@ def run(args):
         workload_note = "rows behind num_points are zero (voxeliser contract): real rows loaded only" if model.assume_zero_padding else "all T rows loaded"
         tv, tn, tc = torch.from_numpy(v).to(dev), torch.from_numpy(n).to(dev), torch.from_numpy(c).to(dev)
         # the layer feeds PointPillarsScatter + the 2-D backbone (out of scope): its upstream gradient is a fixed [P, 64] tensor
-        gout = torch.randn(12000, 64, device=dev) * 1e-3
+        gout = torch.randn(v.shape[0], 64, device=dev) * 1e-3
         loss_fn = None
         units, unit, metric = 1, "frames/s", "pillar frames/sec (fwd+bwd) PillarFeatureNet 12000 pillars x 100 points"
         workload = "PointPillars PillarFeatureNet fwd+bwd+Adam, 12000 pillars x 100 points, one KITTI-shaped frame (BASELINE configs[4]); " + workload_note
-        P, T = 12000, 100
+        if P_diag:
+            metric += " -- DIAGNOSTIC on %d pillars: not a benchmark value" % P_diag
+        P, T = v.shape[0], 100
         feat = P * T * 4 * 4.0
         # three passes over the 19.2 MB of points: the Gram pass (train-mode BN statistics AND the dense part of dW from the inputs' 10x10
         # Gram matrix, csrc/pfn.hip), the apply pass (9 -> 64 layer + BN + ReLU + max, writes [P,64] out + argmax) and the sparse backward
@@ -146,9 +153,8 @@ def run(args):
 
         def update():
             if ADAM_IN_GRAPH:
-                if not ticked[0]:
-                    opt.tick()
-                opt.step_dev(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
+                # no sampling branch took the tick: the update advances the device step count itself (its last-finishing block) -- one launch less
+                opt.step_dev(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM, self_tick=not ticked[0])
 
         if loss_fn is None:                        # PFN: forward + backward of the layer under a given upstream gradient
             out = model(tv, tn, tc)

@@ -884,7 +884,9 @@ int papc_adam_step_zero_f32(float *param, float *grad, float *exp_avg, float *ex
 /* The same update with the step count in DEVICE memory, so that the launch can be part of a captured hipGraph (no host scalar changes from
  * step to step; an eager launch behind a graph replay starts 8-20 us after the graph's last kernel).  step_dev: one int64, the number of the
  * step being applied (1 for the first); papc_adam_tick adds 1 to it -- enqueue it anywhere EARLIER in the step (e.g. on the sampling branch),
- * never concurrently with the update.  zero_grad != 0 also clears the gradient bucket (papc_adam_step_zero_f32). */
+ * never concurrently with the update.  zero_grad: bit 0 also clears the gradient bucket (papc_adam_step_zero_f32); bit 1 = the launch ticks
+ * for itself: step_dev is then TWO int64 ([0] the number of the last step applied, [1] zero), the kernel applies step [0] + 1 and its
+ * last-finishing block stores that number (no papc_adam_tick launch: for a step that has no side branch to hide one on). */
 int papc_adam_tick(int64_t *step_dev, papc_stream_t stream);
 int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,
                            float eps, float weight_decay, const int64_t *step_dev, float grad_scale, int zero_grad, papc_stream_t stream);

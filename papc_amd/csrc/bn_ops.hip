@@ -376,14 +376,20 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
 // can live inside a captured hipGraph (an eager launch behind a graph replay starts 8-20 us after the graph's last kernel).  step_dev[0] is
 // advanced by papc_adam_tick (one thread, anywhere earlier in the step -- e.g. on the sampling branch), never by this kernel: every block
 // reads the same value.  The bias corrections are formed in double from it, like the host form.
-template <bool ZERO>
+// TICK: the kernel advances the count itself -- it applies step step_dev[0] + 1 and the block that FINISHES last (a ticket in step_dev[1],
+// which returns to zero) stores that number: every block has read the old value by then.  One atomic per block; for a step without a branch
+// to hide the tick launch on.
+template <bool ZERO, bool TICK>
 __global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                        float *__restrict__ v, int64_t n, float lr, double beta1, double beta2,
-                                                       float eps, float wd, const int64_t *__restrict__ step_dev, float gscale)
+                                                       float eps, float wd, int64_t *__restrict__ step_dev, float gscale)
 {
     __shared__ float s_bc[2];
+    __shared__ int64_t s_t;
     if (threadIdx.x == 0) {
-        const double t = (double)step_dev[0];
+        const int64_t ti = step_dev[0] + (TICK ? 1 : 0);
+        const double t = (double)ti;
+        s_t = ti;
         s_bc[0] = (float)(1.0 - pow(beta1, t));
         s_bc[1] = (float)(1.0 - pow(beta2, t));
     }
@@ -397,6 +403,16 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ p, fl
         m[i] = mi; v[i] = vi;
         p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
         if (ZERO) g[i] = 0.f;
+    }
+    if (TICK) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long done = atomicAdd(reinterpret_cast<unsigned long long *>(step_dev + 1), 1ull);
+            if (done == (unsigned long long)gridDim.x - 1ull) {
+                step_dev[0] = s_t;
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(step_dev + 1), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 __global__ void adam_tick_kernel(int64_t *step_dev) { step_dev[0] += 1; }
@@ -1133,10 +1149,14 @@ int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp
     PAPC_REQUIRE(n >= 1, PAPC_E_INVALID, "papc_adam_step_dev_f32: n=%lld", (long long)n);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    if (zero_grad)
-        hipLaunchKernelGGL(adam_dev_kernel<true>, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
-    else
-        hipLaunchKernelGGL(adam_dev_kernel<false>, dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale);
+    int64_t *sd = const_cast<int64_t *>(step_dev);
+    const bool zero = (zero_grad & 1) != 0, tick = (zero_grad & 2) != 0;
+#define ADAM_DEV(Z, T) hipLaunchKernelGGL((adam_dev_kernel<Z, T>), dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, sd, grad_scale)
+    if (zero && tick) ADAM_DEV(true, true);
+    else if (zero) ADAM_DEV(true, false);
+    else if (tick) ADAM_DEV(false, true);
+    else ADAM_DEV(false, false);
+#undef ADAM_DEV
     return check_launch("papc_adam_step_dev_f32");
 }
 

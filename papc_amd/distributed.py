@@ -110,7 +110,7 @@ class FlatAdam:
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
         self.t = 0
-        self.t_dev = torch.zeros(1, dtype=torch.int64, device=flat.data.device)   # the step count for the graph-capturable form (tick / step_dev)
+        self.t_dev = torch.zeros(2, dtype=torch.int64, device=flat.data.device)   # [0] the step count for the graph-capturable form (tick / step_dev), [1] the self-ticking launch's ticket
 
     def tick(self):
         """Advance the DEVICE step count (one-thread launch).  Enqueue it anywhere earlier in the step than :meth:`step_dev` -- e.g. on the
@@ -118,15 +118,21 @@ class FlatAdam:
         from . import _lib
         _lib.check(_lib.load().papc_adam_tick(self.t_dev.data_ptr(), _lib.stream_ptr()), "papc_adam_tick")
 
-    def step_dev(self, grad_scale=1.0, zero_grad=False):
+    def step_dev(self, grad_scale=1.0, zero_grad=False, self_tick=False):
         """:meth:`step` with the step count read from device memory (advanced by :meth:`tick`): no host scalar changes between steps, so
         the launch can sit inside a captured hipGraph behind the last backward kernel (an eager launch behind a graph replay starts
-        8-20 us late).  ``self.t`` (host) is not maintained on this path: read ``t_dev``."""
+        8-20 us late).  ``self.t`` (host) is not maintained on this path: read ``t_dev``.  ``self_tick=True``: no :meth:`tick` launch, the
+        kernel advances the count itself (its last-finishing block) -- for a step with no side branch to put the tick on."""
         from . import _lib
         f = self.flat
+        if self_tick and f.numel > 64 * 256:
+            # the self-ticking form costs one same-address atomic per 256-parameter block: measured +33 us at 3 200 blocks (PointNet-Basic), -4 us
+            # at 3 (PillarFeatureNet).  Large buckets take the one-thread tick launch
+            self.tick()
+            self_tick = False
         _lib.check(_lib.load().papc_adam_step_dev_f32(f.data.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), f.numel, self.lr,
                                                       self.betas[0], self.betas[1], self.eps, self.wd, self.t_dev.data_ptr(), float(grad_scale),
-                                                      int(bool(zero_grad)), _lib.stream_ptr()), "papc_adam_step_dev_f32")
+                                                      int(bool(zero_grad)) | (2 if self_tick else 0), _lib.stream_ptr()), "papc_adam_step_dev_f32")
 
     def step(self, grad_scale=1.0, zero_grad=False):
         """``zero_grad=True``: the kernel also clears the flat gradient bucket behind the update (papc_adam_step_zero_f32), so a

@@ -263,6 +263,14 @@ def test_adam_device_step_count_equals_host_form(dev):
                     opt.tick()
                     opt.step_dev(0.5, zero_grad=True)
             torch.cuda.current_stream().wait_stream(s)
+        if mode == "graph_selftick":
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    opt.step_dev(0.5, zero_grad=True, self_tick=True)
+            torch.cuda.current_stream().wait_stream(s)
         for k in range(7):
             flat.grad.copy_(gens[0][k] if k % 2 == 0 else gens[1][k])
             if mode == "host":
@@ -270,16 +278,18 @@ def test_adam_device_step_count_equals_host_form(dev):
             elif mode == "dev":
                 opt.tick()
                 opt.step_dev(0.5, zero_grad=True)
+            elif mode == "selftick":         # the launch advances the count itself (its last-finishing block; 6 blocks here)
+                opt.step_dev(0.5, zero_grad=True, self_tick=True)
             else:
                 g.replay()
         torch.cuda.synchronize()
         assert float(flat.grad.abs().max()) == 0.0
         if mode != "host":
-            assert int(opt.t_dev.item()) == 7
+            assert int(opt.t_dev[0].item()) == 7 and int(opt.t_dev[1].item()) == 0
         return flat.data.detach().cpu().numpy().copy(), opt.m.cpu().numpy().copy(), opt.v.cpu().numpy().copy()
 
     ref = run("host")
-    for mode in ("dev", "graph"):
+    for mode in ("dev", "graph", "selftick", "graph_selftick"):
         got = run(mode)
         for a, b, nm in zip(got, ref, ("param", "exp_avg", "exp_avg_sq")):
             assert_close(a, b, 1e-6, "Adam %s, %s step count vs host scalar" % (nm, mode))
