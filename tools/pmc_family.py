@@ -35,7 +35,7 @@ def collect(d):
     agg = defaultdict(lambda: [0, 0.0])
     with open(d + "/run_counter_collection.csv") as f:
         for r in csv.DictReader(f):
-            if "adam_kernel" in r["Kernel_Name"]:
+            if "adam_kernel" in r["Kernel_Name"] or "adam_dev_kernel" in r["Kernel_Name"]:
                 agg["_steps"][0] += 1          # one optimizer launch per step: the step count of the profiled run
             fam = family(r["Kernel_Name"])
             if fam:
