@@ -802,6 +802,10 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     // one workgroup per CU in total (weights + 8 waves of up to 256 registers fill it); column blocks of the same rows are
     // gridDim.x apart in the flat id, i.e. on the same XCD when gridDim.x % 8 == 0: the second reader of a row finds it in L2
     int gx = std::max(8, (stream_ncu() / ncb) & ~7);
+    // ... except the two flavours light enough for TWO per CU (<= 128 registers, <= 76 KB of LDS: the [P | A] dX of a max layer without stored
+    // output and the coordinates-operand forward): four waves per SIMD overlap their memory, VALU and matrix phases better than two
+    // (round 5, same box: 96-102 -> 88 us and 39.6 -> 35.0 us per launch, step -6 us)
+    if (!CP && (AMODE == A_MAXCAT || AMODE == A_XYZ)) gx *= 2;
     gx = std::min(gx, std::max(1, (geo.n_units + 7) / 8));
     if (gx > p.parts) gx = p.parts;
     dim3 grid((unsigned)gx, (unsigned)ncb);
