@@ -544,7 +544,7 @@ __global__ __launch_bounds__(HT) void head_chain_fwd_kernel(HeadChainFwd c)
             if (bid == 0) softmax_xent_body<true>(a.out, a.Cout, c.labels, a.B, a.Cout, c.loss, c.dlogits, smem);
         }
     }
-    grid_exit(c.bar);
+    if (c.n > 1 || (c.labels && c.l[c.n - 1].Cout > 32)) grid_exit(c.bar);     // (no barrier was taken: nothing to return to zero, no atomic round trip at the end)
 }
 
 struct HeadChainBwd {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(HT) void head_chain_bwd_kernel(HeadChainBwd c)
         }
         if (ph < c.n_phases - 1) grid_barrier(c.bar, (unsigned)(ph + 1) * gridDim.x);
     }
-    grid_exit(c.bar);
+    if (c.n_phases > 1) grid_exit(c.bar);
 }
 
 }  // namespace papc

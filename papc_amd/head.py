@@ -22,6 +22,11 @@ MAX_ROWS = 256
 # 49.6 -> 56.5 us, backward 42.5 -> 52.0 us per step; DESIGN "measured and not kept").  Default: one launch per layer.  The chain stays
 # selectable and tested (bit-identical results).
 CHAIN = os.environ.get("PAPC_HEAD_CHAIN", "0") == "1"
+# PAPC_HEAD_MERGE=1: the hand-over-free merges only -- the last layer's single workgroup computes the loss from the logits it still holds in LDS
+# (no softmax launch) and the backward's two independent first jobs share one launch: 6 launches instead of 8.  Measured on MI355X: the head's
+# span shrinks by 5 us under rocprofv3, the step does not (1.473 / 1.473 ms with a fixed plan, 1.588 / 1.579 ms beside the sampling branch):
+# opt-in as well.
+MERGE = os.environ.get("PAPC_HEAD_MERGE", "0") == "1"
 c_p, c_i, c_f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
 
 
@@ -62,6 +67,7 @@ class HeadSpec:
         self.masks = None              # (keep1, keep2) uint8 tensors of the last forward when export_masks
         self.grad_targets = None
         self.chain = CHAIN             # the layers as phases of one launch each way (False: one launch per layer)
+        self.merge = MERGE             # (chain False) the hand-over-free merges: loss with the last layer, the backward's two independent first jobs
         self._sync = {}                # per stream: the two barrier words of the chain launches (zero between launches)
 
     def sync(self, device):
@@ -141,6 +147,11 @@ class _Head(torch.autograd.Function):
             arr = (HeadFcLayer * 3)(*layers)
             check(lib.papc_head_chain_fwd_f32(ctypes.addressof(arr), 3, B, ptr(rng), ptr(rng), _p(labels), _p(loss), _p(dz), ptr(spec.sync(dev)), st),
                   "papc_head_chain_fwd_f32")
+        elif labels is not None and spec.merge and cout <= 32:
+            # one workgroup makes all the logits: it goes on to the loss from its LDS tile (a one-layer chain launch: no barrier, no hand-over)
+            one = (HeadFcLayer * 1)(HeadFcLayer(ptr(x), ptr(w3), ptr(b3), None, None, cin, cout, 0, 0.0, 0.0, None, None, None, 0.0, 3, None, None, None, None, ptr(logits)))
+            check(lib.papc_head_chain_fwd_f32(ctypes.addressof(one), 1, B, ptr(rng), ptr(rng), ptr(labels), ptr(loss), ptr(dz), ptr(spec.sync(dev)), st),
+                  "papc_head_chain_fwd_f32")
         else:
             check(lib.papc_head_fc_f32(ptr(x), ptr(w3), ptr(b3), 0, 0, B, cin, cout, 0, 0.0, 0.0, 0, 0, 0, 0.0, 0, 3, ptr(rng),
                                        0, 0, 0, 0, ptr(logits), st), "papc_head_fc_f32")
@@ -196,9 +207,13 @@ class _Head(torch.autograd.Function):
             _run_bwd_chain(jobs, B, spec, dev, st)
         else:
             f = lib.papc_head_bwd_f32
-            check(f(ptr(glogits), 0, c3, 0, 0, 0, 0, 0, 0.0, 0, ptr(x2), B, c2, c3, 0, ptr(dw3), ptr(db3), 0, 0, acc, st), "papc_head_bwd_f32")
-            check(f(ptr(glogits), ptr(w3), c3, ptr(x2), ptr(y2), ptr(mean2), ptr(invstd2), ptr(g2), float(p2), 1, ptr(x1), B, c1, c2,
-                    ptr(dy2), ptr(dw2), ptr(db2), ptr(dg2), ptr(dbe2), acc, st), "papc_head_bwd_f32")
+            if spec.merge:      # dW of the last layer and the whole backward of the layer below read the same dlogits and nothing of each other: one launch
+                _run_bwd_chain([_bwd_job(glogits, None, c3, None, None, None, None, None, 0.0, 0, x2, c2, c3, None, dw3, db3, None, None, acc, 0),
+                                _bwd_job(glogits, w3, c3, x2, y2, mean2, invstd2, g2, p2, 1, x1, c1, c2, dy2, dw2, db2, dg2, dbe2, acc, 0)], B, spec, dev, st)
+            else:
+                check(f(ptr(glogits), 0, c3, 0, 0, 0, 0, 0, 0.0, 0, ptr(x2), B, c2, c3, 0, ptr(dw3), ptr(db3), 0, 0, acc, st), "papc_head_bwd_f32")
+                check(f(ptr(glogits), ptr(w3), c3, ptr(x2), ptr(y2), ptr(mean2), ptr(invstd2), ptr(g2), float(p2), 1, ptr(x1), B, c1, c2,
+                        ptr(dy2), ptr(dw2), ptr(db2), ptr(dg2), ptr(dbe2), acc, st), "papc_head_bwd_f32")
             check(f(ptr(dy2), ptr(w2), c2, ptr(x1), ptr(y1), ptr(mean1), ptr(invstd1), ptr(g1), float(p1), 1, ptr(x0), B, c0, c1,
                     ptr(dy1), ptr(dw1), ptr(db1), ptr(dg1), ptr(dbe1), acc, st), "papc_head_bwd_f32")
             if need_dx:

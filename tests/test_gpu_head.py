@@ -306,12 +306,13 @@ def _clone_mods(mods):
     return [copy.deepcopy(m) for m in mods]
 
 
-def _run_head(mods, x0v, glog, chain, labels=None, seed_state=None, steps=1):
+def _run_head(mods, x0v, glog, chain, labels=None, seed_state=None, steps=1, merge=False):
     """`steps` forward + backward passes through the fused head; returns everything a caller can observe"""
     from papc_amd import head
     fc1, bn1, d1, fc2, bn2, d2, fc3 = mods
     spec = head.HeadSpec()
     spec.chain = chain
+    spec.merge = merge
     spec.export_masks = True
     if seed_state is not None:
         spec.rng_state = seed_state.clone()
@@ -368,10 +369,17 @@ def test_head_with_fused_loss_equals_head_then_loss(B, c3):
     st = torch.tensor([99, 0], dtype=torch.int64, device="cuda")
     for seed in (None, torch.tensor(1.7, device="cuda"), head.unit_gradient("cuda")):
         a, _ = _run_head(_clone_mods(mods), x0, seed, True, labels=y, seed_state=st, steps=2)
+        # the default: per-layer launches with the hand-over-free merges (loss with the last layer when one workgroup makes the logits; the backward's
+        # two independent first jobs in one launch)
+        am, _ = _run_head(_clone_mods(mods), x0, seed, False, labels=y, seed_state=st, steps=2, merge=True)
+        for sa, sm in zip(a, am):
+            assert torch.equal(sa["loss"], sm["loss"]) and torch.equal(sa["logits"], sm["logits"]) and torch.equal(sa["dx"], sm["dx"])
+            assert all(torch.equal(x_, y_) for x_, y_ in zip(sa["grads"], sm["grads"]))
         # reference: the per-layer head, then the separate loss
         m2 = _clone_mods(mods)
         spec = head.HeadSpec()
         spec.chain = False
+        spec.merge = False
         spec.rng_state = st.clone()
         for step in range(2):
             x = x0.clone().requires_grad_(True)
