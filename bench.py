@@ -172,7 +172,13 @@ def main():
                     help="(default) software-pipelined sampling: batch i+1's pyramid (FPS + ball query: weight-independent, a serial "
                     "chain on 32 of the 256 CUs) runs on a side stream / graph branch beside batch i's MLP kernels")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="sample in-line at the head of every step")
-    ap.add_argument("--fork", choices=["start", "sa2", "sa3", "loss"], default="sa2", help="where the step forks the next batch's sampling branch")
+    ap.add_argument("--fork", choices=["start", "sa2", "sa3", "loss", "sa2late", "sa2end"], default="sa2", help="where the step forks the next batch's sampling branch "
+                    "(sa2late / sa2end: the branch DEPENDS on the same point as sa2 but its launches are captured later -- behind SA3's forward / behind the whole "
+                    "backward -- so that the main chain's continuation is the fork node's first successor in the captured graph)")
+    ap.add_argument("--in-graph-fork", action="store_true", help="(N = 1) the next batch's sampling pyramid as a FORKED BRANCH of the step's hipGraph (rounds 2-4) "
+                    "instead of the default since round 5: a SECOND hipGraph on the side stream with no graph edge to the step's -- a forked branch costs the "
+                    "main chain ~60 us per replay on MI355X whatever it holds; a device-side gate (papc_flag_wait) holds the pyramid back until the step has "
+                    "enqueued SA2, plain stream events order the plan buffers across steps")
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
@@ -251,6 +257,15 @@ def main():
     # queue -- on a default-priority stream the sampling kernels queue up BEHIND the graphs already enqueued (2.81 ms vs 2.46 ms per step)
     # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
     side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else int(os.environ.get("PAPC_SIDE_PRIO", "0")))   # (PAPC_SIDE_PRIO: A/B)
+    side_graph = not args.in_graph_fork and args.fork == "sa2" and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
+    gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None      # the word papc_flag_set / papc_flag_wait share
+
+    def gate_open(counter=None):
+        _lib.check(lib.papc_flag_set(gate.data_ptr(), 1, counter.data_ptr() if counter is not None else None, _lib.stream_ptr()), "papc_flag_set")
+
+    def gate_wait():
+        _lib.check(lib.papc_flag_wait(gate.data_ptr(), 40000, _lib.stream_ptr()), "papc_flag_wait")      # (bounded: ~35 ms, then it starts anyway)
+
     from papc_amd.head import unit_gradient
     ONE = unit_gradient(dev)                    # d(loss)/d(loss), allocated once; seeding with this tensor skips the loss's multiply-by-one launch
     state = {"plan": None, "ev": None, "last_grad": None}
@@ -337,28 +352,43 @@ def main():
 
         ticked = [not ADAM_IN_GRAPH]
 
-        def fork():
-            side.wait_stream(main)
+        fork_ev = [None]
+
+        def fork(ev=None):
+            if ev is None:
+                side.wait_stream(main)
+            else:
+                side.wait_event(ev)
             with torch.cuda.stream(side):
                 if not ticked[0]:
                     opt.tick()                                     # the optimiser's step count advances off the critical path
                     ticked[0] = True
                 model.plan_sampling(x, (s1, s2), out=plan_out)     # the kernels write the other graph's plan buffers in place
 
+        def mark():                                                # sa2late / sa2end: only the dependency point is taken here
+            fork_ev[0] = torch.cuda.Event()
+            fork_ev[0].record(main)
+
         # (N > 1: the two stages are two graphs and a fork must be joined inside the graph that opened it, so the sampling
         # branch belongs to stage 2 -- the SA2 + SA1 backward, 1.4 ms -- there)
         if plan_out is not None and args.fork == "start" and not use_dist:
             fork()
+        if side_graph and graph_state.get("capturing_main"):
+            def cut():                             # behind SA2's launches: the other stream's pyramid may start; the same one-thread launch advances
+                gate_open(opt.t_dev if not ticked[0] else None)     # the optimiser's device step count (the update is the step's last node)
+                ticked[0] = True
         tap = {} if use_dist else None
         if args.diag_fixed_plan:
             plan_in, plan_out = graph_state["fixed_plan"], None
         loss, _ = model(x, (s1, s2), plan=plan_in, tap=tap,
-                        after_sa2=cut if cut is not None else (fork if plan_out is not None and args.fork == "sa2" and not use_dist else None),
-                       after_sa3=(fork if plan_out is not None and args.fork == "sa3" and not use_dist else None), labels=y)
+                        after_sa2=cut if cut is not None else ((fork if args.fork == "sa2" else (mark if args.fork in ("sa2late", "sa2end") else None)) if plan_out is not None and not use_dist else None),
+                       after_sa3=((fork if args.fork == "sa3" else ((lambda: fork(fork_ev[0])) if args.fork == "sa2late" else None)) if plan_out is not None and not use_dist else None), labels=y)
         if not use_dist:
             if plan_out is not None and args.fork == "loss":
                 fork()
             loss.backward(ONE)
+            if plan_out is not None and args.fork == "sa2end":
+                fork(fork_ev[0])
             if plan_out is not None:
                 main.wait_stream(side)             # join: the branch is part of this step
             if ADAM_IN_GRAPH:
@@ -394,6 +424,28 @@ def main():
                 bufs = [tuple(tuple(t.clone() for t in lvl) for lvl in p0) for _ in range(2)]
                 torch.cuda.synchronize()
             gs, losses = [], []
+            if side_graph:
+                gside = []
+                for i in range(2):
+                    g1 = torch.cuda.CUDAGraph()
+                    graph_state["capturing_main"] = True
+                    with torch.cuda.graph(g1, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                        loss, _, _, _ = stage1(bufs[i], None)
+                    graph_state["capturing_main"] = False
+                    gs.append((g1, None, None))
+                    losses.append(loss)
+                    g2 = torch.cuda.CUDAGraph()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
+                            gate_wait()
+                            model.plan_sampling(x, (s1, s2), out=bufs[1 - i])
+                    main.wait_stream(side)
+                    gside.append(g2)
+                graph_state["g"], graph_state["loss"], graph_state["bufs"], graph_state["gside"] = gs, losses, bufs, gside
+                graph_state["side_ev"] = [None, None]
+                torch.cuda.synchronize()
+                return True
             for i in range(n_sets):
                 pin, pout = (bufs[i], bufs[1 - i]) if args.overlap else (None, None)
                 if ext_sampling:
@@ -475,6 +527,17 @@ def main():
         i = graph_state["i"] % len(graph_state["g"])
         graph_state["i"] += 1
         g1, g1b, g2 = graph_state["g"][i]
+        if side_graph and graph_state.get("gside"):
+            ev = graph_state["side_ev"][i]
+            if ev is not None:
+                main.wait_event(ev)                # bufs[i] was filled by the side graph of the previous step
+            g1.replay()
+            with torch.cuda.stream(side):
+                graph_state["gside"][i].replay()   # gated on the device: starts when this step has enqueued SA2; fills bufs[1 - i]
+                ev = torch.cuda.Event()
+                ev.record(side)
+            graph_state["side_ev"][1 - i] = ev
+            return graph_state["loss"][i]
         if ext_sampling:
             main.wait_stream(side)                 # this batch's plan (bufs[i]) was filled on the side stream during the last step
         g1.replay()
@@ -690,7 +753,10 @@ def main():
                                    "surfaces keep 0.91-0.99 and stay padded -> `value_padded` is their rate)" % row_fraction) if compact_on else "padded (policy)",
                        "sampling": ("software-pipelined: batch i+1's FPS + ball-query pyramid runs as a second branch (side stream) of "
                                     "batch i's step, %s; every timed step computes one full pyramid"
-                                    % ("enqueued on the side stream beside the graph replay" if ext_sampling else "fork at " + args.fork)) if args.overlap else "in-line",
+                                    % ("enqueued on the side stream beside the graph replay" if ext_sampling else
+                                       ("a second hipGraph on the side stream, no graph edge to the step's (a forked branch costs the main chain ~60 us per replay): "
+                                        "gated on the device behind SA2 (papc_flag_set / papc_flag_wait), plan buffers ordered by stream events" if (side_graph and use_graph)
+                                        else "fork at " + args.fork))) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
                        "launch": ("hipGraph replay of fwd+loss+bwd (%d graph(s) per step, two alternating sets), %s"

@@ -145,6 +145,14 @@ def run(args):
     overlap = args.config == "msg_seg" and getattr(args, "overlap", True)
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream() if overlap else None
+    # the sampling pyramid of the next batch as a second hipGraph on the side stream, gated on the device (bench.py --in-graph-fork: as a forked
+    # branch of the step's graph, which costs the main chain ~60 us per replay)
+    # ... for THIS config measured slower (6.15 vs 5.75 ms): the MSG layers fork their radius branches onto further streams inside the step's graph, and
+    # the side graph's kernels then share hardware queues with them.  Opt-in (PAPC_SIDE_GRAPH=1); the headline config takes it by default (bench.py)
+    side_graph = (overlap and os.environ.get("PAPC_SIDE_GRAPH") == "1" and not getattr(args, "in_graph_fork", False) and not args.no_graph
+                  and getattr(args, "fork", "sa2") != "start")
+    gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None
+    cap = {"main": False}
 
     def fwd_bwd(plan_in=None, plan_out=None):
         if not ZERO_IN_ADAM:
@@ -169,6 +177,14 @@ def run(args):
                     ticked[0] = True
                 plan_fn(plan_out)
         fork_at = getattr(args, "fork", "sa2")      # (bench.py's flag; here: "start" = with the step, anything else = behind the encoder)
+        if side_graph and cap["main"]:
+            def gate_open():                       # behind the encoder: the side stream's pyramid may start; the same launch ticks the optimiser's step count
+                _lib.check(lib.papc_flag_set(gate.data_ptr(), 1, opt.t_dev.data_ptr() if not ticked[0] else None, _lib.stream_ptr()), "papc_flag_set")
+                ticked[0] = True
+            loss = loss_fn(plan_in, gate_open)
+            loss.backward(one)
+            update()
+            return loss
         if plan_out is not None and fork_at == "start":
             fork()
         if plan_out is not None and fork_at != "start":
@@ -199,13 +215,26 @@ def run(args):
             if overlap:     # two alternating graphs: each reads one set of plan buffers and fills the other on its side branch
                 bufs = [_clone(plan_fn()) for _ in range(2)]
                 torch.cuda.synchronize()
-                gs, losses = [], []
+                gs, losses, gside = [], [], []
                 for i in range(2):
                     g = torch.cuda.CUDAGraph()
+                    cap["main"] = side_graph
                     with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                        losses.append(fwd_bwd(bufs[i], bufs[1 - i]))
+                        losses.append(fwd_bwd(bufs[i], None if side_graph else bufs[1 - i]))
+                    cap["main"] = False
                     gs.append(g)
+                    if side_graph:
+                        g2 = torch.cuda.CUDAGraph()
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
+                                _lib.check(lib.papc_flag_wait(gate.data_ptr(), 40000, _lib.stream_ptr()), "papc_flag_wait")
+                                plan_fn(bufs[1 - i])
+                        main.wait_stream(side)
+                        gside.append(g2)
                 graph["g"], graph["loss"], graph["bufs"] = gs, losses, bufs
+                graph["gside"], graph["side_ev"] = (gside if side_graph else None), [None, None]
+                torch.cuda.synchronize()
                 return
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
@@ -222,7 +251,18 @@ def run(args):
             return step_eager()
         i = graph["i"] % len(graph["g"])
         graph["i"] += 1
-        graph["g"][i].replay()
+        if graph.get("gside"):
+            ev = graph["side_ev"][i]
+            if ev is not None:
+                main.wait_event(ev)                # this step's plan buffers were filled by the previous step's side graph
+            graph["g"][i].replay()
+            with torch.cuda.stream(side):
+                graph["gside"][i].replay()         # starts when this step has enqueued its encoder (device-side gate); fills the other buffers
+                ev = torch.cuda.Event()
+                ev.record(side)
+            graph["side_ev"][1 - i] = ev
+        else:
+            graph["g"][i].replay()
         if not ADAM_IN_GRAPH:
             opt.step(flat.allreduce_grads(), zero_grad=ZERO_IN_ADAM)
         return graph["loss"][i]
@@ -327,8 +367,11 @@ def run(args):
            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
            "config": {"workload": workload, "final_loss": round(final_loss, 4), "launch": (("hipGraph replay of fwd+loss+bwd+Adam (the update, which also clears the gradient bucket, is the graph's last node)" if ADAM_IN_GRAPH else "hipGraph replay of fwd+loss+bwd, eager Adam (which also clears the gradient bucket)") if ZERO_IN_ADAM else "hipGraph replay of zero_grad+fwd+loss+bwd, eager Adam") if use_graph else "eager",
-                      "sampling": ("software-pipelined: batch i+1's FPS / ball queries / compact plans / 3-NN searches run as a second branch (side stream) of "
-                                   "batch i's graph, two alternating graphs; every timed step computes one full set") if (overlap and use_graph) else "in-line",
+                      "sampling": (("software-pipelined: batch i+1's FPS / ball queries / compact plans / 3-NN searches run as a second hipGraph on a side stream "
+                                    "(no graph edge to the step's; gated on the device behind the encoder, papc_flag_set / papc_flag_wait), two alternating sets; "
+                                    "every timed step computes one full set") if graph.get("gside") else
+                                   ("software-pipelined: batch i+1's FPS / ball queries / compact plans / 3-NN searches run as a second branch (side stream) of "
+                                    "batch i's graph, two alternating graphs; every timed step computes one full set")) if (overlap and use_graph) else "in-line",
                       "families_ms_per_step": {K_NAMES[k]: round(v[0] / 3, 4) for k, v in fam.items() if v[0] > 0}},
            "roofline": roof, "cpu_baseline": cpu}
     print(json.dumps(out))

@@ -888,6 +888,12 @@ int papc_adam_step_zero_f32(float *param, float *grad, float *exp_avg, float *ex
  * for itself: step_dev is then TWO int64 ([0] the number of the last step applied, [1] zero), the kernel applies step [0] + 1 and its
  * last-finishing block stores that number (no papc_adam_tick launch: for a step that has no side branch to hide one on). */
 int papc_adam_tick(int64_t *step_dev, papc_stream_t stream);
+/* A device-side gate between two streams (bench.py --side-graph): papc_flag_wait spins (one wave, bounded by max_spins sleeps of ~1 us) until the
+ * word is non-zero, then returns it to zero; papc_flag_set stores `value` (agent scope).  For two hipGraphs on two streams that must not be joined
+ * by a graph edge (a forked branch costs the main chain ~60 us per replay on MI355X) but where the second has to start behind a point of the first.
+ * The launch that sets the word must be enqueued BEFORE the one that waits when both streams may share a hardware queue. */
+int papc_flag_set(uint32_t *flag, uint32_t value, int64_t *counter, papc_stream_t stream);
+int papc_flag_wait(uint32_t *flag, int64_t max_spins, papc_stream_t stream);
 int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,
                            float eps, float weight_decay, const int64_t *step_dev, float grad_scale, int zero_grad, papc_stream_t stream);
 

@@ -417,6 +417,23 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ p, fl
 }
 __global__ void adam_tick_kernel(int64_t *step_dev) { step_dev[0] += 1; }
 
+// ---- a device-side gate between two streams (papc_flag_set / papc_flag_wait) -----------------------------------------------------------------
+// A forked branch inside a replayed hipGraph costs the MAIN chain ~60 us per step on MI355X whatever the branch holds (bench.py, round 5: an
+// empty branch = fork + join).  Two graphs on two streams with no edge between them cost nothing -- but the second one must not start before the
+// first has reached a given point.  The gate is one lane spinning on a word the other stream's launch sets (agent scope, it returns the word to
+// zero); bounded by `max_spins` sleeps so that a mis-ordered launch sequence ends in a late start, never in a hang.
+__global__ void flag_set_kernel(unsigned *flag, unsigned value, int64_t *counter)
+{
+    if (counter) counter[0] += 1;        // (a step counter riding on the same launch: FlatAdam's device step count)
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_kernel(unsigned *flag, long long max_spins)
+{
+    long long n = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && n < max_spins) { __builtin_amdgcn_s_sleep(32); ++n; }
+    __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ p, int64_t n, float v)
 {
     const int64_t n4 = n >> 2;
@@ -1140,6 +1157,22 @@ int papc_adam_tick(int64_t *step_dev, papc_stream_t stream)
     ProfScope prof(PAPC_K_MISC, st);
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_dev);
     return check_launch("papc_adam_tick");
+}
+
+int papc_flag_set(uint32_t *flag, uint32_t value, int64_t *counter, papc_stream_t stream)
+{
+    PAPC_REQUIRE(flag, PAPC_E_INVALID, "papc_flag_set: null pointer");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(flag_set_kernel, dim3(1), dim3(1), 0, st, flag, value, counter);
+    return check_launch("papc_flag_set");
+}
+
+int papc_flag_wait(uint32_t *flag, int64_t max_spins, papc_stream_t stream)
+{
+    PAPC_REQUIRE(flag && max_spins >= 0, PAPC_E_INVALID, "papc_flag_wait: null pointer / negative max_spins");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, st, flag, (long long)max_spins);
+    return check_launch("papc_flag_wait");
 }
 
 int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,

@@ -1,5 +1,6 @@
-"""What the driver times: bench.py's N = 1 launch structure (two alternating hipGraphs, the next batch's FPS + ball-query pyramid as a
-forked branch of the step's graph, B = 32, N = 4096) held to the same steps launched eagerly with in-line sampling -- loss trajectory
+"""What the driver times: bench.py's N = 1 launch structure (two alternating hipGraphs for the step, the next batch's FPS + ball-query pyramid as
+a second pair of hipGraphs on a side stream, gated on the device -- and the earlier structure, the pyramid as a forked branch of the step's
+graph --, B = 32, N = 4096) held to the same steps launched eagerly with in-line sampling -- loss trajectory
 and the flat parameter buffer after the last step -- and the row-streaming GEMM's STORE_RED flavour repeated bit-identically while a
 second stream runs the sampling kernels beside it (the hazard that flavour's LATE1 ordering closes)."""
 import os
@@ -33,18 +34,21 @@ def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
     routing, ReLU sides -- so at the reference's lr = 1e-3 that atomics noise grows ~30x per step and two eager runs already differ
     by 2 % after ten steps: tools/probe/repro.py.)"""
     g, line = _bench(tmp_path, "graph0", "0")
-    assert int(g["graph"]) == 1 and int(g["overlap"]) == 1, "the default bench must replay captured graphs with the sampling fork: " + line
-    assert '"launch": "hipGraph replay' in line and "fork at sa2" in line
+    assert int(g["graph"]) == 1 and int(g["overlap"]) == 1, "the default bench must replay captured graphs with the overlapped sampling: " + line
+    assert '"launch": "hipGraph replay' in line and "a second hipGraph on the side stream" in line
     e, _ = _bench(tmp_path, "eager0", "0", "--no-graph", "--no-overlap")
     assert int(e["graph"]) == 0 and int(e["overlap"]) == 0
-    assert g["loss"].shape == e["loss"].shape == (10,) and np.all(np.isfinite(g["loss"]))
-    assert np.array_equal(g["loss"], e["loss"]), (g["loss"], e["loss"])
-    assert len(set(g["loss"].tolist())) == 10                                     # a new dropout mask per replay
-    assert np.array_equal(g["params"], g["params0"]) and np.array_equal(e["params"], e["params0"])
-    gs = float(np.max(np.abs(e["grad"])))
-    dg = float(np.max(np.abs(g["grad"] - e["grad"]))) / gs
-    print("lr 0: losses bit-identical, gradient diff %.2e of max |g|" % dg)
-    assert dg <= 1e-5, dg
+    f, line_f = _bench(tmp_path, "fork0", "0", "--in-graph-fork")               # rounds 2-4: the pyramid as a forked branch of the step's graph
+    assert int(f["graph"]) == 1 and "fork at sa2" in line_f
+    for name, r in (("side graph", g), ("in-graph fork", f)):
+        assert r["loss"].shape == e["loss"].shape == (10,) and np.all(np.isfinite(r["loss"]))
+        assert np.array_equal(r["loss"], e["loss"]), (name, r["loss"], e["loss"])
+        assert len(set(r["loss"].tolist())) == 10                                 # a new dropout mask per replay
+        assert np.array_equal(r["params"], r["params0"]) and np.array_equal(e["params"], e["params0"])
+        gs = float(np.max(np.abs(e["grad"])))
+        dg = float(np.max(np.abs(r["grad"] - e["grad"]))) / gs
+        print("lr 0, %s: losses bit-identical, gradient diff %.2e of max |g|" % (name, dg))
+        assert dg <= 1e-5, (name, dg)
     # (b)
     g1, _ = _bench(tmp_path, "graph1", "1e-5")
     e1, _ = _bench(tmp_path, "eager1", "1e-5", "--no-graph", "--no-overlap")

@@ -308,3 +308,32 @@ def test_unit_gradient_seed_skips_the_scale_launch(dev):
     z.grad = None
     softmax_cross_entropy(z, y).backward(torch.full((), 2.0, device=dev))
     assert torch.equal(2.0 * g1, z.grad)
+
+
+def test_flag_gate_orders_two_streams(dev):
+    """papc_flag_wait on one stream holds that stream's later launches back until papc_flag_set runs on another (the device-side gate of
+    bench.py's side-graph structure); the word returns to zero; the same launch advances an int64 counter; a gate nobody opens times out."""
+    lib = _lib.load()
+    flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    buf = torch.zeros(1 << 20, device=dev)
+    out = torch.empty_like(buf)
+    torch.cuda.synchronize()
+    for rep in range(5):
+        # (the setter is enqueued first, as the header asks: two streams may share a hardware queue, where a gate ahead of its setter would spin
+        # until it times out)
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(2_000_000)                 # ~1 ms of spinning on stream a
+            buf.fill_(float(rep + 1))
+            _lib.check(lib.papc_flag_set(flag.data_ptr(), 1, cnt.data_ptr(), a.cuda_stream), "papc_flag_set")
+        with torch.cuda.stream(b):                       # its copy must see what stream a wrote before opening the gate
+            _lib.check(lib.papc_flag_wait(flag.data_ptr(), 400000, b.cuda_stream), "papc_flag_wait")
+            out.copy_(buf)
+        torch.cuda.synchronize()
+        assert float(out.min()) == float(out.max()) == float(rep + 1)
+        assert int(flag[0]) == 0 and int(cnt[0]) == rep + 1
+    with torch.cuda.stream(b):                           # nobody opens: bounded spinning, then it goes on
+        _lib.check(lib.papc_flag_wait(flag.data_ptr(), 200, b.cuda_stream), "papc_flag_wait")
+    torch.cuda.synchronize()
+    assert int(flag[0]) == 0
