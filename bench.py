@@ -257,7 +257,7 @@ def main():
     # queue -- on a default-priority stream the sampling kernels queue up BEHIND the graphs already enqueued (2.81 ms vs 2.46 ms per step)
     # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
     side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else int(os.environ.get("PAPC_SIDE_PRIO", "0")))   # (PAPC_SIDE_PRIO: A/B)
-    side_graph = not args.in_graph_fork and args.fork == "sa2" and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
+    side_graph = not args.in_graph_fork and args.fork in ("start", "sa2", "sa3", "loss") and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
     gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None      # the word papc_flag_set / papc_flag_wait share
 
     def gate_open(counter=None):
@@ -373,17 +373,23 @@ def main():
         # branch belongs to stage 2 -- the SA2 + SA1 backward, 1.4 ms -- there)
         if plan_out is not None and args.fork == "start" and not use_dist:
             fork()
+        gate_at = None
         if side_graph and graph_state.get("capturing_main"):
-            def cut():                             # behind SA2's launches: the other stream's pyramid may start; the same one-thread launch advances
-                gate_open(opt.t_dev if not ticked[0] else None)     # the optimiser's device step count (the update is the step's last node)
+            def open_gate():                       # from here on the other stream's pyramid may start (--fork: behind SA2 by default); the same one-thread
+                gate_open(opt.t_dev if not ticked[0] else None)     # launch advances the optimiser's device step count (the update is the step's last node)
                 ticked[0] = True
+            gate_at = args.fork
+            if gate_at == "start":
+                open_gate()
         tap = {} if use_dist else None
         if args.diag_fixed_plan:
             plan_in, plan_out = graph_state["fixed_plan"], None
         loss, _ = model(x, (s1, s2), plan=plan_in, tap=tap,
-                        after_sa2=cut if cut is not None else ((fork if args.fork == "sa2" else (mark if args.fork in ("sa2late", "sa2end") else None)) if plan_out is not None and not use_dist else None),
-                       after_sa3=((fork if args.fork == "sa3" else ((lambda: fork(fork_ev[0])) if args.fork == "sa2late" else None)) if plan_out is not None and not use_dist else None), labels=y)
+                        after_sa2=cut if cut is not None else (open_gate if gate_at == "sa2" else ((fork if args.fork == "sa2" else (mark if args.fork in ("sa2late", "sa2end") else None)) if plan_out is not None and not use_dist else None)),
+                        after_sa3=open_gate if gate_at == "sa3" else (((fork if args.fork == "sa3" else ((lambda: fork(fork_ev[0])) if args.fork == "sa2late" else None)) if plan_out is not None and not use_dist else None)), labels=y)
         if not use_dist:
+            if gate_at == "loss":
+                open_gate()
             if plan_out is not None and args.fork == "loss":
                 fork()
             loss.backward(ONE)
@@ -755,7 +761,7 @@ def main():
                                     "batch i's step, %s; every timed step computes one full pyramid"
                                     % ("enqueued on the side stream beside the graph replay" if ext_sampling else
                                        ("a second hipGraph on the side stream, no graph edge to the step's (a forked branch costs the main chain ~60 us per replay): "
-                                        "gated on the device behind SA2 (papc_flag_set / papc_flag_wait), plan buffers ordered by stream events" if (side_graph and use_graph)
+                                        "gated on the device behind %s (papc_flag_set / papc_flag_wait), plan buffers ordered by stream events" % args.fork if (side_graph and use_graph)
                                         else "fork at " + args.fork))) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "
                                "accumulate (PAPC_GEMM_F32=1 PAPC_DW_F32=1 select v_mfma_f32_32x32x2_f32); gather-layer dW stays on the f32 MFMA",
