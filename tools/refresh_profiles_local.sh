@@ -8,6 +8,7 @@ grep "^{" $O/bench_line.json > $P/${R}_bench_line.json
 [ -f $O/bench_line_dist1.json ] && grep "^{" $O/bench_line_dist1.json > $P/${R}_bench_line_dist1.json
 [ -f $O/timeline.txt ] && cp $O/timeline.txt $P/${R}_bench_step_timeline.txt
 [ -f $O/timeline_fixed_plan.txt ] && cp $O/timeline_fixed_plan.txt $P/${R}_bench_step_timeline_fixed_plan.txt
+[ -f $O/timeline_side_graph.txt ] && cp $O/timeline_side_graph.txt $P/${R}_bench_step_timeline_side_graph_under_profiler.txt
 {
   echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, with --kernel-trace only) of: python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2"
   echo "# values are KB per dispatch as reported; FETCH_SIZE must be DOUBLED on gfx950 (MI355X_MICROARCH.md, HBM section) -- calibrated in this repo on"
