@@ -179,6 +179,9 @@ def main():
                     "instead of the default since round 5: a SECOND hipGraph on the side stream with no graph edge to the step's -- a forked branch costs the "
                     "main chain ~60 us per replay on MI355X whatever it holds; a device-side gate (papc_flag_wait) holds the pyramid back until the step has "
                     "enqueued SA2, plain stream events order the plan buffers across steps")
+    ap.add_argument("--eager-sampling", action="store_true", help="(N > 1) rounds 3-4: three graphs per step with the next batch's pyramid enqueued eagerly on a "
+                    "high-priority side stream behind the first; default since round 5: two graphs per step (the cut where the tail bucket's all-reduce is "
+                    "issued) and the pyramid as a gated hipGraph on the side stream, as at N = 1")
     ap.add_argument("--profile-all", action="store_true", help="also print per-family kernel times (stderr)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel of the timed steps eagerly instead of "
                     "replaying the captured hipGraph of zero_grad + forward + loss + backward")
@@ -256,7 +259,7 @@ def main():
     # N > 1 (sampling enqueued eagerly beside the graph replays, see ext_sampling below): a high-priority stream gets its own hardware
     # queue -- on a default-priority stream the sampling kernels queue up BEHIND the graphs already enqueued (2.81 ms vs 2.46 ms per step)
     # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
-    side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap) else int(os.environ.get("PAPC_SIDE_PRIO", "0")))   # (PAPC_SIDE_PRIO: A/B)
+    side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap and args.eager_sampling) else int(os.environ.get("PAPC_SIDE_PRIO", "0")))   # (PAPC_SIDE_PRIO: A/B)
     side_graph = not args.in_graph_fork and args.fork in ("start", "sa2", "sa3", "loss") and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
     gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None      # the word papc_flag_set / papc_flag_wait share
 
@@ -333,6 +336,11 @@ def main():
     # enqueued EAGERLY on the side stream right after the graph replay (6 launches of CPU work beside a 2.4 ms graph), ordered with
     # plain stream events outside any capture; the two graphs still alternate between the two plan buffers.
     ext_sampling = dist.is_initialized() and use_graph and args.overlap
+    # ... since round 5 as a hipGraph of its own on the side stream behind a device-side gate (the N = 1 structure): one graph boundary and ten eager
+    # launches less per step (--eager-sampling restores the three-graph form)
+    dist_side_graph = ext_sampling and not args.eager_sampling and args.fork == "sa2" and not args.diag_fixed_plan
+    if dist_side_graph and gate is None:
+        gate = torch.zeros(2, dtype=torch.int32, device=dev)
 
     use_dist = dist.is_initialized()
     # N > 1: the backward runs in two stages around l2_points (the tensor SA3 consumes).  Stage 1 = FC head + SA3, whose
@@ -458,6 +466,36 @@ def main():
                     pout = None                    # filled from outside the graph (step())
                 g1 = torch.cuda.CUDAGraph()
                 g1b = g2 = None
+                if dist_side_graph:
+                    # two graphs per step (one memory pool): forward + loss + the head's and SA3's backward | SA2 + SA1 backward, the tail bucket's
+                    # all-reduce issued between them; the pyramid as a third graph on the side stream, gated behind SA2 on the device
+                    g2 = torch.cuda.CUDAGraph()
+                    g1.capture_begin(capture_error_mode="thread_local")
+                    try:
+                        loss, l2, g_l2, _ = stage1(pin, None, (lambda: gate_open(None)))
+                        g1.capture_end()
+                        g2.capture_begin(pool=g1.pool(), capture_error_mode="thread_local")
+                        stage2(l2, g_l2, None)
+                        g2.capture_end()
+                    except Exception:
+                        for g in (g1, g2):
+                            try:
+                                g.capture_end()
+                            except Exception:     # noqa: BLE001
+                                pass
+                        raise
+                    gsd = torch.cuda.CUDAGraph()
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        with torch.cuda.graph(gsd, stream=side, capture_error_mode="thread_local"):
+                            gate_wait()
+                            model.plan_sampling(x, (s1, s2), out=bufs[1 - i])
+                    main.wait_stream(side)
+                    graph_state.setdefault("gside_dist", [None, None])[i] = gsd
+                    graph_state["side_ev"] = [None, None]
+                    gs.append((g1, None, g2))
+                    losses.append(loss)
+                    continue
                 if ext_sampling:
                     # three graphs per step (one memory pool): forward up to SA2 | SA3 + head + their backward | SA2 + SA1 backward.
                     # The first cut is where the side stream's sampling is released (the SA3 / head kernels are small grids that
@@ -544,6 +582,20 @@ def main():
                 ev.record(side)
             graph_state["side_ev"][1 - i] = ev
             return graph_state["loss"][i]
+        if dist_side_graph and graph_state.get("gside_dist"):
+            ev = graph_state["side_ev"][i]
+            if ev is not None:
+                main.wait_event(ev)
+            g1.replay()
+            with torch.cuda.stream(side):
+                graph_state["gside_dist"][i].replay()
+                ev = torch.cuda.Event()
+                ev.record(side)
+            graph_state["side_ev"][1 - i] = ev
+            _, work = flat.allreduce_grads(split, None, async_op=True)
+            g2.replay()
+            finish(work)
+            return graph_state["loss"][i]
         if ext_sampling:
             main.wait_stream(side)                 # this batch's plan (bufs[i]) was filled on the side stream during the last step
         g1.replay()
@@ -599,7 +651,7 @@ def main():
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "graphs_per_step": (len([g for g in graph_state["g"][0] if g is not None]) if use_graph else 0),
                               "graph_sets": len(graph_state["g"]) if use_graph else 0, "capture_error": graph_state["why"],
-                              "sampling": "side stream beside the graph replays" if ext_sampling else ("in-graph fork" if (use_graph and args.overlap) else "in-line"),
+                              "sampling": ("gated hipGraph on the side stream" if dist_side_graph else "side stream beside the graph replays") if ext_sampling else ("in-graph fork" if (use_graph and args.overlap) else "in-line"),
                               "loss": float(loss.item())}))
         if use_dist:
             dist.barrier()
@@ -759,7 +811,7 @@ def main():
                                    "surfaces keep 0.91-0.99 and stay padded -> `value_padded` is their rate)" % row_fraction) if compact_on else "padded (policy)",
                        "sampling": ("software-pipelined: batch i+1's FPS + ball-query pyramid runs as a second branch (side stream) of "
                                     "batch i's step, %s; every timed step computes one full pyramid"
-                                    % ("enqueued on the side stream beside the graph replay" if ext_sampling else
+                                    % (("a hipGraph of its own on the side stream, gated on the device behind SA2 (papc_flag_set / papc_flag_wait)" if dist_side_graph else "enqueued on the side stream beside the graph replay") if ext_sampling else
                                        ("a second hipGraph on the side stream, no graph edge to the step's (a forked branch costs the main chain ~60 us per replay): "
                                         "gated on the device behind %s (papc_flag_set / papc_flag_wait), plan buffers ordered by stream events" % args.fork if (side_graph and use_graph)
                                         else "fork at " + args.fork))) if args.overlap else "in-line",

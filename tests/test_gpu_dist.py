@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("extra", [["--require-graph"], ["--no-graph"], ["--require-graph", "--dry-run"]])
+@pytest.mark.parametrize("extra", [["--require-graph"], ["--no-graph"], ["--require-graph", "--dry-run"], ["--require-graph", "--eager-sampling"],
+                                   ["--require-graph", "--eager-sampling", "--dry-run"]])
 def test_bench_forced_one_rank_rccl(dev, extra):
     env = dict(os.environ, PAPC_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import socket
@@ -31,8 +32,10 @@ def test_bench_forced_one_rank_rccl(dev, extra):
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    if "--dry-run" in extra:     # the N > 1 launch structure really got captured: three graphs per step, two alternating sets
-        assert out["dry_run"] and out["graphs_per_step"] == 3 and out["graph_sets"] == 2 and out["capture_error"] is None, out
+    if "--dry-run" in extra:     # the N > 1 launch structure really got captured: two graphs per step around the tail bucket's all-reduce + the gated
+                                 # sampling graph on the side stream (rounds 3-4, --eager-sampling: three graphs, sampling enqueued eagerly), two alternating sets
+        n_graphs = 3 if "--eager-sampling" in extra else 2
+        assert out["dry_run"] and out["graphs_per_step"] == n_graphs and out["graph_sets"] == 2 and out["capture_error"] is None, out
         assert "side stream" in out["sampling"] and out["loss"] == out["loss"]
         return
     assert ("hipGraph replay" in out["config"]["launch"]) == ("--no-graph" not in extra), out["config"]["launch"]
