@@ -149,8 +149,7 @@ def run(args):
     # branch of the step's graph, which costs the main chain ~60 us per replay)
     # ... for THIS config measured slower (6.15 vs 5.75 ms): the MSG layers fork their radius branches onto further streams inside the step's graph, and
     # the side graph's kernels then share hardware queues with them.  Opt-in (PAPC_SIDE_GRAPH=1); the headline config takes it by default (bench.py)
-    side_graph = (overlap and os.environ.get("PAPC_SIDE_GRAPH") == "1" and not getattr(args, "in_graph_fork", False) and not args.no_graph
-                  and getattr(args, "fork", "sa2") != "start")
+    side_graph = overlap and os.environ.get("PAPC_SIDE_GRAPH") == "1" and not getattr(args, "in_graph_fork", False) and not args.no_graph
     gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None
     cap = {"main": False}
 
@@ -181,7 +180,11 @@ def run(args):
             def gate_open():                       # behind the encoder: the side stream's pyramid may start; the same launch ticks the optimiser's step count
                 _lib.check(lib.papc_flag_set(gate.data_ptr(), 1, opt.t_dev.data_ptr() if not ticked[0] else None, _lib.stream_ptr()), "papc_flag_set")
                 ticked[0] = True
-            loss = loss_fn(plan_in, gate_open)
+            if fork_at == "start":
+                gate_open()
+                loss = loss_fn(plan_in)
+            else:
+                loss = loss_fn(plan_in, gate_open)
             loss.backward(one)
             update()
             return loss
