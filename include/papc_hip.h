@@ -259,6 +259,10 @@ typedef struct papc_bwd_dy {
     const float *wrow;
     const int32_t *seg_grp;
     const int32_t *rows_dev;
+    /* optional (MAX): scale * p per (group, channel), p = gout where relu(bn(y at the argmax)) is alive, 0 elsewhere -- what
+     * papc_bn_bwd_reduce_max_f32 writes as `psel`.  The compacted row-streaming dX kernel then takes the value as it is instead of repeating
+     * the ReLU test and the scale on every row (same products, bit-identical result; 10.5 -> 8 VALU instructions per MFMA).  NULL: from gout. */
+    const float *psel;
 } papc_bwd_dy;
 
 /* dX[M,Cin] = dY[M,Cout] . w[Cout,Cin], dY produced on the fly from `dy` (never materialised).
@@ -365,6 +369,7 @@ int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t strea
 #define PAPC_SA_NO_PLANES 64u            /* few-row stacks (sample_and_group_all, M <= 16 384) on the row kernels instead of the planes kernels */
 #define PAPC_SA_NO_PLANES_POINTWISE 128u /* ... only the un-pooled point-wise stacks */
 #define PAPC_SA_NO_XYZ_FUSE 256u
+#define PAPC_SA_NO_PSEL 1024u           /* compacted max layer: its dX kernel recomputes scale * p per row from gout instead of streaming the reduction's psel */
 #define PAPC_SA_NO_WSTATS 512u          /* compacted stack: unweighted statistics + one papc_bn_stats_corr_f32 launch per layer instead of weighted ones */        /* the dX above a coordinates-only first layer stored + papc_xyz_l1_bwd_f32 instead of papc_mlp_bwd_dx_xyz_f32 */
 typedef struct papc_sa_desc {
     int32_t B, N, S, K, D;

@@ -30,7 +30,7 @@ class BwdDy(ctypes.Structure):
     """papc_bwd_dy"""
     _fields_ = [("dz_mode", c_i), ("dz", c_p), ("gout", c_p), ("argmax", c_p), ("K", c_i), ("y", c_p),
                 ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("c1", c_p), ("c2", c_p),
-                ("wrow", c_p), ("seg_grp", c_p), ("rows_dev", c_p)]
+                ("wrow", c_p), ("seg_grp", c_p), ("rows_dev", c_p), ("psel", c_p)]
 
 
 class GroupMax(ctypes.Structure):

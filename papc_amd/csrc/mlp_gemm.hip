@@ -932,7 +932,7 @@ void fill_dy(DySrc &d, const papc_bwd_dy *s)
     d.invstd = s->invstd; d.scale = s->scale; d.shift = s->shift; d.c1 = s->c1; d.c2 = s->c2;
     d.divK = make_fastdiv((uint32_t)d.K);
     d.C = 0;  // set by the entry points (channels of the layer)
-    d.wrow = s->wrow; d.seg_grp = s->seg_grp; d.rows_dev = s->rows_dev;
+    d.wrow = s->wrow; d.seg_grp = s->seg_grp; d.rows_dev = s->rows_dev; d.psel = s->psel;
 }
 
 // validates a dY descriptor and says whether its VEC flavour is legal

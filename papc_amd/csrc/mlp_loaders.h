@@ -62,6 +62,7 @@ struct DySrc {
     // compacted stack (compact.hip): per-row multiplicity weight of the BatchNorm-backward term, group of every 8-row segment (ragged
     // groups; argmax then holds absolute rows), physical row count in device memory.  All NULL for a padded stack.
     const float *wrow; const int32_t *seg_grp; const int32_t *rows_dev;
+    const float *psel;    // optional (DY_MAX): scale * relu-masked gout per (group, channel) -- papc_bwd_dy::psel
 };
 
 struct ASrc {

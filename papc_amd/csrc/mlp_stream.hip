@@ -108,9 +108,11 @@ __device__ __forceinline__ void split3_pair(f32x2 x, unsigned &p0, unsigned &p1,
 // CBW (with NR): a column block owns CBW < 32 WN columns and keeps CBW + 1 weight rows in LDS -- the last one zeros, which the lanes of the
 // boundary tile beyond column CBW read -- so that 196 columns are TWO blocks of 98 (four tiles each, two passes over the operand) where
 // whole tiles would need three passes (K = 256: 96 whole-tile rows are the most that fit beside the constants).
-template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32>
+// PS (CP + A_DY_MAX): the streamed [G, C] operand is psel = scale * p (papc_bwd_dy::psel), not gout: no ReLU test, no scale per row.
+template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32, bool PS = false>
 __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo geo)
 {
+    static_assert(!PS || (CP && AMODE == A_DY_MAX), "PS: the compacted max-layer dX only (the one flavour where the result is bit-identical)");
     static_assert(!CP || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && EPI == EPI_STORE_RED && ASM && PAPC_STREAM_PK), "CP: dX flavours of the asm ring only");
     constexpr int NW = 8;
     constexpr bool KR = (KV != KB16 * 16);
@@ -412,10 +414,11 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                 } else {
                     f32x4 c[5][2];
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) {
+                    for (int q = PS ? 2 : 0; q < 5; ++q) {      // (PS: scale and shift are not needed)
                         c[q][0] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64);
                         c[q][1] = *reinterpret_cast<const f32x4 *>(cl + q * K * 4 + kb * 64 + 16);
                     }
+                    if constexpr (PS) __builtin_amdgcn_sched_barrier(0);      // (without it this flavour's schedule needs 256 registers + scratch; with it 222)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const int h = j >> 1, i = 2 * (j & 1);
@@ -425,12 +428,18 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
                             dz.x = (__float_as_int(r[4 + h][i]) == kin) ? dz.x : 0.f;
                             dz.y = (__float_as_int(r[4 + h][i + 1]) == kin) ? dz.y : 0.f;
                         }
-                        const f32x2 c0 = f32x2{c[0][h][i], c[0][h][i + 1]};
-                        const f32x2 z = pk_fma(c0, y, f32x2{c[1][h][i], c[1][h][i + 1]});
-                        const f32x2 pp = f32x2{z.x > 0.f ? dz.x : 0.f, z.y > 0.f ? dz.y : 0.f};
+                        f32x2 c0 = f32x2{0.f, 0.f}, pp = dz;
+                        if constexpr (!PS) {
+                            c0 = f32x2{c[0][h][i], c[0][h][i + 1]};
+                            const f32x2 z = pk_fma(c0, y, f32x2{c[1][h][i], c[1][h][i + 1]});
+                            pp = f32x2{z.x > 0.f ? dz.x : 0.f, z.y > 0.f ? dz.y : 0.f};
+                        }
                         if constexpr (CP) {
                             const f32x2 t = pk_fma(f32x2{c[4][h][i], c[4][h][i + 1]}, y - f32x2{c[2][h][i], c[2][h][i + 1]}, f32x2{c[3][h][i], c[3][h][i + 1]});
-                            v2[j] = pk_fma(f32x2{wcur, wcur}, t, c0 * pp);
+                            // PS: dz IS scale * p at the group's argmax row (the reduction that made the BN-backward sums formed the same product of
+                            // the same two floats): what the other path computes as c0 * pp
+                            if constexpr (PS) v2[j] = pk_fma(f32x2{wcur, wcur}, t, dz);
+                            else v2[j] = pk_fma(f32x2{wcur, wcur}, t, c0 * pp);
                         } else {
                             const f32x2 inner = pk_fma(c0, pp, -f32x2{c[3][h][i], c[3][h][i + 1]});
                             v2[j] = pk_fma(-f32x2{c[4][h][i], c[4][h][i + 1]}, y - f32x2{c[2][h][i], c[2][h][i + 1]}, inner);
@@ -790,7 +799,7 @@ static int stream_ncu()
     return ncu;
 }
 
-template <int AMODE, int EPI, int KB16, int WN, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32>
+template <int AMODE, int EPI, int KB16, int WN, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32, bool PS = false>
 static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
 {
     // k blocks per prefetch chunk: two, unless the flavour's registers do not allow it (an asm-loaded buffer must never spill)
@@ -811,7 +820,13 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     dim3 grid((unsigned)gx, (unsigned)ncb);
     if constexpr (CP) {
         if (!knob(KNOB_STREAM_ASM)) return 0;
-        hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, true>), grid, dim3(512), 0, st, p, geo);
+        if constexpr (PS) {
+            GemmArgs q = p;
+            q.a.d.gout = p.a.d.psel;       // (the kernel streams the [G, C] operand through the gout pointer)
+            hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, true, KB16 * 16, false, WN * 32, true>), grid, dim3(512), 0, st, q, geo);
+        } else {
+            hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, true>), grid, dim3(512), 0, st, p, geo);
+        }
         const int rc = check_launch("mlp stream gemm (compacted)");
         return rc ? rc : 1;
     }
@@ -829,7 +844,12 @@ static int stream_pick(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     const int kb = p.Kin / 16;
     if (geo.wrow) {      // dX of a compacted stack: the two flavours SA2-shaped stacks need (128 -> 128 dense, 256 -> 128 under the max)
         if constexpr (AMODE == A_DY_DENSE && EPI == EPI_STORE_RED) { if (kb == 8 && p.Nout == 128) return stream_go<AMODE, EPI, 8, 4, true>(p, geo, st); }
-        if constexpr (AMODE == A_DY_MAX && EPI == EPI_STORE_RED) { if (kb == 16 && p.Nout == 128) return stream_go<AMODE, EPI, 16, 2, true>(p, geo, st); }
+        if constexpr (AMODE == A_DY_MAX && EPI == EPI_STORE_RED) {
+            if (kb == 16 && p.Nout == 128) {
+                if (p.a.d.psel) return stream_go<AMODE, EPI, 16, 2, true, 256, false, 64, true>(p, geo, st);
+                return stream_go<AMODE, EPI, 16, 2, true>(p, geo, st);
+            }
+        }
         return 0;
     }
     // the MSG segmenter's 196-channel layer pair (segment/pointnet2/pointnet2.py:63, [128, 196, 256]): ragged k (196 = 12 k blocks + 4 channels) and

@@ -705,7 +705,12 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             red = b.red; red_parts = n_parts;
             if (p.sparse_max && l == L - 1)
                 SA_CALL(papc_bn_bwd_reduce_max_f32(ysel, dy.gout, dy.K, dy.mean, dy.invstd, dy.scale, dy.shift, M, cout, n_parts, b.red, b.psel, st));
-            else
+            else if (p.compact && l == L - 1 && dy.dz_mode == PAPC_DZ_MAX && ysel && b.psel && !(d.disable & PAPC_SA_NO_PSEL)) {
+                // the same reduction, which also leaves scale * p per (group, channel): the compacted dX kernel streams that instead of gout and
+                // repeats neither the ReLU test nor the scale on every row (bit-identical: the same product of the same two floats)
+                SA_CALL(papc_bn_bwd_reduce_max_f32(ysel, dy.gout, dy.K, dy.mean, dy.invstd, dy.scale, dy.shift, M, cout, n_parts, b.red, b.psel, st));
+                dy.psel = b.psel;
+            } else
                 SA_CALL(papc_bn_bwd_reduce_f32(dy.dz_mode, dy.dz_mode == PAPC_DZ_MAX ? ysel : dy.dz, dy.gout, dy.argmax, dy.K, dy.y, dy.mean, dy.invstd, dy.scale,
                                                dy.shift, M, cout, n_parts, b.red, st));
         } else { red = fused_red; red_parts = gemm_parts; }
