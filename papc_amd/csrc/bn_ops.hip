@@ -43,33 +43,39 @@ __device__ __forceinline__ void sum_partial_rows(const float *__restrict__ part,
     }
 }
 
+// lane l of a wave holds the double of part-lane l: the sum over the 64 part-lanes in a FIXED shape, left in lane 0 -- groups of four
+// part-lanes as a two-level tree, the sixteen groups added in order (the shape the 16-wave form of the finalizes used: same bits)
+__device__ __forceinline__ double lane_get(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void fold_part_lanes(double &s1, double &s2)
+{
+    s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+    s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { t1 += lane_get(s1, 4 * w); t2 += lane_get(s2, 4 * w); }
+    s1 = t1; s2 = t2;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // stats partials [n_tiles][2][C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
-                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                          float eps, float momentum, float *mean, float *invstd, float *scale,
-                                                          float *shift, float *rmean, float *rvar)
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float eps, float momentum, float *mean, float *invstd, float *scale,
+                                                        float *shift, float *rmean, float *rvar)
 {
-    __shared__ double r1[64][16], r2[64][16];
-    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 channels x 64 part-lanes
-    const int c = blockIdx.x * 16 + cl;
+    // ONE WAVE per channel, no LDS, <= 64 registers: a launch-sized kernel has to find room on a CU that another stream's persistent
+    // GEMM has filled to the last KB of LDS (config 3 runs its MSG branches on three streams: the 1024-thread / 16 KB form of this
+    // kernel waited 13-21 us on average, up to 0.3 ms, for a whole CU to drain).  Lane = part-lane.
+    const int c = blockIdx.x, tl = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C) sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
-    // fixed-shape reduction over the 64 part-lanes (deterministic): the 4 part-lanes of a wave by two shuffles, the 16 waves through
-    // LDS and ONE barrier (a 6-level LDS tree cost seven barriers: ~2 us of a ~6 us, launch-latency-sized kernel that runs 18x per step)
-    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-    if ((threadIdx.x & 63) < 16) { r1[threadIdx.x >> 6][cl] = s1; r2[threadIdx.x >> 6][cl] = s2; }
-    __syncthreads();
+    sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
+    fold_part_lanes(s1, s2);
     if (tl == 0) {
-        double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { t1 += r1[w][cl]; t2 += r2[w][cl]; }
-        r1[0][cl] = t1; r2[0][cl] = t2;   // (only this thread reads them back)
-    }
-    if (tl == 0 && c < C) {
-        s1 = r1[0][cl]; s2 = r2[0][cl];
         const double mu = s1 / (double)M;
         double var = s2 / (double)M - mu * mu;  // biased variance (paddle BatchNorm training)
         if (var < 0.0) var = 0.0;
@@ -232,28 +238,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
-                                                              float *dgamma, float *dbeta, float *c1, float *c2, int accumulate)
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float *__restrict__ part, int n_tiles, int64_t M, int C,
+                                                            float *dgamma, float *dbeta, float *c1, float *c2, int accumulate)
 {
-    __shared__ double r1[64][16], r2[64][16];
-    const int cl = threadIdx.x & 15, tl = threadIdx.x >> 4;  // 16 channels x 64 part-lanes
-    const int c = blockIdx.x * 16 + cl;
+    // one wave per channel, no LDS (see bn_finalize_kernel)
+    const int c = blockIdx.x, tl = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C) sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
-    // fixed-shape reduction over the 64 part-lanes (deterministic): the 4 part-lanes of a wave by two shuffles, the 16 waves through
-    // LDS and ONE barrier (a 6-level LDS tree cost seven barriers: ~2 us of a ~6 us, launch-latency-sized kernel that runs 18x per step)
-    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-    if ((threadIdx.x & 63) < 16) { r1[threadIdx.x >> 6][cl] = s1; r2[threadIdx.x >> 6][cl] = s2; }
-    __syncthreads();
+    sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
+    fold_part_lanes(s1, s2);
     if (tl == 0) {
-        double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { t1 += r1[w][cl]; t2 += r2[w][cl]; }
-        r1[0][cl] = t1; r2[0][cl] = t2;   // (only this thread reads them back)
-    }
-    if (tl == 0 && c < C) {
-        s1 = r1[0][cl]; s2 = r2[0][cl];
         if (dbeta) dbeta[c] = (accumulate & 1) ? dbeta[c] + (float)s1 : (float)s1;
         if (dgamma) dgamma[c] = (accumulate & 1) ? dgamma[c] + (float)s2 : (float)s2;
         // bit 1 of `accumulate`: the BatchNorm ran on its RUNNING statistics (eval mode): the batch-mean terms of its backward vanish
@@ -831,7 +824,7 @@ int papc_bn_finalize_f32(const float *stats_partial, int n_tiles, int64_t M, int
     PAPC_REQUIRE(n_tiles >= 1 && M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_finalize_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, stats_partial, n_tiles, M, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, stats_partial, n_tiles, M, C, gamma,
                        beta, eps, momentum, mean, invstd, scale, shift, running_mean, running_var);
     return check_launch("papc_bn_finalize_f32");
 }
@@ -920,7 +913,7 @@ int papc_bn_bwd_finalize_f32(const float *red_partial, int n_tiles, int64_t M, i
     PAPC_REQUIRE(n_tiles >= 1 && M >= 1 && C >= 1, PAPC_E_INVALID, "papc_bn_bwd_finalize_f32: bad sizes");
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 16)), dim3(1024), 0, st, red_partial, n_tiles, M, C, dgamma, dbeta, c1, c2, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, red_partial, n_tiles, M, C, dgamma, dbeta, c1, c2, accumulate);
     return check_launch("papc_bn_bwd_finalize_f32");
 }
 

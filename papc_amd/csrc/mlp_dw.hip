@@ -1285,13 +1285,13 @@ __global__ __launch_bounds__(512, 2) void dw_rows_max_kernel(DwMaxArgs p)
     }
 }
 
-// chunk partials -> double sums: 64 elements per workgroup, four quarter-ranges of the chunks in parallel (loads unrolled: a serial chain of
-// 128 L2 round trips otherwise), quarters added in fixed order
-__global__ __launch_bounds__(256) void dw_max_fold_kernel(const float *__restrict__ partial, int n_chunks, int64_t part_ld, int n, double *__restrict__ out)
+// chunk partials -> double sums: one wave per 16 elements, four quarter-ranges of the chunks in parallel (loads unrolled: a serial chain of
+// 128 L2 round trips otherwise), quarters added in fixed order.  No LDS and one wave, so that the launch finds room beside another
+// stream's persistent GEMM (config 3: the 256-thread form waited 135 us on average for a CU to drain)
+__global__ __launch_bounds__(64) void dw_max_fold_kernel(const float *__restrict__ partial, int n_chunks, int64_t part_ld, int n, double *__restrict__ out)
 {
-    __shared__ double sm[4][64];
-    const int l = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + l;
+    const int l = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + l;
     const int per = (n_chunks + 3) / 4, c0 = q * per, c1 = min(n_chunks, c0 + per);
     double s = 0.0;
     if (e < n) {
@@ -1305,9 +1305,8 @@ __global__ __launch_bounds__(256) void dw_max_fold_kernel(const float *__restric
         }
         for (; c < c1; ++c) s += (double)partial[(int64_t)c * part_ld + e];
     }
-    sm[q][l] = s;
-    __syncthreads();
-    if (q == 0 && e < n) out[e] = ((sm[0][l] + sm[1][l]) + sm[2][l]) + sm[3][l];
+    const double s1 = __shfl(s, l + 16), s2 = __shfl(s, l + 32), s3 = __shfl(s, l + 48);
+    if (q == 0 && e < n) out[e] = ((s + s1) + s2) + s3;
 }
 
 // dW[c, i] = T[c, i] - sc_c c1_c S_i - e_c sum_j W[c, j] (G[j, i] - S_j S_i / M); four rows of dW per workgroup
@@ -1571,7 +1570,7 @@ extern "C" int papc_mlp_bwd_dw_max_f32(const float *psel, const int32_t *argmax,
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);
     hipLaunchKernelGGL(dw_rows_max_kernel, dim3((unsigned)(2 * p.n_chunks)), dim3(512), 0, st, p);
-    hipLaunchKernelGGL(dw_max_fold_kernel, dim3((unsigned)cdiv(n, 64)), dim3(256), 0, st, workspace, p.n_chunks, (int64_t)n, n, fold);
+    hipLaunchKernelGGL(dw_max_fold_kernel, dim3((unsigned)cdiv(n, 16)), dim3(64), 0, st, workspace, p.n_chunks, (int64_t)n, n, fold);
     hipLaunchKernelGGL(dw_max_finalize_kernel, dim3((unsigned)cdiv(Cout, 4)), dim3(256), 0, st, fold, w, e, scale, c1, 1.0 / (double)M, Cout, dw, accumulate);
     return check_launch("papc_mlp_bwd_dw_max_f32");
 }

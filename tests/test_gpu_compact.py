@@ -178,3 +178,20 @@ def test_weighted_statistics_equal_the_correction_launches(dev, monkeypatch):
         if i % 4 != 1:
             assert_close(a, b, 2e-5, "weighted statistics vs correction launches: gradient %d" % i)
     assert_close(res["1"][2], res["0"][2], 2e-5, "weighted statistics vs correction launches: dfeats")
+
+
+def test_streamed_psel_is_bit_identical(dev, monkeypatch):
+    """The compacted max layer's dX takes scale * p per (group, channel) from the array the BatchNorm-backward reduction already formed
+    (papc_bwd_dy.psel) instead of testing the ReLU and scaling gout per row (PAPC_PSEL=0 / PAPC_SA_NO_PSEL): the same fp32 product either
+    way, so every gradient has the same bits (pointnet2_basic_layers.py:215-219 backward)."""
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PAPC_PSEL", mode)
+        _, _, _, feats, params, _, out = _sa2_like(dev, 8, 3, True)
+        assert out.grad_fn.compact is not None
+        gout = torch.from_numpy(np.random.default_rng(11).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        res[mode] = ([p.grad.cpu().numpy() for p in params], feats.grad.cpu().numpy())
+    for i, (a, b) in enumerate(zip(res["1"][0], res["0"][0])):
+        assert np.array_equal(a, b), "streamed psel: gradient %d differs" % i
+    assert np.array_equal(res["1"][1], res["0"][1]), "streamed psel: dfeats differs"
