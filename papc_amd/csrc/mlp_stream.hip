@@ -109,12 +109,16 @@ __device__ __forceinline__ void split3_pair(f32x2 x, unsigned &p0, unsigned &p1,
 // boundary tile beyond column CBW read -- so that 196 columns are TWO blocks of 98 (four tiles each, two passes over the operand) where
 // whole tiles would need three passes (K = 256: 96 whole-tile rows are the most that fit beside the constants).
 // PS (CP + A_DY_MAX): the streamed [G, C] operand is psel = scale * p (papc_bwd_dy::psel), not gout: no ReLU test, no scale per row.
-template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32, bool PS = false>
-__global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo geo)
+// NWT: waves per workgroup.  8 (two per SIMD, up to 256 registers each) everywhere but the flavours that fit 168 registers: those run TWELVE
+// (three per SIMD: these kernels wait on their loads, not on an execution unit), with the wave-major tile numbering of the device-row-count
+// flavours so that the ragged last round is spread over all CUs.
+template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32, bool PS = false, int NWT = 8>
+__global__ __launch_bounds__(NWT * 64, NWT / 4) void stream_kernel(GemmArgs p, StreamGeo geo)
 {
+    static_assert(NWT == 8 || NWT == 12, "two or three waves per SIMD");
     static_assert(!PS || (CP && AMODE == A_DY_MAX), "PS: the compacted max-layer dX only (the one flavour where the result is bit-identical)");
     static_assert(!CP || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && EPI == EPI_STORE_RED && ASM && PAPC_STREAM_PK), "CP: dX flavours of the asm ring only");
-    constexpr int NW = 8;
+    constexpr int NW = NWT;
     constexpr bool KR = (KV != KB16 * 16);
     // K = extent of the LDS images (weight planes, constants).  Ragged k: KV + 4 -- the partial block's fragment reads of the UPPER half-wave
     // (k = KV + 4 .. KV + 11) run into the next plane / the row's zeroed pad, and that half's operand is forced to zero in the transform
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
         constexpr int NP = NROW * (K / 4);                // float4 pieces of the block's weights
         constexpr int NI = (NP + NW * 64 - 1) / (NW * 64);
         constexpr bool PG = (NP % (NW * 64) != 0);        // (guarded last round)
-        static_assert(KR || CB || !PG, "whole float4 pieces per thread");
+        static_assert(KR || CB || !PG || NW != 8, "whole float4 pieces per thread");
         float4 wv[NI];
 #pragma unroll
         for (int q = 0; q < NI; ++q) {
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(512, 2) void stream_kernel(GemmArgs p, StreamGeo ge
     // (device-side row count: the tile count is whatever the batch gives, so the last round is ragged -- wave-major numbering hands its few
     // tiles to one wave each of as many different workgroups, where a lone wave runs at twice the issue rate, instead of to all eight waves
     // of the first few workgroups while the other CUs idle)
-    const int gw = geo.rows_dev ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * NW + wave;
+    const int gw = (geo.rows_dev || NW != 8) ? wave * (int)gridDim.x + (int)blockIdx.x : (int)blockIdx.x * NW + wave;
     const int U = 1 << geo.ushift;
     const int n_units = geo.rows_dev ? min(geo.n_units, (__builtin_amdgcn_readfirstlane(*geo.rows_dev) >> 5) >> geo.ushift) : geo.n_units;
     const int my_units = n_units > gw ? (n_units - gw + TW - 1) / TW : 0;
@@ -831,7 +835,18 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
         return rc ? rc : 1;
     }
     if constexpr (AMODE == A_XYZ) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);   // (no streamed operand: no asm ring)
-    else if (knob(KNOB_STREAM_ASM)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);
+    else if (knob(KNOB_STREAM_ASM)) {
+        // (two dX flavours hold 150-166 registers and run three waves per SIMD: the one folded into a coordinates-only first layer's sums, 1.558 ->
+        // 1.551 ms per step, and the padded max layer's 256 -> 128, padded step 1.834 -> 1.818; the dense 64- and 96-channel dX kernels of config 3
+        // qualify too and measured SLOWER there -- 5.58 -> 5.63 ms: its three branch streams already fill the SIMDs.  PAPC_STREAM_NW12=0: two waves)
+        if constexpr ((EPI == EPI_XYZ_RED || (EPI == EPI_STORE_RED && AMODE == A_DY_MAX && KB16 == 16)) && WN == 2 && !NR && KV == KB16 * 16) {
+            static const bool nw12 = !getenv("PAPC_STREAM_NW12") || atoi(getenv("PAPC_STREAM_NW12")) != 0;
+            if (nw12) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW, false, 12>), grid, dim3(768), 0, st, p, geo);
+            else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);
+        } else {
+            hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);
+        }
+    }
     else if constexpr (AMODE == A_MAXCAT || EPI == EPI_GMAX || EPI == EPI_XYZ_RED || KR || NR) return 0;   // (the compiler-scheduled ring of these flavours spills / is not built: the caller falls back)
     else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, false>), grid, dim3(512), 0, st, p, geo);
     const int rc = check_launch("mlp stream gemm");
