@@ -372,13 +372,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
 // TICK: the kernel advances the count itself -- it applies step step_dev[0] + 1 and the block that FINISHES last (a ticket in step_dev[1],
 // which returns to zero) stores that number: every block has read the old value by then.  One atomic per block; for a step without a branch
 // to hide the tick launch on.
-template <bool ZERO, bool TICK>
+template <bool ZERO, bool TICK, int V>
 __global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                        float *__restrict__ v, int64_t n, float lr, double beta1, double beta2,
                                                        float eps, float wd, int64_t *__restrict__ step_dev, float gscale)
 {
     __shared__ float s_bc[2];
     __shared__ int64_t s_t;
+    // the first elements' loads go out BEFORE the bias corrections (two double-precision pow of a device-side step count, a microsecond of one
+    // thread's time with the other 255 behind a barrier): V = 4 elements per thread where the bucket allows
+    const int64_t nv = n / V, stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Vec<V> gq, pq, mq, vq;
+    if (i0 < nv) { gq = Vec<V>::load(g + i0 * V); pq = Vec<V>::load(p + i0 * V); mq = Vec<V>::load(m + i0 * V); vq = Vec<V>::load(v + i0 * V); }
     if (threadIdx.x == 0) {
         const int64_t ti = step_dev[0] + (TICK ? 1 : 0);
         const double t = (double)ti;
@@ -389,13 +394,19 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ p, fl
     __syncthreads();
     const float bc1 = s_bc[0], bc2 = s_bc[1];
     const float b1 = (float)beta1, b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float gi = g[i] * gscale + wd * p[i];
-        const float mi = b1 * m[i] + omb1 * gi;
-        const float vi = b2 * v[i] + omb2 * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
-        if (ZERO) g[i] = 0.f;
+    for (int64_t i = i0; i < nv; i += stride) {
+        if (i != i0) { gq = Vec<V>::load(g + i * V); pq = Vec<V>::load(p + i * V); mq = Vec<V>::load(m + i * V); vq = Vec<V>::load(v + i * V); }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float gi = gq[e] * gscale + wd * pq[e];
+            const float mi = b1 * mq[e] + omb1 * gi;
+            const float vi = b2 * vq[e] + omb2 * gi * gi;
+            mq[e] = mi; vq[e] = vi;
+            pq[e] -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+            gq[e] = 0.f;
+        }
+        mq.store(m + i * V); vq.store(v + i * V); pq.store(p + i * V);
+        if (ZERO) gq.store(g + i * V);
     }
     if (TICK) {
         __syncthreads();
@@ -1177,7 +1188,9 @@ int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp
     ProfScope prof(PAPC_K_MISC, st);
     int64_t *sd = const_cast<int64_t *>(step_dev);
     const bool zero = (zero_grad & 1) != 0, tick = (zero_grad & 2) != 0;
-#define ADAM_DEV(Z, T) hipLaunchKernelGGL((adam_dev_kernel<Z, T>), dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, sd, grad_scale)
+    const bool v4 = n % 4 == 0 && aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
+#define ADAM_DEV(Z, T) do { if (v4) hipLaunchKernelGGL((adam_dev_kernel<Z, T, 4>), dim3(ew_grid(n / 4)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, sd, grad_scale); \
+                            else hipLaunchKernelGGL((adam_dev_kernel<Z, T, 1>), dim3(ew_grid(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, sd, grad_scale); } while (0)
     if (zero && tick) ADAM_DEV(true, true);
     else if (zero) ADAM_DEV(true, false);
     else if (tick) ADAM_DEV(false, true);
