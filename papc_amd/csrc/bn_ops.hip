@@ -72,6 +72,9 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict
     // GEMM has filled to the last KB of LDS (config 3 runs its MSG branches on three streams: the 1024-thread / 16 KB form of this
     // kernel waited 13-21 us on average, up to 0.3 ms, for a whole CU to drain).  Lane = part-lane.
     const int c = blockIdx.x, tl = threadIdx.x;
+    // (the channel's affine parameters and running statistics are requested ahead of the partial rows: one round trip, not two)
+    const float gam = gamma ? gamma[c] : 1.f, bet = beta ? beta[c] : 0.f;
+    const float rm0 = rmean ? rmean[c] : 0.f, rv0 = rvar ? rvar[c] : 0.f;
     double s1 = 0.0, s2 = 0.0;
     sum_partial_rows(part, n_tiles, C, c, tl, s1, s2);
     fold_part_lanes(s1, s2);
@@ -80,13 +83,13 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict
         double var = s2 / (double)M - mu * mu;  // biased variance (paddle BatchNorm training)
         if (var < 0.0) var = 0.0;
         const double is = 1.0 / sqrt(var + (double)eps);
-        const double sc = (gamma ? (double)gamma[c] : 1.0) * is;
+        const double sc = (double)gam * is;
         mean[c] = (float)mu;
         invstd[c] = (float)is;
         scale[c] = (float)sc;
-        shift[c] = (float)((beta ? (double)beta[c] : 0.0) - mu * sc);
-        if (rmean) rmean[c] = momentum * rmean[c] + (1.f - momentum) * (float)mu;   // paddle: momentum weighs the running value
-        if (rvar) rvar[c] = momentum * rvar[c] + (1.f - momentum) * (float)var;
+        shift[c] = (float)((double)bet - mu * sc);
+        if (rmean) rmean[c] = momentum * rm0 + (1.f - momentum) * (float)mu;   // paddle: momentum weighs the running value
+        if (rvar) rvar[c] = momentum * rv0 + (1.f - momentum) * (float)var;
     }
 }
 

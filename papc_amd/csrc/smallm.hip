@@ -164,13 +164,33 @@ __global__ __launch_bounds__(256) void pg_prep_kernel(PrepArgs p)
     __shared__ float cs[6][32];
     __shared__ double rd[2][8][32];
     const int cb = blockIdx.x;
-    if (MODE == PG_PREP_BNRELU || MODE == PG_PREP_DY_DENSE || MODE == PG_PREP_DY_MAX) prep_consts<MODE>(p, cb, cs, rd);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r_in = lane & 31, h = lane >> 5;
     const int mb = blockIdx.y * 4 + wv;
     const int64_t m = (int64_t)mb * 32 + r_in;
     const bool mok = m < p.M;
     const int64_t mm = mok ? m : 0;
+    // the raw operands are requested BEFORE the constants are folded (prep_consts: <= 64 partial rows in double precision behind two barriers):
+    // one exposed round trip per launch instead of two (these launches are 9-16 us of which 4.7 is the launch itself)
+    float4 ra[2][2], rdz[2][2];
+    int4 rix[2][2];
+    int64_t gsel = 0;
+    int kinsel = 0;
+    if (MODE != PG_PREP_CONCAT) {
+        if (MODE == PG_PREP_DY_MAX) { gsel = mm / p.K; kinsel = (int)(mm - gsel * p.K); }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k0 = cb * 32 + 16 * j + 8 * h;
+            const int kk = k0 < p.C ? k0 : 0;
+            ra[j][0] = ld4(p.x + mm * p.ldx + kk); ra[j][1] = ld4(p.x + mm * p.ldx + kk + 4);
+            if (MODE == PG_PREP_DY_DENSE) { rdz[j][0] = ld4(p.dz + mm * p.C + kk); rdz[j][1] = ld4(p.dz + mm * p.C + kk + 4); }
+            if (MODE == PG_PREP_DY_MAX) {
+                rdz[j][0] = ld4(p.gout + gsel * p.C + kk); rdz[j][1] = ld4(p.gout + gsel * p.C + kk + 4);
+                rix[j][0] = *reinterpret_cast<const int4 *>(p.argmax + gsel * p.C + kk); rix[j][1] = *reinterpret_cast<const int4 *>(p.argmax + gsel * p.C + kk + 4);
+            }
+        }
+    }
+    if (MODE == PG_PREP_BNRELU || MODE == PG_PREP_DY_DENSE || MODE == PG_PREP_DY_MAX) prep_consts<MODE>(p, cb, cs, rd);
     float v[2][8];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -192,22 +212,20 @@ __global__ __launch_bounds__(256) void pg_prep_kernel(PrepArgs p)
                 v[j][i] = e;
             }
         } else {
-            const int kk = kok ? k0 : 0;
-            const float4 a0 = ld4(p.x + mm * p.ldx + kk), a1 = ld4(p.x + mm * p.ldx + kk + 4);
+            const float4 a0 = ra[j][0], a1 = ra[j][1];
             float e[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             if (MODE == PG_PREP_BNRELU) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) e[i] = fmaxf(fmaf(cs[0][kl + i], e[i], cs[1][kl + i]), 0.f);
             } else if (MODE == PG_PREP_DY_DENSE) {
-                const float4 d0 = ld4(p.dz + mm * p.C + kk), d1 = ld4(p.dz + mm * p.C + kk + 4);
+                const float4 d0 = rdz[j][0], d1 = rdz[j][1];
                 const float d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) e[i] = dy_elem(d[i], e[i], cs[0][kl + i], cs[1][kl + i], cs[2][kl + i], cs[3][kl + i], cs[4][kl + i], cs[5][kl + i]);
             } else if (MODE == PG_PREP_DY_MAX) {
-                const int64_t g = mm / p.K;
-                const int kin = (int)(mm - g * p.K);
-                const float4 g0 = ld4(p.gout + g * p.C + kk), g1 = ld4(p.gout + g * p.C + kk + 4);
-                const int4 i0 = *reinterpret_cast<const int4 *>(p.argmax + g * p.C + kk), i1 = *reinterpret_cast<const int4 *>(p.argmax + g * p.C + kk + 4);
+                const int kin = kinsel;
+                const float4 g0 = rdz[j][0], g1 = rdz[j][1];
+                const int4 i0 = rix[j][0], i1 = rix[j][1];
                 const float d[8] = {i0.x == kin ? g0.x : 0.f, i0.y == kin ? g0.y : 0.f, i0.z == kin ? g0.z : 0.f, i0.w == kin ? g0.w : 0.f,
                                     i1.x == kin ? g1.x : 0.f, i1.y == kin ? g1.y : 0.f, i1.z == kin ? g1.z : 0.f, i1.w == kin ? g1.w : 0.f};
 #pragma unroll
