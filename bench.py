@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--fork", choices=["start", "sa2", "sa3", "loss", "sa2late", "sa2end"], default="sa2", help="where the step forks the next batch's sampling branch "
                     "(sa2late / sa2end: the branch DEPENDS on the same point as sa2 but its launches are captured later -- behind SA3's forward / behind the whole "
                     "backward -- so that the main chain's continuation is the fork node's first successor in the captured graph)")
+    ap.add_argument("--side-cu-mask", type=int, default=0, help="(diagnostic) create the sampling stream with a CU mask of N CUs (hipExtStreamCreateWithCUMask)")
     ap.add_argument("--in-graph-fork", action="store_true", help="(N = 1) the next batch's sampling pyramid as a FORKED BRANCH of the step's hipGraph (rounds 2-4) "
                     "instead of the default since round 5: a SECOND hipGraph on the side stream with no graph edge to the step's -- a forked branch costs the "
                     "main chain ~60 us per replay on MI355X whatever it holds; a device-side gate (papc_flag_wait) holds the pyramid back until the step has "
@@ -260,6 +261,21 @@ def main():
     # queue -- on a default-priority stream the sampling kernels queue up BEHIND the graphs already enqueued (2.81 ms vs 2.46 ms per step)
     # -- whereas as a captured branch of the N = 1 graph the high priority costs 1.5 ms per step (3.89 ms vs 2.43 ms).
     side = torch.cuda.Stream(priority=-1 if (dist.is_initialized() and not args.no_graph and args.overlap and args.eager_sampling) else int(os.environ.get("PAPC_SIDE_PRIO", "0")))   # (PAPC_SIDE_PRIO: A/B)
+    if args.side_cu_mask:
+        # diagnostic: the sampling stream restricted to N of the chip's CUs (hipExtStreamCreateWithCUMask; every (256 / N)-th CU, so that the XCDs
+        # share them evenly) -- does keeping the pyramid off most CUs give the step's persistent kernels their CUs back?
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        every = max(1, ncu // args.side_cu_mask)
+        words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
+        for cu in range(0, ncu, every):
+            words[cu // 32] |= 1 << (cu % 32)
+        hs = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(hs), ctypes.c_uint32(len(words)), words)
+        if rc != 0:
+            raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+        side = torch.cuda.ExternalStream(hs.value, device=dev)
     side_graph = not args.in_graph_fork and args.fork in ("start", "sa2", "sa3", "loss") and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
     gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None      # the word papc_flag_set / papc_flag_wait share
 
