@@ -65,6 +65,7 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_STREAM_MAXCAT", 1, 0, 1},       // papc_mlp_bwd_dx_max_f32 on the row-streaming kernel where it has the flavour (0: tiled kernel)
     {"PAPC_MAX_NOSTORE", 1, 0, 1},         // the max-pooled last layer without its stored output where all three kernels have the flavour (papc_mlp_max_nostore_ok)
     {"PAPC_PFN_FUSED_TAILS", 1, 0, 1},     // papc_pfn_fwd / _bwd: BatchNorm constants / dW finalize as the last-arriving workgroup's tail of the Gram pass / the fold (pfn.hip)
+    {"PAPC_STREAM_NW12", 1, 0, 1},         // twelve waves per workgroup (three per SIMD) for the row-streaming dX flavours that fit 168 registers (0: eight)
 };
 static int g_knobs[KNOB_COUNT];
 static int knob_parse(int id, const char *e)

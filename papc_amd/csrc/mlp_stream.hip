@@ -840,8 +840,7 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
         // 1.551 ms per step, and the padded max layer's 256 -> 128, padded step 1.834 -> 1.818; the dense 64- and 96-channel dX kernels of config 3
         // qualify too and measured SLOWER there -- 5.58 -> 5.63 ms: its three branch streams already fill the SIMDs.  PAPC_STREAM_NW12=0: two waves)
         if constexpr ((EPI == EPI_XYZ_RED || (EPI == EPI_STORE_RED && AMODE == A_DY_MAX && KB16 == 16)) && WN == 2 && !NR && KV == KB16 * 16) {
-            static const bool nw12 = !getenv("PAPC_STREAM_NW12") || atoi(getenv("PAPC_STREAM_NW12")) != 0;
-            if (nw12) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW, false, 12>), grid, dim3(768), 0, st, p, geo);
+            if (knob(KNOB_STREAM_NW12)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW, false, 12>), grid, dim3(768), 0, st, p, geo);
             else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);
         } else {
             hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);

@@ -498,3 +498,44 @@ def test_xyz_first_layer_gram_path_vs_rows_and_f64(dev, mlp):
         for j in (0, 2, 3):
             assert params[4 * l + j].grad is None
             assert torch.allclose(tg[4 * l + j] - 1.0, grads[4 * l + j].reshape(tg[4 * l + j].shape), rtol=1e-4, atol=3e-6), (l, j)
+
+
+@pytest.mark.parametrize("D,K,mlp", [(0, 32, [64, 64, 128]), (128, 64, [128, 128, 256])])
+def test_twelve_wave_dx_flavours_match_eight(dev, D, K, mlp):
+    """Two row-streaming dX flavours run twelve waves per workgroup (three per SIMD; stream_kernel<..., 12>, PAPC_STREAM_NW12): the dX folded into a
+    coordinates-only first layer's sums and the padded max layer's 256 -> 128.  Same products; the tiles reach a lane's running sums in another
+    order, so the gradients agree to rounding with the eight-wave launch (pointnet2_basic_layers.py:215-219 backward)."""
+    B, N, S = 8, 1024, 8192 // K * (2 if K == 64 else 1)
+    x = make_clouds(B, N, 78)
+    xyz = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 2)).to(dev)
+    rng = np.random.default_rng(19)
+    feats0 = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev) if D else None
+    _, new_xyz = F._fps_raw(xyz, S, st)
+    idx = F._ball_query_raw([0.3], [K], xyz, new_xyz)[0]
+    ws = seeded_weights([D + 3] + mlp, 43)
+    gout = None
+    res = {}
+    lib = _lib.load()
+    for nw12 in (1, 0):
+        _lib.check(lib.papc_knob_set(b"PAPC_STREAM_NW12", nw12), "papc_knob_set")
+        try:
+            params = []
+            for (w, b, g, bt) in ws:
+                params += [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b, g, bt)]
+            feats = feats0.clone().requires_grad_(True) if D else None
+            spec = StackSpec(B, N, S, K, D, True)
+            out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+            if gout is None:
+                gout = torch.from_numpy(np.random.default_rng(20).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            res[nw12] = (out.detach().cpu().numpy(), [p.grad.cpu().numpy() for j, p in enumerate(params) if j % 4 != 1],
+                         feats.grad.cpu().numpy() if D else None)
+        finally:
+            _lib.check(lib.papc_knob_set(b"PAPC_STREAM_NW12", 1), "papc_knob_set")
+    assert np.array_equal(res[1][0], res[0][0])
+    for a_, b_ in zip(res[1][1], res[0][1]):
+        assert_close(a_, b_, 2e-5, "twelve-wave vs eight-wave dX: parameter gradients")
+    if D:
+        assert_close(res[1][2], res[0][2], 2e-5, "twelve-wave vs eight-wave dX: feature gradient")
