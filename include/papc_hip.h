@@ -162,6 +162,11 @@ typedef struct papc_group_max {
     float *gmax, *gmin;      /* [M/K, Cout] */
     int32_t *amax, *amin;    /* [M/K, Cout] */
     int K;
+    /* optional (NULL: not given; zero-initialise the struct): [Cout] values with the SIGN of this layer's BatchNorm scale -- its weight gamma,
+     * since scale = gamma * invstd and invstd > 0.  With it a kernel may follow only the extremum the ReLU'd BatchNorm can select (the max of a
+     * channel with sign_src[c] >= 0, the min of the others) and then writes that one to BOTH (gmax, amax) and (gmin, amin):
+     * papc_bn_select_max_f32 finds the same value whichever it reads.  Half the epilogue's compare / select instructions. */
+    const float *sign_src;
 } papc_group_max;
 int papc_mlp_gemm_gmax_ok(int64_t M, int Cout, int K);
 int papc_mlp_gemm_f32(int a_mode, const float *x, int64_t ldx, const papc_group_src *grp,
@@ -370,6 +375,7 @@ int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t strea
 #define PAPC_SA_NO_PLANES_POINTWISE 128u /* ... only the un-pooled point-wise stacks */
 #define PAPC_SA_NO_XYZ_FUSE 256u
 #define PAPC_SA_NO_PSEL 1024u           /* compacted max layer: its dX kernel recomputes scale * p per row from gout instead of streaming the reduction's psel */
+#define PAPC_SA_NO_GSIGN 2048u          /* fused group max: both extrema per channel instead of the one sign(gamma) selects */
 #define PAPC_SA_NO_WSTATS 512u          /* compacted stack: unweighted statistics + one papc_bn_stats_corr_f32 launch per layer instead of weighted ones */        /* the dX above a coordinates-only first layer stored + papc_xyz_l1_bwd_f32 instead of papc_mlp_bwd_dx_xyz_f32 */
 typedef struct papc_sa_desc {
     int32_t B, N, S, K, D;

@@ -35,7 +35,7 @@ class BwdDy(ctypes.Structure):
 
 class GroupMax(ctypes.Structure):
     """papc_group_max"""
-    _fields_ = [("gmax", c_p), ("gmin", c_p), ("amax", c_p), ("amin", c_p), ("K", c_i)]
+    _fields_ = [("gmax", c_p), ("gmin", c_p), ("amax", c_p), ("amin", c_p), ("K", c_i), ("sign_src", c_p)]
 
 
 class BwdRed(ctypes.Structure):

@@ -30,6 +30,7 @@ struct ScatterDst {
 // (pointnet2_basic_layers.py:219) no longer needs a separate pass over y.  K in {32, 64, 128}, M % 128 == 0.
 struct GmaxDst {
     float *gmax, *gmin; int32_t *amax, *amin; int K;
+    const float *sgn;      // papc_group_max::sign_src (row-streaming kernel: one extremum per channel instead of two)
 };
 
 struct GemmArgs {

@@ -1036,7 +1036,7 @@ int papc_mlp_gemm_rows_w_f32(int a_mode, const float *x, int64_t ldx, const papc
         PAPC_REQUIRE(papc_mlp_gemm_gmax_ok(M, Cout, gmax->K), PAPC_E_UNSUPPORTED,
                      "papc_mlp_gemm_f32: fused group max needs K in {32,64,128}, M %% 128 == 0, Cout > 32 (got K=%d M=%lld Cout=%d)",
                      gmax->K, (long long)M, Cout);
-        p.gm.gmax = gmax->gmax; p.gm.gmin = gmax->gmin; p.gm.amax = gmax->amax; p.gm.amin = gmax->amin; p.gm.K = gmax->K;
+        p.gm.gmax = gmax->gmax; p.gm.gmin = gmax->gmin; p.gm.amax = gmax->amax; p.gm.amin = gmax->amin; p.gm.K = gmax->K; p.gm.sgn = gmax->sign_src;
         if (!y) {   // the output exists only as its per-group extrema (papc_mlp_max_nostore_ok says where): row-streaming kernel or nothing
             GemmArgs q = p;
             q.parts = gemm_parts(p.M);

@@ -112,9 +112,14 @@ __device__ __forceinline__ void split3_pair(f32x2 x, unsigned &p0, unsigned &p1,
 // NWT: waves per workgroup.  8 (two per SIMD, up to 256 registers each) everywhere but the flavours that fit 168 registers: those run TWELVE
 // (three per SIMD: these kernels wait on their loads, not on an execution unit), with the wave-major tile numbering of the device-row-count
 // flavours so that the ragged last round is spread over all CUs.
-template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32, bool PS = false, int NWT = 8>
+// GS (group-max epilogues): ONE extremum per channel -- the max of a channel whose BatchNorm weight is >= 0, the min of the others (GmaxDst::sgn,
+// papc_group_max::sign_src) -- followed as the maximum of the value with its sign bit flipped where the minimum is wanted; written to both pairs
+// of arrays, so papc_bn_select_max_f32 reads the same value whichever it picks.  Half the compare / select instructions of the epilogue.
+template <int AMODE, int EPI, int KB16, int CK, int WN, bool ASM, bool CP = false, int KV = KB16 * 16, bool NR = false, int CBW = WN * 32, bool PS = false, int NWT = 8,
+          bool GS = false>
 __global__ __launch_bounds__(NWT * 64, NWT / 4) void stream_kernel(GemmArgs p, StreamGeo geo)
 {
+    static_assert(!GS || EPI == EPI_STORE_GMAX || EPI == EPI_GMAX, "GS: group-max epilogues only");
     static_assert(NWT == 8 || NWT == 12, "two or three waves per SIMD");
     static_assert(!PS || (CP && AMODE == A_DY_MAX), "PS: the compacted max-layer dX only (the one flavour where the result is bit-identical)");
     static_assert(!CP || ((AMODE == A_DY_DENSE || AMODE == A_DY_MAX) && EPI == EPI_STORE_RED && ASM && PAPC_STREAM_PK), "CP: dX flavours of the asm ring only");
@@ -550,6 +555,7 @@ __global__ __launch_bounds__(NWT * 64, NWT / 4) void stream_kernel(GemmArgs p, S
         rsc[wn] = rsh[wn] = rmu[wn] = ris[wn] = 0.f;
         if (EPI == EPI_STORE_RED) { rsc[wn] = p.rd.scale[col]; rsh[wn] = p.rd.shift[col]; rmu[wn] = p.rd.mean[col]; ris[wn] = p.rd.invstd[col]; }
         gmx[wn] = -INFINITY; gmn[wn] = INFINITY; gix[wn] = 0; gin[wn] = 0;
+        if constexpr (GS) gin[wn] = (p.gm.sgn[col] < 0.f) ? (int)0x80000000u : 0;      // (GS: gin holds the channel's sign flip, gmn is unused)
     }
 
     // epilogue of the tile starting at row0 (sub = its index inside the unit).  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 hi.
@@ -610,8 +616,13 @@ __global__ __launch_bounds__(NWT * 64, NWT / 4) void stream_kernel(GemmArgs p, S
                     s2[wn] = fmaf(v, v, s2[wn]);
                     if (GM) {
                         const int off = sub * 32 + ro + 4 * hi;
-                        if (v > gmx[wn]) { gmx[wn] = v; gix[wn] = off; }
-                        if (v < gmn[wn]) { gmn[wn] = v; gin[wn] = off; }
+                        if constexpr (GS) {
+                            const float key = __int_as_float(__float_as_int(v) ^ gin[wn]);      // (v < best  <=>  -v > -best: strict either way, first row wins)
+                            if (key > gmx[wn]) { gmx[wn] = key; gix[wn] = off; }
+                        } else {
+                            if (v > gmx[wn]) { gmx[wn] = v; gix[wn] = off; }
+                            if (v < gmn[wn]) { gmn[wn] = v; gin[wn] = off; }
+                        }
                     }
                 }
             }
@@ -619,6 +630,20 @@ __global__ __launch_bounds__(NWT * 64, NWT / 4) void stream_kernel(GemmArgs p, S
             for (int r = 0; r < 16; ++r) acc[wn][r] = 0.f;
             if (GM && sub == U - 1) {
                 // close the group: merge the two half-waves (first offset wins ties), lanes 0-31 write
+                if constexpr (GS) {
+                    float vmx = gmx[wn];
+                    int imx = gix[wn];
+                    const float omx = __shfl_xor(vmx, 32);
+                    const int oix = __shfl_xor(imx, 32);
+                    if (omx > vmx || (omx == vmx && oix < imx)) { vmx = omx; imx = oix; }
+                    if (hi == 0) {
+                        const int64_t g = (int64_t)(row0 >> 5) >> geo.ushift;
+                        const float sel = __int_as_float(__float_as_int(vmx) ^ gin[wn]);
+                        p.gm.gmax[g * p.Nout + col] = sel; p.gm.amax[g * p.Nout + col] = imx;
+                        p.gm.gmin[g * p.Nout + col] = sel; p.gm.amin[g * p.Nout + col] = imx;
+                    }
+                    gmx[wn] = -INFINITY; gix[wn] = 0;
+                } else {
                 float vmx = gmx[wn], vmn = gmn[wn];
                 int imx = gix[wn], imn = gin[wn];
                 const float omx = __shfl_xor(vmx, 32), omn = __shfl_xor(vmn, 32);
@@ -631,6 +656,7 @@ __global__ __launch_bounds__(NWT * 64, NWT / 4) void stream_kernel(GemmArgs p, S
                     p.gm.gmin[g * p.Nout + col] = vmn; p.gm.amin[g * p.Nout + col] = imn;
                 }
                 gmx[wn] = -INFINITY; gmn[wn] = INFINITY; gix[wn] = 0; gin[wn] = 0;
+                }
             }
         }
     };
@@ -841,6 +867,9 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
         // qualify too and measured SLOWER there -- 5.58 -> 5.63 ms: its three branch streams already fill the SIMDs.  PAPC_STREAM_NW12=0: two waves)
         if constexpr ((EPI == EPI_XYZ_RED || (EPI == EPI_STORE_RED && AMODE == A_DY_MAX && KB16 == 16)) && WN == 2 && !NR && KV == KB16 * 16) {
             if (knob(KNOB_STREAM_NW12)) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW, false, 12>), grid, dim3(768), 0, st, p, geo);
+            else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);
+        } else if constexpr ((EPI == EPI_GMAX || EPI == EPI_STORE_GMAX) && !NR && KV == KB16 * 16) {
+            if (p.gm.sgn) hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW, false, 8, true>), grid, dim3(512), 0, st, p, geo);
             else hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);
         } else {
             hipLaunchKernelGGL((stream_kernel<AMODE, EPI, KB16, CK, WN, true, false, KV, NR, CBW>), grid, dim3(512), 0, st, p, geo);

@@ -561,6 +561,7 @@ int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_
         const papc_group_max *gm_ref = nullptr;
         if (l == L - 1 && p.gmax) {
             gm.gmax = s.gbuf_f; gm.gmin = s.gbuf_f + G * cout; gm.amax = f.gbuf_i; gm.amin = f.gbuf_i + G * cout; gm.K = d.K;
+            gm.sign_src = (d.disable & PAPC_SA_NO_GSIGN) ? nullptr : ly.gamma;      // (one extremum per channel in the row-streaming kernel's epilogue)
             gm_ref = &gm;
         }
         float *y = s.y[l];

@@ -17,7 +17,7 @@ from ._lib import check, ptr, stream_ptr
 
 MAXL = 8
 c_p, c_i, c_l, c_f = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
-NO_LINGATHER, NO_XYZ1, NO_NOSTORE, NO_GMAX, NO_FUSED_RED, NO_COMPACT, NO_PLANES, NO_PLANES_POINTWISE, NO_XYZ_FUSE, NO_WSTATS, NO_PSEL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024
+NO_LINGATHER, NO_XYZ1, NO_NOSTORE, NO_GMAX, NO_FUSED_RED, NO_COMPACT, NO_PLANES, NO_PLANES_POINTWISE, NO_XYZ_FUSE, NO_WSTATS, NO_PSEL, NO_GSIGN = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
 
 
 class SaDesc(ctypes.Structure):
@@ -84,6 +84,7 @@ def _disable_bits():
     if not smallm.ENABLED: bits |= NO_PLANES
     if not smallm.POINTWISE: bits |= NO_PLANES_POINTWISE
     if not mlp._XYZ_FUSE: bits |= NO_XYZ_FUSE
+    if os.environ.get("PAPC_GSIGN", "1") == "0": bits |= NO_GSIGN       # A/B: both extrema per channel in the fused group max (no sign(gamma) hint)
     if os.environ.get("PAPC_PSEL", "1") == "0": bits |= NO_PSEL         # A/B: the compacted max layer's dX from gout (ReLU test + scale per row)
     if os.environ.get("PAPC_WSTATS", "1") == "0": bits |= NO_WSTATS     # A/B: unweighted statistics + papc_bn_stats_corr_f32 per layer
     return bits
