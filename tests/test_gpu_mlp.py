@@ -539,3 +539,35 @@ def test_twelve_wave_dx_flavours_match_eight(dev, D, K, mlp):
         assert_close(a_, b_, 2e-5, "twelve-wave vs eight-wave dX: parameter gradients")
     if D:
         assert_close(res[1][2], res[0][2], 2e-5, "twelve-wave vs eight-wave dX: feature gradient")
+
+
+def test_group_max_sign_hint_is_bit_identical(dev, monkeypatch):
+    """papc_group_max.sign_src (the layer's gamma): the fused group max follows one extremum per channel -- the max where gamma >= 0, the min
+    elsewhere (seeded_weights draws a quarter of the gammas negative) -- and writes it to both pairs of arrays.  papc_bn_select_max_f32 picks the
+    same value either way: output and gradients have the bits of the two-extrema epilogue (PAPC_GSIGN=0 / PAPC_SA_NO_GSIGN;
+    pointnet2_basic_layers.py:215-219)."""
+    B, N, K, mlp = 8, 1024, 32, [64, 64, 128]
+    S = 8192 // K
+    x = make_clouds(B, N, 79)
+    xyz = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 3)).to(dev)
+    _, new_xyz = F._fps_raw(xyz, S, st)
+    idx = F._ball_query_raw([0.3], [K], xyz, new_xyz)[0]
+    ws = seeded_weights([3] + mlp, 47)
+    assert any((g < 0).any() for (_, _, g, _) in ws)
+    gout = None
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PAPC_GSIGN", mode)
+        params = []
+        for (w, b, g, bt) in ws:
+            params += [torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b, g, bt)]
+        out = shared_mlp_max(StackSpec(B, N, S, K, 0, True), None, xyz, new_xyz, None, idx, params)
+        if gout is None:
+            gout = torch.from_numpy(np.random.default_rng(21).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        res[mode] = (out.detach().cpu().numpy(), [p.grad.cpu().numpy() for j, p in enumerate(params) if j % 4 != 1])
+    assert np.array_equal(res["1"][0], res["0"][0])
+    for a_, b_ in zip(res["1"][1], res["0"][1]):
+        assert np.array_equal(a_, b_)
