@@ -172,7 +172,7 @@ def main():
                     help="(default) software-pipelined sampling: batch i+1's pyramid (FPS + ball query: weight-independent, a serial "
                     "chain on 32 of the 256 CUs) runs on a side stream / graph branch beside batch i's MLP kernels")
     ap.add_argument("--no-overlap", dest="overlap", action="store_false", help="sample in-line at the head of every step")
-    ap.add_argument("--fork", choices=["start", "sa2", "sa3", "loss", "sa2late", "sa2end"], default="sa2", help="where the step forks the next batch's sampling branch "
+    ap.add_argument("--fork", choices=["start", "sa1", "sa2", "sa3", "loss", "sa2late", "sa2end"], default="sa2", help="where the step forks the next batch's sampling branch "
                     "(sa2late / sa2end: the branch DEPENDS on the same point as sa2 but its launches are captured later -- behind SA3's forward / behind the whole "
                     "backward -- so that the main chain's continuation is the fork node's first successor in the captured graph)")
     ap.add_argument("--side-cu-mask", type=int, default=0, help="(diagnostic) create the sampling stream with a CU mask of N CUs (hipExtStreamCreateWithCUMask)")
@@ -276,7 +276,7 @@ def main():
         if rc != 0:
             raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
         side = torch.cuda.ExternalStream(hs.value, device=dev)
-    side_graph = not args.in_graph_fork and args.fork in ("start", "sa2", "sa3", "loss") and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
+    side_graph = not args.in_graph_fork and args.fork in ("start", "sa1", "sa2", "sa3", "loss") and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
     gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None      # the word papc_flag_set / papc_flag_wait share
 
     def gate_open(counter=None):
@@ -410,6 +410,7 @@ def main():
             plan_in, plan_out = graph_state["fixed_plan"], None
         loss, _ = model(x, (s1, s2), plan=plan_in, tap=tap,
                         after_sa2=cut if cut is not None else (open_gate if gate_at == "sa2" else ((fork if args.fork == "sa2" else (mark if args.fork in ("sa2late", "sa2end") else None)) if plan_out is not None and not use_dist else None)),
+                        after_sa1=open_gate if gate_at == "sa1" else None,
                         after_sa3=open_gate if gate_at == "sa3" else (((fork if args.fork == "sa3" else ((lambda: fork(fork_ev[0])) if args.fork == "sa2late" else None)) if plan_out is not None and not use_dist else None)), labels=y)
         if not use_dist:
             if gate_at == "loss":

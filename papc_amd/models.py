@@ -103,7 +103,7 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
             p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1], out=o[1])
         return p1, p2
 
-    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None, after_sa3=None, labels=None):
+    def forward(self, inputs, start_idx=None, plan=None, after_sa2=None, tap=None, after_sa3=None, labels=None, after_sa1=None):
         """inputs [B,3,N]; ``labels`` = optional int64 [B]: return (loss, logits) instead of logits, the cross-entropy of train.py:106-109
         computed by the head's own launch; ``start_idx`` = optional (s1 [B], s2 [B]) FPS start indices (the source draws them at random);
         ``plan`` = optional result of :meth:`plan_sampling` for these inputs; ``after_sa2`` = optional callable invoked
@@ -130,6 +130,8 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
                 ws += [c.weight for c in self.sa3.mlp_convs]    # (the planes path builds its own W^T planes: nothing to transpose for it)
             wt = precompute_wt(ws)
         l1_xyz, l1_points = self.sa1(xyz, norm, s[0], sampled=pl[0], wt_table=wt)
+        if after_sa1 is not None:
+            after_sa1()
         l2_xyz, l2_points = self.sa2(l1_xyz, l1_points, s[1], sampled=pl[1], wt_table=wt)
         if after_sa2 is not None:
             after_sa2()
