@@ -91,13 +91,15 @@ static bool defer_fold(const papc_sa_grads &gr, const float *partial, int n_chun
 static bool defer_room(const papc_sa_grads &gr, int n) { return gr.defer && gr.defer->jobs && gr.defer->count + n <= gr.defer->capacity; }
 static inline int cin_of(const papc_sa_plan &p, int l) { return l == 0 ? p.cin0 : p.d.cout[l - 1]; }
 
-static int dw_rows_per_chunk(int64_t M, int cout, int cin)      // (mlp.py::_dw_rows_per_chunk: one residency wave of workgroups in total)
+// rows per dW chunk, at least 256 -- except the gather-add layer's dW_f = G^T feats over the B N source points: 64 (at 256 its 16 384 rows ran on 64
+// workgroups, a quarter of the chip, for 24 us: step 1.482 -> 1.464 ms; the same floor for every small-M launch cost config 3 0.03 ms)
+static int dw_rows_per_chunk(int64_t M, int cout, int cin, int min_rows = 256)      // (mlp.py::_dw_rows_per_chunk: one residency wave of workgroups in total)
 {
     const bool wide = cin > 128 && cin <= 160;
     const int tiles = ((cout + 127) / 128) * (wide ? 1 : (cin + 127) / 128);
     const int want = std::max(1, 512 / tiles);
     int64_t rpc = (M + want - 1) / want;
-    rpc = std::max<int64_t>(256, ((rpc + 63) / 64) * 64);
+    rpc = std::max<int64_t>(min_rows, ((rpc + 63) / 64) * 64);
     return (int)rpc;
 }
 
@@ -195,7 +197,7 @@ static size_t layout_bwd(const papc_sa_plan &p, void *base, BwdPtrs &b)
         const int64_t BN = (int64_t)p.d.B * p.d.N;
         b.dwx_part = c.take<float>((size_t)papc_lingather_parts(M) * c0 * 3);
         b.Gs = c.take<float>((size_t)BN * c0);
-        const int rpc_g = dw_rows_per_chunk(BN, c0, p.d.D);
+        const int rpc_g = dw_rows_per_chunk(BN, c0, p.d.D, 64);
         b.part_g = c.take<float>((size_t)((BN + rpc_g - 1) / rpc_g) * ((size_t)c0 * p.d.D + c0));
         b.wft = c.take<float>((size_t)p.d.D * c0);
     }
@@ -732,7 +734,7 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             memset(&dyg, 0, sizeof(dyg));
             dyg.dz_mode = PAPC_DZ_DENSE; dyg.dz = b.Gs; dyg.K = 1; dyg.y = b.Gs;
             dyg.mean = zeros; dyg.invstd = ones; dyg.scale = ones; dyg.shift = big; dyg.c1 = zeros; dyg.c2 = zeros;
-            const int rpc_g = dw_rows_per_chunk(BN, cout, d.D);
+            const int rpc_g = dw_rows_per_chunk(BN, cout, d.D, 64);
             const int n_chunks_g = (int)((BN + rpc_g - 1) / rpc_g);
             const int64_t pld_g = (int64_t)cout * d.D + cout;
             SA_CALL(papc_mlp_bwd_dw_f32(&dyg, A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, BN, d.D, cout, rpc_g, b.part_g, b.part_g + (int64_t)cout * d.D, pld_g, st));

@@ -72,14 +72,15 @@ _XYZ1 = os.environ.get("PAPC_XYZ1", "1") == "1"             # coordinates-only f
 _XYZ_FUSE = os.environ.get("PAPC_XYZ_FUSE", "1") == "1"   # A/B switch (library orchestration only): 0 = the dX above a coordinates-only first layer is stored and read back by papc_xyz_l1_bwd_f32
 
 
-def _dw_rows_per_chunk(M, cout, cin):
+def _dw_rows_per_chunk(M, cout, cin, min_rows=256):
     """Row-chunk size for the dW kernel: ONE residency wave of workgroups (256 CUs x 2 per CU = 512) in total, so
-    no tail round; chunks of >= 256 rows."""
+    no tail round; chunks of >= 256 rows -- >= 64 for the gather-add layer's dW_f over the B N source points (sa_mlp.hip::dw_rows_per_chunk:
+    the same rule, bit for bit the same partial sums)."""
     wide = 128 < cin <= 160
     tiles = ((cout + 127) // 128) * (1 if wide else (cin + 127) // 128)
     want = max(1, _DW_WGS // tiles)
     rpc = (M + want - 1) // want
-    rpc = max(256, ((rpc + 63) // 64) * 64)
+    rpc = max(min_rows, ((rpc + 63) // 64) * 64)
     return rpc
 
 
@@ -463,7 +464,7 @@ class SharedMLPMax(torch.autograd.Function):
                 dyg.y = Gs.data_ptr()
                 dyg.mean, dyg.invstd, dyg.scale, dyg.shift = zero.data_ptr(), one.data_ptr(), one.data_ptr(), big.data_ptr()
                 dyg.c1, dyg.c2 = zero.data_ptr(), zero.data_ptr()
-                rpc_g = _dw_rows_per_chunk(BN_, cout, spec.D)
+                rpc_g = _dw_rows_per_chunk(BN_, cout, spec.D, 64)
                 n_chunks_g = (BN_ + rpc_g - 1) // rpc_g
                 pld_g = cout * spec.D + cout
                 part_g = torch.empty(n_chunks_g, pld_g, device=dev, dtype=torch.float32)
