@@ -537,13 +537,23 @@ __global__ __launch_bounds__(256) void pg_final_kernel(const float *__restrict__
     if (tpg > 1) {
         // a group spans tpg consecutive 128-row tiles (nsample = 128 tpg: PointNet-Basic's max over the N points of a cloud, pointnet_base.py:44):
         // the extreme of the tiles' extrema, the first tile winning ties (= the first row of the group); ysel goes to its own [G, C] array
+        const float *gsel = up ? gmax : gmin;             // (the extremum the ReLU'd BatchNorm can select: one array, one index array)
+        const int32_t *asel = up ? amax : amin;
         for (int64_t g = gl; g < G; g += 4) {
             float best = up ? -INFINITY : INFINITY;
             int arg = 0;
-            for (int t = 0; t < tpg; ++t) {
-                const int64_t e = (g * tpg + t) * C + c;
-                const float v = up ? gmax[e] : gmin[e];
-                if (up ? v > best : v < best) { best = v; arg = t * 128 + (up ? amax[e] : amin[e]); }
+            for (int t0 = 0; t0 < tpg; t0 += 8) {          // eight tiles' values and offsets in flight (a dependent chain of tpg round trips otherwise)
+                float v[8];
+                int a[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = t0 + j < tpg ? t0 + j : t0;
+                    const int64_t e = (g * tpg + t) * C + c;
+                    v[j] = gsel[e]; a[j] = asel[e];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (t0 + j < tpg && (up ? v[j] > best : v[j] < best)) { best = v[j]; arg = (t0 + j) * 128 + a[j]; }
             }
             out[g * C + c] = relu_np(fmaf(sc, best, sh));
             ysel[g * C + c] = best;
