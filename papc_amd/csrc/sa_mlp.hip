@@ -217,11 +217,14 @@ struct PlanesSaved {
 struct PlanesFwd { void *wp[PAPC_SA_MAX_LAYERS]; void *P; float *stats[PAPC_SA_MAX_LAYERS]; int32_t *gbuf_i; };
 struct PlanesBwd { void *dyp, *dypt; float *dz[2], *red[3], *part[PAPC_SA_MAX_LAYERS], *tmp_gb; };
 
-static int pg_split_for(int R1, int R2, int nst)      // (smallm.py::_split_for: about one workgroup per CU, >= 8 k32 stages each, a power of two dividing nst)
+static int pg_split_for(int R1, int R2, int nst)      // (smallm.py::_split_for: about one workgroup per CU, >= 8 k32 stages each -- 2 for one- or two-tile products --, a power of two dividing nst)
 {
     const int tiles = ((R1 + 127) / 128) * ((R2 + 127) / 128);
     int s = 1;
-    while (s * 2 * tiles <= 256 && nst % (s * 2) == 0 && nst / (s * 2) >= 8) s *= 2;
+    // (a product of one or two output tiles -- PointNet-Basic's 64-channel layers -- is split down to 2 stages per workgroup: 128 workgroups instead of 32,
+    // config 0 0.359 -> 0.335 ms; the same for the wide layers of config 2's SA3 costs more in partial traffic than it gains: 1.512 -> 1.533 ms)
+    const int min_stages = tiles <= 2 ? 2 : 8;
+    while (s * 2 * tiles <= 256 && nst % (s * 2) == 0 && nst / (s * 2) >= min_stages) s *= 2;
     return s;
 }
 static inline int pg_n_in(const papc_sa_plan &p) { return p.d.input == PAPC_SA_IN_ROWS ? p.cin0 : p.d.D; }

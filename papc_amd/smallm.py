@@ -93,10 +93,12 @@ def _planes(lib, R, K, dev):
 
 
 def _split_for(R1, R2, nst):
-    """split-K factor of a dW product: about one workgroup per CU, at least 8 k32 stages each, a power of two dividing nst"""
+    """split-K factor of a dW product: about one workgroup per CU, at least 8 k32 stages each (2 for products of one or two output tiles), a power
+    of two dividing nst (sa_mlp.hip::pg_split_for: the same rule)"""
     tiles = ((R1 + 127) // 128) * ((R2 + 127) // 128)
     s = 1
-    while s * 2 * tiles <= 256 and nst % (s * 2) == 0 and nst // (s * 2) >= 8:
+    min_stages = 2 if tiles <= 2 else 8
+    while s * 2 * tiles <= 256 and nst % (s * 2) == 0 and nst // (s * 2) >= min_stages:
         s *= 2
     return s
 
