@@ -192,6 +192,13 @@ def main():
                     "(`value_padded` in the JSON line)")
     ap.add_argument("--require-graph", action="store_true", help="fail instead of falling back to eager launches when the hipGraph capture "
                     "does not succeed (a multi-GPU run must not quietly measure the slow path)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct resident batches the steps cycle through (step j trains on batch j mod this; the side "
+                    "stream loads and samples batch j + 1 meanwhile): the compacted stack's row count and the sampling pyramid see different clouds")
+    ap.add_argument("--min-timed-steps", type=int, default=50, help="per-step statistics (ms_median / ms_min / ms_p95, device events around every step) are taken "
+                    "over at least this many steps: when --steps is smaller, further windows of --steps steps follow the contract window")
+    ap.add_argument("--allow-gate-timeout", action="store_true", help="(tests) do not abort when a device-side gate wait gave up (papc_flag_wait's sticky count)")
+    ap.add_argument("--diag-stall-ms", type=float, default=0.0, help="(tests) stall the main stream for about this long ahead of every third timed step (a spinning "
+                    "one-lane kernel): the side graph's gate must hold through it, and the plan buffers stay ordered by stream events whatever the gate does")
     ap.add_argument("--dry-run", action="store_true", help="capture, run the warm-up steps, print the launch structure as JSON and exit")
     ap.add_argument("--lr", type=float, default=1e-3, help="Adam learning rate (train.py:62-65: 1e-3).  (tests) A training step is a "
                     "discontinuous function of the weights -- which row wins a neighbourhood max, which side of 0 a pre-activation falls -- "
@@ -247,11 +254,31 @@ def main():
     params0 = flat.data.detach().cpu().numpy() if args.dump_trajectory else None
     opt = FlatAdam(flat, lr=args.lr, weight_decay=1e-3)
 
-    seed = 1234 + rank                            # each rank owns its own shard of clouds
-    x = torch.from_numpy(make_clouds(B, N, seed)).to(dev)
-    y = torch.from_numpy(make_labels(B, 16, seed)).reshape(-1).to(dev)
-    s1 = torch.from_numpy(make_start_idx(B, N, seed)).to(dev)
-    s2 = torch.from_numpy(make_start_idx(B, 512, seed + 1)).to(dev)
+    # each rank owns its own shard of clouds; NB distinct resident batches, step j trains on batch j mod NB (batch 0 = the one batch of rounds 1-5)
+    NB = 1 if args.diag_fixed_plan else max(1, args.batches)
+
+    def make_batch(k):
+        seed = 1234 + rank + 100003 * k
+        xb = torch.from_numpy(make_clouds(B, N, seed)).to(dev)
+        ints = torch.stack([torch.from_numpy(make_labels(B, 16, seed)).reshape(-1), torch.from_numpy(make_start_idx(B, N, seed)),
+                            torch.from_numpy(make_start_idx(B, 512, seed + 1))]).to(dev)            # int64 [3, B]: labels, FPS start indices of SA1 / SA2
+        return xb, ints
+
+    batches = [make_batch(k) for k in range(NB)]
+    # the captured graphs read their inputs from two static slots (set i trains on slot i while the side stream loads slot 1 - i with the next batch)
+    slots = [tuple(t.clone() for t in batches[0]) for _ in range(2)]
+    cur = {"j": 0}                                # steps enqueued so far = index of the batch the next step trains on
+
+    def unpack(b):
+        return b[0], b[1][0], b[1][1], b[1][2]    # x [B,3,N], y [B], s1 [B], s2 [B]
+
+    def bt(j):
+        return unpack(batches[j % NB])
+
+    def load_slot(i, j):
+        """slot i <- batch j (two device copies on the current stream)"""
+        slots[i][0].copy_(batches[j % NB][0])
+        slots[i][1].copy_(batches[j % NB][1])
 
     # Sampling pipeline: FPS / ball query depend on the batch only (not on the weights) and FPS is a serial chain that
     # occupies B=32 of the 256 CUs, so the sampling pyramid of batch i+1 is computed on a side stream while batch i's
@@ -277,13 +304,15 @@ def main():
             raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
         side = torch.cuda.ExternalStream(hs.value, device=dev)
     side_graph = not args.in_graph_fork and args.fork in ("start", "sa1", "sa2", "sa3", "loss") and not dist.is_initialized() and not args.no_graph and args.overlap and not args.diag_fixed_plan
-    gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None      # the word papc_flag_set / papc_flag_wait share
+    gate = torch.zeros(4, dtype=torch.int32, device=dev) if side_graph else None      # the words papc_flag_set / papc_flag_wait share: openings, waits, give-ups
+    GATE_SPINS = int(os.environ.get("PAPC_GATE_SPINS", "2400000"))                    # ~2 s: a wait that gives up is an ERROR (sync() aborts), not a late start
+    stall_gate = torch.zeros(4, dtype=torch.int32, device=dev) if args.diag_stall_ms > 0 else None
 
     def gate_open(counter=None):
         _lib.check(lib.papc_flag_set(gate.data_ptr(), 1, counter.data_ptr() if counter is not None else None, _lib.stream_ptr()), "papc_flag_set")
 
     def gate_wait():
-        _lib.check(lib.papc_flag_wait(gate.data_ptr(), 40000, _lib.stream_ptr()), "papc_flag_wait")      # (bounded: ~35 ms, then it starts anyway)
+        _lib.check(lib.papc_flag_wait(gate.data_ptr(), GATE_SPINS, _lib.stream_ptr()), "papc_flag_wait")
 
     from papc_amd.head import unit_gradient
     ONE = unit_gradient(dev)                    # d(loss)/d(loss), allocated once; seeding with this tensor skips the loss's multiply-by-one launch
@@ -296,24 +325,30 @@ def main():
     # eager launch: the gradient all-reduce sits between the backward and the update.  PAPC_ADAM_IN_GRAPH=0: eager everywhere.
     ADAM_IN_GRAPH = os.environ.get("PAPC_ADAM_IN_GRAPH", "1") != "0" and not dist.is_initialized()
 
-    def launch_plan():
+    def launch_plan(j):
+        """batch j's pyramid on the side stream"""
+        xb, _, s1b, s2b = bt(j)
         side.wait_stream(main)                     # the inputs (and the allocator) are ordered behind the main stream
         with torch.cuda.stream(side):
-            plan = model.plan_sampling(x, (s1, s2))
+            plan = model.plan_sampling(xb, (s1b, s2b))
             ev = torch.cuda.Event()
             ev.record(side)
         for lvl in plan:
             for t in lvl:
                 t.record_stream(main)              # consumed by main-stream kernels: keep the blocks alive for them
-        state["plan"], state["ev"] = plan, ev
+        state["plan"], state["ev"], state["plan_j"] = plan, ev, j
 
     def step_eager(exchange=True):
         """exchange=False (N > 1, ahead of the graph capture): forward + backward only -- no collective, no optimiser step, so the
         replicas stay identical and no collective runs on the stream about to be captured"""
+        j = cur["j"]
+        cur["j"] = j + 1
+        x, y, s1, s2 = bt(j)
+        nxt = lambda: launch_plan(j + 1)          # noqa: E731
         plan = None
         if args.overlap:
-            if state["plan"] is None:
-                launch_plan()
+            if state["plan"] is None or state.get("plan_j") != j:
+                launch_plan(j)
             plan, ev = state["plan"], state["ev"]
             main.wait_event(ev)
         # the next batch's pyramid is enqueued on the side stream beside this batch's MLP kernels (--fork sa2: only once the
@@ -323,9 +358,9 @@ def main():
         if ADAM_IN_GRAPH and exchange:
             opt.tick()
         if args.overlap and args.fork == "start":
-            launch_plan()
+            nxt()
         tap = {} if use_dist else None
-        loss, _ = model(x, (s1, s2), plan=plan, after_sa2=(launch_plan if args.overlap and args.fork == "sa2" else None), tap=tap, labels=y)
+        loss, _ = model(x, (s1, s2), plan=plan, after_sa2=(nxt if args.overlap and args.fork == "sa2" else None), tap=tap, labels=y)
         work = None
         if use_dist and exchange:
             l2 = tap["l2_points"]
@@ -356,7 +391,7 @@ def main():
     # launches less per step (--eager-sampling restores the three-graph form)
     dist_side_graph = ext_sampling and not args.eager_sampling and args.fork == "sa2" and not args.diag_fixed_plan
     if dist_side_graph and gate is None:
-        gate = torch.zeros(2, dtype=torch.int32, device=dev)
+        gate = torch.zeros(4, dtype=torch.int32, device=dev)
 
     use_dist = dist.is_initialized()
     # N > 1: the backward runs in two stages around l2_points (the tensor SA3 consumes).  Stage 1 = FC head + SA3, whose
@@ -370,7 +405,10 @@ def main():
         assert all(getattr(p, "_papc_inplace_grad", False) for p in model.parameters()), "two-stage backward needs FlatParams-owned parameters"
         assert 2 <= B <= 256, "two-stage backward needs the fused classifier head (2 <= B <= 256)"
 
-    def stage1(plan_in=None, plan_out=None, cut=None):
+    def stage1(plan_in=None, plan_out=None, cut=None, si=0):
+        """``si`` = the input slot this graph trains on; a forked sampling branch reads the OTHER slot (the next batch)"""
+        x, y, s1, s2 = unpack(slots[si])
+        xn, _, s1n, s2n = unpack(slots[1 - si])
         if not ZERO_IN_ADAM:
             flat.zero_grad()
 
@@ -387,7 +425,7 @@ def main():
                 if not ticked[0]:
                     opt.tick()                                     # the optimiser's step count advances off the critical path
                     ticked[0] = True
-                model.plan_sampling(x, (s1, s2), out=plan_out)     # the kernels write the other graph's plan buffers in place
+                model.plan_sampling(xn, (s1n, s2n), out=plan_out)     # the kernels write the other graph's plan buffers in place
 
         def mark():                                                # sa2late / sa2end: only the dependency point is taken here
             fork_ev[0] = torch.cuda.Event()
@@ -445,13 +483,16 @@ def main():
             flat.zero_grad()                       # (the passes ahead of a capture may have ended without an optimiser step)
         torch.cuda.synchronize()
         try:
+            load_slot(0, cur["j"])                 # the first replayed step (set 0) trains on batch cur["j"]: its inputs and, below, its plan
+            x0, _, s10, s20 = unpack(slots[0])
             if args.diag_fixed_plan:
-                graph_state["fixed_plan"] = model.plan_sampling(x, (s1, s2))
+                graph_state["fixed_plan"] = model.plan_sampling(x0, (s10, s20))
                 torch.cuda.synchronize()
             n_sets = 2 if args.overlap else 1
+            graph_state["prev_end"] = None
             bufs = None
             if args.overlap:
-                p0 = model.plan_sampling(x, (s1, s2))
+                p0 = model.plan_sampling(x0, (s10, s20))
                 bufs = [tuple(tuple(t.clone() for t in lvl) for lvl in p0) for _ in range(2)]
                 torch.cuda.synchronize()
             gs, losses = [], []
@@ -461,7 +502,7 @@ def main():
                     g1 = torch.cuda.CUDAGraph()
                     graph_state["capturing_main"] = True
                     with torch.cuda.graph(g1, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                        loss, _, _, _ = stage1(bufs[i], None)
+                        loss, _, _, _ = stage1(bufs[i], None, si=i)
                     graph_state["capturing_main"] = False
                     gs.append((g1, None, None))
                     losses.append(loss)
@@ -470,7 +511,8 @@ def main():
                     with torch.cuda.stream(side):
                         with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
                             gate_wait()
-                            model.plan_sampling(x, (s1, s2), out=bufs[1 - i])
+                            xn, _, s1n, s2n = unpack(slots[1 - i])
+                            model.plan_sampling(xn, (s1n, s2n), out=bufs[1 - i])
                     main.wait_stream(side)
                     gside.append(g2)
                 graph_state["g"], graph_state["loss"], graph_state["bufs"], graph_state["gside"] = gs, losses, bufs, gside
@@ -489,7 +531,7 @@ def main():
                     g2 = torch.cuda.CUDAGraph()
                     g1.capture_begin(capture_error_mode="thread_local")
                     try:
-                        loss, l2, g_l2, _ = stage1(pin, None, (lambda: gate_open(None)))
+                        loss, l2, g_l2, _ = stage1(pin, None, (lambda: gate_open(None)), si=i)
                         g1.capture_end()
                         g2.capture_begin(pool=g1.pool(), capture_error_mode="thread_local")
                         stage2(l2, g_l2, None)
@@ -506,7 +548,8 @@ def main():
                     with torch.cuda.stream(side):
                         with torch.cuda.graph(gsd, stream=side, capture_error_mode="thread_local"):
                             gate_wait()
-                            model.plan_sampling(x, (s1, s2), out=bufs[1 - i])
+                            xn, _, s1n, s2n = unpack(slots[1 - i])
+                            model.plan_sampling(xn, (s1n, s2n), out=bufs[1 - i])
                     main.wait_stream(side)
                     graph_state.setdefault("gside_dist", [None, None])[i] = gsd
                     graph_state["side_ev"] = [None, None]
@@ -525,7 +568,7 @@ def main():
 
                     g1.capture_begin(capture_error_mode="thread_local")
                     try:
-                        loss, l2, g_l2, fork = stage1(pin, None, cut)
+                        loss, l2, g_l2, fork = stage1(pin, None, cut, si=i)
                         g1b.capture_end()
                         g2.capture_begin(pool=g1.pool(), capture_error_mode="thread_local")
                         stage2(l2, g_l2, None)
@@ -542,7 +585,7 @@ def main():
                     continue
                 # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
                 with torch.cuda.graph(g1, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
-                    loss, l2, g_l2, fork = stage1(pin, pout)
+                    loss, l2, g_l2, fork = stage1(pin, pout, si=i)
                 if use_dist:   # stage 2 is a second graph (same memory pool): the collective of the tail bucket goes between them
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2, pool=g1.pool(), stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
@@ -577,48 +620,62 @@ def main():
         else:
             opt.step(scale, zero_grad=ZERO_IN_ADAM)
 
-    def sample_into(plan_out):
-        """the next batch's pyramid, enqueued on the side stream beside the graph that is being replayed (N > 1)"""
+    def sample_into(plan_out, si):
+        """the next batch's pyramid (slot si), enqueued on the side stream beside the graph that is being replayed (N > 1)"""
+        xn, _, s1n, s2n = unpack(slots[si])
         with torch.cuda.stream(side):
-            model.plan_sampling(x, (s1, s2), out=plan_out)
+            model.plan_sampling(xn, (s1n, s2n), out=plan_out)
 
-    def step():
-        if graph_state["g"] is None:
-            return step_eager()
+    def side_replay(g, i, j):
+        """The gated pyramid graph of set i on the side stream: loads slot 1 - i with batch j + 1 and fills bufs[1 - i] from it.  Their last readers are
+        the PREVIOUS step's kernels (set 1 - i: its backward reads the grouping lists to the end), so the side stream first waits for that step's
+        end-of-step event -- outside any graph, no edge on the main chain.  The device-side gate inside the graph only PLACES the pyramid (behind this
+        step's SA2); the buffers' safety does not rest on it (round 5: it did, and a gate wait that gave up let the pyramid overwrite a plan under
+        its readers)."""
+        with torch.cuda.stream(side):
+            if graph_state.get("prev_end") is not None:
+                side.wait_event(graph_state["prev_end"])
+            load_slot(1 - i, j + 1)
+            g.replay()                             # gated on the device: starts when this step has enqueued SA2
+            ev = torch.cuda.Event()
+            ev.record(side)
+        graph_state["side_ev"][1 - i] = ev
+
+    def step_graph():
         i = graph_state["i"] % len(graph_state["g"])
         graph_state["i"] += 1
+        j = cur["j"]
+        cur["j"] = j + 1
         g1, g1b, g2 = graph_state["g"][i]
         if side_graph and graph_state.get("gside"):
             ev = graph_state["side_ev"][i]
             if ev is not None:
-                main.wait_event(ev)                # bufs[i] was filled by the side graph of the previous step
+                main.wait_event(ev)                # slot i and bufs[i] were filled by the side stream during the previous step
             g1.replay()
-            with torch.cuda.stream(side):
-                graph_state["gside"][i].replay()   # gated on the device: starts when this step has enqueued SA2; fills bufs[1 - i]
-                ev = torch.cuda.Event()
-                ev.record(side)
-            graph_state["side_ev"][1 - i] = ev
+            side_replay(graph_state["gside"][i], i, j)
             return graph_state["loss"][i]
         if dist_side_graph and graph_state.get("gside_dist"):
             ev = graph_state["side_ev"][i]
             if ev is not None:
                 main.wait_event(ev)
             g1.replay()
-            with torch.cuda.stream(side):
-                graph_state["gside_dist"][i].replay()
-                ev = torch.cuda.Event()
-                ev.record(side)
-            graph_state["side_ev"][1 - i] = ev
+            side_replay(graph_state["gside_dist"][i], i, j)
             _, work = flat.allreduce_grads(split, None, async_op=True)
             g2.replay()
             finish(work)
             return graph_state["loss"][i]
+        # the other structures load the inputs on the main stream ahead of the replay: the next batch (a forked branch of this graph, or the eager
+        # side-stream sampling behind it, reads slot 1 - i), or -- in-line sampling, one graph -- this step's own
+        if args.overlap:
+            load_slot(1 - i, j + 1)
+        else:
+            load_slot(0, j)
         if ext_sampling:
             main.wait_stream(side)                 # this batch's plan (bufs[i]) was filled on the side stream during the last step
         g1.replay()
         if ext_sampling:
             side.wait_stream(main)                 # released when the main stream reaches SA3; bufs[1 - i]'s last reader is long done
-            sample_into(graph_state["bufs"][1 - i])
+            sample_into(graph_state["bufs"][1 - i], 1 - i)
             g1b.replay()
         work = None
         if g2 is not None:
@@ -628,9 +685,33 @@ def main():
             finish(work)
         return graph_state["loss"][i]
 
+    step_events = []                               # (timed region) one end-of-step event per step
+
+    def step():
+        if stall_gate is not None and graph_state.get("timing") and len(step_events) % 3 == 2:
+            # (tests) nobody opens this gate: the launch spins for ~diag_stall_ms on the main stream, then gives up
+            _lib.check(lib.papc_flag_wait(stall_gate.data_ptr(), int(args.diag_stall_ms * 1150), main.cuda_stream), "papc_flag_wait")
+        loss = step_eager() if graph_state["g"] is None else step_graph()
+        end = torch.cuda.Event(enable_timing=True)
+        end.record(main)
+        graph_state["prev_end"] = end              # what the next step's side graph waits for before it touches the buffers this step read
+        if graph_state.get("timing"):
+            step_events.append(end)
+        return loss
+
+
+    gate_timeouts = [0]
 
     def sync():
         torch.cuda.synchronize()
+        if gate is not None:
+            n = int(gate[2].item())
+            if n != gate_timeouts[0]:
+                gate_timeouts[0] = n
+                msg = "[bench] %d device-side gate wait(s) gave up after PAPC_GATE_SPINS=%d sleeps: the sampling graph started without its opening" % (n, GATE_SPINS)
+                if not args.allow_gate_timeout:
+                    raise SystemExit(msg + " -- aborting (the plan buffers stay ordered by stream events, but the measured overlap is not the designed one)")
+                print(msg, file=sys.stderr)
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
@@ -681,8 +762,14 @@ def main():
     # ---- timed region
     traj = []
 
-    def timed_region():
+    def timed_region(step_ms=None):
+        """EXACTLY --steps steps between barrier + synchronize on both sides (max over ranks); ``step_ms`` (a list) receives every step's duration
+        from device events: end-of-step event to end-of-step event on the main stream (the first from an event recorded behind the opening sync)"""
         sync()
+        del step_events[:]
+        start = torch.cuda.Event(enable_timing=True)
+        start.record(main)
+        graph_state["timing"] = True
         t0 = time.perf_counter()
         ls = None
         for _ in range(args.steps):
@@ -691,14 +778,31 @@ def main():
                 traj.append(ls.detach().clone())  # (the replayed graphs overwrite their loss tensor)
         sync()
         el = time.perf_counter() - t0
+        graph_state["timing"] = False
+        if step_ms is not None:
+            evs = [start] + step_events
+            step_ms.extend(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
         if use_dist:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, ls
 
-    elapsed, loss = timed_region()
+    def stats_of(ms):
+        ms = sorted(ms)
+        n = len(ms)
+        return {"ms_median": round(0.5 * (ms[(n - 1) // 2] + ms[n // 2]), 4), "ms_min": round(ms[0], 4), "ms_p95": round(ms[min(n - 1, int(0.95 * n))], 4),
+                "steps_timed": n}
+
+    def more_windows(step_ms):
+        """further windows of --steps steps until the per-step statistics stand on --min-timed-steps steps (the contract window stays the first)"""
+        while len(step_ms) < args.min_timed_steps and not args.dump_trajectory and not args.diag_stall_ms:
+            timed_region(step_ms)
+
+    step_ms = []
+    elapsed, loss = timed_region(step_ms)
     final_loss = float(loss.item())
+    more_windows(step_ms)
     if args.dump_trajectory and rank == 0:
         import numpy as np
         np.savez(args.dump_trajectory, loss=torch.stack(traj).cpu().numpy(), params=flat.data.detach().cpu().numpy(), params0=params0, grad=(state["last_grad"] if state["last_grad"] is not None else flat.grad).detach().cpu().numpy(),
@@ -726,13 +830,16 @@ def main():
     rows_sa2, row_fraction = None, 1.0
     sa2_key = (B * 128 * 64, (128, 128, 256))
     compact_on = bool(plans_used.get(sa2_key, {}).get("compact"))
+    row_fractions = []
     if compact_on:
-        pl2 = (graph_state["bufs"][0][1] if (use_graph and args.overlap) else state["plan"][1]) if args.overlap else None
-        if pl2 is None:
-            pl2 = model.plan_sampling(x, (s1, s2))[1]
-        if len(pl2) == 9:
-            rows_sa2 = int(pl2[4][0].item())
-            row_fraction = rows_sa2 / float(B * 128 * 64)
+        for k in range(NB):                       # the compacted stack's device-side row count, batch by batch (the step cycles through them)
+            xb, _, s1b, s2b = bt(k)
+            pl2 = model.plan_sampling(xb, (s1b, s2b))[1]
+            if len(pl2) == 9:
+                row_fractions.append(int(pl2[4][0].item()) / float(B * 128 * 64))
+        if row_fractions:
+            row_fraction = sum(row_fractions) / len(row_fractions)
+            rows_sa2 = int(round(row_fraction * B * 128 * 64))
     padded = None
     if compact_on and not use_dist and not args.diag_fixed_plan and not args.dump_trajectory and not args.no_padded_leg:     # (one process: a second capture behind collectives would trip RCCL's watchdog, see `comm` above)
         model.sa2.compact = False                 # forced padded (layers.PointNetSetAbstraction._compact_mode)
@@ -747,10 +854,12 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
-        el_p, loss_p = timed_region()
+        ms_p = []
+        el_p, loss_p = timed_region(ms_p)
+        more_windows(ms_p)
         assert not _stack.LAST_PLANS.get(sa2_key, {}).get("compact"), "the padded leg still ran the compacted stack"
         padded = {"value": round(B * args.steps / el_p, 2), "ms_per_step": round(1e3 * el_p / args.steps, 3),
-                  "graph": graph_state["g"] is not None}
+                  "graph": graph_state["g"] is not None, "stats": stats_of(ms_p)}
         model.sa2.compact = None
 
     if rank == 0:
@@ -819,11 +928,16 @@ def main():
         out = {
             "metric": "point-clouds/sec (fwd+bwd) PointNet++SSG B=32 N=4096" + (" -- DIAGNOSTIC, sampling excluded: not a benchmark value" if args.diag_fixed_plan else ""),
             "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), **stats_of(step_ms), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
-                       "compact_row_fraction": round(row_fraction, 4),
+                       "compact_row_fraction": round(row_fraction, 4), "compact_row_fraction_per_batch": [round(f, 4) for f in row_fractions],
+                       "batches": "%d distinct resident batches of B clouds (seeds 1234 + rank + 100003 k), step j trains on batch j mod %d; the next batch is loaded into the "
+                                  "graphs' input slot and sampled on the side stream" % (NB, NB),
+                       "timing": "value / ms_per_step: wall clock around the first window of --steps steps between barrier + synchronize (max over ranks); ms_median / ms_min / "
+                                 "ms_p95: device events around every step (end-of-step event to end-of-step event on the launch stream, rank 0) over steps_timed steps",
+                       "gate_timeouts": gate_timeouts[0],
                        "compact": ("SA2 on its distinct neighbours (auto policy: kept rows %.3f of the padded count on this generator; ShapeNet-like "
                                    "surfaces keep 0.91-0.99 and stay padded -> `value_padded` is their rate)" % row_fraction) if compact_on else "padded (policy)",
                        "sampling": ("software-pipelined: batch i+1's FPS + ball-query pyramid runs as a second branch (side stream) of "
@@ -846,6 +960,7 @@ def main():
                                       if use_dist else "none (one process)"},
             "value_padded": padded["value"] if padded else None,
             "ms_per_step_padded": padded["ms_per_step"] if padded else None,
+            "padded_stats": padded["stats"] if padded else None,
             "roofline": roof,
             "cpu_baseline": cpu,
         }

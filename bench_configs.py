@@ -150,7 +150,8 @@ def run(args):
     # ... for THIS config measured slower (6.15 vs 5.75 ms): the MSG layers fork their radius branches onto further streams inside the step's graph, and
     # the side graph's kernels then share hardware queues with them.  Opt-in (PAPC_SIDE_GRAPH=1); the headline config takes it by default (bench.py)
     side_graph = overlap and os.environ.get("PAPC_SIDE_GRAPH") == "1" and not getattr(args, "in_graph_fork", False) and not args.no_graph
-    gate = torch.zeros(2, dtype=torch.int32, device=dev) if side_graph else None
+    gate = torch.zeros(4, dtype=torch.int32, device=dev) if side_graph else None      # openings, waits, give-ups (include/papc_hip.h: papc_flag_set)
+    GATE_SPINS = int(os.environ.get("PAPC_GATE_SPINS", "2400000"))                    # ~2 s; a wait that gives up is an error, checked behind the timed region
     cap = {"main": False}
 
     def fwd_bwd(plan_in=None, plan_out=None):
@@ -231,7 +232,7 @@ def run(args):
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
                             with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
-                                _lib.check(lib.papc_flag_wait(gate.data_ptr(), 40000, _lib.stream_ptr()), "papc_flag_wait")
+                                _lib.check(lib.papc_flag_wait(gate.data_ptr(), GATE_SPINS, _lib.stream_ptr()), "papc_flag_wait")
                                 plan_fn(bufs[1 - i])
                         main.wait_stream(side)
                         gside.append(g2)
@@ -259,11 +260,16 @@ def run(args):
             if ev is not None:
                 main.wait_event(ev)                # this step's plan buffers were filled by the previous step's side graph
             graph["g"][i].replay()
+            end = torch.cuda.Event()
+            end.record(main)
             with torch.cuda.stream(side):
+                if graph.get("prev_end") is not None:
+                    side.wait_event(graph["prev_end"])     # the buffers it fills were read by the previous step to its end: ordered by events, not by the gate
                 graph["gside"][i].replay()         # starts when this step has enqueued its encoder (device-side gate); fills the other buffers
                 ev = torch.cuda.Event()
                 ev.record(side)
             graph["side_ev"][1 - i] = ev
+            graph["prev_end"] = end
         else:
             graph["g"][i].replay()
         if not ADAM_IN_GRAPH:

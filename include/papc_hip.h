@@ -37,6 +37,18 @@ typedef void *papc_stream_t; /* hipStream_t */
 
 /* library version (major*10000 + minor*100 + patch) */
 int papc_version(void);
+/* ABI of the descriptor structs below.  They carry no size field: optional trailing fields have been appended round by round (papc_group_src.wstat,
+ * papc_group_max.sign_src, papc_bwd_dy.psel, papc_sa_grads.defer, papc_pfn_io.tickets, papc_pfn_desc.zero_padded, ...), and a kernel dereferences
+ * or writes through whatever such a pointer holds.  The contract therefore is:
+ *   (1) ZERO-INITIALISE every descriptor struct (memset / = {0}) before setting fields -- NULL / 0 in an optional field always selects the
+ *       behaviour the library had before the field existed;
+ *   (2) a caller compiled against this header checks papc_abi_version() == PAPC_ABI_VERSION once after loading the library (the number changes
+ *       whenever a struct's layout or a function's signature does; papc_amd/_lib.py refuses a mismatching library);
+ *   (3) a binding that mirrors the structs by hand (ctypes, cgo, JNA) can compare its sizes with papc_abi_sizeof("papc_sa_io") etc.
+ *       (-1 for an unknown name; tests/test_abi.py does this for every ctypes mirror in papc_amd/). */
+#define PAPC_ABI_VERSION 6
+int papc_abi_version(void);
+int64_t papc_abi_sizeof(const char *struct_name);
 /* text of the last error raised on this thread ("" if none) */
 const char *papc_last_error_string(void);
 
@@ -373,10 +385,10 @@ int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t strea
 #define PAPC_SA_NO_COMPACT 32u
 #define PAPC_SA_NO_PLANES 64u            /* few-row stacks (sample_and_group_all, M <= 16 384) on the row kernels instead of the planes kernels */
 #define PAPC_SA_NO_PLANES_POINTWISE 128u /* ... only the un-pooled point-wise stacks */
-#define PAPC_SA_NO_XYZ_FUSE 256u
+#define PAPC_SA_NO_XYZ_FUSE 256u         /* the dX above a coordinates-only first layer stored + papc_xyz_l1_bwd_f32 instead of papc_mlp_bwd_dx_xyz_f32 */
 #define PAPC_SA_NO_PSEL 1024u           /* compacted max layer: its dX kernel recomputes scale * p per row from gout instead of streaming the reduction's psel */
 #define PAPC_SA_NO_GSIGN 2048u          /* fused group max: both extrema per channel instead of the one sign(gamma) selects */
-#define PAPC_SA_NO_WSTATS 512u          /* compacted stack: unweighted statistics + one papc_bn_stats_corr_f32 launch per layer instead of weighted ones */        /* the dX above a coordinates-only first layer stored + papc_xyz_l1_bwd_f32 instead of papc_mlp_bwd_dx_xyz_f32 */
+#define PAPC_SA_NO_WSTATS 512u          /* compacted stack: unweighted statistics + one papc_bn_stats_corr_f32 launch per layer instead of weighted ones */
 typedef struct papc_sa_desc {
     int32_t B, N, S, K, D;
     int32_t n_layers;
@@ -899,10 +911,15 @@ int papc_adam_step_zero_f32(float *param, float *grad, float *exp_avg, float *ex
  * for itself: step_dev is then TWO int64 ([0] the number of the last step applied, [1] zero), the kernel applies step [0] + 1 and its
  * last-finishing block stores that number (no papc_adam_tick launch: for a step that has no side branch to hide one on). */
 int papc_adam_tick(int64_t *step_dev, papc_stream_t stream);
-/* A device-side gate between two streams (bench.py --side-graph): papc_flag_wait spins (one wave, bounded by max_spins sleeps of ~1 us) until the
- * word is non-zero, then returns it to zero; papc_flag_set stores `value` (agent scope).  For two hipGraphs on two streams that must not be joined
+/* A device-side gate between two streams (bench.py --side-graph).  `flag` = FOUR zero-initialised uint32 words owned by the gate: [0] openings so far,
+ * [1] openings waited for so far, [2] sticky count of waits that gave up, [3] reserved.  papc_flag_set adds `value` (1) to [0] (release, agent
+ * scope); papc_flag_wait (one lane) spins, bounded by max_spins sleeps of ~1 us, until opening number [1] + 1 has happened, then advances [1].  A
+ * wait that gives up increments [2] and still advances [1], so the late opening behind it does not let the NEXT wait through early; the host
+ * reads [2] (a plain copy of the word) and must treat a non-zero value as an error.  For two hipGraphs on two streams that must not be joined
  * by a graph edge (a forked branch costs the main chain ~60 us per replay on MI355X) but where the second has to start behind a point of the first.
- * The launch that sets the word must be enqueued BEFORE the one that waits when both streams may share a hardware queue. */
+ * The gate only PLACES work; whatever buffers the two streams share must also be ordered by stream events (bench.py does: the gated graph waits
+ * for the end-of-step event of the previous step before it is replayed).  The launch that opens must be enqueued BEFORE the one that waits when
+ * both streams may share a hardware queue. */
 int papc_flag_set(uint32_t *flag, uint32_t value, int64_t *counter, papc_stream_t stream);
 int papc_flag_wait(uint32_t *flag, int64_t max_spins, papc_stream_t stream);
 int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,

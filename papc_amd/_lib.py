@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPC_LIB") or os.path.join(_HERE, "libpapc_hip.so")   # PAPC_LIB: A/B a second build of the library
 
+ABI_VERSION = 6          # include/papc_hip.h: PAPC_ABI_VERSION
+
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
 c_l = ctypes.c_int64
@@ -63,6 +65,8 @@ class ScatterDst(ctypes.Structure):
 # every exported symbol of include/papc_hip.h: name -> (restype, argtypes)
 SIGNATURES = {
     "papc_version": (c_i, []),
+    "papc_abi_version": (c_i, []),
+    "papc_abi_sizeof": (c_l, [ctypes.c_char_p]),
     "papc_last_error_string": (ctypes.c_char_p, []),
     "papc_fps_f32": (c_i, [c_p, c_l, c_l, c_l, c_i, c_i, c_i, c_p, c_f, c_p, c_p, c_p]),
     "papc_ball_query_f32": (c_i, [c_p, c_l, c_l, c_l, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
@@ -200,6 +204,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.papc_abi_version() != ABI_VERSION:   # the structs this package mirrors by hand would not match the library's
+            raise PapcError("libpapc_hip.so speaks ABI %d, this package ABI %d (include/papc_hip.h: PAPC_ABI_VERSION): rebuild with "
+                            "`python -m papc_amd.build`" % (lib.papc_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

@@ -427,18 +427,29 @@ __global__ void adam_tick_kernel(int64_t *step_dev) { step_dev[0] += 1; }
 // ---- a device-side gate between two streams (papc_flag_set / papc_flag_wait) -----------------------------------------------------------------
 // A forked branch inside a replayed hipGraph costs the MAIN chain ~60 us per step on MI355X whatever the branch holds (bench.py, round 5: an
 // empty branch = fork + join).  Two graphs on two streams with no edge between them cost nothing -- but the second one must not start before the
-// first has reached a given point.  The gate is one lane spinning on a word the other stream's launch sets (agent scope, it returns the word to
-// zero); bounded by `max_spins` sleeps so that a mis-ordered launch sequence ends in a late start, never in a hang.
+// first has reached a given point.  The gate is FOUR 32-bit words: [0] the number of openings so far (papc_flag_set adds `value`, release, agent
+// scope), [1] the number of openings waited for so far (owned by the waiting stream), [2] a STICKY count of waits that gave up, [3] reserved.
+// A wait expects opening number [1] + 1 and spins (one lane, bounded by `max_spins` sleeps so that a mis-ordered launch sequence cannot hang the
+// queue) until [0] has reached it; it never writes [0], so a wait that gave up and the late opening behind it leave the two counts aligned --
+// the next wait expects the NEXT opening (rounds 4-5 used one word that the wait returned to zero: a late opening then left a stale 1 and every
+// later wait passed one opening early, silently).  A give-up is counted in [2] for the host to read and abort on (papc_flag_timeouts' contract:
+// correctness of whatever the gate orders must not rest on it once [2] != 0).
 __global__ void flag_set_kernel(unsigned *flag, unsigned value, int64_t *counter)
 {
     if (counter) counter[0] += 1;        // (a step counter riding on the same launch: FlatAdam's device step count)
-    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ void flag_wait_kernel(unsigned *flag, long long max_spins)
 {
+    if (threadIdx.x != 0) return;
+    const unsigned want = flag[1] + 1u;
     long long n = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && n < max_spins) { __builtin_amdgcn_s_sleep(32); ++n; }
-    __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+        if (n >= max_spins) { __hip_atomic_fetch_add(flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        __builtin_amdgcn_s_sleep(32);
+        ++n;
+    }
+    flag[1] = want;
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ p, int64_t n, float v)

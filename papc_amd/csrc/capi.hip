@@ -140,7 +140,40 @@ static void prof_drain(int k)
 
 extern "C" {
 
-int papc_version(void) { return 100; /* 0.1.0 */ }
+int papc_version(void) { return 600; /* 0.6.0 */ }
+
+int papc_abi_version(void) { return PAPC_ABI_VERSION; }
+
+int64_t papc_abi_sizeof(const char *struct_name)
+{
+    if (!struct_name) return -1;
+#define PAPC_SIZEOF(T) if (strcmp(struct_name, #T) == 0) return (int64_t)sizeof(T);
+    PAPC_SIZEOF(papc_group_src)
+    PAPC_SIZEOF(papc_group_max)
+    PAPC_SIZEOF(papc_bwd_dy)
+    PAPC_SIZEOF(papc_scatter_dst)
+    PAPC_SIZEOF(papc_bwd_red)
+    PAPC_SIZEOF(papc_reduce_job)
+    PAPC_SIZEOF(papc_fold_job)
+    PAPC_SIZEOF(papc_fold_list)
+    PAPC_SIZEOF(papc_sa_desc)
+    PAPC_SIZEOF(papc_sa_layer)
+    PAPC_SIZEOF(papc_compact_src)
+    PAPC_SIZEOF(papc_sa_io)
+    PAPC_SIZEOF(papc_sa_plan)
+    PAPC_SIZEOF(papc_sa_grads)
+    PAPC_SIZEOF(papc_pfn_desc)
+    PAPC_SIZEOF(papc_pfn_io)
+    PAPC_SIZEOF(papc_head_fc_layer)
+    PAPC_SIZEOF(papc_head_bwd_job)
+    PAPC_SIZEOF(papc_pg_wjob)
+    PAPC_SIZEOF(papc_pg_prep)
+    PAPC_SIZEOF(papc_pg_gemm)
+    PAPC_SIZEOF(papc_pg_fold_job)
+    PAPC_SIZEOF(papc_copy_job)
+#undef PAPC_SIZEOF
+    return -1;
+}
 
 const char *papc_last_error_string(void) { return papc::g_err; }
 

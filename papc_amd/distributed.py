@@ -111,20 +111,52 @@ class FlatAdam:
         self.v = torch.zeros_like(flat.data)
         self.t = 0
         self.t_dev = torch.zeros(2, dtype=torch.int64, device=flat.data.device)   # [0] the step count for the graph-capturable form (tick / step_dev), [1] the self-ticking launch's ticket
+        # ONE step count, two homes: the host integer (step) and the device word (tick / step_dev, so that the update can sit inside a captured
+        # hipGraph).  Whichever path ran last owns the count; switching paths carries it over (device -> host costs one synchronising read, host ->
+        # device one fill ahead of the launch -- never inside a stream capture, where a baked-in fill would reset the count at every replay)
+        self._owner = "host"
+
+    def _to_dev(self):
+        if self._owner == "host":
+            if self.t_dev.is_cuda and torch.cuda.is_current_stream_capturing():
+                if self.t != 0:
+                    raise RuntimeError("FlatAdam: the step count lives on the host (step() ran last); run one eager tick() / step_dev() before capturing "
+                                       "the device-counted update into a graph")
+            elif self.t != 0:                       # (a fresh optimiser: both counts are zero already)
+                self.t_dev[0].fill_(self.t)
+            self._owner = "dev"
+
+    def step_count(self):
+        """The number of updates applied so far, whichever path applied them (reads the device word when it owns the count: synchronises)."""
+        return int(self.t_dev[0].item()) if self._owner == "dev" else self.t
+
+    def state_dict(self):
+        return {"step": self.step_count(), "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone()}
+
+    def load_state_dict(self, sd):
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
+        self.t = int(sd["step"])
+        self.t_dev[0].fill_(self.t)
+        self.t_dev[1].fill_(0)
+        self._owner = "host"
 
     def tick(self):
         """Advance the DEVICE step count (one-thread launch).  Enqueue it anywhere earlier in the step than :meth:`step_dev` -- e.g. on the
         sampling branch, off the critical path -- and both can be captured into a hipGraph."""
         from . import _lib
+        self._to_dev()
         _lib.check(_lib.load().papc_adam_tick(self.t_dev.data_ptr(), _lib.stream_ptr()), "papc_adam_tick")
 
     def step_dev(self, grad_scale=1.0, zero_grad=False, self_tick=False):
         """:meth:`step` with the step count read from device memory (advanced by :meth:`tick`): no host scalar changes between steps, so
         the launch can sit inside a captured hipGraph behind the last backward kernel (an eager launch behind a graph replay starts
-        8-20 us late).  ``self.t`` (host) is not maintained on this path: read ``t_dev``.  ``self_tick=True``: no :meth:`tick` launch, the
+        8-20 us late).  ``self.t`` (host) is not advanced on this path: :meth:`step_count` reads whichever count is current, and a later :meth:`step`
+        picks the device count up.  ``self_tick=True``: no :meth:`tick` launch, the
         kernel advances the count itself (its last-finishing block) -- for a step with no side branch to put the tick on."""
         from . import _lib
         f = self.flat
+        self._to_dev()
         if self_tick and f.numel > 64 * 256:
             # the self-ticking form costs one same-address atomic per 256-parameter block: measured +33 us at 3 200 blocks (PointNet-Basic), -4 us
             # at 3 (PillarFeatureNet).  Large buckets take the one-thread tick launch
@@ -138,6 +170,9 @@ class FlatAdam:
         """``zero_grad=True``: the kernel also clears the flat gradient bucket behind the update (papc_adam_step_zero_f32), so a
         training loop whose every backward is followed by a step needs no ``FlatParams.zero_grad()`` launch."""
         from . import _lib
+        if self._owner == "dev":
+            self.t = int(self.t_dev[0].item())     # the device-counted path ran last (synchronises; only on a change of path)
+            self._owner = "host"
         self.t += 1
         f = self.flat
         fn = _lib.load().papc_adam_step_zero_f32 if zero_grad else _lib.load().papc_adam_step_f32

@@ -60,3 +60,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_abi_version_and_struct_sizes():
+    """Every ctypes mirror of a descriptor struct in papc_amd/ has the size the library was compiled with (papc_abi_sizeof), the header's
+    PAPC_ABI_VERSION is what the library and the binding report, and every struct of the header is known to papc_abi_sizeof."""
+    import importlib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "papc_hip.h")).read()
+    assert int(re.search(r"#define PAPC_ABI_VERSION (\d+)", hdr).group(1)) == lib.papc_abi_version() == _lib.ABI_VERSION
+    for name in re.findall(r"^typedef struct (papc_[a-z0-9_]+)", hdr, flags=re.M):
+        assert lib.papc_abi_sizeof(name.encode()) > 0, name
+    assert lib.papc_abi_sizeof(b"no_such_struct") == -1 and lib.papc_abi_sizeof(None) == -1
+    mirrors = {"_lib": {"GroupSrc": "papc_group_src", "BwdDy": "papc_bwd_dy", "GroupMax": "papc_group_max", "BwdRed": "papc_bwd_red",
+                        "CopyJob": "papc_copy_job", "ReduceJob": "papc_reduce_job", "ScatterDst": "papc_scatter_dst"},
+               "folds": {"FoldJob": "papc_fold_job", "FoldList": "papc_fold_list"},
+               "head": {"HeadFcLayer": "papc_head_fc_layer", "HeadBwdJob": "papc_head_bwd_job"},
+               "pillars": {"PfnDesc": "papc_pfn_desc", "PfnIo": "papc_pfn_io"},
+               "smallm": {"PgWJob": "papc_pg_wjob", "PgPrep": "papc_pg_prep", "PgGemm": "papc_pg_gemm", "PgFoldJob": "papc_pg_fold_job"},
+               "stack": {"SaDesc": "papc_sa_desc", "SaLayer": "papc_sa_layer", "CompactSrc": "papc_compact_src", "SaIo": "papc_sa_io",
+                         "SaPlan": "papc_sa_plan", "SaGrads": "papc_sa_grads"}}
+    for mod, table in mirrors.items():
+        m = importlib.import_module("papc_amd." + mod)
+        for cls, cname in table.items():
+            assert ctypes.sizeof(getattr(m, cls)) == lib.papc_abi_sizeof(cname.encode()), (mod, cls, cname)

@@ -15,12 +15,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(tmp_path, name, lr, *flags):
+def _bench(tmp_path, name, lr, *flags, env_extra=None, expect_fail=False):
     out = str(tmp_path / (name + ".npz"))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline",
                         "--lr", lr, "--dump-trajectory", out, *flags], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
+    if expect_fail:
+        assert r.returncode != 0, "bench.py was expected to abort: " + r.stdout[-500:]
+        return None, r.stderr
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     return np.load(out), line
@@ -62,6 +65,32 @@ def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
     assert moved >= 5e-5, moved
     assert dl <= max(3 * noise_l, 5e-4), (dl, noise_l)
     assert dp <= max(3 * noise_p, 1e-4), (dp, noise_p)
+
+
+def test_side_graph_survives_a_main_stream_stall(tmp_path):
+    """Round-5 review: the sampling graph's device-side gate gave up after ~35 ms and "started anyway", after which every later pyramid ran one
+    gate early and could overwrite a plan under the previous step's backward.  Now (i) the gate counts openings, so a give-up cannot shift the
+    sequence, (ii) the side graph also waits for the previous step's end-of-step EVENT before it touches the shared buffers, (iii) a give-up is a
+    sticky error bench.py aborts on.  Here the main stream is stalled ~60 ms ahead of every third timed step (a spinning kernel, > the old 35 ms
+    bound): the loss trajectory at lr = 0 must equal the eager in-line structure's bit for bit -- with the default bound (the gate simply holds),
+    and with a bound of ~2 ms (every stalled step's gate gives up: the events alone keep the buffers ordered; bench.py must report the give-ups,
+    and abort unless told otherwise)."""
+    import json
+    e, _ = _bench(tmp_path, "eager0", "0", "--no-graph", "--no-overlap")
+    g, line = _bench(tmp_path, "stall0", "0", "--diag-stall-ms", "60")
+    assert int(g["graph"]) == 1 and "a second hipGraph on the side stream" in line
+    assert json.loads(line)["config"]["gate_timeouts"] == 0
+    assert np.array_equal(g["loss"], e["loss"]), (g["loss"], e["loss"])
+    t, line_t = _bench(tmp_path, "stall1", "0", "--diag-stall-ms", "60", "--allow-gate-timeout", env_extra={"PAPC_GATE_SPINS": "2000"})
+    assert json.loads(line_t)["config"]["gate_timeouts"] >= 2, line_t
+    assert np.array_equal(t["loss"], e["loss"]), (t["loss"], e["loss"])
+    gs = float(np.max(np.abs(e["grad"])))
+    for name, r in (("gate holds", g), ("gate gives up", t)):
+        dg = float(np.max(np.abs(r["grad"] - e["grad"]))) / gs
+        print("stalled main stream, %s: losses bit-identical, gradient diff %.2e of max |g|" % (name, dg))
+        assert dg <= 1e-5, (name, dg)
+    _, err = _bench(tmp_path, "stall2", "0", "--diag-stall-ms", "60", env_extra={"PAPC_GATE_SPINS": "2000"}, expect_fail=True)
+    assert "gave up" in err, err[-500:]
 
 
 def test_store_red_stream_kernel_bit_identical_beside_sampling_stream(dev):

@@ -97,3 +97,42 @@ def test_deferred_folds_equal_per_stack_folds(dev):
         # (the gather-add backward's float atomics make two runs differ in the last bits whatever the fold does)
         assert_close(g1, g0, 2e-5, "flat gradient, deferred vs per-stack folds (graph=%s)" % graph)
     assert np.abs(g0).max() > 0
+
+
+def test_failed_backward_leaves_no_stale_fold_jobs(dev):
+    """A backward that raises after a stack has queued its folds (here: a hook on l2_points, i.e. behind SA3's backward) never runs the
+    engine's final callbacks.  The NEXT pass must fold exactly its own jobs: gradients equal the per-stack-fold result (round-5 advisor
+    finding: the armed thread-local list kept the stale jobs and skipped the registration of every later pass)."""
+    l0, g0 = _step(dev, False, False)
+    old = folds.ENABLED
+    folds.ENABLED = True
+    try:
+        B, N = 4, 1024
+        torch.manual_seed(11)
+        model = PointNet2_SSG_Clas(num_classes=16).to(dev).train()
+        model.drop1.p = model.drop2.p = 0.0
+        flat = FlatParams(model)
+        x = torch.from_numpy(make_clouds(B, N, 3)).to(dev)
+        y = torch.from_numpy(make_labels(B, 16, 3)).reshape(-1).to(dev)
+        st = (torch.from_numpy(make_start_idx(B, N, 3)).to(dev), torch.from_numpy(make_start_idx(B, 512, 4)).to(dev))
+        one = torch.ones((), device=dev)
+
+        def boom(g):
+            raise RuntimeError("injected failure behind SA3's backward")
+
+        tap = {}
+        loss = softmax_cross_entropy(model(x, st, tap=tap), y)
+        tap["l2_points"].register_hook(boom)
+        with pytest.raises(RuntimeError, match="injected"):
+            loss.backward(one)
+        torch.cuda.synchronize()
+        assert len(folds._live) == 1 and next(iter(folds._live.values())).lst.count > 0     # the failed pass's jobs were never folded
+        flat.zero_grad()
+        loss = softmax_cross_entropy(model(x, st), y)
+        loss.backward(one)
+        torch.cuda.synchronize()
+        assert float(loss) == l0
+        assert_close(flat.grad.detach().cpu().numpy(), g0, 2e-5, "flat gradient of the pass after a failed one")
+    finally:
+        folds.ENABLED = old
+        folds._live.clear()

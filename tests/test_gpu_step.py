@@ -280,16 +280,28 @@ def test_adam_device_step_count_equals_host_form(dev):
                 opt.step_dev(0.5, zero_grad=True)
             elif mode == "selftick":         # the launch advances the count itself (its last-finishing block; 6 blocks here)
                 opt.step_dev(0.5, zero_grad=True, self_tick=True)
+            elif mode == "mixed":            # eager warm-up on the host count, then device-counted steps, then the host path again: ONE count
+                if k < 2 or k == 6:
+                    opt.step(0.5, zero_grad=True)
+                else:
+                    opt.tick()
+                    opt.step_dev(0.5, zero_grad=True)
             else:
                 g.replay()
         torch.cuda.synchronize()
         assert float(flat.grad.abs().max()) == 0.0
-        if mode != "host":
+        assert opt.step_count() == 7
+        if mode not in ("host", "mixed"):
             assert int(opt.t_dev[0].item()) == 7 and int(opt.t_dev[1].item()) == 0
+        sd = opt.state_dict()
+        assert sd["step"] == 7
+        opt2 = FlatAdam(flat)
+        opt2.load_state_dict(sd)
+        assert opt2.step_count() == 7 and torch.equal(opt2.m, opt.m)
         return flat.data.detach().cpu().numpy().copy(), opt.m.cpu().numpy().copy(), opt.v.cpu().numpy().copy()
 
     ref = run("host")
-    for mode in ("dev", "graph", "selftick", "graph_selftick"):
+    for mode in ("dev", "graph", "selftick", "graph_selftick", "mixed"):
         got = run(mode)
         for a, b, nm in zip(got, ref, ("param", "exp_avg", "exp_avg_sq")):
             assert_close(a, b, 1e-6, "Adam %s, %s step count vs host scalar" % (nm, mode))
@@ -312,9 +324,11 @@ def test_unit_gradient_seed_skips_the_scale_launch(dev):
 
 def test_flag_gate_orders_two_streams(dev):
     """papc_flag_wait on one stream holds that stream's later launches back until papc_flag_set runs on another (the device-side gate of
-    bench.py's side-graph structure); the word returns to zero; the same launch advances an int64 counter; a gate nobody opens times out."""
+    bench.py's side-graph structure).  The gate counts: word 0 = openings, word 1 = openings waited for, word 2 = sticky count of waits that gave
+    up; the opening launch also advances an int64 counter.  A wait that gives up and the LATE opening behind it must not let the next wait
+    through early (round 5's single word did: it was returned to zero by the wait, so the late store left a stale 1)."""
     lib = _lib.load()
-    flag = torch.zeros(2, dtype=torch.int32, device=dev)
+    flag = torch.zeros(4, dtype=torch.int32, device=dev)
     cnt = torch.zeros(2, dtype=torch.int64, device=dev)
     a, b = torch.cuda.Stream(), torch.cuda.Stream()
     buf = torch.zeros(1 << 20, device=dev)
@@ -322,7 +336,7 @@ def test_flag_gate_orders_two_streams(dev):
     torch.cuda.synchronize()
     for rep in range(5):
         # (the setter is enqueued first, as the header asks: two streams may share a hardware queue, where a gate ahead of its setter would spin
-        # until it times out)
+        # until it gives up)
         with torch.cuda.stream(a):
             torch.cuda._sleep(2_000_000)                 # ~1 ms of spinning on stream a
             buf.fill_(float(rep + 1))
@@ -332,8 +346,22 @@ def test_flag_gate_orders_two_streams(dev):
             out.copy_(buf)
         torch.cuda.synchronize()
         assert float(out.min()) == float(out.max()) == float(rep + 1)
-        assert int(flag[0]) == 0 and int(cnt[0]) == rep + 1
-    with torch.cuda.stream(b):                           # nobody opens: bounded spinning, then it goes on
+        assert flag.tolist() == [rep + 1, rep + 1, 0, 0] and int(cnt[0]) == rep + 1
+    # a wait nobody opens in time: bounded spinning, counted, and the late opening does NOT open the next wait
+    with torch.cuda.stream(b):
         _lib.check(lib.papc_flag_wait(flag.data_ptr(), 200, b.cuda_stream), "papc_flag_wait")
     torch.cuda.synchronize()
-    assert int(flag[0]) == 0
+    assert flag.tolist() == [5, 6, 1, 0]
+    with torch.cuda.stream(a):                           # the late opening (number 6)
+        _lib.check(lib.papc_flag_set(flag.data_ptr(), 1, None, a.cuda_stream), "papc_flag_set")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):                           # opening number 7 arrives ~1 ms after the wait for it starts
+        torch.cuda._sleep(2_000_000)
+        buf.fill_(77.0)
+        _lib.check(lib.papc_flag_set(flag.data_ptr(), 1, None, a.cuda_stream), "papc_flag_set")
+    with torch.cuda.stream(b):
+        _lib.check(lib.papc_flag_wait(flag.data_ptr(), 400000, b.cuda_stream), "papc_flag_wait")
+        out.copy_(buf)
+    torch.cuda.synchronize()
+    assert float(out.min()) == float(out.max()) == 77.0, "the wait behind a late opening passed one opening early"
+    assert flag.tolist() == [7, 7, 1, 0]

@@ -1,4 +1,5 @@
 """CPU tests of the host-side logic (no GPU compute)."""
+import pytest
 import numpy as np
 import torch
 
@@ -130,3 +131,49 @@ def test_checkpoint_pointnet_basic_reference_names_and_restricted_pickle(tmp_pat
         pickle.dump({"fc.0.weight": Evil()}, f, protocol=2)
     with pytest.raises(pickle.UnpicklingError):
         C.load_pdparams(bad)
+
+
+def test_deferred_fold_list_survives_a_backward_that_raises(monkeypatch):
+    """papc_amd/folds.py: a backward pass that raises never runs the engine's final callbacks; the next pass must get a FRESH list and
+    its own callback (advisor finding, round 5: the thread-local state stayed armed with stale jobs and later folds were skipped), and the
+    callback must work from a thread that never called pending()."""
+    import torch
+    from papc_amd import folds
+    launched = []
+    monkeypatch.setattr(folds, "_cur_stream", lambda: "s0")
+    monkeypatch.setattr(folds, "_launch", lambda p: launched.append((p.task_id, p.lst.count)))
+    monkeypatch.setattr(folds, "ENABLED", True)
+    folds._live.clear()
+
+    class Stack(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, fail):
+            ctx.fail = fail
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            lst = folds.pending(["scratch"])
+            assert lst is not None
+            lst.contents.count += 2                 # what papc_sa_mlp_bwd does: append jobs
+            if ctx.fail:
+                raise RuntimeError("boom")
+            return g * 2, None
+
+    assert folds.pending([]) is None                # not inside a backward pass
+    x = torch.ones(3, requires_grad=True)
+    with pytest.raises(RuntimeError):
+        Stack.apply(Stack.apply(x, True), False).sum().backward()
+    assert launched == [] and len(folds._live) == 1         # the failed pass left its entry behind
+    Stack.apply(Stack.apply(x, False), False).sum().backward()
+    assert len(launched) == 1 and launched[0][1] == 4       # the next pass folded exactly its own four jobs
+    assert len(folds._live) == 1                            # (the stale entry: bounded, dropped below)
+    for _ in range(folds.MAX_LIVE + 2):
+        with pytest.raises(RuntimeError):
+            Stack.apply(x, True).sum().backward()
+    assert len(folds._live) <= folds.MAX_LIVE
+    stale = list(folds._live.values())
+    Stack.apply(x, False).sum().backward()
+    assert launched[-1][1] == 2
+    assert all(q.keep == ["scratch"] or (q.done and not q.keep) for q in stale)
+    folds._live.clear()
