@@ -586,7 +586,9 @@ int papc_pillar_scatter_bwd_f32(const float *grad_canvas, const int32_t *coords,
  * Cin % 4 == 0.  has_bn = 2: ReLU + dropout without a norm (the PointNet-Basic head, classify/pointnet_base/pointnet_base.py:26-33;
  * gamma / beta / mean / invstd unused, y optional).  has_bn = 1: train-mode BatchNorm1D over the B rows (biased variance, eps), running_mean/var updated with `momentum`
  * (new = (1-m) old + m batch, BIASED batch variance -- the paddle.nn.BatchNorm1D convention; nullable), num_batches_tracked[0] += 1 (nullable); y [B,Cout] (linear output),
- * mean/invstd [Cout] are saved for the backward.  Dropout p = drop_p in upscale_in_train mode from a counter-based hash of
+ * mean/invstd [Cout] are saved for the backward.  has_bn = 3: EVAL-mode BatchNorm1D (model.eval(): the head's norms are registered layers): running_mean /
+ * running_var (required, read only) normalise, nothing is updated, mean / invstd (nullable) receive running_mean and 1/sqrt(running_var + eps);
+ * papc_head_bwd_f32 with has_bn = 3 is the backward through the frozen norm (no batch-mean terms).  Dropout p = drop_p in upscale_in_train mode from a counter-based hash of
  * rng_state = {seed, counter} (device int64[2]; null or drop_p == 0: none); keep [B,Cout] (uint8, nullable) receives the mask;
  * rng_bump (nullable, the same int64[2]): counter += 1 at the end of this launch -- pass it on the head's last layer.
  * papc_head_bwd_f32 for layer l: g = gnext . wnext (gnext [B,Cn] = dY of layer l+1, wnext [Cn,Cout]; wnext null: g = gnext),

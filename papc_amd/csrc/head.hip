@@ -254,7 +254,19 @@ __device__ __forceinline__ void head_fwd_body(const HeadFwd &a, const int bx)
             s_scale[tid] = invstd * a.gamma[c];
             s_shift[tid] = a.beta[c];
         }
-        if (tid == 0 && bx == 0 && a.num_batches_tracked) a.num_batches_tracked[0] += 1;
+        if (tid < ncol && a.has_bn == 3) {
+            // eval-mode BatchNorm1D (model.eval(): classify/pointnet2/pointnet2.py:18,21 are registered layers): the RUNNING statistics normalise,
+            // nothing is updated; mean / invstd are handed out for a backward through the frozen norm
+            const int c = c0 + tid;
+            const float rm = a.running_mean[c];
+            const float invstd = 1.0f / sqrtf(a.running_var[c] + a.eps);
+            if (a.mean) a.mean[c] = rm;
+            if (a.invstd) a.invstd[c] = invstd;
+            s_mean[tid] = rm;
+            s_scale[tid] = invstd * a.gamma[c];
+            s_shift[tid] = a.beta[c];
+        }
+        if (tid == 0 && bx == 0 && a.num_batches_tracked && a.has_bn == 1) a.num_batches_tracked[0] += 1;
     }
     __syncthreads();
     uint64_t seed = 0, counter = 0;
@@ -268,8 +280,8 @@ __device__ __forceinline__ void head_fwd_body(const HeadFwd &a, const int bx)
         const float yv = tile[b * TP + t];
         if (a.y) a.y[o] = yv;
         float v = yv;
-        if (a.has_bn) {                   // 1: BatchNorm + ReLU + dropout; 2: ReLU + dropout (pointnet_base.py:26-33 has no norm in its head)
-            if (a.has_bn == 1) v = (yv - s_mean[t]) * s_scale[t] + s_shift[t];
+        if (a.has_bn) {                   // 1: BatchNorm + ReLU + dropout; 2: ReLU + dropout (pointnet_base.py:26-33 has no norm in its head); 3: eval-mode norm
+            if (a.has_bn != 2) v = (yv - s_mean[t]) * s_scale[t] + s_shift[t];
             v = fmaxf(v, 0.f);
             bool k = true;
             if (drop) k = hash_uniform(seed, counter, (uint32_t)a.layer_tag, (uint32_t)o) >= a.drop_p;
@@ -372,8 +384,9 @@ __device__ __forceinline__ void head_bwd_body(const HeadBwd &a, const int bx, co
             } else {
                 s_k1[tid] = 0.f;
             }
-            s_k2[tid] = sg / (float)a.B;
-            s_k3[tid] = sgx / (float)a.B;
+            // (3 = eval-mode norm: the statistics are constants, so the batch-mean terms of the train-mode backward vanish)
+            s_k2[tid] = a.has_bn == 3 ? 0.f : sg / (float)a.B;
+            s_k3[tid] = a.has_bn == 3 ? 0.f : sgx / (float)a.B;
         }
         __syncthreads();
         for (int e = tid; e < Bpad * 32; e += HT) {
@@ -584,8 +597,9 @@ int papc_head_fc_f32(const float *x, const float *w, const float *bias, const fl
     PAPC_REQUIRE(x && w && out, PAPC_E_INVALID, "papc_head_fc_f32: null pointer");
     PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_fc_f32: B=%d not in [1, %d]", B, HROWS_MAX);
     PAPC_REQUIRE(Cin >= 4 && Cin % 4 == 0 && Cout >= 1, PAPC_E_INVALID, "papc_head_fc_f32: Cin=%d must be a multiple of 4", Cin);
-    PAPC_REQUIRE(has_bn >= 0 && has_bn <= 2, PAPC_E_INVALID, "papc_head_fc_f32: has_bn=%d not in {0, 1, 2}", has_bn);
+    PAPC_REQUIRE(has_bn >= 0 && has_bn <= 3, PAPC_E_INVALID, "papc_head_fc_f32: has_bn=%d not in {0, 1, 2, 3}", has_bn);
     PAPC_REQUIRE(has_bn != 1 || (gamma && beta && mean && invstd && y), PAPC_E_INVALID, "papc_head_fc_f32: BatchNorm needs gamma/beta/mean/invstd/y");
+    PAPC_REQUIRE(has_bn != 3 || (gamma && beta && running_mean && running_var), PAPC_E_INVALID, "papc_head_fc_f32: eval-mode BatchNorm needs gamma/beta/running_mean/running_var");
     PAPC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, PAPC_E_INVALID, "papc_head_fc_f32: drop_p=%f", (double)drop_p);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_MISC, st);
@@ -607,8 +621,8 @@ int papc_head_bwd_f32(const float *gnext, const float *wnext, int Cn, const floa
     PAPC_REQUIRE(B >= 1 && B <= HROWS_MAX, PAPC_E_INVALID, "papc_head_bwd_f32: B=%d not in [1, %d]", B, HROWS_MAX);
     PAPC_REQUIRE(Cout >= 1 && (!wnext || (Cn >= 4 && Cn % 4 == 0)), PAPC_E_INVALID, "papc_head_bwd_f32: Cn=%d must be a multiple of 4", Cn);
     PAPC_REQUIRE(wnext || Cn == Cout, PAPC_E_INVALID, "papc_head_bwd_f32: without wnext, gnext must be [B, Cout]");
-    PAPC_REQUIRE(has_bn >= 0 && has_bn <= 2, PAPC_E_INVALID, "papc_head_bwd_f32: has_bn=%d not in {0, 1, 2}", has_bn);
-    PAPC_REQUIRE(has_bn != 1 || (out && y && mean && invstd && gamma && dgamma && dbeta), PAPC_E_INVALID, "papc_head_bwd_f32: BatchNorm backward needs the saved forward");
+    PAPC_REQUIRE(has_bn >= 0 && has_bn <= 3, PAPC_E_INVALID, "papc_head_bwd_f32: has_bn=%d not in {0, 1, 2, 3}", has_bn);
+    PAPC_REQUIRE((has_bn != 1 && has_bn != 3) || (out && y && mean && invstd && gamma && dgamma && dbeta), PAPC_E_INVALID, "papc_head_bwd_f32: BatchNorm backward needs the saved forward");
     PAPC_REQUIRE(has_bn != 2 || out, PAPC_E_INVALID, "papc_head_bwd_f32: ReLU backward needs the layer's output");
     PAPC_REQUIRE(!x || (dw && Cin >= 1), PAPC_E_INVALID, "papc_head_bwd_f32: x without dw");
     PAPC_REQUIRE(drop_p >= 0.f && drop_p < 1.f, PAPC_E_INVALID, "papc_head_bwd_f32: drop_p=%f", (double)drop_p);
@@ -654,8 +668,9 @@ int papc_head_chain_fwd_f32(const papc_head_fc_layer *layers, int n_layers, int 
         const papc_head_fc_layer &l = layers[i];
         PAPC_REQUIRE(l.x && l.w && l.out, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: null pointer", i);
         PAPC_REQUIRE(l.Cin >= 4 && l.Cin % 4 == 0 && l.Cout >= 1, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: Cin=%d must be a multiple of 4", i, l.Cin);
-        PAPC_REQUIRE(l.has_bn >= 0 && l.has_bn <= 2, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: has_bn=%d", i, l.has_bn);
+        PAPC_REQUIRE(l.has_bn >= 0 && l.has_bn <= 3, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: has_bn=%d", i, l.has_bn);
         PAPC_REQUIRE(l.has_bn != 1 || (l.gamma && l.beta && l.mean && l.invstd && l.y), PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: BatchNorm needs gamma/beta/mean/invstd/y", i);
+        PAPC_REQUIRE(l.has_bn != 3 || (l.gamma && l.beta && l.running_mean && l.running_var), PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: eval-mode BatchNorm needs gamma/beta/running statistics", i);
         PAPC_REQUIRE(l.drop_p >= 0.f && l.drop_p < 1.f, PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d: drop_p=%f", i, (double)l.drop_p);
         PAPC_REQUIRE(i == 0 || (l.x == layers[i - 1].out && l.Cin == layers[i - 1].Cout), PAPC_E_INVALID, "papc_head_chain_fwd_f32: layer %d does not consume layer %d's output", i, i - 1);
         c.l[i] = HeadFwd{l.x, l.w, l.bias, l.gamma, l.beta, B, l.Cin, l.Cout, l.has_bn, l.eps, l.momentum, l.running_mean, l.running_var, l.num_batches_tracked,
@@ -692,8 +707,8 @@ int papc_head_chain_bwd_f32(const papc_head_bwd_job *jobs, int n_jobs, int B, ui
         PAPC_REQUIRE(j.gnext, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: null gnext", i);
         PAPC_REQUIRE(j.Cout >= 1 && (!j.wnext || (j.Cn >= 4 && j.Cn % 4 == 0)), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: Cn=%d must be a multiple of 4", i, j.Cn);
         PAPC_REQUIRE(j.wnext || j.Cn == j.Cout, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: without wnext, gnext must be [B, Cout]", i);
-        PAPC_REQUIRE(j.has_bn >= 0 && j.has_bn <= 2, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: has_bn=%d", i, j.has_bn);
-        PAPC_REQUIRE(j.has_bn != 1 || (j.out && j.y && j.mean && j.invstd && j.gamma && j.dgamma && j.dbeta), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: BatchNorm backward needs the saved forward", i);
+        PAPC_REQUIRE(j.has_bn >= 0 && j.has_bn <= 3, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: has_bn=%d", i, j.has_bn);
+        PAPC_REQUIRE((j.has_bn != 1 && j.has_bn != 3) || (j.out && j.y && j.mean && j.invstd && j.gamma && j.dgamma && j.dbeta), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: BatchNorm backward needs the saved forward", i);
         PAPC_REQUIRE(j.has_bn != 2 || j.out, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: ReLU backward needs the layer's output", i);
         PAPC_REQUIRE(!j.x || (j.dw && j.Cin >= 1), PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: x without dw", i);
         PAPC_REQUIRE(j.drop_p >= 0.f && j.drop_p < 1.f, PAPC_E_INVALID, "papc_head_chain_bwd_f32: job %d: drop_p=%f", i, (double)j.drop_p);

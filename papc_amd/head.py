@@ -4,7 +4,9 @@ Reference: PAPC/models/classify/pointnet2/pointnet2.py:17-23, :37-39 (SSG) / :51
     x = drop1(relu(bn1(fc1(x)))); x = drop2(relu(bn2(fc2(x)))); x = fc3(x)
 One launch per layer forward, one per layer backward (+ one for the input gradient); the library-op chain it replaces is ~60
 launch-latency-sized kernels per training step.  The ``nn.Linear`` / ``nn.BatchNorm1d`` / ``nn.Dropout`` modules stay the parameter
-holders (state_dict unchanged); eval mode and shapes outside the kernel's limits run the modules themselves.
+holders (state_dict unchanged).  ``model.eval()`` runs the same launches with the norms in eval mode (has_bn = 3: running statistics, nothing
+updated, no dropout; batches beyond the kernel's 256 rows in chunks, rows being independent there); only TRAIN-mode shapes outside the kernel's
+limits (more than 256 rows, widths that are no multiple of 4) fall back to the modules.
 """
 import ctypes
 import os
@@ -66,6 +68,7 @@ class HeadSpec:
         self.export_masks = False
         self.masks = None              # (keep1, keep2) uint8 tensors of the last forward when export_masks
         self.grad_targets = None
+        self.training = True           # set per forward by the wrappers: False = model.eval() (norms on running statistics, no dropout)
         self.chain = CHAIN             # the layers as phases of one launch each way (False: one launch per layer)
         self.merge = MERGE             # (chain False) the hand-over-free merges: loss with the last layer, the backward's two independent first jobs
         self._sync = {}                # per stream: the two barrier words of the chain launches (zero between launches)
@@ -92,7 +95,8 @@ class HeadSpec:
 
 
 def usable(x, fc1, fc2, fc3, training):
-    return (training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 2 <= x.shape[0] <= MAX_ROWS   # (one row: BatchNorm1d itself refuses to train)
+    rows_ok = (2 <= x.shape[0] <= MAX_ROWS) if training else x.shape[0] >= 1   # (train: one row -- BatchNorm1d itself refuses; eval: chunks of MAX_ROWS)
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and rows_ok
             and fc1.in_features % 4 == 0 and fc1.out_features % 4 == 0 and fc2.out_features % 4 == 0
             and fc3.out_features % 4 == 0 and fc1.bias is not None and fc2.bias is not None and fc3.bias is not None)
 
@@ -105,6 +109,10 @@ class _Head(torch.autograd.Function):
     def forward(ctx, spec, bns, drops, labels, x0, w1, b1, g1, be1, w2, b2, g2, be2, w3, b3):
         lib = _lib.load()
         x0 = x0.contiguous()
+        ev = not spec.training                      # model.eval(): the norms use their running statistics (has_bn = 3), no dropout, nothing updated
+        mode = 3 if ev else 1
+        if ev:
+            drops = (0.0, 0.0)
         B = x0.shape[0]
         dev = x0.device
         st = stream_ptr()
@@ -122,13 +130,15 @@ class _Head(torch.autograd.Function):
             keep = torch.empty(B, cout, device=dev, dtype=torch.uint8) if spec.export_masks else None
             mom = 0.1 if bn.momentum is None else float(bn.momentum)
             track = bn.track_running_stats and bn.running_mean is not None
+            if ev and not track:
+                raise _lib.PapcError("eval-mode head: BatchNorm1d without running statistics (track_running_stats=False) has nothing to normalise with")
             rm, rv = (bn.running_mean, bn.running_var) if track else (None, None)
-            nbt = bn.num_batches_tracked if track and bn.num_batches_tracked is not None else None
+            nbt = bn.num_batches_tracked if track and bn.num_batches_tracked is not None and not ev else None
             if spec.chain:
-                layers.append(HeadFcLayer(ptr(x), ptr(w), ptr(b), ptr(g), ptr(be), cin, cout, 1, float(bn.eps), mom, _p(rm), _p(rv), _p(nbt), float(p), li + 1,
+                layers.append(HeadFcLayer(ptr(x), ptr(w), ptr(b), ptr(g), ptr(be), cin, cout, mode, float(bn.eps), mom, _p(rm), _p(rv), _p(nbt), float(p), li + 1,
                                           ptr(y), ptr(mean), ptr(invstd), _p(keep), ptr(out)))
             else:
-                check(lib.papc_head_fc_f32(ptr(x), ptr(w), ptr(b), ptr(g), ptr(be), B, cin, cout, 1, float(bn.eps), mom, ptr(rm) if track else 0,
+                check(lib.papc_head_fc_f32(ptr(x), ptr(w), ptr(b), ptr(g), ptr(be), B, cin, cout, mode, float(bn.eps), mom, ptr(rm) if track else 0,
                                            ptr(rv) if track else 0, ptr(nbt) if nbt is not None else 0,
                                            float(p), ptr(rng), li + 1, 0, ptr(y), ptr(mean), ptr(invstd), ptr(keep), ptr(out), st),
                       "papc_head_fc_f32")
@@ -160,6 +170,7 @@ class _Head(torch.autograd.Function):
         spec.masks = tuple(keeps) if spec.export_masks else None
         ctx.spec = spec
         ctx.drops = drops
+        ctx.mode = mode
         ctx.with_loss = labels is not None
         ctx.set_materialize_grads(False)             # (the logits that ride along with the loss carry no gradient: no zeros tensor made for them)
         ctx.save_for_backward(x0, w1, g1, w2, g2, w3, *saved, *((dz,) if dz is not None else ()))
@@ -179,6 +190,7 @@ class _Head(torch.autograd.Function):
             glogits = gs[0].contiguous().float()
         spec = ctx.spec
         p1, p2 = ctx.drops
+        bm = ctx.mode                               # 1: train-mode norms, 3: eval-mode (frozen) norms
         B = x0.shape[0]
         dev = x0.device
         st = stream_ptr()
@@ -200,8 +212,8 @@ class _Head(torch.autograd.Function):
         dx0 = torch.empty(B, c0, device=dev, dtype=torch.float32) if need_dx else None
         if spec.chain:
             jobs = [_bwd_job(glogits, None, c3, None, None, None, None, None, 0.0, 0, x2, c2, c3, None, dw3, db3, None, None, acc, 0),
-                    _bwd_job(glogits, w3, c3, x2, y2, mean2, invstd2, g2, p2, 1, x1, c1, c2, dy2, dw2, db2, dg2, dbe2, acc, 0),
-                    _bwd_job(dy2, w2, c2, x1, y1, mean1, invstd1, g1, p1, 1, x0, c0, c1, dy1, dw1, db1, dg1, dbe1, acc, 1)]
+                    _bwd_job(glogits, w3, c3, x2, y2, mean2, invstd2, g2, p2, bm, x1, c1, c2, dy2, dw2, db2, dg2, dbe2, acc, 0),
+                    _bwd_job(dy2, w2, c2, x1, y1, mean1, invstd1, g1, p1, bm, x0, c0, c1, dy1, dw1, db1, dg1, dbe1, acc, 1)]
             if need_dx:
                 jobs.append(_bwd_job(dy1, w1, c1, None, None, None, None, None, 0.0, 0, None, 0, c0, dx0, None, None, None, None, 0, 2))
             _run_bwd_chain(jobs, B, spec, dev, st)
@@ -209,12 +221,12 @@ class _Head(torch.autograd.Function):
             f = lib.papc_head_bwd_f32
             if spec.merge:      # dW of the last layer and the whole backward of the layer below read the same dlogits and nothing of each other: one launch
                 _run_bwd_chain([_bwd_job(glogits, None, c3, None, None, None, None, None, 0.0, 0, x2, c2, c3, None, dw3, db3, None, None, acc, 0),
-                                _bwd_job(glogits, w3, c3, x2, y2, mean2, invstd2, g2, p2, 1, x1, c1, c2, dy2, dw2, db2, dg2, dbe2, acc, 0)], B, spec, dev, st)
+                                _bwd_job(glogits, w3, c3, x2, y2, mean2, invstd2, g2, p2, bm, x1, c1, c2, dy2, dw2, db2, dg2, dbe2, acc, 0)], B, spec, dev, st)
             else:
                 check(f(ptr(glogits), 0, c3, 0, 0, 0, 0, 0, 0.0, 0, ptr(x2), B, c2, c3, 0, ptr(dw3), ptr(db3), 0, 0, acc, st), "papc_head_bwd_f32")
-                check(f(ptr(glogits), ptr(w3), c3, ptr(x2), ptr(y2), ptr(mean2), ptr(invstd2), ptr(g2), float(p2), 1, ptr(x1), B, c1, c2,
+                check(f(ptr(glogits), ptr(w3), c3, ptr(x2), ptr(y2), ptr(mean2), ptr(invstd2), ptr(g2), float(p2), bm, ptr(x1), B, c1, c2,
                         ptr(dy2), ptr(dw2), ptr(db2), ptr(dg2), ptr(dbe2), acc, st), "papc_head_bwd_f32")
-            check(f(ptr(dy2), ptr(w2), c2, ptr(x1), ptr(y1), ptr(mean1), ptr(invstd1), ptr(g1), float(p1), 1, ptr(x0), B, c0, c1,
+            check(f(ptr(dy2), ptr(w2), c2, ptr(x1), ptr(y1), ptr(mean1), ptr(invstd1), ptr(g1), float(p1), bm, ptr(x0), B, c0, c1,
                     ptr(dy1), ptr(dw1), ptr(db1), ptr(dg1), ptr(dbe1), acc, st), "papc_head_bwd_f32")
             if need_dx:
                 check(f(ptr(dy1), ptr(w1), c1, 0, 0, 0, 0, 0, 0.0, 0, 0, B, 0, c0, ptr(dx0), 0, 0, 0, 0, 0, st), "papc_head_bwd_f32")
@@ -222,18 +234,31 @@ class _Head(torch.autograd.Function):
         return (None, None, None, None, dx0) + grads
 
 
-def classifier_head(spec, x, fc1, bn1, drop1, fc2, bn2, drop2, fc3):
-    """logits = fc3(drop2(relu(bn2(fc2(drop1(relu(bn1(fc1(x)))))))))  in train mode, fused."""
+def _row_chunks(x, labels, training):
+    """train mode: the whole batch (its statistics couple the rows; usable() bounds it); eval mode: rows are independent -> chunks of MAX_ROWS"""
+    if training or x.shape[0] <= MAX_ROWS:
+        return [(x, labels)]
+    return [(x[i:i + MAX_ROWS], None if labels is None else labels.reshape(-1)[i:i + MAX_ROWS]) for i in range(0, x.shape[0], MAX_ROWS)]
+
+
+def classifier_head(spec, x, fc1, bn1, drop1, fc2, bn2, drop2, fc3, training=True):
+    """logits = fc3(drop2(relu(bn2(fc2(drop1(relu(bn1(fc1(x)))))))))  fused; ``training=False``: the norms in eval mode, no dropout."""
     params = (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias)
+    spec.training = bool(training)
     spec.grad_targets = grad_targets_of(params) if torch.is_grad_enabled() else None   # per forward: see mlp.shared_mlp_max
-    return _Head.apply(spec, (bn1, bn2), (float(drop1.p), float(drop2.p)), None, x, *params)
+    outs = [_Head.apply(spec, (bn1, bn2), (float(drop1.p), float(drop2.p)), None, xc, *params) for xc, _ in _row_chunks(x, None, training)]
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
-def classifier_head_loss(spec, x, labels, fc1, bn1, drop1, fc2, bn2, drop2, fc3):
+def classifier_head_loss(spec, x, labels, fc1, bn1, drop1, fc2, bn2, drop2, fc3, training=True):
     """(loss, logits): the head AND the mean softmax cross-entropy of its logits (train.py:106-109) -- with the chain path one launch forward
     and one backward; ``logits`` is returned for metrics and carries no gradient."""
     params = (fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias)
+    spec.training = bool(training)
     spec.grad_targets = grad_targets_of(params) if torch.is_grad_enabled() else None
+    if not training and x.shape[0] > MAX_ROWS:      # eval beyond the kernel's rows: logits in chunks, then the loss's own launch over all of them
+        logits = classifier_head(spec, x, fc1, bn1, drop1, fc2, bn2, drop2, fc3, training=False)
+        return softmax_cross_entropy(logits, labels), logits.detach()
     return _Head.apply(spec, (bn1, bn2), (float(drop1.p), float(drop2.p)), labels, x, *params)
 
 
@@ -318,16 +343,18 @@ class _HeadPlain(torch.autograd.Function):
 
 
 def plain_usable(x, fc1, fc2, fc3, training):
-    return (training and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= MAX_ROWS
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] and (x.shape[0] <= MAX_ROWS or not training)
             and fc1.in_features % 4 == 0 and fc1.out_features % 4 == 0 and fc2.out_features % 4 == 0
             and fc3.out_features % 4 == 0 and fc1.bias is not None and fc2.bias is not None and fc3.bias is not None)
 
 
-def plain_head(spec, x, fc1, fc2, drop, fc3):
-    """logits = fc3(drop(relu(fc2(relu(fc1(x))))))  in train mode, three launches each way."""
+def plain_head(spec, x, fc1, fc2, drop, fc3, training=True):
+    """logits = fc3(drop(relu(fc2(relu(fc1(x))))))  three launches each way; ``training=False``: no dropout (rows then independent: chunks of MAX_ROWS)."""
     params = (fc1.weight, fc1.bias, fc2.weight, fc2.bias, fc3.weight, fc3.bias)
     spec.grad_targets = grad_targets_of(params) if torch.is_grad_enabled() else None
-    return _HeadPlain.apply(spec, float(drop.p), x, *params)
+    p = float(drop.p) if training else 0.0
+    outs = [_HeadPlain.apply(spec, p, xc, *params) for xc, _ in _row_chunks(x, None, training)]
+    return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 
 
 _UNIT = {}

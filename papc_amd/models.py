@@ -4,8 +4,9 @@
   PointNet_Basic_Clas                      <- /root/reference/PAPC/models/classify/pointnet_base/pointnet_base.py:4-47
   PointNet2_SSG_Seg / PointNet2_MSG_Seg    <- /root/reference/PAPC/models/segment/pointnet2/pointnet2.py:6-52, :54-100
 
-Inputs are ``[B,3,N]`` float32 (``[B,6,N]`` with normals).  The FC head (661 776 parameters, 0.04 GFLOP) uses
-plain library ops (nn.Linear / BatchNorm1d / Dropout); everything upstream runs in libpapc_hip.so.
+Inputs are ``[B,3,N]`` float32 (``[B,6,N]`` with normals).  Everything runs in libpapc_hip.so, in train AND eval mode, the FC heads included
+(head.py); the nn.Linear / BatchNorm1d / Dropout modules are the parameter holders.  CPU tensors raise PapcError (there is no CPU path); the
+module chain remains only for TRAIN-mode head shapes outside the kernels' limits (more than 256 rows, widths that are no multiple of 4).
 """
 import torch
 import torch.nn as nn
@@ -48,7 +49,7 @@ def _bn1d(bn, y):
 
 
 class _ClasHead:
-    """fc1/bn1/drop1/fc2/bn2/drop2/fc3 (pointnet2.py:37-39): fused launches in train mode on the GPU (head.py), the modules otherwise."""
+    """fc1/bn1/drop1/fc2/bn2/drop2/fc3 (pointnet2.py:37-39): fused launches (head.py) in train and eval mode."""
 
     def _head(self, x, labels=None):
         """logits, or with ``labels`` (int64 [B]) the pair (mean softmax cross-entropy, logits): train.py:106-109's loss computed by the head's own
@@ -56,10 +57,14 @@ class _ClasHead:
         spec = self.__dict__.get("_head_spec")
         if spec is None:
             spec = self.__dict__["_head_spec"] = _head.HeadSpec()
+        if not x.is_cuda:
+            raise _lib.PapcError("the classifier head needs CUDA (ROCm) tensors: there is no CPU fallback")
         if _FUSED_HEAD and _head.usable(x, self.fc1, self.fc2, self.fc3, self.training):
             if labels is not None:
-                return _head.classifier_head_loss(spec, x, labels, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3)
-            return _head.classifier_head(spec, x, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3)
+                return _head.classifier_head_loss(spec, x, labels, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3,
+                                                  training=self.training)
+            return _head.classifier_head(spec, x, self.fc1, self.bn1, self.drop1, self.fc2, self.bn2, self.drop2, self.fc3, training=self.training)
+        # (train-mode shapes outside the kernels' limits, or PAPC_NO_FUSED_HEAD=1: the modules)
         x = self.drop1(F.relu(_bn1d(self.bn1, self.fc1(x))))
         x = self.drop2(F.relu(_bn1d(self.bn2, self.fc2(x))))
         logits = self.fc3(x)
@@ -211,7 +216,7 @@ class PointNet_Basic_Clas(nn.Module):
             spec = self.__dict__.get("_head_spec")
             if spec is None:
                 spec = self.__dict__["_head_spec"] = _head.HeadSpec()
-            return _head.plain_head(spec, feat, self.fc[0], self.fc[2], self.fc[4], self.fc[5])      # :26-33, :45 on the head kernels
+            return _head.plain_head(spec, feat, self.fc[0], self.fc[2], self.fc[4], self.fc[5], training=self.training)      # :26-33, :45 on the head kernels
         return self.fc(feat)                                      # :45
 
 
@@ -278,20 +283,15 @@ class _PartSegBase(nn.Module):
         l0_points = self.fp1(l0_xyz, l1_xyz, cat_copy([cls_label_one_hot, l0_xyz.float(), l0_points.float()], 1), l1_points,
                              planned=pl[3])                                                        # :45
         rows = l0_points.transpose(1, 2).reshape(B * N, 128)            # point-major rows (a view of fp1's buffer)
-        if self.training:                                               # :47 relu(bn1(conv1(.))) on the fused stack
-            spec = StackSpec(B, N, N, 1, 128, True, eps=self.bn1.eps, momentum=0.9, pool=False)
-            feat = shared_mlp_max(spec, _bn_buffers([self.bn1]), None, None, None, None,
-                                  _stack_params([self.conv1], [self.bn1]), x_rows=rows)
-        else:                                                           # eval: running statistics (bn1 IS registered in the source)
-            y = F.linear(rows, self.conv1.weight.reshape(128, 128), self.conv1.bias)
-            feat = F.relu(F.batch_norm(y, self.bn1.running_mean, self.bn1.running_var, self.bn1.weight, self.bn1.bias,
-                                       False, 0.0, self.bn1.eps))
+        if not rows.is_cuda:
+            raise _lib.PapcError("the segmentation head needs CUDA (ROCm) tensors: there is no CPU fallback")
+        # :47 relu(bn1(conv1(.))) on the fused stack; eval: the running statistics normalise (bn1 IS registered in the source) and stay untouched
+        spec = StackSpec(B, N, N, 1, 128, True, eps=self.bn1.eps, momentum=0.9, pool=False, eval_bn=not self.training)
+        feat = shared_mlp_max(spec, _bn_buffers([self.bn1]), None, None, None, None,
+                              _stack_params([self.conv1], [self.bn1]), x_rows=rows)
         x = self.drop1(feat)                                                                        # :48
-        if x.is_cuda:
-            from .linear import linear_rows
-            x = linear_rows(x, self.conv2.weight, self.conv2.bias)                                   # :49 (own row kernels, no library GEMM)
-        else:
-            x = F.linear(x, self.conv2.weight.reshape(self.conv2.out_channels, 128), self.conv2.bias)
+        from .linear import linear_rows
+        x = linear_rows(x, self.conv2.weight, self.conv2.bias)                                       # :49 (own row kernels, no library GEMM)
         return x.view(B, N, -1)                                                                     # :50 [B,N,num_parts]
 
 

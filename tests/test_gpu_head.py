@@ -437,3 +437,96 @@ def test_head_chain_replays_in_a_graph():
             assert all(torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in (fc1.weight, fc2.weight, fc3.weight))
         assert len(set(losses)) > 1              # fresh dropout masks on every replay
     assert all(int(v) == 0 for t in spec._sync.values() for v in t.cpu())
+
+
+@pytest.mark.parametrize("B,c3,dims", [(32, 40, None), (1, 16, None), (300, 16, None), (5, 12, (132, 72, 40))])
+def test_eval_mode_head_matches_float64(B, c3, dims):
+    """model.eval(): fc1/bn1/fc2/bn2 are registered layers of the source (classify/pointnet2/pointnet2.py:17-23), so the norms use their running
+    statistics, dropout is the identity (:37-39 under eval) and nothing is updated.  The head kernels' has_bn = 3 mode vs a float64 restatement,
+    forward and backward (frozen norms: no batch-mean terms); 300 rows = beyond the kernel's 256 (eval rows are independent: chunks); the running
+    statistics and num_batches_tracked must stay untouched."""
+    from papc_amd import head
+    c0, c1, c2 = dims if dims else (1024, 512, 256)
+    mods = [m.cuda().eval() for m in _modules(c0, c1, c2, c3, 9 + B)]
+    fc1, bn1, d1, fc2, bn2, d2, fc3 = mods
+    params = [fc1.weight, fc1.bias, bn1.weight, bn1.bias, fc2.weight, fc2.bias, bn2.weight, bn2.bias, fc3.weight, fc3.bias]
+    rm0 = [t.clone() for t in (bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var)]
+    x0 = torch.randn(B, c0, device="cuda", requires_grad=True)
+    glog = torch.randn(B, c3, device="cuda")
+    spec = head.HeadSpec()
+    assert head.usable(x0, fc1, fc2, fc3, False)
+    logits = head.classifier_head(spec, x0, fc1, bn1, d1, fc2, bn2, d2, fc3, training=False)
+    logits.backward(glog)
+    torch.cuda.synchronize()
+    P = lambda t: t.detach().double().cpu().requires_grad_(True)
+    prm = [P(t) for t in params]
+    x = P(x0)
+    h = x
+    for (w, b, g, be), bn in ((prm[0:4], bn1), (prm[4:8], bn2)):
+        y = h @ w.t() + b
+        h = torch.relu((y - bn.running_mean.double().cpu()) / torch.sqrt(bn.running_var.double().cpu() + bn.eps) * g + be)
+    ref = h @ prm[8].t() + prm[9]
+    ref.backward(glog.double().cpu())
+
+    def close(got, want, tol=1e-5):
+        got = got.detach().double().cpu()
+        err = (got - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+        assert err <= tol, err
+
+    close(logits, ref.detach())
+    close(x0.grad, x.grad, 2e-5)
+    for p, w in zip(params, prm):
+        close(p.grad, w.grad, 2e-5)
+    for a, b in zip(rm0, (bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var)):
+        assert torch.equal(a, b)
+    assert int(bn1.num_batches_tracked.item()) == 0 and int(bn2.num_batches_tracked.item()) == 0
+    # with labels: (loss, logits) in eval mode too
+    y = torch.randint(0, c3, (B,), device="cuda")
+    loss, lg = head.classifier_head_loss(spec, x0.detach(), y, fc1, bn1, d1, fc2, bn2, d2, fc3, training=False)
+    close(lg, ref.detach())
+    close(loss.reshape(1), F.cross_entropy(ref.detach(), y.cpu()).reshape(1), 2e-5)
+
+
+def test_models_in_eval_mode_run_the_library_kernels():
+    """PointNet2_SSG_Clas / PointNet_Basic_Clas / PointNet2_SSG_Seg under model.eval(): the heads are this library's launches (round-5 review:
+    eval fell to nn.Linear / F.linear / F.batch_norm) -- the classifier heads' autograd node is the head kernels', two forwards agree bit for
+    bit (no dropout), running statistics stay put; the segmentation head's eval output equals the float64 restatement of conv1/bn1(running)/
+    relu/conv2 (segment/pointnet2/pointnet2.py:47-50) on the decoder's own features."""
+    from papc_amd.models import PointNet2_SSG_Clas, PointNet2_SSG_Seg, PointNet_Basic_Clas
+    from papc_amd.synthetic import make_clouds, make_start_idx
+    dev = torch.device("cuda")
+    torch.manual_seed(2)
+    x = torch.from_numpy(make_clouds(4, 1024, 5)).to(dev)
+    st = (torch.from_numpy(make_start_idx(4, 1024, 5)).to(dev), torch.from_numpy(make_start_idx(4, 512, 6)).to(dev))
+    for model, args in ((PointNet2_SSG_Clas(num_classes=16), (x, st)), (PointNet_Basic_Clas(num_classes=16), (x,))):
+        model = model.to(dev)
+        model.train()
+        model(*args)                                   # one train step's worth of running statistics
+        model.eval()
+        stats = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+        a = model(*args)
+        b = model(*args)
+        assert "Head" in type(a.grad_fn).__name__, type(a.grad_fn).__name__
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+        for k, v in model.state_dict().items():
+            if k in stats:
+                assert torch.equal(v, stats[k]), k
+    seg = PointNet2_SSG_Seg(num_classes=16, num_parts=50).to(dev)
+    cls = torch.randint(0, 16, (4, 1), device=dev)
+    seg.train()
+    seg((x, cls), st)
+    seg.eval()
+    feats = {}
+    h = seg.fp1.register_forward_hook(lambda m, i, o: feats.__setitem__("l0", o.detach()))
+    out = seg((x, cls), st)
+    h.remove()
+    l0 = feats["l0"].double().cpu()                    # [B, 128, N]
+    rows = l0.transpose(1, 2).reshape(-1, 128)
+    w1, b1 = seg.conv1.weight.detach().double().cpu().reshape(128, 128), seg.conv1.bias.detach().double().cpu()
+    y = rows @ w1.t() + b1
+    z = torch.relu((y - seg.bn1.running_mean.double().cpu()) / torch.sqrt(seg.bn1.running_var.double().cpu() + seg.bn1.eps)
+                   * seg.bn1.weight.detach().double().cpu() + seg.bn1.bias.detach().double().cpu())
+    ref = z @ seg.conv2.weight.detach().double().cpu().reshape(50, 128).t() + seg.conv2.bias.detach().double().cpu()
+    got = out.detach().double().cpu().reshape(-1, 50)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-5, err
