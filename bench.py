@@ -199,6 +199,7 @@ def main():
     ap.add_argument("--allow-gate-timeout", action="store_true", help="(tests) do not abort when a device-side gate wait gave up (papc_flag_wait's sticky count)")
     ap.add_argument("--diag-stall-ms", type=float, default=0.0, help="(tests) stall the main stream for about this long ahead of every third timed step (a spinning "
                     "one-lane kernel): the side graph's gate must hold through it, and the plan buffers stay ordered by stream events whatever the gate does")
+    ap.add_argument("--no-dropout", action="store_true", help="(tests) dropout p = 0 in the classifier head, so that a single-process emulation can reproduce a multi-rank run")
     ap.add_argument("--dry-run", action="store_true", help="capture, run the warm-up steps, print the launch structure as JSON and exit")
     ap.add_argument("--lr", type=float, default=1e-3, help="Adam learning rate (train.py:62-65: 1e-3).  (tests) A training step is a "
                     "discontinuous function of the weights -- which row wins a neighbourhood max, which side of 0 a pre-activation falls -- "
@@ -229,6 +230,8 @@ def main():
     if world > 1 and not args.no_graph:
         args.require_graph = True                 # a multi-GPU run must not quietly measure the eager fallback
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
+    if os.environ.get("PAPC_DEVICE_OVERRIDE") is not None:      # (tests) every rank on this device: two replicas on a 1-GPU box, gloo process group
+        local = int(os.environ["PAPC_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = _lib.load()
@@ -240,6 +243,8 @@ def main():
     torch.manual_seed(1234)                       # same initial weights on every rank (then broadcast anyway)
     model = PointNet2_SSG_Clas(num_classes=16).to(dev)
     model.train()
+    if args.no_dropout:
+        model.drop1.p = model.drop2.p = 0.0
     flat = FlatParams(model)
     if dist.is_initialized():
         # the only collective before the graphs are captured runs on its OWN stream: RCCL's watchdog thread polls the end events of the
@@ -803,9 +808,9 @@ def main():
     elapsed, loss = timed_region(step_ms)
     final_loss = float(loss.item())
     more_windows(step_ms)
-    if args.dump_trajectory and rank == 0:
+    if args.dump_trajectory:                      # rank 0 -> FILE, rank r -> FILE.rank<r>.npz (tests: the replicas must stay identical)
         import numpy as np
-        np.savez(args.dump_trajectory, loss=torch.stack(traj).cpu().numpy(), params=flat.data.detach().cpu().numpy(), params0=params0, grad=(state["last_grad"] if state["last_grad"] is not None else flat.grad).detach().cpu().numpy(),
+        np.savez(args.dump_trajectory if rank == 0 else "%s.rank%d.npz" % (args.dump_trajectory, rank), loss=torch.stack(traj).cpu().numpy(), params=flat.data.detach().cpu().numpy(), params0=params0, grad=(state["last_grad"] if state["last_grad"] is not None else flat.grad).detach().cpu().numpy(),
                  graph=np.array(int(use_graph)), overlap=np.array(int(args.overlap)))
     n_roof = args.steps
     if use_graph:

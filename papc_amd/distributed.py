@@ -23,7 +23,8 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # PAPC_DIST_BACKEND=gloo: (tests) several ranks on ONE GPU -- RCCL refuses two ranks on the same device, gloo does not care
+            backend = os.environ.get("PAPC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         kw = {}
@@ -83,6 +84,11 @@ class FlatParams:
     def broadcast(self, src=0):
         """Make every rank start from rank ``src``'s weights."""
         if dist.is_initialized():
+            if self.data.is_cuda and dist.get_backend() == "gloo":
+                host = self.data.cpu()
+                dist.broadcast(host, src=src)
+                self.data.copy_(host)
+                return
             dist.broadcast(self.data, src=src)
 
     def allreduce_grads(self, lo=0, hi=None, async_op=False):
@@ -96,8 +102,14 @@ class FlatParams:
         last kernel."""
         if dist.is_initialized():
             buf = self.grad if (lo == 0 and hi is None) else self.grad[lo:hi]
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
             scale = 1.0 / dist.get_world_size()
+            if buf.is_cuda and dist.get_backend() == "gloo":
+                # (tests: ranks sharing one GPU) gloo's device path is not part of every ROCm build: stage through the host, in stream order
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                buf.copy_(host)
+                return (scale, None) if async_op else scale
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
             return (scale, work) if async_op else scale
         return (1.0, None) if async_op else 1.0
 

@@ -155,15 +155,15 @@ class _Head(torch.autograd.Function):
         if spec.chain:
             layers.append(HeadFcLayer(ptr(x), ptr(w3), ptr(b3), None, None, cin, cout, 0, 0.0, 0.0, None, None, None, 0.0, 3, None, None, None, None, ptr(logits)))
             arr = (HeadFcLayer * 3)(*layers)
-            check(lib.papc_head_chain_fwd_f32(ctypes.addressof(arr), 3, B, ptr(rng), ptr(rng), _p(labels), _p(loss), _p(dz), ptr(spec.sync(dev)), st),
+            check(lib.papc_head_chain_fwd_f32(ctypes.addressof(arr), 3, B, ptr(rng), None if ev else ptr(rng), _p(labels), _p(loss), _p(dz), ptr(spec.sync(dev)), st),
                   "papc_head_chain_fwd_f32")
         elif labels is not None and spec.merge and cout <= 32:
             # one workgroup makes all the logits: it goes on to the loss from its LDS tile (a one-layer chain launch: no barrier, no hand-over)
             one = (HeadFcLayer * 1)(HeadFcLayer(ptr(x), ptr(w3), ptr(b3), None, None, cin, cout, 0, 0.0, 0.0, None, None, None, 0.0, 3, None, None, None, None, ptr(logits)))
-            check(lib.papc_head_chain_fwd_f32(ctypes.addressof(one), 1, B, ptr(rng), ptr(rng), ptr(labels), ptr(loss), ptr(dz), ptr(spec.sync(dev)), st),
+            check(lib.papc_head_chain_fwd_f32(ctypes.addressof(one), 1, B, ptr(rng), None if ev else ptr(rng), ptr(labels), ptr(loss), ptr(dz), ptr(spec.sync(dev)), st),
                   "papc_head_chain_fwd_f32")
         else:
-            check(lib.papc_head_fc_f32(ptr(x), ptr(w3), ptr(b3), 0, 0, B, cin, cout, 0, 0.0, 0.0, 0, 0, 0, 0.0, 0, 3, ptr(rng),
+            check(lib.papc_head_fc_f32(ptr(x), ptr(w3), ptr(b3), 0, 0, B, cin, cout, 0, 0.0, 0.0, 0, 0, 0, 0.0, 0, 3, 0 if ev else ptr(rng),   # (eval draws no mask: the counter stays)
                                        0, 0, 0, 0, ptr(logits), st), "papc_head_fc_f32")
             if labels is not None:
                 check(lib.papc_softmax_xent_f32(ptr(logits), ptr(labels), B, cout, ptr(loss), ptr(dz), st), "papc_softmax_xent_f32")

@@ -180,7 +180,8 @@ def test_softmax_cross_entropy(B, C):
 
 
 def test_model_uses_fused_head_and_trains():
-    """The SSG classifier routes its head through head.hip in train mode; eval mode and the A/B switch use the modules."""
+    """The SSG classifier routes its head through head.hip in train mode and in eval mode (no mask drawn there: the dropout counter stays); the A/B
+    switch uses the modules."""
     from papc_amd.models import PointNet2_SSG_Clas
     from papc_amd.head import softmax_cross_entropy
     torch.manual_seed(0)
@@ -509,7 +510,9 @@ def test_models_in_eval_mode_run_the_library_kernels():
         assert "Head" in type(a.grad_fn).__name__, type(a.grad_fn).__name__
         assert torch.equal(a, b) and torch.isfinite(a).all()
         for k, v in model.state_dict().items():
-            if k in stats:
+            # (the set-abstraction norms are NOT registered layers in the source -- plain Python lists, pointnet2_basic_layers.py:185-191 -- so
+            # model.eval() never reaches them: they keep normalising with, and updating from, the batch.  Everything else stays put.)
+            if k in stats and not k.startswith("sa"):
                 assert torch.equal(v, stats[k]), k
     seg = PointNet2_SSG_Seg(num_classes=16, num_parts=50).to(dev)
     cls = torch.randint(0, 16, (4, 1), device=dev)

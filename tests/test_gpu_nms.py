@@ -137,6 +137,37 @@ def test_rbbox_iou_and_riou_cc_match_oracle():
     assert rbbox_iou(np.zeros((0, 4, 2), np.float32), qc).shape == (0, 33)
 
 
+def _attribute_keep_list(dets, thr, got, want, ious, band=1e-5):
+    """The library's rotated IoU is another algorithm than the source's (Sutherland-Hodgman clipping against the numba routine's vertex sort,
+    nms_gpu.py:235-278), equal to 1e-5, so a keep list may differ from the oracle's ONLY through pairs whose IoU is within 1e-5 of the threshold.
+    Round 5 forgave any mismatch as soon as SOME pair was that close; here EVERY decision of the library's greedy sweep is attributed: walking
+    the boxes in the oracle's score order with the library's own kept set, a box the library KEPT must have no kept predecessor with an oracle
+    IoU above thr + band (clearly suppressed), and a box it DROPPED must have a kept predecessor with an oracle IoU above thr - band (plausibly
+    suppressed).  Equal lists pass the same walk with a zero band."""
+    dets = np.asarray(dets, np.float32)
+    n = dets.shape[0]
+    order = dets[:, 5].argsort(kind="stable")[::-1]                 # nms_gpu.py:463 (the oracle's and the library's sweep order)
+    pos = {int(b): i for i, b in enumerate(order)}
+    assert sorted(set(got)) == sorted(got) and all(0 <= g < n for g in got), got
+    assert [pos[g] for g in got] == sorted(pos[g] for g in got), "the keep list is not in score order"
+    if got == want:
+        band = 0.0
+    kept = []
+    keep_set = set(got)
+    thr = float(np.float32(thr))
+    for j in range(n):
+        box = int(order[j])
+        worst = max([ious[(i, j)] for i in kept], default=-1.0)
+        if box in keep_set:
+            assert worst <= thr + band, "box %d kept although a kept predecessor overlaps it by %.7f > %.7f" % (box, worst, thr)
+            kept.append(j)
+        else:
+            assert worst > thr - band, "box %d dropped although no kept predecessor reaches the threshold (largest IoU %.7f, thr %.7f)" % (box, worst, thr)
+    if got != want:
+        diff = sorted(set(got) ^ set(want))
+        print("rotated NMS: keep lists differ in boxes %s, each attributed to an IoU within %.0e of the threshold" % (diff, band))
+
+
 @pytest.mark.parametrize("n,thr", [(1, 0.5), (64, 0.3), (65, 0.5), (150, 0.1)])
 def test_rotate_nms_matches_oracle(n, thr):
     from papc_amd.nms import rotate_nms_gpu
@@ -144,12 +175,7 @@ def test_rotate_nms_matches_oracle(n, thr):
     dets = np.concatenate([_rboxes(rng, n, extent=12.0), rng.uniform(0, 1, (n, 1)).astype(np.float32)], 1)
     want, ious = R.rotate_nms_gpu(dets, thr, return_ious=True)
     got = rotate_nms_gpu(dets, thr)
-    if got != [int(i) for i in want]:
-        # a legitimate difference needs an IoU within last-place distance of the threshold (cos/sin rounding)
-        near = [v for v in ious.values() if abs(v - thr) < 1e-5]
-        assert near, (got, want)
-    else:
-        assert got == [int(i) for i in want]
+    _attribute_keep_list(dets, thr, got, [int(i) for i in want], ious)
 
 
 def test_rotate_nms_edge_cases():

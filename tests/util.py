@@ -16,20 +16,31 @@ def seeded_weights(chans, seed, bias_scale=0.1):
     return ws
 
 
-def assert_close(got, ref, rel=1e-5, what=""):
-    """|got-ref| <= rel * max|ref| elementwise-max criterion (activations are O(1) after BN); the north-star
-    tolerance for MLP activations is 1e-5 relative."""
+ELEM_FLOOR = 1e-3       # entries at least this fraction of max|ref| are also held elementwise
+ELEM_FACTOR = 100.0     # ... to ELEM_FACTOR * rel of THEIR OWN magnitude (default)
+
+
+def assert_close(got, ref, rel=1e-5, what="", elem=None):
+    """Two bars, both asserted.
+    (1) max-norm: max|got-ref| <= rel * max|ref| -- the north-star tolerance read on the tensor's scale (activations are O(1) after a BatchNorm,
+        and an fp32 accumulation's error is proportional to the magnitude of its terms, not of its result: 1e-5 relative for MLP activations).
+    (2) elementwise: every entry with |ref| >= 1e-3 * max|ref| is within ``elem`` of ITS OWN magnitude (default 100 * rel, i.e. 1e-3 at the 1e-5
+        bar).  The max-norm bar alone implies only rel / 1e-3 = 1000 * rel there, so this is ten times tighter than what (1) already forces: an
+        entry of a thousandth of the tensor's scale may not be off by more than 0.1 % of itself at the 1e-5 bar.  (Round-5 review: a wrong small
+        entry hides under a max-norm bar.  Measured on MI355X, round 6: forward comparisons against the float64 oracle sit at 1e-4 .. 5e-4
+        elementwise with 3e-7 .. 2e-6 max-norm -- absolute errors are uniform in size, ~1e-6 of the scale, whatever the entry.)
+    Callers whose reference legitimately differs in single entries (near-tie routing allowances) state their own ``elem``."""
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     scale = max(float(np.max(np.abs(ref))), 1e-30)
     err = float(np.max(np.abs(got - ref))) / scale
-    # second figure, reported next to the max-norm one: the worst ELEMENTWISE relative error among the entries that are not tiny
-    # (|ref| >= 1e-3 of the largest) -- a wrong small entry hides under a max-norm bar
-    big = np.abs(ref) >= 1e-3 * scale
-    elem = float(np.max(np.abs(got - ref)[big] / np.abs(ref)[big])) if big.any() else 0.0
-    print("[assert_close] %s: %.2e of max|ref|, elementwise %.2e (entries >= 1e-3 max)" % (what, err, elem))
-    assert err <= rel, "%s: max rel err %.3e > %.1e (elementwise %.3e)" % (what, err, rel, elem)
+    big = np.abs(ref) >= ELEM_FLOOR * scale
+    el = float(np.max(np.abs(got - ref)[big] / np.abs(ref)[big])) if big.any() else 0.0
+    ebar = ELEM_FACTOR * rel if elem is None else elem
+    print("[assert_close] %s: %.2e of max|ref| (bar %.1e), elementwise %.2e (entries >= 1e-3 max; bar %.1e)" % (what, err, rel, el, ebar))
+    assert err <= rel, "%s: max rel err %.3e > %.1e (elementwise %.3e)" % (what, err, rel, el)
+    assert el <= ebar, "%s: elementwise rel err %.3e > %.1e on entries >= 1e-3 of max|ref| (max-norm %.3e)" % (what, el, ebar, err)
     return err
 
 
