@@ -73,7 +73,7 @@ def test_train_step_matches_golden(dev):
     # ... and what that 3e-2 allowance would let through is closed here, on the fixture's own inputs and weights: the float64 chain ROUTED through
     # the kernels' decisions (round-5 review: "this fixture would not notice a 1 % wrong term in SA1 / SA2 dW").  (i) the routed chain IS the
     # fixture's computation up to routing: its logits and loss equal the committed ones to 1e-9 (the forward is continuous in the routing); (ii)
-    # only a handful of decisions differ from float64's own; (iii) every SA gradient of the kernels is within 2e-4 of the routed chain's (3x plain
+    # only a handful of alive / dead decisions differ from float64's own; (iii) every SA gradient of the kernels is within 2e-4 of the routed chain's (3x plain
     # fp32 autograd on the same routed graph where that is worse) -- all elements, not the fixture's sample
     stats = {}
     p64, lg64, ls64 = _routed_reference(model, x, plan, labels, argmaxes, pooled, torch.float64, stats)
@@ -82,7 +82,9 @@ def test_train_step_matches_golden(dev):
     assert abs(ls64 - float(g["loss"])) <= 1e-7 * abs(float(g["loss"]))
     for nm, (moved, flips, ndec) in stats.items():
         print("%s: %d winner rows and %d alive/dead decisions differ from float64's own (of %d)" % (nm, moved, flips, ndec))
-        assert moved + flips <= max(4, 2e-4 * ndec), (nm, moved, flips, ndec)
+        # (winner rows: ball-query padding copies are exact ties, and torch's argmax does not promise the first of them -- only the alive / dead
+        # decisions are held to "a handful")
+        assert flips <= max(4, 2e-4 * ndec), (nm, moved, flips, ndec)
     bad = []
     for n in names:
         if _bn_fed_bias(n):
