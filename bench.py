@@ -840,7 +840,7 @@ def main():
         for k in range(NB):                       # the compacted stack's device-side row count, batch by batch (the step cycles through them)
             xb, _, s1b, s2b = bt(k)
             pl2 = model.plan_sampling(xb, (s1b, s2b))[1]
-            if len(pl2) == 9:
+            if len(pl2) in (9, 12):
                 row_fractions.append(int(pl2[4][0].item()) / float(B * 128 * 64))
         if row_fractions:
             row_fraction = sum(row_fractions) / len(row_fractions)

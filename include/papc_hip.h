@@ -46,7 +46,7 @@ int papc_version(void);
  *       whenever a struct's layout or a function's signature does; papc_amd/_lib.py refuses a mismatching library);
  *   (3) a binding that mirrors the structs by hand (ctypes, cgo, JNA) can compare its sizes with papc_abi_sizeof("papc_sa_io") etc.
  *       (-1 for an unknown name; tests/test_abi.py does this for every ctypes mirror in papc_amd/). */
-#define PAPC_ABI_VERSION 6
+#define PAPC_ABI_VERSION 7
 int papc_abi_version(void);
 int64_t papc_abi_sizeof(const char *struct_name);
 /* text of the last error raised on this thread ("" if none) */
@@ -141,6 +141,20 @@ int papc_three_interpolate_bwd_first3_f32(const float *grad_out, const float *we
                           * with (x, y, z) = xc[m]; x = xc [M, 4] (ldx = 4, papc_xyz_group_f32), bn_scale = wf [Cin, 4] (papc_xyz_l1_finalize_f32).
                           * Forward (no group max) and dW only, where papc_mlp_xyz_ok(M, Cin, Cout) != 0 */
 
+/* Point lists of a grouping (papc_point_lists_f32): for every source point of every cloud the physical rows that gathered it, ascending -- the
+ * inverse of the ball-query lists.  Weight-independent like the lists themselves, so a training loop builds them with the sampling pyramid of the
+ * next batch; with them the gather-add first layer's backward sums a point's rows in FIXED order (no float atomics: bit-reproducible gradients, no
+ * pre-zeroed G).  prange [B*N][2] = (first entry, one past the last) into prow / pmeta; prow [cap] physical row per entry; pmeta [cap][4] per entry:
+ * xyz_j - centre (3 floats) and the row's multiplicity weight (1 for a padded grouping).  cap = rows of the grouping (G * K, rounded up to 128 for
+ * a compacted one).  `compact` says which row numbering the lists index: 1 = the compacted layout of papc_compact_plan_f32, 0 = the padded
+ * [B,S,K] lists; a consumer whose stack runs the other layout ignores the lists (and takes the atomic path). */
+typedef struct papc_point_lists {
+    const int32_t *prange;
+    const int32_t *prow;
+    const float *pmeta;
+    int32_t compact;
+} papc_point_lists;
+
 typedef struct papc_group_src {
     const float *xyz;      /* strided cloud */
     int64_t sb, sn, sc;
@@ -156,6 +170,8 @@ typedef struct papc_group_src {
      * first row).  With it papc_lingather_fwd_f32 writes the statistics of the PADDED tensor (sum w y, sum w y^2) itself, without it the
      * unweighted sums of the physical rows (the copies' share then comes from papc_bn_stats_corr_f32). */
     const float *wstat;
+    /* optional (papc_lingather_bwd_f32 only): the grouping's point lists -- deterministic segmented sums instead of float atomics */
+    const papc_point_lists *plists;
 } papc_group_src;
 
 /* One conv1x1 layer on rows with fp32 MFMA: y[M,Cout] = A(x)[M,Cin] . w[Cout,Cin]^T + bias.
@@ -424,6 +440,8 @@ typedef struct papc_sa_io {
     papc_sa_layer layer[PAPC_SA_MAX_LAYERS];
     float *out;
     void *saved, *scratch;
+    const papc_point_lists *plists;       /* optional: point lists of idx (papc_point_lists_f32), used by the gather-add first layer's backward when they
+                                             index the row layout the stack runs (plists->compact == plan.compact) */
 } papc_sa_io;
 typedef struct papc_sa_plan {
     papc_sa_desc d;
@@ -674,6 +692,8 @@ int papc_riou_f32(const float *rbboxes, const float *qrbboxes, float standup_thr
  * xyz / new_xyz / idx / N / S / K (feats, D unused); bias may be NULL.  C % 4 == 0.
  * papc_lingather_bwd_f32: from the layer's dense dY source (papc_bwd_dy, DENSE), G [B*N, C] += sum of dY rows per source point
  * (pre-zeroed by the caller, float atomics) and dwx_partial [papc_lingather_parts(M), C, 3] = partial sums of dY^T (xyz_j - centre);
+ * with grp->plists (matching the row layout, 256 % (C / 4) == 0): G [B*N, C] = the same sums in fixed order, every row of G WRITTEN (no pre-zeroing),
+ * dwx_partial [papc_lingather_list_parts(B * N), C, 3] -- papc_lingather_bwd_parts(grp, B, C) says how many partial rows the call will write;
  * the caller finishes with grad_feats = G W_f, dW_f = G^T feats, dW_x = sum of the partials. */
 int papc_lingather_parts(int64_t M);
 /* The COMPACTED form of a grouped stack: distinct neighbours only (csrc/compact.hip).  query_ball_point pads every neighbourhood to
@@ -702,6 +722,13 @@ int papc_bn_relu_max_seg_f32(const float *y, int C, const int32_t *start, const 
 int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, const float *w, int ldw, int xcol0, const float *bias, int C,
                            float *y, float *stats_partial, papc_stream_t stream);
 int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream);
+int papc_lingather_list_parts(int64_t BN);
+int papc_lingather_bwd_parts(const papc_group_src *grp, int B, int C);
+int papc_lingather_bwd_lists_ok(const papc_group_src *grp, int C);     /* 1: papc_lingather_bwd_f32 will take the point-list path (G need not be zeroed) */
+/* Build the point lists of a grouping: grp gives xyz / new_xyz / idx / N / S / K and, for a compacted grouping, cidx / seg_grp / rows_dev / wstat
+ * (= wrow) plus `start` [G + 1] (papc_compact_plan_f32); start == NULL: the padded lists.  One wave per cloud walks its groups in order, so every
+ * list is ascending in the row index.  Entries whose index is outside [0, N) (the no-hit sentinel) are in no list.  N <= 8192. */
+int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start, int32_t *prange, int32_t *prow, float *pmeta, papc_stream_t stream);
 
 /* dX of the layer ABOVE a coordinates-only first layer (papc_mlp_xyz_ok), folded into that first layer's backward: dX [M, Cin] is never
  * stored -- per channel c the four sums of p = dX[m, c] [wf_c . x_m + t_c > 0] against (x, y, z, 1) of the row's centred coordinates are all

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPC_LIB") or os.path.join(_HERE, "libpapc_hip.so")   # PAPC_LIB: A/B a second build of the library
 
-ABI_VERSION = 6          # include/papc_hip.h: PAPC_ABI_VERSION
+ABI_VERSION = 7          # include/papc_hip.h: PAPC_ABI_VERSION
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -25,7 +25,12 @@ class GroupSrc(ctypes.Structure):
     """papc_group_src"""
     _fields_ = [("xyz", c_p), ("sb", c_l), ("sn", c_l), ("sc", c_l), ("new_xyz", c_p), ("feats", c_p),
                 ("idx", c_p), ("N", c_i), ("S", c_i), ("K", c_i), ("D", c_i), ("xyz_first", c_i),
-                ("cidx", c_p), ("seg_grp", c_p), ("rows_dev", c_p), ("wstat", c_p)]
+                ("cidx", c_p), ("seg_grp", c_p), ("rows_dev", c_p), ("wstat", c_p), ("plists", c_p)]
+
+
+class PointLists(ctypes.Structure):
+    """papc_point_lists"""
+    _fields_ = [("prange", c_p), ("prow", c_p), ("pmeta", c_p), ("compact", c_i)]
 
 
 class BwdDy(ctypes.Structure):
@@ -138,6 +143,10 @@ SIGNATURES = {
     "papc_lingather_parts": (c_i, [c_l]),
     "papc_lingather_fwd_f32": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "papc_lingather_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "papc_lingather_list_parts": (c_i, [c_l]),
+    "papc_lingather_bwd_parts": (c_i, [c_p, c_i, c_i]),
+    "papc_lingather_bwd_lists_ok": (c_i, [c_p, c_i]),
+    "papc_point_lists_f32": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "papc_bn_max_prep_f32": (c_i, [c_p] * 10 + [c_l, c_i, c_i] + [c_p] * 6),
     "papc_mlp_max_nostore_ok": (c_i, [c_l, c_i, c_i, c_i]),
     "papc_mlp_bwd_dw_max_ws_floats": (c_l, [c_l, c_i, c_i]),

@@ -54,6 +54,53 @@ def plan(idx, out=None):
     return CompactPlan(t, G, K)
 
 
+class PointLists:
+    """The inverse of a grouping (csrc/lingather.hip, papc_point_lists_f32): for every source point the physical rows that gathered it, ascending.
+    prange [B*N, 2] int32 | prow [cap] int32 | pmeta [cap, 4] float32 (xyz_j - centre, multiplicity weight); ``compact`` = which row layout the
+    lists index (the compacted plan's, or the padded [B,S,K] lists').  With them the gather-add first layer's backward (the only float-atomic
+    kernel of a training step) becomes a segmented sum in fixed order: bit-reproducible gradients, and about half the time on MI355X."""
+    __slots__ = ("prange", "prow", "pmeta", "compact")
+
+    def __init__(self, tensors, compact):
+        self.prange, self.prow, self.pmeta = tensors
+        self.compact = bool(compact)
+
+    def tensors(self):
+        return (self.prange, self.prow, self.pmeta)
+
+
+# "0": never (the float-atomic backward everywhere); "1" (default): for compacted stacks; "2": for padded ones too.  Measured on MI355X (round 6,
+# SA2 of the SSG classifier): compacted 76.7 + 5.5 (atomics + the fill of G) -> 62 us; PADDED 0.41 ms SLOWER per step -- the ball query's padding
+# copies all sit in the list of their group's first neighbour (lists of hundreds of rows on one wave) where the atomic kernel pre-sums them per
+# group in a register.  The padded layout therefore keeps the atomic kernel.
+LISTS = int(os.environ.get("PAPC_POINT_LISTS", "1"))
+MAX_LIST_POINTS = 8192                                      # source points per cloud the list builder holds in LDS
+
+
+def alloc_lists(B, N, G, K, device):
+    cap = (G * K + 127) // 128 * 128
+    return (torch.empty(B * N, 2, device=device, dtype=torch.int32), torch.empty(cap, device=device, dtype=torch.int32),
+            torch.empty(cap, 4, device=device, dtype=torch.float32))
+
+
+def point_lists(xyz, new_xyz, idx, cplan=None, out=None):
+    """xyz [B,N,3] (any strides), new_xyz [B,S,3], idx [B,S,K] int32, ``cplan`` = the grouping's CompactPlan when its stack runs compacted
+    -> PointLists; ``out`` = optional preallocated tensors (``alloc_lists``) the kernel writes into."""
+    B, S, K = idx.shape
+    N = xyz.shape[1]
+    t = out if out is not None else alloc_lists(B, N, B * S, K, idx.device)
+    g = _lib.GroupSrc()
+    g.xyz, g.sb, g.sn, g.sc = xyz.data_ptr(), xyz.stride(0), xyz.stride(1), xyz.stride(2)
+    g.new_xyz, g.idx = new_xyz.data_ptr(), idx.data_ptr()
+    g.N, g.S, g.K = N, S, K
+    start = None
+    if cplan is not None:
+        g.cidx, g.seg_grp, g.rows_dev, g.wstat = cplan.cidx.data_ptr(), cplan.seg_grp.data_ptr(), cplan.rows.data_ptr(), cplan.wrow.data_ptr()
+        start = cplan.start.data_ptr()
+    check(_lib.load().papc_point_lists_f32(ctypes.byref(g), B, start, *(ptr(x) for x in t), stream_ptr()), "papc_point_lists_f32")
+    return PointLists(t, cplan is not None)
+
+
 def stack_ok(M, K, couts):
     """whether a gather-add-first stack of these output widths has its compacted kernel flavours (papc_mlp_compact_ok)"""
     if POLICY == "0":

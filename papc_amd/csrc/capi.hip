@@ -66,6 +66,7 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_MAX_NOSTORE", 1, 0, 1},         // the max-pooled last layer without its stored output where all three kernels have the flavour (papc_mlp_max_nostore_ok)
     {"PAPC_PFN_FUSED_TAILS", 1, 0, 1},     // papc_pfn_fwd / _bwd: BatchNorm constants / dW finalize as the last-arriving workgroup's tail of the Gram pass / the fold (pfn.hip)
     {"PAPC_STREAM_NW12", 1, 0, 1},         // twelve waves per workgroup (three per SIMD) for the row-streaming dX flavours that fit 168 registers (0: eight)
+    {"PAPC_LG_LISTS", 1, 0, 1},            // gather-add backward over the grouping's point lists where the caller supplies them (0: float atomics)
 };
 static int g_knobs[KNOB_COUNT];
 static int knob_parse(int id, const char *e)
@@ -149,6 +150,7 @@ int64_t papc_abi_sizeof(const char *struct_name)
     if (!struct_name) return -1;
 #define PAPC_SIZEOF(T) if (strcmp(struct_name, #T) == 0) return (int64_t)sizeof(T);
     PAPC_SIZEOF(papc_group_src)
+    PAPC_SIZEOF(papc_point_lists)
     PAPC_SIZEOF(papc_group_max)
     PAPC_SIZEOF(papc_bwd_dy)
     PAPC_SIZEOF(papc_scatter_dst)

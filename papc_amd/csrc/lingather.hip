@@ -231,6 +231,185 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
     }
 }
 
+// ---- point lists: the inverse of the grouping (papc_point_lists_f32) ------------------------------------------------------------------------
+// One WAVE per cloud.  (1) counts per source point in LDS, (2) exclusive scan -> prange, (3) the cloud's groups in order, 64 rows a step: a row
+// takes the next slot of its point's list, so every list is ascending in the row index -- a FIXED summation order for the backward below.
+// Within a step the ball query's structure makes the slots unique except for the padding copies of the group's first neighbour (one ballot ranks
+// them); any other repeated index inside a step (a caller's own lists) is detected after the LDS atomics and ranked by a 64-step lane sweep.
+struct PlArgs {
+    const float *xyz; int64_t sb, sn, sc;
+    const float *new_xyz;
+    const int32_t *idx, *cidx, *start, *rows_dev;
+    const float *wrow;
+    int N, S, K, G;
+    int32_t *prange, *prow;
+    float4 *pmeta;
+};
+
+__global__ __launch_bounds__(64) void point_lists_kernel(PlArgs a)
+{
+    extern __shared__ int pl_lds[];
+    int *cnt = pl_lds, *cur = pl_lds + a.N;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const bool cp = a.cidx != nullptr;
+    const int g0 = b * a.S, g1 = g0 + a.S;
+    const int r0 = cp ? a.start[g0] : g0 * a.K;
+    const int r1 = cp ? (g1 == a.G ? a.rows_dev[0] : a.start[g1]) : g1 * a.K;
+    const int32_t *src = cp ? a.cidx : a.idx;
+    for (int p = lane; p < a.N; p += 64) cnt[p] = 0;
+    __syncthreads();
+    for (int m = r0 + lane; m < r1; m += 64) {
+        const int j = src[m];
+        if (j >= 0 && j < a.N) atomicAdd(&cnt[j], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan of cnt over the cloud's points: a lane owns a contiguous block, the blocks' sums are scanned across the wave
+        const int per = (a.N + 63) / 64;
+        const int p0 = min(a.N, lane * per), p1 = min(a.N, p0 + per);
+        int s = 0;
+        for (int p = p0; p < p1; ++p) s += cnt[p];
+        int incl = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        int run = r0 + incl - s;
+        for (int p = p0; p < p1; ++p) {
+            const int c = cnt[p];
+            cur[p] = run;
+            a.prange[2 * ((int64_t)b * a.N + p)] = run;
+            a.prange[2 * ((int64_t)b * a.N + p) + 1] = run + c;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int g = g0; g < g1; ++g) {
+        const int s = cp ? a.start[g] : g * a.K;
+        const int n = cp ? ((g == a.G - 1 ? a.rows_dev[0] : a.start[g + 1]) - s) : a.K;
+        const int first = src[s];
+        const float cx = a.new_xyz[(int64_t)g * 3], cy = a.new_xyz[(int64_t)g * 3 + 1], cz = a.new_xyz[(int64_t)g * 3 + 2];
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            const bool in = k < n;
+            const int m = s + (in ? k : 0);
+            const int p = in ? src[m] : -1;
+            const bool valid = in && p >= 0 && p < a.N;
+            const bool copy = valid && k > 0 && p == first;
+            const bool uniq = valid && !copy;
+            int pos = 0;
+            if (uniq) pos = atomicAdd(&cur[p], 1);
+            // (a single wave: the LDS atomics of one instruction have all retired before the next LDS read of the same wave)
+            const bool clash = uniq && cur[p] != pos + 1;
+            if (__ballot(clash)) {                 // repeated indices that are not padding copies: rank them by lane
+                int base = pos, rank = 0;
+                for (int l = 0; l < 64; ++l) {
+                    const int pl = __builtin_amdgcn_readlane(p, l), ol = __builtin_amdgcn_readlane(pos, l);
+                    const int ul = __builtin_amdgcn_readlane((int)uniq, l);
+                    if (ul && pl == p) { base = min(base, ol); rank += l < lane ? 1 : 0; }
+                }
+                if (uniq) pos = base + rank;
+            }
+            const unsigned long long cm = __ballot(copy);
+            if (cm) {
+                const int leader = __ffsll((long long)cm) - 1;
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&cur[first], __popcll(cm));
+                base = __builtin_amdgcn_readlane(base, leader);
+                if (copy) pos = base + __popcll(cm & lt);
+            }
+            if (valid) {
+                const float *q = a.xyz + (int64_t)b * a.sb + (int64_t)p * a.sn;
+                a.prow[pos] = m;
+                a.pmeta[pos] = make_float4(q[0] - cx, q[a.sc] - cy, q[2 * a.sc] - cz, a.wrow ? a.wrow[m] : 1.f);
+            }
+        }
+    }
+}
+
+// ---- backward over the point lists: G[p] = sum over p's rows (ascending) of dY[m], no atomics; the xyz columns of dW as before -------------------
+// A WAVE owns a point at a time: its two half-waves take the list's even and odd entries (lane & 31 = channel quad for C = 128: one 512-byte row
+// per half-wave and load), U entries each per pass, so both halves always work on the same list (no divergence between them) and an average list
+// (9 rows) is two dependent round trips: the entries, then their rows.  The halves' sums are added in fixed order (even + odd).  Eight points per
+// workgroup keep ~2000 workgroups in flight: the kernel is a latency-bound gather of 4C-byte rows, it wants every wave slot of the chip.
+constexpr int LGL_PPW = 8;                      // points per workgroup (two per wave)
+
+template <bool CP>
+__global__ __launch_bounds__(LG_T) void lingather_bwd_lists_kernel(LinGatherArgs a, const int32_t *__restrict__ prange, const int32_t *__restrict__ prow,
+                                                                   const float4 *__restrict__ pmeta, int64_t BN)
+{
+    __shared__ float4 red[LG_T * 3];
+    const int tid = threadIdx.x;
+    const int CQ = a.C >> 2;                      // host-checked: 64 % CQ == 0 (C in {16, 32, 64, 128, 256})
+    const int lane = tid & 63, wave = tid >> 6;
+    const int SUB = 64 / CQ;                      // list entries a wave takes per load (2 for C = 128)
+    const int cq = lane % CQ, sub = lane / CQ, c = cq * 4;
+    const DySrc &d = a.d;
+    const float4 ksc = ld4(d.scale + c), ksh = ld4(d.shift + c), kmu = ld4(d.mean + c);
+    float4 kA, kB;
+    {
+        const float4 c1 = ld4(d.c1 + c), c2 = ld4(d.c2 + c), is = ld4(d.invstd + c);
+        kA = make_float4(ksc.x * c1.x, ksc.y * c1.y, ksc.z * c1.z, ksc.w * c1.w);
+        kB = make_float4(ksc.x * c2.x * is.x, ksc.y * c2.y * is.y, ksc.z * c2.z * is.z, ksc.w * c2.w * is.w);
+    }
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    const int64_t p0 = (int64_t)blockIdx.x * LGL_PPW;
+    constexpr int U = 4;
+    auto gval = [&](float y, float z, float sc, float sh, float mu, float A, float Bc, float w) {
+        const float pre = fmaf(sc, y, sh);
+        const float pp = pre > 0.f ? z : 0.f;
+        return CP ? fmaf(-w, fmaf(Bc, y - mu, A), sc * pp) : fmaf(sc, pp, -fmaf(Bc, y - mu, A));
+    };
+    for (int64_t pt = p0 + wave; pt < min(BN, p0 + LGL_PPW); pt += LG_T / 64) {
+        const int rs = prange[2 * pt], re = prange[2 * pt + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = rs + sub; k < re + sub; k += U * SUB) {      // (uniform trip count across the wave: the halves differ by one entry at most)
+            int m[U];
+            float4 mt[U], vy[U], vz[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = min(k + u * SUB, re - 1);
+                m[u] = prow[kk];
+                mt[u] = pmeta[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                vy[u] = ld4(d.y + (int64_t)m[u] * a.C + c);
+                vz[u] = ld4(d.dz + (int64_t)m[u] * a.C + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (k + u * SUB >= re) continue;
+                float4 g;
+                g.x = gval(vy[u].x, vz[u].x, ksc.x, ksh.x, kmu.x, kA.x, kB.x, mt[u].w);
+                g.y = gval(vy[u].y, vz[u].y, ksc.y, ksh.y, kmu.y, kA.y, kB.y, mt[u].w);
+                g.z = gval(vy[u].z, vz[u].z, ksc.z, ksh.z, kmu.z, kA.z, kB.z, mt[u].w);
+                g.w = gval(vy[u].w, vz[u].w, ksc.w, ksh.w, kmu.w, kA.w, kB.w, mt[u].w);
+                acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+                a0.x = fmaf(g.x, mt[u].x, a0.x); a0.y = fmaf(g.y, mt[u].x, a0.y); a0.z = fmaf(g.z, mt[u].x, a0.z); a0.w = fmaf(g.w, mt[u].x, a0.w);
+                a1.x = fmaf(g.x, mt[u].y, a1.x); a1.y = fmaf(g.y, mt[u].y, a1.y); a1.z = fmaf(g.z, mt[u].y, a1.z); a1.w = fmaf(g.w, mt[u].y, a1.w);
+                a2.x = fmaf(g.x, mt[u].z, a2.x); a2.y = fmaf(g.y, mt[u].z, a2.y); a2.z = fmaf(g.z, mt[u].z, a2.z); a2.w = fmaf(g.w, mt[u].z, a2.w);
+            }
+        }
+        // the wave's SUB partial sums, added in sub order (fixed): sub 0 collects
+        for (int o = CQ; o < 64; o <<= 1) {
+            acc.x += __shfl_down(acc.x, o); acc.y += __shfl_down(acc.y, o); acc.z += __shfl_down(acc.z, o); acc.w += __shfl_down(acc.w, o);
+        }
+        if (sub == 0) *reinterpret_cast<float4 *>(a.G + pt * a.C + c) = acc;
+    }
+    red[tid * 3 + 0] = a0; red[tid * 3 + 1] = a1; red[tid * 3 + 2] = a2;
+    __syncthreads();
+    float *out = a.dwx + (int64_t)blockIdx.x * a.C * 3;
+    const int SL = LG_T / CQ;                     // (wave, sub) slots per channel quad
+    for (int t = tid; t < a.C * 3; t += LG_T) {       // (channel, coordinate): the slots summed in slot order
+        const int ch = t / 3, k = t - ch * 3;
+        float sacc = 0.f;
+        for (int sl = 0; sl < SL; ++sl) {
+            const float4 v = red[(sl * CQ + (ch >> 2)) * 3 + k];
+            sacc += (ch & 3) == 0 ? v.x : (ch & 3) == 1 ? v.y : (ch & 3) == 2 ? v.z : v.w;
+        }
+        out[t] = sacc;
+    }
+}
+
 }  // namespace papc
 
 using namespace papc;
@@ -283,6 +462,43 @@ int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, con
     return check_launch("papc_lingather_fwd_f32");
 }
 
+int papc_lingather_list_parts(int64_t BN) { return (int)((BN + LGL_PPW - 1) / LGL_PPW); }
+
+static bool lg_lists_usable(const papc_group_src *g, int C)
+{
+    return g->plists && g->plists->prange && g->plists->prow && g->plists->pmeta && (g->plists->compact != 0) == (g->cidx != nullptr) && C % 4 == 0 &&
+           C / 4 <= 64 && 64 % (C / 4) == 0 && knob(KNOB_LG_LISTS) != 0;
+}
+
+int papc_lingather_bwd_lists_ok(const papc_group_src *grp, int C) { return grp && lg_lists_usable(grp, C) ? 1 : 0; }
+
+int papc_lingather_bwd_parts(const papc_group_src *grp, int B, int C)
+{
+    if (!grp) return 0;
+    const int64_t M = (int64_t)B * grp->S * grp->K;
+    return lg_lists_usable(grp, C) ? papc_lingather_list_parts((int64_t)B * grp->N) : papc_lingather_parts(M);
+}
+
+int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start, int32_t *prange, int32_t *prow, float *pmeta, papc_stream_t stream)
+{
+    int rc = lg_check(grp, B, 4, "papc_point_lists_f32");
+    if (rc) return rc;
+    PAPC_REQUIRE(prange && prow && pmeta, PAPC_E_INVALID, "papc_point_lists_f32: null pointer");
+    PAPC_REQUIRE(!grp->cidx == !start, PAPC_E_INVALID, "papc_point_lists_f32: a compacted grouping needs start, a padded one must not pass it");
+    PAPC_REQUIRE(!grp->cidx || grp->wstat, PAPC_E_INVALID, "papc_point_lists_f32: a compacted grouping needs its row weights (grp->wstat = wrow)");
+    PAPC_REQUIRE(grp->N <= 8192, PAPC_E_UNSUPPORTED, "papc_point_lists_f32: N=%d > 8192 source points per cloud", grp->N);
+    PAPC_REQUIRE(aligned16(pmeta), PAPC_E_INVALID, "papc_point_lists_f32: pmeta must be 16-byte aligned");
+    PlArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xyz = grp->xyz; a.sb = grp->sb; a.sn = grp->sn; a.sc = grp->sc; a.new_xyz = grp->new_xyz; a.idx = grp->idx; a.cidx = grp->cidx; a.start = start;
+    a.rows_dev = grp->rows_dev; a.wrow = grp->cidx ? grp->wstat : nullptr; a.N = grp->N; a.S = grp->S; a.K = grp->K; a.G = B * grp->S;
+    a.prange = prange; a.prow = prow; a.pmeta = reinterpret_cast<float4 *>(pmeta);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_GROUP, st);
+    hipLaunchKernelGGL(point_lists_kernel, dim3((unsigned)B), dim3(64), (size_t)grp->N * 2 * sizeof(int), st, a);
+    return check_launch("papc_point_lists_f32");
+}
+
 int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream)
 {
     int rc = lg_check(grp, B, C, "papc_lingather_bwd_f32");
@@ -298,10 +514,22 @@ int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int
     a.d.c1 = dy->c1; a.d.c2 = dy->c2; a.d.C = C; a.d.wrow = dy->wrow;
     PAPC_REQUIRE(!a.cidx == !dy->wrow, PAPC_E_INVALID, "papc_lingather_bwd_f32: compacted group source and compacted dY source go together");
     a.G = G; a.dwx = dwx_partial;
-    const int parts = papc_lingather_parts(a.M);
-    a.rows_per_wg = (int)((a.M + parts - 1) / parts);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DW, st);
+    if (lg_lists_usable(grp, C)) {
+        // the grouping's point lists: every row of G is written (a point in no group gets zeros), each as the sum of its rows in ascending order
+        PAPC_REQUIRE(aligned16(G) && aligned16(dy->y) && aligned16(dy->dz), PAPC_E_INVALID, "papc_lingather_bwd_f32: G / y / dz must be 16-byte aligned");
+        const int64_t BN = (int64_t)B * grp->N;
+        const unsigned nwg = (unsigned)papc_lingather_list_parts(BN);
+        const papc_point_lists &pl = *grp->plists;
+        if (a.cidx)
+            hipLaunchKernelGGL(lingather_bwd_lists_kernel<true>, dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, reinterpret_cast<const float4 *>(pl.pmeta), BN);
+        else
+            hipLaunchKernelGGL(lingather_bwd_lists_kernel<false>, dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, reinterpret_cast<const float4 *>(pl.pmeta), BN);
+        return check_launch("papc_lingather_bwd_f32");
+    }
+    const int parts = papc_lingather_parts(a.M);
+    a.rows_per_wg = (int)((a.M + parts - 1) / parts);
     hipLaunchKernelGGL(lingather_bwd_kernel, dim3((unsigned)parts), dim3(LG_T), 0, st, a);
     return check_launch("papc_lingather_bwd_f32");
 }

@@ -195,7 +195,7 @@ static size_t layout_bwd(const papc_sa_plan &p, void *base, BwdPtrs &b)
     if (p.lin0) {
         const int c0 = p.d.cout[0];
         const int64_t BN = (int64_t)p.d.B * p.d.N;
-        b.dwx_part = c.take<float>((size_t)papc_lingather_parts(M) * c0 * 3);
+        b.dwx_part = c.take<float>((size_t)std::max(papc_lingather_parts(M), papc_lingather_list_parts(BN)) * c0 * 3);
         b.Gs = c.take<float>((size_t)BN * c0);
         const int rpc_g = dw_rows_per_chunk(BN, c0, p.d.D, 64);
         b.part_g = c.take<float>((size_t)((BN + rpc_g - 1) / rpc_g) * ((size_t)c0 * p.d.D + c0));
@@ -444,6 +444,7 @@ static void fill_grp(papc_group_src &g, const papc_sa_desc &d, const papc_sa_io 
     g.xyz = io.xyz; g.sb = io.sb; g.sn = io.sn; g.sc = io.sc; g.new_xyz = io.new_xyz; g.feats = io.feats; g.idx = io.idx;
     g.N = d.N; g.S = d.S; g.K = d.K; g.D = d.D; g.xyz_first = d.xyz_first;
     if (compact && io.compact) { g.cidx = io.compact->cidx; g.seg_grp = io.compact->seg_grp; g.rows_dev = io.compact->rows; }
+    g.plists = io.plists;     // (papc_lingather_bwd_f32 uses them only when they index the row layout this stack runs)
 }
 
 __global__ void mul_vec_kernel(const float *__restrict__ a, const float *__restrict__ b, int n, float *__restrict__ out, int accumulate)
@@ -724,8 +725,9 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
         if (l == 0 && p.lin0) {
             // G[j] = sum of the dY rows that gathered point j (+ the xyz columns of dW, streamed); the D-wide products run on B*N rows
             const int64_t BN = (int64_t)d.B * d.N;
-            const int parts_l = papc_lingather_parts(M);
-            SA_CALL(papc_fill_f32(b.Gs, BN * cout, 0.f, st));
+            const int parts_l = papc_lingather_bwd_parts(&grp, d.B, cout);
+            // (with the grouping's point lists every row of G is written in a fixed summation order: no atomics, nothing to pre-zero)
+            if (!papc_lingather_bwd_lists_ok(&grp, cout)) SA_CALL(papc_fill_f32(b.Gs, BN * cout, 0.f, st));
             SA_CALL(papc_lingather_bwd_f32(&dy, &grp, d.B, cout, b.Gs, b.dwx_part, st));
             const int fcol0 = d.xyz_first ? 3 : 0, xcol0 = d.xyz_first ? 0 : d.D;
             float *dw = gr->dw[l];

@@ -121,10 +121,40 @@ class PointNetSetAbstraction(nn.Module):
             from .mlp import xyz_pregroup
             xc, gpart = xyz_pregroup(xyz, new_xyz, idx, out=None if (out is None or len(out) < 4) else (out[2], out[3]))
             return new_xyz, idx, xc, gpart
-        cp = self._compact_plan(idx, out=None if (out is None or len(out) < 9) else tuple(out[2:9]))
-        if cp is not None:              # (new_xyz, idx, cnt8, start, rows, cidx, seg_grp, wrow, coef): part of the plan like the lists themselves
-            return (new_xyz, idx) + cp.tensors()
-        return new_xyz, idx
+        cp = self._compact_plan(idx, out=None if (out is None or len(out) not in (9, 12)) else tuple(out[2:9]))
+        # (new_xyz, idx[, cnt8, start, rows, cidx, seg_grp, wrow, coef][, prange, prow, pmeta]): the compact plan and the grouping's point
+        # lists (the inverse index the gather-add backward sums over) are part of the plan like the lists themselves
+        res = (new_xyz, idx) + (cp.tensors() if cp is not None else ())
+        if self._wants_lists(xyz, cp):
+            from . import compact as _c
+            have = out is not None and len(out) == len(res) + 3
+            pl = _c.point_lists(xyz, new_xyz, idx, cp, out=tuple(out[len(res):]) if have else None)
+            res = res + pl.tensors()
+        return res
+
+    def _wants_lists(self, xyz, cplan):
+        """point lists are made for a training layer whose first layer can run as a gather-add (features present: decided by the stack plan) --
+        by default only when the stack runs compacted (compact.LISTS)"""
+        from . import compact as _c
+        D = self.mlp_convs[0].in_channels - 3
+        on = _c.LISTS >= 2 or (_c.LISTS == 1 and cplan is not None)
+        return (on and self.training and not self.group_all and D >= 16 and D % 4 == 0 and len(self.mlp_convs) >= 2
+                and xyz.shape[1] <= _c.MAX_LIST_POINTS and not self.reference_quirks)
+
+    @staticmethod
+    def _parse_plan(sampled, G, K):
+        """(new_xyz, idx, xyz_pre, CompactPlan, PointLists) from a :meth:`sample` result"""
+        from .compact import CompactPlan, PointLists
+        new_xyz, idx = sampled[0], sampled[1]
+        rest = tuple(sampled[2:])
+        xyz_pre = rest if len(rest) == 2 else None
+        cplan = plists = None
+        if len(rest) in (7, 10):
+            cplan = CompactPlan(rest[:7], G, K)
+            rest = rest[7:]
+        if len(rest) == 3:
+            plists = PointLists(rest, cplan is not None)
+        return new_xyz, idx, xyz_pre, cplan, plists
 
     def _xyz_first(self, B):
         from .mlp import xyz_first_layer_ok
@@ -151,18 +181,17 @@ class PointNetSetAbstraction(nn.Module):
         else:                                                                   # sample_and_group :129-157
             S, K = self.npoint, self.nsample
             xyz_pre = None
-            cplan = None
+            cplan = plists = None
             if sampled is not None:
-                new_xyz, idx = sampled[0], sampled[1]
-                xyz_pre = tuple(sampled[2:4]) if len(sampled) == 4 else None
-                if len(sampled) == 9:
-                    from .compact import CompactPlan
-                    cplan = CompactPlan(tuple(sampled[2:9]), B * S, K)
+                new_xyz, idx, xyz_pre, cplan, plists = self._parse_plan(sampled, B * S, K)
             else:
                 _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)
                 idx = F_._ball_query_raw([self.radius], [K], xyz, new_xyz)[0]
                 if feats is not None:
                     cplan = self._compact_plan(idx)
+                    if self._wants_lists(xyz, cplan) and torch.is_grad_enabled():
+                        from . import compact as _c
+                        plists = _c.point_lists(xyz, new_xyz, idx, cplan)
         params = _stack_params(self.mlp_convs, self.mlp_bns)
         if feats is not None:
             feats, params, D = _pad_features(feats, params, True)
@@ -173,6 +202,7 @@ class PointNetSetAbstraction(nn.Module):
             spec.xyz_pre = xyz_pre
         if not self.group_all and feats is not None:
             spec.compact = cplan
+            spec.plists = plists
         out = shared_mlp_max(spec, _bn_buffers(self.mlp_bns), xyz, new_xyz, feats, idx, params)   # :214-219
         new_points = out.view(B, S, -1).transpose(1, 2)                         # [B,D',S]
         # (group_all: new_xyz is the cached READ-ONLY zero centre of sample_and_group_all, :170 -- a clone here would put a copy kernel

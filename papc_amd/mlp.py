@@ -45,6 +45,7 @@ class StackSpec:
         self.xyz_pre = None
         # optional: compact.CompactPlan of these very idx lists -- the stack then runs on the distinct neighbours only (csrc/compact.hip)
         self.compact = None
+        self.plists = None             # optional compact.PointLists of (xyz, new_xyz, idx): the gather-add backward as a segmented sum (stack.py)
 
 
 def _group_src(spec, xyz, new_xyz, feats, idx):

@@ -41,7 +41,7 @@ class SaIo(ctypes.Structure):
     """papc_sa_io"""
     _fields_ = [("xyz", c_p), ("sb", c_l), ("sn", c_l), ("sc", c_l), ("new_xyz", c_p), ("feats", c_p), ("idx", c_p), ("x_rows", c_p),
                 ("xc", c_p), ("xc_gram", c_p), ("compact", ctypes.POINTER(CompactSrc)), ("consts3", c_p), ("consts3_ld", c_i),
-                ("layer", SaLayer * MAXL), ("out", c_p), ("saved", c_p), ("scratch", c_p)]
+                ("layer", SaLayer * MAXL), ("out", c_p), ("saved", c_p), ("scratch", c_p), ("plists", c_p)]
 
 
 class SaPlan(ctypes.Structure):
@@ -106,6 +106,12 @@ def _fill_io(io, spec, xyz, new_xyz, feats, idx, x_rows, params, bn_buffers, kee
         src = CompactSrc(cp.start.data_ptr(), cp.rows.data_ptr(), cp.cidx.data_ptr(), cp.seg_grp.data_ptr(), cp.wrow.data_ptr(), cp.coef.data_ptr(), cp.G)
         keep.append(src)
         io.compact = ctypes.pointer(src)
+    pl = getattr(spec, "plists", None)
+    if pl is not None:          # the grouping's point lists (compact.point_lists): deterministic gather-add backward
+        src = _lib.PointLists(pl.prange.data_ptr(), pl.prow.data_ptr(), pl.pmeta.data_ptr(), int(pl.compact))
+        keep.append(src)
+        keep.append(pl)
+        io.plists = ctypes.addressof(src)
     c3 = _consts3(params[0].device)
     keep.append(c3)
     io.consts3, io.consts3_ld = c3.data_ptr(), c3.shape[1]

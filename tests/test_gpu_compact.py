@@ -134,7 +134,7 @@ def test_compacted_layer_follows_the_device_side_row_count(dev):
         pts = torch.from_numpy(np.random.default_rng(seed).normal(size=(B, 128, 512)).astype(np.float32)).to(dev)
         st = torch.from_numpy(make_start_idx(B, 512, seed)).to(dev)
         plan = layer.sample(x, st, out=bufs)
-        assert len(plan) == 9
+        assert len(plan) == 12            # (new_xyz, idx) + the 7 compact-plan tensors + the 3 point-list tensors of a training layer
         if bufs is None:
             bufs = plan
         else:
@@ -153,9 +153,11 @@ def test_auto_policy_measures_once(dev):
     x = torch.from_numpy(make_clouds(B, 512, 5)).to(dev)
     st = torch.from_numpy(make_start_idx(B, 512, 5)).to(dev)
     sparse = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False).to(dev)
-    assert len(sparse.sample(x, st)) == 9 and sparse._compact_on is True
+    assert len(sparse.sample(x, st)) == 12 and sparse._compact_on is True       # compact plan + point lists
     full = PointNetSetAbstraction(128, 3.0, 64, 131, [128, 128, 256], False).to(dev)      # radius covers the cloud: every list is full
-    assert len(full.sample(x, st)) == 2 and full._compact_on is False
+    assert len(full.sample(x, st)) == 2 and full._compact_on is False           # padded: no point lists either (compact.LISTS == 1)
+    sparse.eval()
+    assert len(sparse.sample(x, st)) == 9                                        # no backward will follow: no lists
     other = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 128], False).to(dev)     # widths without a compacted flavour
     assert len(other.sample(x, st)) == 2 and other._compact_on is None
 
@@ -198,3 +200,133 @@ def test_streamed_psel_is_bit_identical(dev, monkeypatch):
         elif i % 4 != 1:  # the gather-add first layer sums its rows with float atomics: same numbers, not the same bits run to run
             assert_close(a, b, 2e-5, "streamed psel: gradient %d" % i)
     assert_close(res["1"][1], res["0"][1], 2e-5, "streamed psel: dfeats")
+
+
+def _numpy_lists(B, N, S, K, xyz, new_xyz, rows_pt, rows_grp, w):
+    """expected (prange, prow, pmeta): per (cloud, point) its rows in ascending order; rows_pt / rows_grp = point index / group of every physical
+    row (point outside [0, N): in no list)"""
+    n = len(rows_pt)
+    b = rows_grp // S
+    ok = (rows_pt >= 0) & (rows_pt < N)
+    key = (b.astype(np.int64) * N + rows_pt)[ok]
+    rws = np.arange(n)[ok]
+    order = np.lexsort((rws, key))
+    key, rws = key[order], rws[order]
+    cnt = np.bincount(key, minlength=B * N)
+    prange = np.zeros((B * N, 2), np.int64)
+    # lists of cloud b start at the cloud's first physical row and are packed in point order
+    first_row = np.array([np.min(np.arange(n)[b == c]) if (b == c).any() else 0 for c in range(B)])
+    pos = {}
+    out_rows = {}
+    for c in range(B):
+        run = int(first_row[c])
+        for p in range(N):
+            prange[c * N + p] = (run, run + cnt[c * N + p])
+            run += cnt[c * N + p]
+    meta = {}
+    for k_, r in zip(key, rws):
+        c, p = divmod(int(k_), N)
+        d = xyz[c, p] - new_xyz.reshape(-1, 3)[rows_grp[r]]
+        meta[r] = (d[0], d[1], d[2], w[r])
+    return prange, key, rws, meta
+
+
+@pytest.mark.parametrize("B,N,S,K,radius,compact", [(4, 512, 128, 64, 0.4, True), (4, 512, 128, 64, 0.4, False), (2, 1024, 64, 128, 0.3, True),
+                                                    (3, 300, 20, 16, 0.25, False), (1, 256, 16, 8, 0.05, True)])
+def test_point_lists_match_numpy(dev, B, N, S, K, radius, compact):
+    """papc_point_lists_f32: the inverse of a grouping -- per source point its physical rows ASCENDING (the fixed summation order of the gather-add
+    backward), xyz_j - centre and the row's multiplicity weight per entry -- for the compacted and the padded row layout, bit for bit against numpy."""
+    xyz, new_xyz, idx = _lists(dev, B, N, S, K, radius, 5)
+    cp = C.plan(idx) if compact else None
+    pl = C.point_lists(xyz, new_xyz, idx, cp)
+    torch.cuda.synchronize()
+    if compact:
+        rows = int(cp.rows[0])
+        rows_pt = cp.cidx.cpu().numpy()[:rows].astype(np.int64)
+        rows_grp = np.repeat(cp.seg_grp.cpu().numpy()[:rows // 8], 8).astype(np.int64)
+        w = cp.wrow.cpu().numpy()[:rows]
+    else:
+        rows_pt = idx.cpu().numpy().reshape(-1).astype(np.int64)
+        rows_grp = np.repeat(np.arange(B * S), K)
+        w = np.ones(len(rows_pt), np.float32)
+    prange, key, rws, meta = _numpy_lists(B, N, S, K, xyz.cpu().numpy(), new_xyz.cpu().numpy(), rows_pt, rows_grp, w)
+    got_range = pl.prange.cpu().numpy()
+    assert np.array_equal(got_range, prange)
+    prow, pmeta = pl.prow.cpu().numpy(), pl.pmeta.cpu().numpy()
+    seen = 0
+    for q in range(B * N):
+        a, b_ = prange[q]
+        want = rws[key == q] if b_ > a else np.zeros(0, np.int64)
+        assert np.array_equal(prow[a:b_], want), q
+        for e, r in zip(range(a, b_), want):
+            assert tuple(pmeta[e]) == tuple(np.float32(v) for v in meta[int(r)]), (q, r)
+        seen += b_ - a
+    assert seen == int(((rows_pt >= 0) & (rows_pt < N)).sum())          # every valid row in exactly one list
+    assert pl.compact == compact
+
+
+def test_point_lists_with_repeated_indices_inside_a_step(dev):
+    """lists a caller made up: repeated indices that are NOT ball-query padding (the builder's lane-sweep ranking), out-of-range entries (in no
+    list) and an index that equals the group's first entry in the middle of the list"""
+    B, N, S, K = 2, 64, 4, 64
+    rng = np.random.default_rng(3)
+    ii = rng.integers(0, 12, size=(B, S, K)).astype(np.int32)          # 12 distinct values over 64 slots: every step is full of repeats
+    ii[0, 1, 5] = N                                                      # the no-hit sentinel
+    ii[1, 2, 7] = -1
+    idx = torch.from_numpy(ii).to(dev)
+    xyz = torch.from_numpy(rng.normal(size=(B, N, 3)).astype(np.float32)).to(dev)
+    new_xyz = torch.from_numpy(rng.normal(size=(B, S, 3)).astype(np.float32)).to(dev)
+    pl = C.point_lists(xyz, new_xyz, idx, None)
+    torch.cuda.synchronize()
+    rows_pt = ii.reshape(-1).astype(np.int64)
+    prange, key, rws, meta = _numpy_lists(B, N, S, K, xyz.cpu().numpy(), new_xyz.cpu().numpy(), rows_pt, np.repeat(np.arange(B * S), K),
+                                          np.ones(len(rows_pt), np.float32))
+    assert np.array_equal(pl.prange.cpu().numpy(), prange)
+    prow = pl.prow.cpu().numpy()
+    for q in range(B * N):
+        a, b_ = prange[q]
+        assert np.array_equal(prow[a:b_], rws[key == q]), q
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_list_backward_equals_atomic_backward_and_is_bit_reproducible(dev, compact, monkeypatch):
+    """The gather-add first layer's backward over the grouping's point lists (a segmented sum in fixed order) against the float-atomic kernel it
+    replaces (PAPC_LG_LISTS=0 through papc_knob_set): every gradient of an SA2-shaped stack equal to 2e-6 / 2e-5 (another summation order of the
+    same terms) -- and two runs of the list path BIT-identical in every gradient, which the atomic path is not (the only non-deterministic kernel
+    of a training step, pointnet2_basic_layers.py:146-153 backward)."""
+    lib = _lib.load()
+
+    def run(lists):
+        old = _lib.ctypes.c_int(0)
+        _lib.check(lib.papc_knob_get(b"PAPC_LG_LISTS", _lib.ctypes.byref(old)), "papc_knob_get")
+        _lib.check(lib.papc_knob_set(b"PAPC_LG_LISTS", 1 if lists else 0), "papc_knob_set")
+        try:
+            N, S, K, D, B = 512, 128, 64, 128, 8
+            xyz, new_xyz, idx = _lists(dev, B, N, S, K, 0.4, 4)
+            rng = np.random.default_rng(4)
+            feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev).requires_grad_(True)
+            ws = seeded_weights([D + 3, 128, 128, 256], 54)
+            params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+            spec = StackSpec(B, N, S, K, D, True)
+            cp = C.plan(idx) if compact else None
+            spec.compact = cp
+            spec.plists = C.point_lists(xyz, new_xyz, idx, cp)
+            out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+            assert (out.grad_fn.compact is not None) == compact
+            gout = torch.from_numpy(np.random.default_rng(8).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            return [p.grad.cpu().numpy() for p in params], feats.grad.cpu().numpy()
+        finally:
+            _lib.check(lib.papc_knob_set(b"PAPC_LG_LISTS", old.value), "papc_knob_set")
+
+    ga, fa = run(False)
+    g1, f1 = run(True)
+    g2, f2 = run(True)
+    for i, (a, b) in enumerate(zip(g1, g2)):
+        assert np.array_equal(a, b), "list backward: gradient %d differs between two runs" % i
+    assert np.array_equal(f1, f2), "list backward: dfeats differs between two runs"
+    for i, (a, b) in enumerate(zip(g1, ga)):
+        if i % 4 != 1:
+            assert_close(a, b, 2e-5, "list vs atomic backward: gradient %d" % i)
+    assert_close(f1, fa, 2e-5, "list vs atomic backward: dfeats")
