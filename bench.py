@@ -180,6 +180,12 @@ def main():
                     "instead of the default since round 5: a SECOND hipGraph on the side stream with no graph edge to the step's -- a forked branch costs the "
                     "main chain ~60 us per replay on MI355X whatever it holds; a device-side gate (papc_flag_wait) holds the pyramid back until the step has "
                     "enqueued SA2, plain stream events order the plan buffers across steps")
+    ap.add_argument("--split-pyramid", action="store_true", help="(N = 1, opt-in; measured SLOWER on MI355X in round 6: 1.62 against 1.555 ms per step, same box) the "
+                    "pyramid split over two side streams -- the first level's farthest-point sampling (a serial chain of 512 argmax steps on 32 CUs, 0.32 ms) "
+                    "for the batch TWO steps ahead, beside the rest of the NEXT batch's pyramid (ball queries, second level, compact plan, point lists: 0.2 ms) "
+                    "-- three alternating sets of graphs and buffers.  Built on the idea that both halves would fit into the window in which the step's own "
+                    "kernels are small grids (SA3, head: 0.36 ms); they do fit, and the small-grid kernels slow down by more than the pyramid's tail costs "
+                    "the backward kernels it otherwise lands on")
     ap.add_argument("--eager-sampling", action="store_true", help="(N > 1) rounds 3-4: three graphs per step with the next batch's pyramid enqueued eagerly on a "
                     "high-priority side stream behind the first; default since round 5: two graphs per step (the cut where the tail bucket's all-reduce is "
                     "issued) and the pyramid as a gated hipGraph on the side stream, as at N = 1")
@@ -271,7 +277,7 @@ def main():
 
     batches = [make_batch(k) for k in range(NB)]
     # the captured graphs read their inputs from two static slots (set i trains on slot i while the side stream loads slot 1 - i with the next batch)
-    slots = [tuple(t.clone() for t in batches[0]) for _ in range(2)]
+    slots = [tuple(t.clone() for t in batches[0]) for _ in range(3)]     # (the split pyramid cycles through three)
     cur = {"j": 0}                                # steps enqueued so far = index of the batch the next step trains on
 
     def unpack(b):
@@ -316,8 +322,11 @@ def main():
     def gate_open(counter=None):
         _lib.check(lib.papc_flag_set(gate.data_ptr(), 1, counter.data_ptr() if counter is not None else None, _lib.stream_ptr()), "papc_flag_set")
 
-    def gate_wait():
-        _lib.check(lib.papc_flag_wait(gate.data_ptr(), GATE_SPINS, _lib.stream_ptr()), "papc_flag_wait")
+    def gate_wait(slot=0):
+        _lib.check(lib.papc_flag_wait_slot(gate.data_ptr(), slot, GATE_SPINS, _lib.stream_ptr()), "papc_flag_wait_slot")
+
+    split_pyr = side_graph and args.split_pyramid       # the pyramid on two side streams, FPS1 one batch further ahead (three sets of graphs / buffers)
+    side2 = torch.cuda.Stream() if split_pyr else None
 
     from papc_amd.head import unit_gradient
     ONE = unit_gradient(dev)                    # d(loss)/d(loss), allocated once; seeding with this tensor skips the loss's multiply-by-one launch
@@ -413,7 +422,7 @@ def main():
     def stage1(plan_in=None, plan_out=None, cut=None, si=0):
         """``si`` = the input slot this graph trains on; a forked sampling branch reads the OTHER slot (the next batch)"""
         x, y, s1, s2 = unpack(slots[si])
-        xn, _, s1n, s2n = unpack(slots[1 - si])
+        xn, _, s1n, s2n = unpack(slots[1 - si] if si < 2 else slots[0])
         if not ZERO_IN_ADAM:
             flat.zero_grad()
 
@@ -501,6 +510,37 @@ def main():
                 bufs = [tuple(tuple(t.clone() for t in lvl) for lvl in p0) for _ in range(2)]
                 torch.cuda.synchronize()
             gs, losses = [], []
+            if split_pyr:
+                bufs.append(tuple(tuple(t.clone() for t in lvl) for lvl in p0))      # a third set
+                gB, gA = [], []
+                for i in range(3):
+                    g1 = torch.cuda.CUDAGraph()
+                    graph_state["capturing_main"] = True
+                    with torch.cuda.graph(g1, stream=torch.cuda.current_stream(), capture_error_mode="thread_local"):
+                        loss, _, _, _ = stage1(bufs[i], None, si=i)
+                    graph_state["capturing_main"] = False
+                    gs.append((g1, None, None))
+                    losses.append(loss)
+                    for strm, lst, stage, k, slot_w in ((side, gB, "rest", (i + 1) % 3, 0), (side2, gA, "fps1", (i + 2) % 3, 1)):
+                        g2 = torch.cuda.CUDAGraph()
+                        strm.wait_stream(main)
+                        with torch.cuda.stream(strm):
+                            with torch.cuda.graph(g2, stream=strm, capture_error_mode="thread_local"):
+                                gate_wait(slot_w)
+                                xk, _, s1k, s2k = unpack(slots[k])
+                                model.plan_sampling(xk, (s1k, s2k), out=bufs[k], stage=stage)
+                        main.wait_stream(strm)
+                        lst.append(g2)
+                # the pipeline's first step needs batch j + 1 in its slot and its first-level centroids in its buffers (what graph A of a
+                # previous step would have left there)
+                load_slot(1, cur["j"] + 1)
+                x1, _, s11, s21 = unpack(slots[1])
+                model.plan_sampling(x1, (s11, s21), out=bufs[1], stage="fps1")
+                graph_state["g"], graph_state["loss"], graph_state["bufs"], graph_state["gB"], graph_state["gA"] = gs, losses, bufs, gB, gA
+                graph_state["gside"] = None
+                graph_state["evB"], graph_state["evA"] = [None] * 3, [None] * 3
+                torch.cuda.synchronize()
+                return True
             if side_graph:
                 gside = []
                 for i in range(2):
@@ -652,6 +692,30 @@ def main():
         j = cur["j"]
         cur["j"] = j + 1
         g1, g1b, g2 = graph_state["g"][i]
+        if split_pyr and graph_state.get("gB"):
+            ev = graph_state["evB"][i]
+            if ev is not None:
+                main.wait_event(ev)                # slot i and bufs[i] are complete: graph B of the previous step (which waited for graph A of the one before)
+            g1.replay()
+            prev_end = graph_state.get("prev_end")
+            with torch.cuda.stream(side):          # B: the rest of batch j + 1's pyramid, from the centroids graph A left in bufs[i + 1] one step ago
+                if prev_end is not None:
+                    side.wait_event(prev_end)
+                if graph_state["evA"][(i + 1) % 3] is not None:
+                    side.wait_event(graph_state["evA"][(i + 1) % 3])
+                graph_state["gB"][i].replay()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                graph_state["evB"][(i + 1) % 3] = ev
+            with torch.cuda.stream(side2):         # A: batch j + 2 into its slot, its first-level farthest-point sampling into bufs[i + 2]
+                if prev_end is not None:
+                    side2.wait_event(prev_end)     # (their last reader: the previous step, set i + 2 = i - 1)
+                load_slot((i + 2) % 3, j + 2)
+                graph_state["gA"][i].replay()
+                ev = torch.cuda.Event()
+                ev.record(side2)
+                graph_state["evA"][(i + 2) % 3] = ev
+            return graph_state["loss"][i]
         if side_graph and graph_state.get("gside"):
             ev = graph_state["side_ev"][i]
             if ev is not None:
@@ -948,7 +1012,9 @@ def main():
                        "sampling": ("software-pipelined: batch i+1's FPS + ball-query pyramid runs as a second branch (side stream) of "
                                     "batch i's step, %s; every timed step computes one full pyramid"
                                     % (("a hipGraph of its own on the side stream, gated on the device behind SA2 (papc_flag_set / papc_flag_wait)" if dist_side_graph else "enqueued on the side stream beside the graph replay") if ext_sampling else
-                                       ("a second hipGraph on the side stream, no graph edge to the step's (a forked branch costs the main chain ~60 us per replay): "
+                                       (("two hipGraphs on two side streams, no graph edge to the step's: the first level's farthest-point sampling of the batch TWO steps "
+                                         "ahead beside the rest of the NEXT batch's pyramid (three alternating sets), both " if split_pyr else
+                                         "a second hipGraph on the side stream, no graph edge to the step's (a forked branch costs the main chain ~60 us per replay): ") +
                                         "gated on the device behind %s (papc_flag_set / papc_flag_wait), plan buffers ordered by stream events" % args.fork if (side_graph and use_graph)
                                         else "fork at " + args.fork))) if args.overlap else "in-line",
                        "mfma": "fp32 operands as exact 3-way bf16 splits, 6 v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 "

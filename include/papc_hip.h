@@ -948,9 +948,11 @@ int papc_adam_tick(int64_t *step_dev, papc_stream_t stream);
  * by a graph edge (a forked branch costs the main chain ~60 us per replay on MI355X) but where the second has to start behind a point of the first.
  * The gate only PLACES work; whatever buffers the two streams share must also be ordered by stream events (bench.py does: the gated graph waits
  * for the end-of-step event of the previous step before it is replayed).  The launch that opens must be enqueued BEFORE the one that waits when
- * both streams may share a hardware queue. */
+ * both streams may share a hardware queue.  papc_flag_wait_slot: a SECOND waiter on the same gate (slot 1 keeps its count of openings waited for
+ * in word [3]; slot 0 is papc_flag_wait) -- two streams released by the same opening. */
 int papc_flag_set(uint32_t *flag, uint32_t value, int64_t *counter, papc_stream_t stream);
 int papc_flag_wait(uint32_t *flag, int64_t max_spins, papc_stream_t stream);
+int papc_flag_wait_slot(uint32_t *flag, int slot, int64_t max_spins, papc_stream_t stream);
 int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,
                            float eps, float weight_decay, const int64_t *step_dev, float grad_scale, int zero_grad, papc_stream_t stream);
 

@@ -184,6 +184,7 @@ SIGNATURES = {
     "papc_adam_tick": (c_i, [c_p, c_p]),
     "papc_flag_set": (c_i, [c_p, ctypes.c_uint32, c_p, c_p]),
     "papc_flag_wait": (c_i, [c_p, c_l, c_p]),
+    "papc_flag_wait_slot": (c_i, [c_p, c_i, c_l, c_p]),
     "papc_adam_step_dev_f32": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, ctypes.c_double, ctypes.c_double, c_f, c_f, c_p, c_f, c_i, c_p]),
     "papc_knob_set": (c_i, [ctypes.c_char_p, c_i]),
     "papc_knob_get": (c_i, [ctypes.c_char_p, ctypes.POINTER(c_i)]),

@@ -439,17 +439,17 @@ __global__ void flag_set_kernel(unsigned *flag, unsigned value, int64_t *counter
     if (counter) counter[0] += 1;        // (a step counter riding on the same launch: FlatAdam's device step count)
     __hip_atomic_fetch_add(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ void flag_wait_kernel(unsigned *flag, long long max_spins)
+__global__ void flag_wait_kernel(unsigned *flag, long long max_spins, int widx)
 {
     if (threadIdx.x != 0) return;
-    const unsigned want = flag[1] + 1u;
+    const unsigned want = flag[widx] + 1u;        // (widx: this waiter's own count -- word 1, or word 3 for a second waiter on the same gate)
     long long n = 0;
     while ((int)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
         if (n >= max_spins) { __hip_atomic_fetch_add(flag + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
         __builtin_amdgcn_s_sleep(32);
         ++n;
     }
-    flag[1] = want;
+    flag[widx] = want;
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float *__restrict__ p, int64_t n, float v)
@@ -1189,8 +1189,16 @@ int papc_flag_wait(uint32_t *flag, int64_t max_spins, papc_stream_t stream)
 {
     PAPC_REQUIRE(flag && max_spins >= 0, PAPC_E_INVALID, "papc_flag_wait: null pointer / negative max_spins");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, st, flag, (long long)max_spins);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, st, flag, (long long)max_spins, 1);
     return check_launch("papc_flag_wait");
+}
+
+int papc_flag_wait_slot(uint32_t *flag, int slot, int64_t max_spins, papc_stream_t stream)
+{
+    PAPC_REQUIRE(flag && max_spins >= 0 && (slot == 0 || slot == 1), PAPC_E_INVALID, "papc_flag_wait_slot: null pointer / negative max_spins / slot not in {0, 1}");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(64), 0, st, flag, (long long)max_spins, slot == 0 ? 1 : 3);
+    return check_launch("papc_flag_wait_slot");
 }
 
 int papc_adam_step_dev_f32(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, float lr, double beta1, double beta2,

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
 }
 
 // ---- point lists: the inverse of the grouping (papc_point_lists_f32) ------------------------------------------------------------------------
-// One WAVE per cloud.  (1) counts per source point in LDS, (2) exclusive scan -> prange, (3) the cloud's groups in order, 64 rows a step: a row
+// One workgroup per cloud.  (1) counts per source point in LDS, (2) exclusive scan -> prange, (3) the cloud's groups in order, 64 rows a step: a row
 // takes the next slot of its point's list, so every list is ascending in the row index -- a FIXED summation order for the backward below.
 // Within a step the ball query's structure makes the slots unique except for the padding copies of the group's first neighbour (one ballot ranks
 // them); any other repeated index inside a step (a caller's own lists) is detected after the LDS atomics and ranked by a 64-step lane sweep.
@@ -246,43 +246,65 @@ struct PlArgs {
     float4 *pmeta;
 };
 
-__global__ __launch_bounds__(64) void point_lists_kernel(PlArgs a)
+// W waves per cloud, each owning a contiguous chunk of the cloud's groups and its own cursor row cw[w][.] in LDS: the serial walk (the LDS cursor
+// chain of step (3)) is S / W groups long instead of S, and a point's list is the concatenation of the waves' pieces in wave order -- still
+// ascending in the row index.
+constexpr int PL_MAXW = 8;
+
+__global__ __launch_bounds__(64 * PL_MAXW) void point_lists_kernel(PlArgs a, int W)
 {
     extern __shared__ int pl_lds[];
-    int *cnt = pl_lds, *cur = pl_lds + a.N;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    int *cw = pl_lds;                              // [W][N]: counts, then cursors
+    __shared__ int scan[64 * PL_MAXW];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = 64 * W;
     const bool cp = a.cidx != nullptr;
     const int g0 = b * a.S, g1 = g0 + a.S;
-    const int r0 = cp ? a.start[g0] : g0 * a.K;
-    const int r1 = cp ? (g1 == a.G ? a.rows_dev[0] : a.start[g1]) : g1 * a.K;
     const int32_t *src = cp ? a.cidx : a.idx;
-    for (int p = lane; p < a.N; p += 64) cnt[p] = 0;
+    const int gper = (a.S + W - 1) / W;
+    const int wg0 = min(g1, g0 + wave * gper), wg1 = min(g1, wg0 + gper);      // this wave's groups
+    auto row_of = [&](int g) { return cp ? (g == a.G ? a.rows_dev[0] : a.start[g]) : g * a.K; };
+    const int r0 = row_of(g0);
+    for (int e = tid; e < W * a.N; e += NT) cw[e] = 0;
     __syncthreads();
-    for (int m = r0 + lane; m < r1; m += 64) {
-        const int j = src[m];
-        if (j >= 0 && j < a.N) atomicAdd(&cnt[j], 1);
-    }
-    __syncthreads();
-    {   // exclusive scan of cnt over the cloud's points: a lane owns a contiguous block, the blocks' sums are scanned across the wave
-        const int per = (a.N + 63) / 64;
-        const int p0 = min(a.N, lane * per), p1 = min(a.N, p0 + per);
-        int s = 0;
-        for (int p = p0; p < p1; ++p) s += cnt[p];
-        int incl = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        int run = r0 + incl - s;
-        for (int p = p0; p < p1; ++p) {
-            const int c = cnt[p];
-            cur[p] = run;
-            a.prange[2 * ((int64_t)b * a.N + p)] = run;
-            a.prange[2 * ((int64_t)b * a.N + p) + 1] = run + c;
-            run += c;
+    if (wave < W) {
+        int *cnt = cw + wave * a.N;
+        const int m0 = row_of(wg0), m1 = row_of(wg1);
+        for (int m = m0 + lane; m < m1; m += 64) {
+            const int j = src[m];
+            if (j >= 0 && j < a.N) atomicAdd(&cnt[j], 1);
         }
     }
     __syncthreads();
+    {   // a thread owns a contiguous block of points: totals over the waves, block scan across threads, then every wave's first slot per point
+        const int per = (a.N + NT - 1) / NT;
+        const int p0 = min(a.N, tid * per), p1 = min(a.N, p0 + per);
+        int s = 0;
+        for (int p = p0; p < p1; ++p)
+            for (int w = 0; w < W; ++w) s += cw[w * a.N + p];
+        scan[tid] = s;
+        __syncthreads();
+        for (int o = 1; o < NT; o <<= 1) {          // Hillis-Steele inclusive scan of the threads' sums
+            const int v = tid >= o ? scan[tid - o] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        int run = r0 + scan[tid] - s;
+        for (int p = p0; p < p1; ++p) {
+            a.prange[2 * ((int64_t)b * a.N + p)] = run;
+            for (int w = 0; w < W; ++w) {
+                const int c = cw[w * a.N + p];
+                cw[w * a.N + p] = run;
+                run += c;
+            }
+            a.prange[2 * ((int64_t)b * a.N + p) + 1] = run;
+        }
+    }
+    __syncthreads();
+    if (wave >= W) return;
+    int *cur = cw + wave * a.N;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int g = g0; g < g1; ++g) {
+    for (int g = wg0; g < wg1; ++g) {
         const int s = cp ? a.start[g] : g * a.K;
         const int n = cp ? ((g == a.G - 1 ? a.rows_dev[0] : a.start[g + 1]) - s) : a.K;
         const int first = src[s];
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(64) void point_lists_kernel(PlArgs a)
             const bool uniq = valid && !copy;
             int pos = 0;
             if (uniq) pos = atomicAdd(&cur[p], 1);
-            // (a single wave: the LDS atomics of one instruction have all retired before the next LDS read of the same wave)
+            // (one wave per cursor row: the LDS atomics of one instruction have all retired before the wave's next LDS read)
             const bool clash = uniq && cur[p] != pos + 1;
             if (__ballot(clash)) {                 // repeated indices that are not padding copies: rank them by lane
                 int base = pos, rank = 0;
@@ -495,7 +517,8 @@ int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start,
     a.prange = prange; a.prow = prow; a.pmeta = reinterpret_cast<float4 *>(pmeta);
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_GROUP, st);
-    hipLaunchKernelGGL(point_lists_kernel, dim3((unsigned)B), dim3(64), (size_t)grp->N * 2 * sizeof(int), st, a);
+    const int W = std::max(1, std::min(PL_MAXW, 16384 / grp->N));          // waves per cloud: W cursor rows of N ints in LDS (<= 64 KB)
+    hipLaunchKernelGGL(point_lists_kernel, dim3((unsigned)B), dim3(64 * W), (size_t)W * grp->N * sizeof(int), st, a, W);
     return check_launch("papc_point_lists_f32");
 }
 

@@ -103,17 +103,30 @@ class PointNetSetAbstraction(nn.Module):
             return cp if self._compact_on else None
         return C.plan(idx, out)
 
-    def sample(self, xyz, start_idx=None, out=None):
-        """The weight-independent half of the layer (FPS + ball query, :143-145) on its own: xyz [B,3,N] ->
-        (new_xyz [B,S,3], idx [B,S,K] int32).  Lets a training loop run batch i+1's sampling on a side stream while
-        batch i's MLP kernels own the other CUs (FPS is a serial chain that occupies only B of the 256 CUs).
-        ``out`` = optional preallocated (new_xyz, idx) the kernels write straight into (no copies in a captured step)."""
+    def sample_fps(self, xyz, start_idx=None, out=None):
+        """Farthest-point sampling alone (:143-144): xyz [B,3,N] -> new_xyz [B,S,3] (written into ``out`` when given).  The serial half of
+        :meth:`sample` -- npoint dependent argmax steps on B workgroups -- which a training loop can run TWO batches ahead, beside the rest of
+        the previous batch's pyramid (bench.py: the split pyramid)."""
         if self.group_all:
             return None
         xyz = xyz.transpose(1, 2)
         if xyz.dtype != torch.float32:
             xyz = xyz.float()
-        _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=None if out is None else out[0])
+        return F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=out)[1]
+
+    def sample(self, xyz, start_idx=None, out=None, new_xyz=None):
+        """The weight-independent half of the layer (FPS + ball query, :143-145) on its own: xyz [B,3,N] ->
+        (new_xyz [B,S,3], idx [B,S,K] int32).  Lets a training loop run batch i+1's sampling on a side stream while
+        batch i's MLP kernels own the other CUs (FPS is a serial chain that occupies only B of the 256 CUs).
+        ``out`` = optional preallocated (new_xyz, idx) the kernels write straight into (no copies in a captured step);
+        ``new_xyz`` = the centroids :meth:`sample_fps` already made for this xyz (no FPS here)."""
+        if self.group_all:
+            return None
+        xyz = xyz.transpose(1, 2)
+        if xyz.dtype != torch.float32:
+            xyz = xyz.float()
+        if new_xyz is None:
+            _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=None if out is None else out[0])
         idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz, outs=None if out is None else [out[1]])[0]
         if self._xyz_first(xyz.shape[0]):
             # coordinates-only stack whose first layer runs through its input moments: the grouped centred coordinates and their

@@ -93,18 +93,22 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
         self.drop2 = nn.Dropout(0.4)
         self.fc3 = nn.Linear(256, num_classes)
 
-    def plan_sampling(self, inputs, start_idx=None, out=None):
+    def plan_sampling(self, inputs, start_idx=None, out=None, stage=None):
         """The whole weight-independent sampling pyramid of one batch (FPS1, ball query 1, FPS2, ball query 2): returns
         ((new_xyz1, idx1), (new_xyz2, idx2)).  Pass it to forward(plan=...); a training loop can compute it for batch
         i+1 on a side stream while batch i trains (see bench.py).  ``out`` = optional preallocated plan (same structure) that the
-        kernels fill in place."""
+        kernels fill in place.  ``stage`` (needs ``out``): "fps1" = only the first level's farthest-point sampling, into out[0][0] (returns
+        that tensor); "rest" = everything else, from the centroids out[0][0] already holds -- the two halves of a pyramid that a loop runs
+        on two streams, the serial FPS chain one batch further ahead than the rest."""
         xyz = torch.as_tensor(inputs)
         if self.normal_channel:
             xyz = xyz[:, :3, :]
         s = _starts(start_idx, 2)
         with torch.no_grad():
             o = out if out is not None else (None, None)
-            p1 = self.sa1.sample(xyz, s[0], out=o[0])
+            if stage == "fps1":
+                return self.sa1.sample_fps(xyz, s[0], out=o[0][0])
+            p1 = self.sa1.sample(xyz, s[0], out=o[0], new_xyz=o[0][0] if stage == "rest" else None)
             p2 = self.sa2.sample(p1[0].transpose(1, 2), s[1], out=o[1])
         return p1, p2
 

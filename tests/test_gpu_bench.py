@@ -1,6 +1,7 @@
 """What the driver times: bench.py's N = 1 launch structure (two alternating hipGraphs for the step, the next batch's FPS + ball-query pyramid as
-a second pair of hipGraphs on a side stream, gated on the device -- and the earlier structure, the pyramid as a forked branch of the step's
-graph --, B = 32, N = 4096) held to the same steps launched eagerly with in-line sampling -- loss trajectory
+a second pair of hipGraphs on a side stream, gated on the device -- and the other structures kept selectable: the pyramid as a forked branch of the
+step's graph (rounds 2-4), or split over two gated side-stream graphs with the first level's farthest-point sampling two batches ahead (round 6,
+measured slower) --, B = 32, N = 4096) held to the same steps launched eagerly with in-line sampling -- loss trajectory
 and the flat parameter buffer after the last step -- and the row-streaming GEMM's STORE_RED flavour repeated bit-identically while a
 second stream runs the sampling kernels beside it (the hazard that flavour's LATE1 ordering closes)."""
 import os
@@ -43,7 +44,9 @@ def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
     assert int(e["graph"]) == 0 and int(e["overlap"]) == 0
     f, line_f = _bench(tmp_path, "fork0", "0", "--in-graph-fork")               # rounds 2-4: the pyramid as a forked branch of the step's graph
     assert int(f["graph"]) == 1 and "fork at sa2" in line_f
-    for name, r in (("side graph", g), ("in-graph fork", f)):
+    o, line_o = _bench(tmp_path, "split0", "0", "--split-pyramid")              # round 6, opt-in: two gated side graphs, FPS1 two batches ahead, three sets
+    assert int(o["graph"]) == 1 and "two hipGraphs on two side streams" in line_o
+    for name, r in (("side graph", g), ("in-graph fork", f), ("split pyramid", o)):
         assert r["loss"].shape == e["loss"].shape == (10,) and np.all(np.isfinite(r["loss"]))
         assert np.array_equal(r["loss"], e["loss"]), (name, r["loss"], e["loss"])
         assert len(set(r["loss"].tolist())) == 10                                 # a new dropout mask per replay
@@ -80,6 +83,9 @@ def test_side_graph_survives_a_main_stream_stall(tmp_path):
     g, line = _bench(tmp_path, "stall0", "0", "--diag-stall-ms", "60")
     assert int(g["graph"]) == 1 and "a second hipGraph on the side stream" in line
     assert json.loads(line)["config"]["gate_timeouts"] == 0
+    g1, line1 = _bench(tmp_path, "stall0b", "0", "--diag-stall-ms", "60", "--split-pyramid")
+    assert "two hipGraphs on two side streams" in line1 and json.loads(line1)["config"]["gate_timeouts"] == 0
+    assert np.array_equal(g1["loss"], e["loss"]), (g1["loss"], e["loss"])
     assert np.array_equal(g["loss"], e["loss"]), (g["loss"], e["loss"])
     t, line_t = _bench(tmp_path, "stall1", "0", "--diag-stall-ms", "60", "--allow-gate-timeout", env_extra={"PAPC_GATE_SPINS": "2000"})
     assert json.loads(line_t)["config"]["gate_timeouts"] >= 2, line_t
