@@ -750,9 +750,13 @@ struct FoldBatch {
     unsigned acc_mask, wide_mask, vec_mask;
     int count;
 };
-__global__ __launch_bounds__(1024) void fold_jobs_kernel(FoldBatch b)
+// FW = chunk lanes (waves) per workgroup (PAPC_FOLD_WAVES).  Round 6 tried 8 instead of 16 -- the step's 654 workgroups of 1024 threads are two
+// residency rounds (512 fit the chip), the second a quarter full; at 512 threads all are resident at once -- and measured it 7 us SLOWER per step
+// (1.461 against 1.454 ms, same box, fixed plan): 16 stays the default.
+template <int FW>
+__global__ __launch_bounds__(64 * FW) void fold_jobs_kernel(FoldBatch b)
 {
-    __shared__ float red[16][64];
+    __shared__ float red[FW][64];
     int job = 0;
     while (job + 1 < b.count && (int)blockIdx.x >= b.wg0[job + 1]) ++job;       // (<= 24 scalar compares)
     const int wg = (int)blockIdx.x - b.wg0[job];
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(1024) void fold_jobs_kernel(FoldBatch b)
     const int64_t n = (int64_t)b.rows[job] * cols;
     const bool acc = (b.acc_mask >> job) & 1u;
     if ((b.wide_mask >> job) & 1u) {        // few chunks, contiguous output (out_ld == cols), n % 4 == 0, 16-byte aligned
-        const int64_t e = ((int64_t)wg * 1024 + threadIdx.x) * 4;
+        const int64_t e = ((int64_t)wg * (64 * FW) + threadIdx.x) * 4;
         if (e >= n) return;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int t0 = 0; t0 < n_chunks; t0 += 8) {          // 8 loads in flight, summed in chunk order
@@ -781,27 +785,27 @@ __global__ __launch_bounds__(1024) void fold_jobs_kernel(FoldBatch b)
     }
     const int el = threadIdx.x & 63, cl = threadIdx.x >> 6;  // lane = element (coalesced), wave = chunk lane
     if ((b.vec_mask >> job) & 1u) {         // many chunks, float4 lanes (n % 4 == 0, contiguous output): the same order per element, 1 KB per wave and chunk
-        __shared__ float4 red4[16][64];
+        __shared__ float4 red4[FW][64];
         const int64_t i4 = ((int64_t)wg * 64 + el) * 4;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i4 < n) {
-            for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {
+            for (int t0 = cl; t0 < n_chunks; t0 += FW * 8) {
                 float4 v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int t = t0 + 16 * j;
+                    const int t = t0 + FW * j;
                     v[j] = *reinterpret_cast<const float4 *>(part + (int64_t)(t < n_chunks ? t : t0) * ld + i4);
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (t0 + 16 * j < n_chunks) { s4.x += v[j].x; s4.y += v[j].y; s4.z += v[j].z; s4.w += v[j].w; }
+                    if (t0 + FW * j < n_chunks) { s4.x += v[j].x; s4.y += v[j].y; s4.z += v[j].z; s4.w += v[j].w; }
             }
         }
         red4[cl][el] = s4;
         __syncthreads();
         if (cl == 0 && i4 < n) {
 #pragma unroll
-            for (int g = 1; g < 16; ++g) { const float4 r = red4[g][el]; s4.x += r.x; s4.y += r.y; s4.z += r.z; s4.w += r.w; }
+            for (int g = 1; g < FW; ++g) { const float4 r = red4[g][el]; s4.x += r.x; s4.y += r.y; s4.z += r.z; s4.w += r.w; }
             float4 *o = reinterpret_cast<float4 *>(out + i4);
             if (acc) { const float4 a = *o; s4.x += a.x; s4.y += a.y; s4.z += a.z; s4.w += a.w; }
             *o = s4;
@@ -811,22 +815,22 @@ __global__ __launch_bounds__(1024) void fold_jobs_kernel(FoldBatch b)
     const int64_t i = (int64_t)wg * 64 + el;
     float s = 0.f;
     if (i < n) {
-        for (int t0 = cl; t0 < n_chunks; t0 += 16 * 8) {     // 8 loads in flight per lane; summed in chunk order
+        for (int t0 = cl; t0 < n_chunks; t0 += FW * 8) {     // 8 loads in flight per lane; summed in chunk order
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int t = t0 + 16 * j;
+                const int t = t0 + FW * j;
                 v[j] = part[(int64_t)(t < n_chunks ? t : t0) * ld + i];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (t0 + 16 * j < n_chunks) ? v[j] : 0.f;
+            for (int j = 0; j < 8; ++j) s += (t0 + FW * j < n_chunks) ? v[j] : 0.f;
         }
     }
     red[cl][el] = s;
     __syncthreads();
     if (cl == 0 && i < n) {
 #pragma unroll
-        for (int g = 1; g < 16; ++g) s += red[g][el];
+        for (int g = 1; g < FW; ++g) s += red[g][el];
         const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
         float *o = out + (int64_t)r * out_ld + c;
         *o = acc ? *o + s : s;
@@ -1008,6 +1012,7 @@ int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t strea
     PAPC_REQUIRE(jobs, PAPC_E_INVALID, "papc_fold_jobs_f32: null jobs");
     PAPC_REQUIRE(count >= 1, PAPC_E_INVALID, "papc_fold_jobs_f32: count=%d", count);
     hipStream_t st = as_stream(stream);
+    const int FW = knob(KNOB_FOLD_WAVES) == 16 ? 16 : 8;
     for (int j0 = 0; j0 < count; j0 += PAPC_FOLD_MAX) {
         const int nj = std::min(PAPC_FOLD_MAX, count - j0);
         FoldBatch b;
@@ -1026,13 +1031,14 @@ int papc_fold_jobs_f32(const papc_fold_job *jobs, int count, papc_stream_t strea
             if (wide) b.wide_mask |= 1u << i;
             if (vec) b.vec_mask |= 1u << i;
             b.wg0[i] = (int)wgs;
-            wgs += wide ? cdiv(n, 4096) : (vec ? cdiv(n, 256) : cdiv(n, 64));
+            wgs += wide ? cdiv(n, 4 * 64 * FW) : (vec ? cdiv(n, 256) : cdiv(n, 64));
             PAPC_REQUIRE(wgs < (1ll << 30), PAPC_E_UNSUPPORTED, "papc_fold_jobs_f32: too many elements");
         }
         b.wg0[nj] = (int)wgs;
         b.count = nj;
         ProfScope prof(PAPC_K_BWD_DW, st);
-        hipLaunchKernelGGL(fold_jobs_kernel, dim3((unsigned)wgs), dim3(1024), 0, st, b);
+        if (FW == 8) hipLaunchKernelGGL(fold_jobs_kernel<8>, dim3((unsigned)wgs), dim3(512), 0, st, b);
+        else hipLaunchKernelGGL(fold_jobs_kernel<16>, dim3((unsigned)wgs), dim3(1024), 0, st, b);
         const int rc = check_launch("papc_fold_jobs_f32");
         if (rc != PAPC_OK) return rc;
     }

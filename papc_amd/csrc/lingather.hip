@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64 * PL_MAXW) void point_lists_kernel(PlArgs a, int
 // workgroup keep ~2000 workgroups in flight: the kernel is a latency-bound gather of 4C-byte rows, it wants every wave slot of the chip.
 constexpr int LGL_PPW = 8;                      // points per workgroup (two per wave)
 
-template <bool CP>
+template <bool CP, int U = 4, int PPW = LGL_PPW>
 __global__ __launch_bounds__(LG_T) void lingather_bwd_lists_kernel(LinGatherArgs a, const int32_t *__restrict__ prange, const int32_t *__restrict__ prow,
                                                                    const float4 *__restrict__ pmeta, int64_t BN)
 {
@@ -373,14 +373,13 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_lists_kernel(LinGatherArgs
         kB = make_float4(ksc.x * c2.x * is.x, ksc.y * c2.y * is.y, ksc.z * c2.z * is.z, ksc.w * c2.w * is.w);
     }
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
-    const int64_t p0 = (int64_t)blockIdx.x * LGL_PPW;
-    constexpr int U = 4;
+    const int64_t p0 = (int64_t)blockIdx.x * PPW;
     auto gval = [&](float y, float z, float sc, float sh, float mu, float A, float Bc, float w) {
         const float pre = fmaf(sc, y, sh);
         const float pp = pre > 0.f ? z : 0.f;
         return CP ? fmaf(-w, fmaf(Bc, y - mu, A), sc * pp) : fmaf(sc, pp, -fmaf(Bc, y - mu, A));
     };
-    for (int64_t pt = p0 + wave; pt < min(BN, p0 + LGL_PPW); pt += LG_T / 64) {
+    for (int64_t pt = p0 + wave; pt < min(BN, p0 + PPW); pt += LG_T / 64) {
         const int rs = prange[2 * pt], re = prange[2 * pt + 1];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int k = rs + sub; k < re + sub; k += U * SUB) {      // (uniform trip count across the wave: the halves differ by one entry at most)
@@ -484,7 +483,8 @@ int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, con
     return check_launch("papc_lingather_fwd_f32");
 }
 
-int papc_lingather_list_parts(int64_t BN) { return (int)((BN + LGL_PPW - 1) / LGL_PPW); }
+static int lgl_ppw() { const int v = knob(KNOB_LGL_VARIANT); return v == 2 ? 16 : LGL_PPW; }
+int papc_lingather_list_parts(int64_t BN) { return (int)((BN + lgl_ppw() - 1) / lgl_ppw()); }
 
 static bool lg_lists_usable(const papc_group_src *g, int C)
 {
@@ -545,7 +545,12 @@ int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int
         const int64_t BN = (int64_t)B * grp->N;
         const unsigned nwg = (unsigned)papc_lingather_list_parts(BN);
         const papc_point_lists &pl = *grp->plists;
-        if (a.cidx)
+        const int var = knob(KNOB_LGL_VARIANT);
+        const float4 *pm = reinterpret_cast<const float4 *>(pl.pmeta);
+        if (a.cidx && var == 1) hipLaunchKernelGGL((lingather_bwd_lists_kernel<true, 2, 8>), dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, pm, BN);
+        else if (a.cidx && var == 2) hipLaunchKernelGGL((lingather_bwd_lists_kernel<true, 4, 16>), dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, pm, BN);
+        else if (a.cidx && var == 3) hipLaunchKernelGGL((lingather_bwd_lists_kernel<true, 8, 8>), dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, pm, BN);
+        else if (a.cidx)
             hipLaunchKernelGGL(lingather_bwd_lists_kernel<true>, dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, reinterpret_cast<const float4 *>(pl.pmeta), BN);
         else
             hipLaunchKernelGGL(lingather_bwd_lists_kernel<false>, dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, reinterpret_cast<const float4 *>(pl.pmeta), BN);
