@@ -31,12 +31,12 @@ def _bench(tmp_path, name, lr, *flags, env_extra=None, expect_fail=False):
 
 
 def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
-    """(a) lr = 0: the weights stay put, so all 17 steps of both structures run the same forward (fresh dropout masks every step) --
-    the loss trajectories must be BIT-identical (the forward has no atomics) and the last step's gradients equal up to the order of
-    the float atomics of the gather-add backward.  (b) lr = 1e-5: the graphs must read LIVE weights; trajectories are compared
-    against the run-to-run noise of the eager structure itself.  (A train step is a discontinuous function of the weights -- max
-    routing, ReLU sides -- so at the reference's lr = 1e-3 that atomics noise grows ~30x per step and two eager runs already differ
-    by 2 % after ten steps: tools/probe/repro.py.)"""
+    """(a) lr = 0: the weights stay put, so all steps of every structure run the same forward (fresh dropout masks every step) -- the loss
+    trajectories AND the last step's gradients must be BIT-identical.  (b) lr = 1e-5: the graphs must read LIVE weights; the graph-replayed
+    trajectory (losses, parameters after the last step) equals the eager one bit for bit, and so do two eager runs.  (Rounds 1-5 compared against
+    a noise floor here: the gather-add backward summed with float atomics.  Since round 6 it sums over the grouping's point lists in fixed
+    order -- papc_point_lists_f32 -- and a training step is bit-reproducible, so any mis-ordering between the streams of a launch structure
+    shows up as a non-zero difference instead of hiding under that floor.)"""
     g, line = _bench(tmp_path, "graph0", "0")
     assert int(g["graph"]) == 1 and int(g["overlap"]) == 1, "the default bench must replay captured graphs with the overlapped sampling: " + line
     assert '"launch": "hipGraph replay' in line and "a second hipGraph on the side stream" in line
@@ -54,7 +54,9 @@ def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
         gs = float(np.max(np.abs(e["grad"])))
         dg = float(np.max(np.abs(r["grad"] - e["grad"]))) / gs
         print("lr 0, %s: losses bit-identical, gradient diff %.2e of max |g|" % (name, dg))
-        assert dg <= 1e-5, (name, dg)
+        # round 6: the gather-add backward sums over the grouping's point lists in fixed order (no float atomics left in the step), so the last
+        # step's gradient is the same BITS whatever the launch structure -- any ordering bug between the streams shows as a non-zero difference
+        assert np.array_equal(r["grad"], e["grad"]), (name, dg)
     # (b)
     g1, _ = _bench(tmp_path, "graph1", "1e-5")
     e1, _ = _bench(tmp_path, "eager1", "1e-5", "--no-graph", "--no-overlap")
@@ -66,8 +68,9 @@ def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
     moved = float(np.max(np.abs(e1["params"] - e1["params0"])))
     print("lr 1e-5: graph vs eager loss %.2e params %.2e | eager vs eager loss %.2e params %.2e | weights moved %.2e" % (dl, dp, noise_l, noise_p, moved))
     assert moved >= 5e-5, moved
-    assert dl <= max(3 * noise_l, 5e-4), (dl, noise_l)
-    assert dp <= max(3 * noise_p, 1e-4), (dp, noise_p)
+    # a step is bit-reproducible since round 6 (no float atomics): the graph-replayed structure reading LIVE weights walks the very same trajectory
+    assert noise_l == 0.0 and noise_p == 0.0, (noise_l, noise_p)
+    assert np.array_equal(g1["loss"], e1["loss"]) and np.array_equal(g1["params"], e1["params"]), (dl, dp)
 
 
 def test_side_graph_survives_a_main_stream_stall(tmp_path):
@@ -94,7 +97,7 @@ def test_side_graph_survives_a_main_stream_stall(tmp_path):
     for name, r in (("gate holds", g), ("gate gives up", t)):
         dg = float(np.max(np.abs(r["grad"] - e["grad"]))) / gs
         print("stalled main stream, %s: losses bit-identical, gradient diff %.2e of max |g|" % (name, dg))
-        assert dg <= 1e-5, (name, dg)
+        assert np.array_equal(r["grad"], e["grad"]), (name, dg)
     _, err = _bench(tmp_path, "stall2", "0", "--diag-stall-ms", "60", env_extra={"PAPC_GATE_SPINS": "2000"}, expect_fail=True)
     assert "gave up" in err, err[-500:]
 
