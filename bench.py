@@ -836,6 +836,7 @@ def main():
         from device events: end-of-step event to end-of-step event on the main stream (the first from an event recorded behind the opening sync)"""
         sync()
         del step_events[:]
+        j0 = cur["j"]
         start = torch.cuda.Event(enable_timing=True)
         start.record(main)
         graph_state["timing"] = True
@@ -851,6 +852,7 @@ def main():
         if step_ms is not None:
             evs = [start] + step_events
             step_ms.extend(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+            step_batch.extend((j0 + k) % NB for k in range(len(step_events)))
         if use_dist:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -868,7 +870,7 @@ def main():
         while len(step_ms) < args.min_timed_steps and not args.dump_trajectory and not args.diag_stall_ms:
             timed_region(step_ms)
 
-    step_ms = []
+    step_ms, step_batch = [], []               # per-step durations (device events) and the batch each step trained on
     elapsed, loss = timed_region(step_ms)
     final_loss = float(loss.item())
     more_windows(step_ms)
@@ -924,9 +926,11 @@ def main():
             step()
         torch.cuda.synchronize()
         ms_p = []
+        n_main = len(step_batch)
         el_p, loss_p = timed_region(ms_p)
         more_windows(ms_p)
         assert not _stack.LAST_PLANS.get(sa2_key, {}).get("compact"), "the padded leg still ran the compacted stack"
+        del step_batch[n_main:]                    # (the padded leg's steps are not part of the per-batch medians below)
         padded = {"value": round(B * args.steps / el_p, 2), "ms_per_step": round(1e3 * el_p / args.steps, 3),
                   "graph": graph_state["g"] is not None, "stats": stats_of(ms_p)}
         model.sa2.compact = None
@@ -1002,6 +1006,8 @@ def main():
             "config": {"workload": "PointNet++SSG classify fwd+bwd+Adam, B=%d clouds/GPU, N=%d (BASELINE configs[1])" % (B, N),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
                        "compact_row_fraction": round(row_fraction, 4), "compact_row_fraction_per_batch": [round(f, 4) for f in row_fractions],
+                       "ms_median_per_batch": [round(stats_of([m for m, bi in zip(step_ms, step_batch) if bi == k])["ms_median"], 4) if any(bi == k for bi in step_batch) else None
+                                               for k in range(NB)],
                        "batches": "%d distinct resident batches of B clouds (seeds 1234 + rank + 100003 k), step j trains on batch j mod %d; the next batch is loaded into the "
                                   "graphs' input slot and sampled on the side stream" % (NB, NB),
                        "timing": "value / ms_per_step: wall clock around the first window of --steps steps between barrier + synchronize (max over ranks); ms_median / ms_min / "

@@ -11,7 +11,7 @@ from collections import defaultdict
 
 def family(name):
     n = re.sub(r"^void ", "", name).replace("papc::", "")
-    if n.startswith(("dw_ws_kernel", "dw_kernel", "dw_xyz_kernel", "dw_rows_kernel", "dw_rowsx_kernel", "lingather_bwd_kernel", "pg_fold_kernel",
+    if n.startswith(("dw_ws_kernel", "dw_kernel", "dw_xyz_kernel", "dw_rows_kernel", "dw_rowsx_kernel", "lingather_bwd", "pg_fold_kernel",
                      "xyz_l1_bwd_kernel", "dw_rows_max_kernel", "dw_max_fold_kernel", "dw_max_finalize_kernel")):
         return "bwd_dw_gemm"
     m = re.match(r"pg_gemm_kernel<(\d+),", n)      # planes GEMM (smallm.hip): epilogue 1 / 2 = forward, 3 = dX (+ BN-backward sums), 0 = dW partials (and the last dX)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Turn gpurun_out/ of tools/refresh_profiles.sh into the committed summaries under profiles/ (round tag = $1, default r01).
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out
 P=profiles
 cp $O/prof_stats/run_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
