@@ -203,6 +203,14 @@ def main():
     ap.add_argument("--min-timed-steps", type=int, default=50, help="per-step statistics (ms_median / ms_min / ms_p95, device events around every step) are taken "
                     "over at least this many steps: when --steps is smaller, further windows of --steps steps follow the contract window")
     ap.add_argument("--allow-gate-timeout", action="store_true", help="(tests) do not abort when a device-side gate wait gave up (papc_flag_wait's sticky count)")
+    ap.add_argument("--side-events", action="store_true", help="the gated sampling graph ALSO waits for the previous step's end-of-step event before it is replayed "
+                    "(ordering of the shared buffers by stream events as well as by the gate).  Off by default since it was measured: the cross-stream wait costs the "
+                    "step 25-31 us (1.452 against 1.421 ms, same box, EMPTY side graph) -- the counting gate orders the buffers, and a gate wait that gives up is "
+                    "counted and makes bench.py abort, so a mis-ordered run cannot report a number")
+    ap.add_argument("--diag-empty-side", action="store_true", help="DIAGNOSTIC ONLY (not a benchmark value): the side graph holds its gate (and --side-delay-us) but NO "
+                    "pyramid -- one batch, stale plans -- : what the gate's spinning wave and the two-stream launch structure cost the step by themselves")
+    ap.add_argument("--side-delay-us", type=float, default=0.0, help="(diagnostic) the gated sampling graph spins for about this long behind its gate before the pyramid "
+                    "starts: with --fork sa1 it places the pyramid anywhere between the end of SA1's and of SA2's forward")
     ap.add_argument("--diag-stall-ms", type=float, default=0.0, help="(tests) stall the main stream for about this long ahead of every third timed step (a spinning "
                     "one-lane kernel): the side graph's gate must hold through it, and the plan buffers stay ordered by stream events whatever the gate does")
     ap.add_argument("--no-dropout", action="store_true", help="(tests) dropout p = 0 in the classifier head, so that a single-process emulation can reproduce a multi-rank run")
@@ -266,7 +274,7 @@ def main():
     opt = FlatAdam(flat, lr=args.lr, weight_decay=1e-3)
 
     # each rank owns its own shard of clouds; NB distinct resident batches, step j trains on batch j mod NB (batch 0 = the one batch of rounds 1-5)
-    NB = 1 if args.diag_fixed_plan else max(1, args.batches)
+    NB = 1 if (args.diag_fixed_plan or args.diag_empty_side) else max(1, args.batches)
 
     def make_batch(k):
         seed = 1234 + rank + 100003 * k
@@ -278,6 +286,11 @@ def main():
     batches = [make_batch(k) for k in range(NB)]
     # the captured graphs read their inputs from two static slots (set i trains on slot i while the side stream loads slot 1 - i with the next batch)
     slots = [tuple(t.clone() for t in batches[0]) for _ in range(3)]     # (the split pyramid cycles through three)
+    # the next batch reaches its slot in two hops: an eager copy into a STAGING pair on the sampling stream ahead of the gated graph (stream order
+    # keeps it behind the previous replay's read of the staging pair), then a copy node INSIDE the gated graph, behind the gate -- i.e. behind the
+    # end of the previous step, the slot's last reader -- so that no cross-stream event is needed to order the slot
+    stage_in = tuple(t.clone() for t in batches[0])
+    stage_in2 = tuple(t.clone() for t in batches[0])
     cur = {"j": 0}                                # steps enqueued so far = index of the batch the next step trains on
 
     def unpack(b):
@@ -290,6 +303,15 @@ def main():
         """slot i <- batch j (two device copies on the current stream)"""
         slots[i][0].copy_(batches[j % NB][0])
         slots[i][1].copy_(batches[j % NB][1])
+
+    def load_stage(st, j):
+        st[0].copy_(batches[j % NB][0])
+        st[1].copy_(batches[j % NB][1])
+
+    def stage_to_slot(st, i):
+        """(captured into the gated graph) slot i <- the staging pair"""
+        slots[i][0].copy_(st[0])
+        slots[i][1].copy_(st[1])
 
     # Sampling pipeline: FPS / ball query depend on the batch only (not on the weights) and FPS is a serial chain that
     # occupies B=32 of the 256 CUs, so the sampling pyramid of batch i+1 is computed on a side stream while batch i's
@@ -322,8 +344,12 @@ def main():
     def gate_open(counter=None):
         _lib.check(lib.papc_flag_set(gate.data_ptr(), 1, counter.data_ptr() if counter is not None else None, _lib.stream_ptr()), "papc_flag_set")
 
+    delay_gate = torch.zeros(4, dtype=torch.int32, device=dev) if args.side_delay_us > 0 else None
+
     def gate_wait(slot=0):
         _lib.check(lib.papc_flag_wait_slot(gate.data_ptr(), slot, GATE_SPINS, _lib.stream_ptr()), "papc_flag_wait_slot")
+        if delay_gate is not None:          # (diagnostic) nobody opens this one: it spins for its bound, then gives up
+            _lib.check(lib.papc_flag_wait(delay_gate.data_ptr(), int(args.side_delay_us * 1.15), _lib.stream_ptr()), "papc_flag_wait")
 
     split_pyr = side_graph and args.split_pyramid       # the pyramid on two side streams, FPS1 one batch further ahead (three sets of graphs / buffers)
     side2 = torch.cuda.Stream() if split_pyr else None
@@ -521,14 +547,16 @@ def main():
                     graph_state["capturing_main"] = False
                     gs.append((g1, None, None))
                     losses.append(loss)
-                    for strm, lst, stage, k, slot_w in ((side, gB, "rest", (i + 1) % 3, 0), (side2, gA, "fps1", (i + 2) % 3, 1)):
+                    for strm, lst, stg, k, slot_w in ((side, gB, "rest", (i + 1) % 3, 0), (side2, gA, "fps1", (i + 2) % 3, 1)):
                         g2 = torch.cuda.CUDAGraph()
                         strm.wait_stream(main)
                         with torch.cuda.stream(strm):
                             with torch.cuda.graph(g2, stream=strm, capture_error_mode="thread_local"):
                                 gate_wait(slot_w)
+                                if stg == "fps1":
+                                    stage_to_slot(stage_in2, k)
                                 xk, _, s1k, s2k = unpack(slots[k])
-                                model.plan_sampling(xk, (s1k, s2k), out=bufs[k], stage=stage)
+                                model.plan_sampling(xk, (s1k, s2k), out=bufs[k], stage=stg)
                         main.wait_stream(strm)
                         lst.append(g2)
                 # the pipeline's first step needs batch j + 1 in its slot and its first-level centroids in its buffers (what graph A of a
@@ -556,8 +584,10 @@ def main():
                     with torch.cuda.stream(side):
                         with torch.cuda.graph(g2, stream=side, capture_error_mode="thread_local"):
                             gate_wait()
+                            stage_to_slot(stage_in, 1 - i)
                             xn, _, s1n, s2n = unpack(slots[1 - i])
-                            model.plan_sampling(xn, (s1n, s2n), out=bufs[1 - i])
+                            if not args.diag_empty_side:
+                                model.plan_sampling(xn, (s1n, s2n), out=bufs[1 - i])
                     main.wait_stream(side)
                     gside.append(g2)
                 graph_state["g"], graph_state["loss"], graph_state["bufs"], graph_state["gside"] = gs, losses, bufs, gside
@@ -593,6 +623,7 @@ def main():
                     with torch.cuda.stream(side):
                         with torch.cuda.graph(gsd, stream=side, capture_error_mode="thread_local"):
                             gate_wait()
+                            stage_to_slot(stage_in, 1 - i)
                             xn, _, s1n, s2n = unpack(slots[1 - i])
                             model.plan_sampling(xn, (s1n, s2n), out=bufs[1 - i])
                     main.wait_stream(side)
@@ -671,20 +702,65 @@ def main():
         with torch.cuda.stream(side):
             model.plan_sampling(xn, (s1n, s2n), out=plan_out)
 
+    PREV_END_MODE = os.environ.get("PAPC_PREV_END_MODE", "timing")
+
+    class _HipEvent:
+        """a raw HIP event with flags torch does not expose (A/B of what the cross-stream wait costs)"""
+        _hip = None
+
+        def __init__(self):
+            if _HipEvent._hip is None:
+                _HipEvent._hip = ctypes.CDLL("libamdhip64.so")
+            self.h = ctypes.c_void_p()
+            rc = _HipEvent._hip.hipEventCreateWithFlags(ctypes.byref(self.h), ctypes.c_uint(0x2 | 0x40000000))     # DisableTiming | ReleaseToDevice
+            assert rc == 0, rc
+
+        def record(self, stream):
+            rc = _HipEvent._hip.hipEventRecord(self.h, ctypes.c_void_p(stream.cuda_stream))
+            assert rc == 0, rc
+            return self
+
+        def wait_on(self, stream):
+            rc = _HipEvent._hip.hipStreamWaitEvent(ctypes.c_void_p(stream.cuda_stream), self.h, ctypes.c_uint(0))
+            assert rc == 0, rc
+
+        def __del__(self):
+            try:
+                _HipEvent._hip.hipEventDestroy(self.h)
+            except Exception:     # noqa: BLE001
+                pass
+
+    def wait_prev_end(stream):
+        pe = graph_state.get("prev_end")
+        if pe is None:
+            return
+        if isinstance(pe, _HipEvent):
+            pe.wait_on(stream)
+        else:
+            stream.wait_event(pe)
+
+    # (diagnostics with --diag-empty-side only: pieces of the two-stream structure switched off one at a time -- results are then garbage)
+    DIAG_NO_SLOT_COPY = os.environ.get("PAPC_DIAG_NO_SLOT_COPY") == "1"
+    DIAG_NO_SIDE_EV = os.environ.get("PAPC_DIAG_NO_SIDE_EV") == "1"
+    DIAG_NO_PREV_END = os.environ.get("PAPC_DIAG_NO_PREV_END") == "1"
+
     def side_replay(g, i, j):
-        """The gated pyramid graph of set i on the side stream: loads slot 1 - i with batch j + 1 and fills bufs[1 - i] from it.  Their last readers are
-        the PREVIOUS step's kernels (set 1 - i: its backward reads the grouping lists to the end), so the side stream first waits for that step's
-        end-of-step event -- outside any graph, no edge on the main chain.  The device-side gate inside the graph only PLACES the pyramid (behind this
-        step's SA2); the buffers' safety does not rest on it (round 5: it did, and a gate wait that gave up let the pyramid overwrite a plan under
-        its readers)."""
+        """The gated pyramid graph of set i on the side stream: batch j + 1 goes into the staging pair (eagerly, in stream order behind the previous
+        replay), the graph copies it on into slot 1 - i behind its gate and fills bufs[1 - i] from it.  Slot and plan buffers were last read by the
+        PREVIOUS step's kernels (set 1 - i: its backward reads the grouping lists to the end); what orders the graph behind them is the device-side gate,
+        which this step opens behind its SA2 -- in stream order behind the whole previous step -- and which COUNTS its openings: a wait that gives
+        up (after ~2 s) is a sticky error that makes the run abort (sync()), never a silently mis-ordered step (round 5: a give-up after 35 ms "started
+        anyway" and shifted every later pyramid one opening early).  --side-events adds the belt to the braces: the side stream also waits for the
+        previous step's end-of-step event before anything is enqueued -- measured at 25-31 us per step, hence opt-in."""
         with torch.cuda.stream(side):
-            if graph_state.get("prev_end") is not None:
-                side.wait_event(graph_state["prev_end"])
-            load_slot(1 - i, j + 1)
+            if args.side_events and not DIAG_NO_PREV_END:
+                wait_prev_end(side)
+            if not DIAG_NO_SLOT_COPY:
+                load_stage(stage_in, j + 1)           # (the graph copies it on into slot 1 - i behind its gate)
             g.replay()                             # gated on the device: starts when this step has enqueued SA2
             ev = torch.cuda.Event()
             ev.record(side)
-        graph_state["side_ev"][1 - i] = ev
+        graph_state["side_ev"][1 - i] = None if DIAG_NO_SIDE_EV else ev
 
     def step_graph():
         i = graph_state["i"] % len(graph_state["g"])
@@ -699,7 +775,7 @@ def main():
             g1.replay()
             prev_end = graph_state.get("prev_end")
             with torch.cuda.stream(side):          # B: the rest of batch j + 1's pyramid, from the centroids graph A left in bufs[i + 1] one step ago
-                if prev_end is not None:
+                if prev_end is not None and args.side_events:
                     side.wait_event(prev_end)
                 if graph_state["evA"][(i + 1) % 3] is not None:
                     side.wait_event(graph_state["evA"][(i + 1) % 3])
@@ -708,9 +784,9 @@ def main():
                 ev.record(side)
                 graph_state["evB"][(i + 1) % 3] = ev
             with torch.cuda.stream(side2):         # A: batch j + 2 into its slot, its first-level farthest-point sampling into bufs[i + 2]
-                if prev_end is not None:
+                if prev_end is not None and args.side_events:
                     side2.wait_event(prev_end)     # (their last reader: the previous step, set i + 2 = i - 1)
-                load_slot((i + 2) % 3, j + 2)
+                load_stage(stage_in2, j + 2)          # (graph A copies it on into slot i + 2 behind its gate)
                 graph_state["gA"][i].replay()
                 ev = torch.cuda.Event()
                 ev.record(side2)
@@ -763,7 +839,14 @@ def main():
         loss = step_eager() if graph_state["g"] is None else step_graph()
         end = torch.cuda.Event(enable_timing=True)
         end.record(main)
-        graph_state["prev_end"] = end              # what the next step's side graph waits for before it touches the buffers this step read
+        if PREV_END_MODE == "plain":               # a second, non-timing event for the cross-stream wait
+            pe = torch.cuda.Event()
+            pe.record(main)
+            graph_state["prev_end"] = pe
+        elif PREV_END_MODE == "hipdev":            # ... created with hipEventDisableTiming | hipEventReleaseToDevice (device-scope release)
+            graph_state["prev_end"] = _HipEvent().record(main)
+        else:
+            graph_state["prev_end"] = end          # what the next step's side graph waits for before it touches the buffers this step read
         if graph_state.get("timing"):
             step_events.append(end)
         return loss
@@ -1019,7 +1102,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(N)
         out = {
-            "metric": "point-clouds/sec (fwd+bwd) PointNet++SSG B=32 N=4096" + (" -- DIAGNOSTIC, sampling excluded: not a benchmark value" if args.diag_fixed_plan else ""),
+            "metric": "point-clouds/sec (fwd+bwd) PointNet++SSG B=32 N=4096" + (" -- DIAGNOSTIC, sampling excluded: not a benchmark value" if (args.diag_fixed_plan or args.diag_empty_side) else ""),
             "value": round(value, 2), "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), **stats_of(step_ms), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
