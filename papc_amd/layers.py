@@ -125,19 +125,32 @@ class PointNetSetAbstraction(nn.Module):
         xyz = xyz.transpose(1, 2)
         if xyz.dtype != torch.float32:
             xyz = xyz.float()
+        skip = _diag_skip(self.npoint) if out is not None else ()      # (timing diagnostics: stages left out, their buffers stale)
         if new_xyz is None:
-            _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=None if out is None else out[0])
-        idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz, outs=None if out is None else [out[1]])[0]
+            if "fps" in skip:
+                new_xyz = out[0]
+            else:
+                _, new_xyz = F_._fps_raw(xyz, self.npoint, start_idx, self.init_dist, new_xyz_out=None if out is None else out[0])
+        if "bq" in skip:
+            idx = out[1]
+        else:
+            idx = F_._ball_query_raw([self.radius], [self.nsample], xyz, new_xyz, outs=None if out is None else [out[1]])[0]
         if self._xyz_first(xyz.shape[0]):
             # coordinates-only stack whose first layer runs through its input moments: the grouped centred coordinates and their
             # moments are weight-independent too (mlp.xyz_pregroup) -- part of the plan
             from .mlp import xyz_pregroup
+            if "xyzpre" in skip and len(out) >= 4:
+                return new_xyz, idx, out[2], out[3]
             xc, gpart = xyz_pregroup(xyz, new_xyz, idx, out=None if (out is None or len(out) < 4) else (out[2], out[3]))
             return new_xyz, idx, xc, gpart
+        if "compact" in skip and len(out) in (9, 12):
+            return tuple(out)
         cp = self._compact_plan(idx, out=None if (out is None or len(out) not in (9, 12)) else tuple(out[2:9]))
         # (new_xyz, idx[, cnt8, start, rows, cidx, seg_grp, wrow, coef][, prange, prow, pmeta]): the compact plan and the grouping's point
         # lists (the inverse index the gather-add backward sums over) are part of the plan like the lists themselves
         res = (new_xyz, idx) + (cp.tensors() if cp is not None else ())
+        if "lists" in skip and out is not None and len(out) == len(res) + 3:
+            return res + tuple(out[len(res):])
         if self._wants_lists(xyz, cp):
             from . import compact as _c
             have = out is not None and len(out) == len(res) + 3
@@ -221,6 +234,16 @@ class PointNetSetAbstraction(nn.Module):
         # (group_all: new_xyz is the cached READ-ONLY zero centre of sample_and_group_all, :170 -- a clone here would put a copy kernel
         # into every training step; callers must not edit the returned coordinates in place)
         return new_xyz.transpose(1, 2), new_points                              # :220-221
+
+
+def _diag_skip(npoint):
+    """PAPC_DIAG_SKIP=fps512,bq512,xyzpre512,fps128,bq128,compact128,lists128: stages of sample() to leave out when it writes into preallocated
+    buffers (bench.py's sampling graph) -- what each stage costs the step; the plan is then STALE, results garbage.  Timing diagnostics only."""
+    v = os.environ.get("PAPC_DIAG_SKIP")
+    if not v:
+        return ()
+    suf = str(npoint)
+    return tuple(t[:-len(suf)] for t in v.split(",") if t.endswith(suf))
 
 
 MSG_BRANCH_STREAMS = os.environ.get("PAPC_MSG_STREAMS", "1") != "0"     # the MSG layers' radius branches on parallel streams
