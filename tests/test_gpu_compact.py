@@ -330,3 +330,31 @@ def test_list_backward_equals_atomic_backward_and_is_bit_reproducible(dev, compa
         if i % 4 != 1:
             assert_close(a, b, 2e-5, "list vs atomic backward: gradient %d" % i)
     assert_close(f1, fa, 2e-5, "list vs atomic backward: dfeats")
+
+
+def test_point_lists_of_the_other_row_layout_are_ignored(dev):
+    """Lists index ONE row layout (papc_point_lists.compact).  A stack that runs the other layout -- here: lists of the compacted rows handed to a
+    stack that runs padded -- must ignore them and take the atomic path (a mismatch would gather arbitrary rows): gradients equal the padded
+    stack's without lists."""
+    N, S, K, D, B = 512, 128, 64, 128, 8
+    res = []
+    for with_lists in (False, True):
+        xyz, new_xyz, idx = _lists(dev, B, N, S, K, 0.4, 6)
+        rng = np.random.default_rng(6)
+        feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev).requires_grad_(True)
+        ws = seeded_weights([D + 3, 128, 128, 256], 56)
+        params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+        spec = StackSpec(B, N, S, K, D, True)
+        if with_lists:
+            spec.plists = C.point_lists(xyz, new_xyz, idx, C.plan(idx))      # compacted numbering ...
+            assert spec.plists.compact
+        out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)   # ... for a stack that runs padded (spec.compact is None)
+        assert out.grad_fn.compact is None
+        gout = torch.from_numpy(np.random.default_rng(8).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        res.append(([p.grad.cpu().numpy() for p in params], feats.grad.cpu().numpy()))
+    for i, (a, b) in enumerate(zip(res[1][0], res[0][0])):
+        if i % 4 != 1:
+            assert_close(a, b, 2e-5, "padded stack with mismatching lists vs without: gradient %d" % i)
+    assert_close(res[1][1], res[0][1], 2e-5, "padded stack with mismatching lists vs without: dfeats")
