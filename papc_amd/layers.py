@@ -320,10 +320,18 @@ class PointNetSetAbstractionMsg(nn.Module):
         self._compact_on[i] = True      # forced (compact=True / PAPC_COMPACT=1): sample() and forward() read the branch's layout from this one flag
         return C.plan(idx, out)
 
+    def _branch_wants_lists(self, i, N):
+        """point lists (compact.point_lists) for a compacted branch of a training layer: its gather-add backward as a segmented sum"""
+        from . import compact as C
+        D = self.conv_blocks[i][0].in_channels - 3
+        return (C.LISTS >= 1 and self.training and not self.reference_quirks and D + ((-D) % 4) >= 16 and len(self.conv_blocks[i]) >= 2
+                and N <= C.MAX_LIST_POINTS)
+
     def sample(self, xyz, start_idx=None, out=None):
         """The weight-independent half (one FPS, one ball-query scan for all radii, :258-262) on its own: xyz [B,3,N] ->
-        (new_xyz [B,S,3], idx_0 .. idx_{R-1} [B,S,K_r] int32, then the 7 compact-plan tensors of every branch that runs compacted).
-        ``out`` = a previous result of this method for the same shapes: the kernels write into it."""
+        (new_xyz [B,S,3], idx_0 .. idx_{R-1} [B,S,K_r] int32, then per branch that runs compacted its 7 compact-plan tensors and -- for a
+        training layer -- the 3 point-list tensors of that layout).  ``out`` = a previous result of this method for the same shapes: the kernels
+        write into it."""
         xyz = xyz.transpose(1, 2)
         if xyz.dtype != torch.float32:
             xyz = xyz.float()
@@ -339,6 +347,11 @@ class PointNetSetAbstractionMsg(nn.Module):
             if cp is not None:
                 res += list(cp.tensors())
                 pos += 7
+                if self._branch_wants_lists(i, xyz.shape[1]):
+                    from . import compact as C
+                    have_l = out is not None and len(out) >= pos + 3
+                    res += list(C.point_lists(xyz, new_xyz, idxs[i], cp, out=tuple(out[pos:pos + 3]) if have_l else None).tensors())
+                    pos += 3
         return tuple(res)
 
     def forward(self, xyz, points, start_idx=None, sampled=None):
@@ -353,19 +366,29 @@ class PointNetSetAbstractionMsg(nn.Module):
         S = self.npoint
         R = len(self.radius_list)
         cplans = [None] * R
+        plists = [None] * R
         if sampled is not None:
-            from .compact import CompactPlan
+            from .compact import CompactPlan, PointLists
             new_xyz, idxs = sampled[0], list(sampled[1:1 + R])
             pos = 1 + R
             for i in range(R):
                 if self._compact_on.get(i) is True and self._branch_compact_mode(i, B) is True and len(sampled) >= pos + 7:
                     cplans[i] = CompactPlan(tuple(sampled[pos:pos + 7]), B * S, self.nsample_list[i])
                     pos += 7
+                    # (the lists are recognised by their shapes -- prange is [B*N, 2], pmeta [cap, 4] -- not by this layer's current mode: a plan
+                    # made in another mode parses all the same)
+                    if len(sampled) >= pos + 3 and sampled[pos].dim() == 2 and sampled[pos].shape[1] == 2 and sampled[pos + 2].dim() == 2:
+                        plists[i] = PointLists(tuple(sampled[pos:pos + 3]), True)
+                        pos += 3
         else:
             _, new_xyz = F_._fps_raw(xyz, S, start_idx, self.init_dist)             # :258 (one FPS for all radii)
             idxs = F_._ball_query_raw(self.radius_list, self.nsample_list, xyz, new_xyz)   # :260-262, one scan
             if feats is not None:
                 cplans = [self._branch_plan(i, idxs[i]) for i in range(R)]
+                if torch.is_grad_enabled():
+                    from . import compact as C
+                    plists = [C.point_lists(xyz, new_xyz, idxs[i], cplans[i]) if (cplans[i] is not None and self._branch_wants_lists(i, N)) else None
+                              for i in range(R)]
         feats_in = feats
         padded = None
         if feats_in is not None and D % 4 != 0:          # (one padded copy of the features for all branches)
@@ -387,6 +410,7 @@ class PointNetSetAbstractionMsg(nn.Module):
                              cut_gather_grad=self.reference_quirks)             # feats first, then xyz (:267)
             if feats_in is not None:
                 spec.compact = cplans[i]
+                spec.plists = plists[i]
             o = shared_mlp_max(spec, _bn_buffers(self.bn_blocks[i]), xyz, new_xyz, feats_i, idxs[i], params)   # :271-276
             return o.view(B, S, -1)
 
@@ -400,6 +424,8 @@ class PointNetSetAbstractionMsg(nn.Module):
                 shared = [xyz, new_xyz, idxs[i], feats_in, None if padded is None else padded[0]]
                 if cplans[i] is not None:
                     shared += list(cplans[i].tensors())
+                if plists[i] is not None:
+                    shared += list(plists[i].tensors())
                 for t in shared:
                     if t is not None:
                         t.record_stream(side[i - 1])

@@ -358,3 +358,48 @@ def test_point_lists_of_the_other_row_layout_are_ignored(dev):
         if i % 4 != 1:
             assert_close(a, b, 2e-5, "padded stack with mismatching lists vs without: gradient %d" % i)
     assert_close(res[1][1], res[0][1], 2e-5, "padded stack with mismatching lists vs without: dfeats")
+
+
+def test_msg_layer_compacted_branch_uses_point_lists(dev):
+    """PointNetSetAbstractionMsg (pointnet2_basic_layers.py:224-281): a compacted radius branch of a training layer carries its point lists in the
+    sampling plan (7 compact tensors + 3 list tensors) and its gather-add backward sums over them -- two runs give the same BITS in every gradient,
+    through sample() + forward(sampled=) and through the in-line path alike, and they agree with the float-atomic backward to 2e-5."""
+    from papc_amd.layers import PointNetSetAbstractionMsg
+    lib = _lib.load()
+    B, N, S, D = 8, 512, 128, 128
+    x = torch.from_numpy(make_clouds(B, N, 21)).to(dev)
+    pts = torch.from_numpy(np.random.default_rng(21).normal(size=(B, D, N)).astype(np.float32)).to(dev)
+    st = torch.from_numpy(make_start_idx(B, N, 21)).to(dev)
+
+    def run(lists, planned):
+        old = _lib.ctypes.c_int(0)
+        _lib.check(lib.papc_knob_get(b"PAPC_LG_LISTS", _lib.ctypes.byref(old)), "papc_knob_get")
+        _lib.check(lib.papc_knob_set(b"PAPC_LG_LISTS", 1 if lists else 0), "papc_knob_set")
+        try:
+            torch.manual_seed(3)
+            layer = PointNetSetAbstractionMsg(S, [0.4, 0.8], [64, 128], D, [[128, 128, 256], [128, 196, 256]]).to(dev).train()
+            layer.compact = True
+            p = pts.clone().requires_grad_(True)
+            plan = layer.sample(x, st) if planned else None
+            if planned:
+                # branch 0 ([128, 128, 256], K = 64) has the compacted flavour, branch 1 (196 channels) has not: 1 + 2 + 7 + 3 tensors
+                assert len(plan) == 13 and tuple(plan[10].shape) == (B * N, 2) and plan[12].shape[1] == 4
+            _, out = layer(x, p, st, sampled=plan)
+            out.backward(torch.from_numpy(np.random.default_rng(5).normal(size=tuple(out.shape)).astype(np.float32)).to(dev))
+            torch.cuda.synchronize()
+            return {n: q.grad.cpu().numpy() for n, q in layer.named_parameters()}, p.grad.cpu().numpy()
+        finally:
+            _lib.check(lib.papc_knob_set(b"PAPC_LG_LISTS", old.value), "papc_knob_set")
+
+    ga, fa = run(False, True)
+    g1, f1 = run(True, True)
+    g2, f2 = run(True, True)
+    g3, f3 = run(True, False)
+    for n in g1:
+        if ".0." in n[:14]:      # conv_blocks.0.* / bn_blocks.0.*: the compacted branch -- no atomics left in its backward
+            assert np.array_equal(g1[n], g2[n]), "MSG layer, list backward: %s differs between two runs" % n
+            assert np.array_equal(g1[n], g3[n]), "MSG layer: planned and in-line sampling give different %s" % n
+        if np.abs(ga[n]).max() > 0:       # (the 196-channel branch stays padded: float atomics, same numbers up to their order; so does dfeats, the sum of both)
+            assert_close(g1[n], ga[n], 2e-5, "MSG layer, list vs atomic backward: %s" % n, elem=1.0)
+    assert_close(f1, fa, 2e-5, "MSG layer, list vs atomic backward: dfeats")
+    assert_close(f1, f3, 2e-5, "MSG layer, planned vs in-line: dfeats")
