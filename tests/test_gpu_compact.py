@@ -403,3 +403,40 @@ def test_msg_layer_compacted_branch_uses_point_lists(dev):
             assert_close(g1[n], ga[n], 2e-5, "MSG layer, list vs atomic backward: %s" % n, elem=1.0)
     assert_close(f1, fa, 2e-5, "MSG layer, list vs atomic backward: dfeats")
     assert_close(f1, f3, 2e-5, "MSG layer, planned vs in-line: dfeats")
+
+
+@pytest.mark.parametrize("c0", [32, 64, 256])
+def test_list_backward_other_first_layer_widths(dev, c0):
+    """The list backward maps CQ = C / 4 lanes to a row and 64 / CQ list entries to a wave pass: first-layer widths 32 (8 entries per pass), 64 (4)
+    and 256 (1) besides SA2's 128 (2), on a padded grouping (lists of the padded rows), against the float-atomic kernel."""
+    lib = _lib.load()
+    N, S, K, D, B = 256, 32, 16, 32, 4
+
+    def run(lists):
+        old = _lib.ctypes.c_int(0)
+        _lib.check(lib.papc_knob_get(b"PAPC_LG_LISTS", _lib.ctypes.byref(old)), "papc_knob_get")
+        _lib.check(lib.papc_knob_set(b"PAPC_LG_LISTS", 1 if lists else 0), "papc_knob_set")
+        try:
+            xyz, new_xyz, idx = _lists(dev, B, N, S, K, 0.3, 9)
+            rng = np.random.default_rng(9)
+            feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev).requires_grad_(True)
+            ws = seeded_weights([D + 3, c0, 64], 59)
+            params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+            spec = StackSpec(B, N, S, K, D, True)
+            spec.plists = C.point_lists(xyz, new_xyz, idx, None)
+            out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+            assert out.grad_fn.lin0, "the gather-add first layer was not taken"
+            out.backward(torch.from_numpy(np.random.default_rng(8).normal(size=tuple(out.shape)).astype(np.float32)).to(dev))
+            torch.cuda.synchronize()
+            return [p.grad.cpu().numpy() for p in params], feats.grad.cpu().numpy()
+        finally:
+            _lib.check(lib.papc_knob_set(b"PAPC_LG_LISTS", old.value), "papc_knob_set")
+
+    ga, fa = run(False)
+    g1, f1 = run(True)
+    g2, f2 = run(True)
+    assert all(np.array_equal(a, b) for a, b in zip(g1, g2)) and np.array_equal(f1, f2)
+    for i, (a, b) in enumerate(zip(g1, ga)):
+        if i % 4 != 1:
+            assert_close(a, b, 2e-5, "c0 = %d, list vs atomic backward: gradient %d" % (c0, i), elem=1.0)
+    assert_close(f1, fa, 2e-5, "c0 = %d, list vs atomic backward: dfeats" % c0, elem=1.0)
