@@ -73,6 +73,21 @@ def test_graph_replayed_forked_step_equals_eager_inline_step(tmp_path):
     assert np.array_equal(g1["loss"], e1["loss"]) and np.array_equal(g1["params"], e1["params"]), (dl, dp)
 
 
+def test_training_run_is_bit_reproducible_at_the_reference_learning_rate(tmp_path):
+    """Two runs of the timed launch structure at the reference's lr = 1e-3 (PAPC/train.py:62-65) -- where rounds 1-5 saw the float atomics' last-bit
+    noise grow ~30x per step until two runs differed by percents after ten steps -- end in the SAME BITS: loss trajectory, parameters, last
+    gradient.  And the eager in-line structure walks the same trajectory."""
+    a, _ = _bench(tmp_path, "repro_a", "1e-3")
+    b, _ = _bench(tmp_path, "repro_b", "1e-3")
+    e, _ = _bench(tmp_path, "repro_e", "1e-3", "--no-graph", "--no-overlap")
+    assert int(a["graph"]) == 1 and int(e["graph"]) == 0
+    assert float(np.max(np.abs(a["params"] - a["params0"]))) > 1e-3          # the weights really moved
+    for name, r in (("second graph run", b), ("eager in-line run", e)):
+        assert np.array_equal(r["loss"], a["loss"]), (name, r["loss"], a["loss"])
+        assert np.array_equal(r["params"], a["params"]), name
+        assert np.array_equal(r["grad"], a["grad"]), name
+
+
 def test_side_graph_survives_a_main_stream_stall(tmp_path):
     """Round-5 review: the sampling graph's device-side gate gave up after ~35 ms and "started anyway", after which every later pyramid ran one
     gate early and could overwrite a plan under the previous step's backward.  Now (i) the gate counts openings, so a give-up cannot shift the
