@@ -25,6 +25,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_$c.log 2>&1
 done
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -o run -- python bench.py --no-cpu-baseline --no-graph --steps 6 --warmup 2 > $O/pmc_sq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_WAVES --output-format csv -d $O/pmc_lds -o run -- python bench.py --no-cpu-baseline --no-graph --no-padded-leg --steps 6 --warmup 2 > $O/pmc_lds.log 2>&1
 # the other BASELINE configs (bench.py --config): bench line + kernel stats; PFN also its HBM traffic
 for c in msg_seg pfn basic; do
   timeout 400 python bench.py --config $c > $O/bench_line_$c.json 2> $O/bench_line_$c.err

@@ -25,6 +25,7 @@ grep "^{" $O/bench_line.json > $P/${R}_bench_line.json
   python tools/pmc_table.py $O/pmc_sq 30
 } > $P/${R}_bench_pmc_sq.txt
 python tools/pmc_family.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $P/${R}_bench_pmc_family.json
+[ -d $O/pmc_lds ] && { echo "# rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_WAVES (own pass) of: python bench.py --no-cpu-baseline --no-graph --no-padded-leg --steps 6 --warmup 2"; python tools/pmc_table.py $O/pmc_lds 40; } > $P/${R}_bench_pmc_lds.txt
 for c in msg_seg pfn basic; do
   cp $O/prof_stats_$c/run_kernel_stats.csv $P/${R}_cfg_${c}_kernel_stats.csv
   grep "^{" $O/bench_line_$c.json > $P/${R}_cfg_${c}_bench_line.json
