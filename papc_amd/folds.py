@@ -85,7 +85,8 @@ def _launch(p):
 # (its entry stays behind with stale jobs), and the next pass must neither inherit those jobs nor skip its own registration.
 _live = {}
 _lock = threading.Lock()
-MAX_LIVE = 4        # more than this many unfinished passes = leftovers of failed ones (reentrant nesting is never that deep): oldest dropped
+MAX_LIVE = 8        # more than this many unfinished passes = leftovers of failed ones (reentrant nesting is never that deep): oldest dropped,
+                    # with a warning -- if such an entry WERE a live outer pass its queued folds would be lost, so the drop must not be silent
 
 
 def pending(keep):
@@ -108,7 +109,13 @@ def pending(keep):
         with _lock:
             _live[tid] = p
             while len(_live) > MAX_LIVE:
-                _live.pop(min(_live)).drop()
+                old = _live.pop(min(_live))
+                if old.lst.count:
+                    import warnings
+                    warnings.warn("papc_amd.folds: dropping %d deferred fold job(s) of autograd pass %d, which never completed (a backward that raised?); "
+                                  "if that pass is in fact still running -- more than %d nested backward passes -- its parameter gradients are incomplete: "
+                                  "set PAPC_DEFER_FOLDS=0" % (old.lst.count, old.task_id, MAX_LIVE))
+                old.drop()
     elif p.done or p.stream != _cur_stream():
         return None
     if p.lst.count > CAPACITY - 16:     # (a stack appends at most 2 jobs per layer + 2)
