@@ -709,19 +709,24 @@ def main():
         _hip = None
 
         def __init__(self):
+            import ctypes as C
             if _HipEvent._hip is None:
-                _HipEvent._hip = ctypes.CDLL("libamdhip64.so")
-            self.h = ctypes.c_void_p()
-            rc = _HipEvent._hip.hipEventCreateWithFlags(ctypes.byref(self.h), ctypes.c_uint(0x2 | 0x40000000))     # DisableTiming | ReleaseToDevice
+                # the HIP runtime torch itself loaded (its own copy: a second instance would know nothing of torch's streams)
+                path = next((l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64.so" in l), "libamdhip64.so")
+                _HipEvent._hip = C.CDLL(path)
+            self.h = C.c_void_p()
+            rc = _HipEvent._hip.hipEventCreateWithFlags(C.byref(self.h), C.c_uint(0x2 | 0x40000000))     # DisableTiming | ReleaseToDevice
             assert rc == 0, rc
 
         def record(self, stream):
-            rc = _HipEvent._hip.hipEventRecord(self.h, ctypes.c_void_p(stream.cuda_stream))
+            import ctypes as C
+            rc = _HipEvent._hip.hipEventRecord(self.h, C.c_void_p(stream.cuda_stream))
             assert rc == 0, rc
             return self
 
         def wait_on(self, stream):
-            rc = _HipEvent._hip.hipStreamWaitEvent(ctypes.c_void_p(stream.cuda_stream), self.h, ctypes.c_uint(0))
+            import ctypes as C
+            rc = _HipEvent._hip.hipStreamWaitEvent(C.c_void_p(stream.cuda_stream), self.h, C.c_uint(0))
             assert rc == 0, rc
 
         def __del__(self):
