@@ -1116,6 +1116,8 @@ def main():
                        "compact_row_fraction": round(row_fraction, 4), "compact_row_fraction_per_batch": [round(f, 4) for f in row_fractions],
                        "ms_median_per_batch": [round(stats_of([m for m, bi in zip(step_ms, step_batch) if bi == k])["ms_median"], 4) if any(bi == k for bi in step_batch) else None
                                                for k in range(NB)],
+                       "clouds_per_s_per_batch": [round(world * B / (1e-3 * stats_of([m for m, bi in zip(step_ms, step_batch) if bi == k])["ms_median"]), 1)
+                                                  if any(bi == k for bi in step_batch) else None for k in range(NB)],      # (batch 0 = the one batch rounds 1-5 timed)
                        "batches": "%d distinct resident batches of B clouds (seeds 1234 + rank + 100003 k), step j trains on batch j mod %d; the next batch is loaded into the "
                                   "graphs' input slot and sampled on the side stream" % (NB, NB),
                        "timing": "value / ms_per_step: wall clock around the first window of --steps steps between barrier + synchronize (max over ranks); ms_median / ms_min / "
