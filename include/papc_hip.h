@@ -46,7 +46,7 @@ int papc_version(void);
  *       whenever a struct's layout or a function's signature does; papc_amd/_lib.py refuses a mismatching library);
  *   (3) a binding that mirrors the structs by hand (ctypes, cgo, JNA) can compare its sizes with papc_abi_sizeof("papc_sa_io") etc.
  *       (-1 for an unknown name; tests/test_abi.py does this for every ctypes mirror in papc_amd/). */
-#define PAPC_ABI_VERSION 7
+#define PAPC_ABI_VERSION 8
 int papc_abi_version(void);
 int64_t papc_abi_sizeof(const char *struct_name);
 /* text of the last error raised on this thread ("" if none) */
@@ -153,6 +153,8 @@ typedef struct papc_point_lists {
     const int32_t *prow;
     const float *pmeta;
     int32_t compact;
+    const float *pmom;     /* optional (NULL: not built): [B*N][12] per-point moments of the list's entries (w, d) = pmeta -- w_j = sum w | D_j = sum w d (3) |
+                              M2_j = sum w d d^T as (00, 01, 02, 11, 12, 22) | 2 floats of padding.  What papc_lingather_bwd_pp_f32 needs instead of y */
 } papc_point_lists;
 
 typedef struct papc_group_src {
@@ -318,6 +320,9 @@ typedef struct papc_bwd_red {
     const float *y;                                  /* [M,Cin] pre-BN output of the previous layer */
     const float *mean, *invstd, *scale, *shift;      /* [Cin] */
     float *red_partial;                              /* [papc_mlp_gemm_parts(M), 2, Cin] */
+    int32_t store_masked;                            /* != 0: dx is stored with the previous layer's ReLU mask already applied (p = dx where scale y + shift > 0, else
+                                                        0 -- the value the sums above are formed from).  Every consumer of dx applies that mask itself, so the
+                                                        stored tensor is interchangeable; papc_lingather_bwd_pp_f32 relies on it (it never reads y) */
 } papc_bwd_red;
 int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int Cin, int Cout, float *dx,
                         const papc_scatter_dst *scatter, const papc_bwd_red *next_red, papc_stream_t stream);
@@ -722,13 +727,28 @@ int papc_bn_relu_max_seg_f32(const float *y, int C, const int32_t *start, const 
 int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, const float *w, int ldw, int xcol0, const float *bias, int C,
                            float *y, float *stats_partial, papc_stream_t stream);
 int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream);
+/* The list backward WITHOUT the layer's own output: with dz already masked (papc_bwd_red.store_masked on the dX launch that wrote it) everything the
+ * gradient needs from y[m] = P[j] + W_x (xyz_j - centre) + b is linear in per-point sums of the list entries' (weight, xyz_j - centre) -- which pmeta
+ * carries -- and in P[j] itself:
+ *   G[j]       = scale S1[j] - kB (w_j (P[j] + b - mean) + W_x D_j) - kA w_j,       S1 = sum of the masked dz rows of j, w_j = sum of weights, D_j = sum w d
+ *   dW_x[c, t] = scale sum_m p d_t - kB (sum_j (P[j] + b - mean)_c D_j[t] + sum_s W_x[c, s] M2[s, t]) - kA Dtot[t],   M2 = sum w d d^T
+ * (kA = scale c1, kB = scale c2 invstd) -- so the kernel gathers ONE [rows, C] stream (dz) instead of two (y and dz), and the moments w_j, D_j, M2
+ * come with the lists (papc_point_lists.pmom).  Needs grp->plists with pmom (any layout they match), P [B*N, C] (the table papc_lingather_fwd_f32
+ * was given), the layer weight's xyz columns and bias as in the forward; C in {64, 128, 256} (papc_lingather_bwd_pp_ok != 0, else
+ * PAPC_E_UNSUPPORTED).  Results equal papc_lingather_bwd_f32's up to fp32 rounding (the forward's own rounding of y is not re-read); same
+ * partial-row count. */
+int papc_lingather_bwd_pp_ok(const papc_group_src *grp, int B, int C);
+int papc_lingather_bwd_pp_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, const float *P, const float *w, int ldw, int xcol0,
+                              const float *bias, float *G, float *dwx_partial, papc_stream_t stream);
 int papc_lingather_list_parts(int64_t BN);
 int papc_lingather_bwd_parts(const papc_group_src *grp, int B, int C);
 int papc_lingather_bwd_lists_ok(const papc_group_src *grp, int C);     /* 1: papc_lingather_bwd_f32 will take the point-list path (G need not be zeroed) */
 /* Build the point lists of a grouping: grp gives xyz / new_xyz / idx / N / S / K and, for a compacted grouping, cidx / seg_grp / rows_dev / wstat
  * (= wrow) plus `start` [G + 1] (papc_compact_plan_f32); start == NULL: the padded lists.  One wave per cloud walks its groups in order, so every
- * list is ascending in the row index.  Entries whose index is outside [0, N) (the no-hit sentinel) are in no list.  N <= 8192. */
-int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start, int32_t *prange, int32_t *prow, float *pmeta, papc_stream_t stream);
+ * list is ascending in the row index.  Entries whose index is outside [0, N) (the no-hit sentinel) are in no list.  N <= 8192.
+ * pmom (may be NULL): [B*N][12], the lists' per-point moments (papc_point_lists.pmom; a second small launch, one lane per point in list order). */
+int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start, int32_t *prange, int32_t *prow, float *pmeta, float *pmom,
+                         papc_stream_t stream);
 
 /* dX of the layer ABOVE a coordinates-only first layer (papc_mlp_xyz_ok), folded into that first layer's backward: dX [M, Cin] is never
  * stored -- per channel c the four sums of p = dX[m, c] [wf_c . x_m + t_c > 0] against (x, y, z, 1) of the row's centred coordinates are all

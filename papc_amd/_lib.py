@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PAPC_LIB") or os.path.join(_HERE, "libpapc_hip.so")   # PAPC_LIB: A/B a second build of the library
 
-ABI_VERSION = 7          # include/papc_hip.h: PAPC_ABI_VERSION
+ABI_VERSION = 8          # include/papc_hip.h: PAPC_ABI_VERSION
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
@@ -30,7 +30,7 @@ class GroupSrc(ctypes.Structure):
 
 class PointLists(ctypes.Structure):
     """papc_point_lists"""
-    _fields_ = [("prange", c_p), ("prow", c_p), ("pmeta", c_p), ("compact", c_i)]
+    _fields_ = [("prange", c_p), ("prow", c_p), ("pmeta", c_p), ("compact", c_i), ("pmom", c_p)]
 
 
 class BwdDy(ctypes.Structure):
@@ -47,7 +47,7 @@ class GroupMax(ctypes.Structure):
 
 class BwdRed(ctypes.Structure):
     """papc_bwd_red"""
-    _fields_ = [("y", c_p), ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("red_partial", c_p)]
+    _fields_ = [("y", c_p), ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("red_partial", c_p), ("store_masked", c_i)]
 
 
 class CopyJob(ctypes.Structure):
@@ -143,10 +143,12 @@ SIGNATURES = {
     "papc_lingather_parts": (c_i, [c_l]),
     "papc_lingather_fwd_f32": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "papc_lingather_bwd_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    "papc_lingather_bwd_pp_f32": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "papc_lingather_list_parts": (c_i, [c_l]),
     "papc_lingather_bwd_parts": (c_i, [c_p, c_i, c_i]),
     "papc_lingather_bwd_lists_ok": (c_i, [c_p, c_i]),
-    "papc_point_lists_f32": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "papc_point_lists_f32": (c_i, [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "papc_lingather_bwd_pp_ok": (c_i, [c_p, c_i, c_i]),
     "papc_bn_max_prep_f32": (c_i, [c_p] * 10 + [c_l, c_i, c_i] + [c_p] * 6),
     "papc_mlp_max_nostore_ok": (c_i, [c_l, c_i, c_i, c_i]),
     "papc_mlp_bwd_dw_max_ws_floats": (c_l, [c_l, c_i, c_i]),

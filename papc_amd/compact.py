@@ -56,14 +56,16 @@ def plan(idx, out=None):
 
 class PointLists:
     """The inverse of a grouping (csrc/lingather.hip, papc_point_lists_f32): for every source point the physical rows that gathered it, ascending.
-    prange [B*N, 2] int32 | prow [cap] int32 | pmeta [cap, 4] float32 (xyz_j - centre, multiplicity weight); ``compact`` = which row layout the
-    lists index (the compacted plan's, or the padded [B,S,K] lists').  With them the gather-add first layer's backward (the only float-atomic
+    prange [B*N, 2] int32 | prow [cap] int32 | pmeta [cap (+ 3 B N), 4] float32 (xyz_j - centre, multiplicity weight); ``compact`` = which row layout
+    the lists index (the compacted plan's, or the padded [B,S,K] lists').  The 3 B N rows after the entries (``pmom``, a view; None when the tensor
+    has no room for them) hold the lists' per-point moments (sum w | sum w d | sum w d d^T): with them the backward reads dz alone.  With the lists the gather-add first layer's backward (the only float-atomic
     kernel of a training step) becomes a segmented sum in fixed order: bit-reproducible gradients, and about half the time on MI355X."""
-    __slots__ = ("prange", "prow", "pmeta", "compact")
+    __slots__ = ("prange", "prow", "pmeta", "compact", "pmom")
 
     def __init__(self, tensors, compact):
         self.prange, self.prow, self.pmeta = tensors
         self.compact = bool(compact)
+        self.pmom = _moments_view(self.prange, self.prow, self.pmeta)
 
     def tensors(self):
         return (self.prange, self.prow, self.pmeta)
@@ -77,10 +79,16 @@ LISTS = int(os.environ.get("PAPC_POINT_LISTS", "1"))
 MAX_LIST_POINTS = 8192                                      # source points per cloud the list builder holds in LDS
 
 
+def _moments_view(prange, prow, pmeta):
+    """the rows of pmeta after its ``cap`` entries: [B*N, 12] per-point moments, or None (a caller's tensor of exactly ``cap`` rows)"""
+    cap, BN = prow.shape[0], prange.shape[0]
+    return pmeta[cap:cap + 3 * BN].view(BN, 12) if pmeta.shape[0] >= cap + 3 * BN else None
+
+
 def alloc_lists(B, N, G, K, device):
     cap = (G * K + 127) // 128 * 128
     return (torch.empty(B * N, 2, device=device, dtype=torch.int32), torch.empty(cap, device=device, dtype=torch.int32),
-            torch.empty(cap, 4, device=device, dtype=torch.float32))
+            torch.empty(cap + 3 * B * N, 4, device=device, dtype=torch.float32))
 
 
 def point_lists(xyz, new_xyz, idx, cplan=None, out=None):
@@ -97,8 +105,10 @@ def point_lists(xyz, new_xyz, idx, cplan=None, out=None):
     if cplan is not None:
         g.cidx, g.seg_grp, g.rows_dev, g.wstat = cplan.cidx.data_ptr(), cplan.seg_grp.data_ptr(), cplan.rows.data_ptr(), cplan.wrow.data_ptr()
         start = cplan.start.data_ptr()
-    check(_lib.load().papc_point_lists_f32(ctypes.byref(g), B, start, *(ptr(x) for x in t), stream_ptr()), "papc_point_lists_f32")
-    return PointLists(t, cplan is not None)
+    pl = PointLists(t, cplan is not None)
+    check(_lib.load().papc_point_lists_f32(ctypes.byref(g), B, start, *(ptr(x) for x in t), ptr(pl.pmom) if pl.pmom is not None else None, stream_ptr()),
+          "papc_point_lists_f32")
+    return pl
 
 
 def stack_ok(M, K, couts):

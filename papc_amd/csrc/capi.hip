@@ -68,7 +68,8 @@ static const KnobDef g_knob_defs[KNOB_COUNT] = {
     {"PAPC_STREAM_NW12", 1, 0, 1},         // twelve waves per workgroup (three per SIMD) for the row-streaming dX flavours that fit 168 registers (0: eight)
     {"PAPC_LG_LISTS", 1, 0, 1},            // gather-add backward over the grouping's point lists where the caller supplies them (0: float atomics)
     {"PAPC_FOLD_WAVES", 16, 8, 16},        // papc_fold_jobs_f32: chunk lanes (waves) per workgroup, 8 or 16
-    {"PAPC_LGL_VARIANT", 0, 0, 3},         // lingather_bwd_lists_kernel geometry (A/B): 0 = 4 entries per half-wave and pass, 8 points per workgroup; 1 = 2 entries; 2 = 16 points; 3 = 8 entries
+    {"PAPC_LGL_VARIANT", 0, 0, 3},         // lingather_bwd_lists_kernel geometry (A/B): 0 = 4 entries per half-wave and pass; 1 = 2 entries; 3 = 8 entries
+    {"PAPC_LG_PP", 1, 0, 1},               // gather-add backward over point lists WITHOUT re-reading y: dz stored masked by the dX above, y's share from P and the lists' moments (0: gathers y and dz)
 };
 static int g_knobs[KNOB_COUNT];
 static int knob_parse(int id, const char *e)

@@ -28,7 +28,7 @@ int check_launch(const char *what);
 enum Knob {
     KNOB_LG_PARTS, KNOB_DW_F32, KNOB_DW_DBG, KNOB_DW_XYZ, KNOB_PARTS, KNOB_GEMM_F32, KNOB_GEMM_WAVES, KNOB_MAXCAT_WAVES,
     KNOB_GEMM_WS, KNOB_GEMM_OCC, KNOB_GEMM_DBG, KNOB_GEMM_KB, KNOB_GEMM_MINWG, KNOB_GEMM_TL, KNOB_FPS_THREADS,
-    KNOB_FPS_THREADS_SMALL, KNOB_STREAM, KNOB_STREAM_MINTILES, KNOB_STREAM_CK, KNOB_STREAM_ASM, KNOB_PFN_MFMA, KNOB_DW_RS64, KNOB_DW_ROWS, KNOB_DW_ROWS_BLOCKS, KNOB_DW_ROWSX, KNOB_PG_DBG, KNOB_PG_NB, KNOB_PG_NS, KNOB_STREAM_MAXCAT, KNOB_MAX_NOSTORE, KNOB_PFN_FUSED_TAILS, KNOB_STREAM_NW12, KNOB_LG_LISTS, KNOB_FOLD_WAVES, KNOB_LGL_VARIANT, KNOB_COUNT
+    KNOB_FPS_THREADS_SMALL, KNOB_STREAM, KNOB_STREAM_MINTILES, KNOB_STREAM_CK, KNOB_STREAM_ASM, KNOB_PFN_MFMA, KNOB_DW_RS64, KNOB_DW_ROWS, KNOB_DW_ROWS_BLOCKS, KNOB_DW_ROWSX, KNOB_PG_DBG, KNOB_PG_NB, KNOB_PG_NS, KNOB_STREAM_MAXCAT, KNOB_MAX_NOSTORE, KNOB_PFN_FUSED_TAILS, KNOB_STREAM_NW12, KNOB_LG_LISTS, KNOB_FOLD_WAVES, KNOB_LGL_VARIANT, KNOB_LG_PP, KNOB_COUNT
 };
 int knob(int id);
 

@@ -431,6 +431,151 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_lists_kernel(LinGatherArgs
     }
 }
 
+
+// ---- per-point moments of the lists (papc_point_lists.pmom) -------------------------------------------------------------------------------------
+// Eight lanes per source point take its list's entries round robin and add up in a fixed tree: w_j = sum w, D_j = sum w d, M2_j = sum w d d^T over
+// the list's entries (w, d) = pmeta.  Weight-independent like the lists: built with them (papc_point_lists_f32), read by the backward below.
+__global__ __launch_bounds__(256) void point_moments_kernel(const int32_t *__restrict__ prange, const float4 *__restrict__ pmeta, float4 *__restrict__ pmom,
+                                                            int64_t BN)
+{
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pt = min(gid >> 3, BN - 1);      // (whole 8-lane groups stay converged for the shuffles; the surplus groups repeat the last point)
+    const int l = (int)(gid & 7);
+    const int rs = prange[2 * pt], re = prange[2 * pt + 1];
+    float v[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // w | d0 d1 d2 | m00 m01 m02 m11 m12 m22
+    for (int k = rs + l; k < re; k += 8) {
+        const float4 e = pmeta[k];
+        const float wx = e.w * e.x, wy = e.w * e.y, wz = e.w * e.z;
+        v[0] += e.w; v[1] += wx; v[2] += wy; v[3] += wz;
+        v[4] = fmaf(wx, e.x, v[4]); v[5] = fmaf(wx, e.y, v[5]); v[6] = fmaf(wx, e.z, v[6]);
+        v[7] = fmaf(wy, e.y, v[7]); v[8] = fmaf(wy, e.z, v[8]); v[9] = fmaf(wz, e.z, v[9]);
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        v[i] += __shfl_xor(v[i], 4); v[i] += __shfl_xor(v[i], 2); v[i] += __shfl_xor(v[i], 1);
+    }
+    if (l == 0 && (gid >> 3) < BN) {
+        pmom[3 * pt] = make_float4(v[0], v[1], v[2], v[3]);
+        pmom[3 * pt + 1] = make_float4(v[4], v[5], v[6], v[7]);
+        pmom[3 * pt + 2] = make_float4(v[8], v[9], 0.f, 0.f);
+    }
+}
+
+// ---- the list backward WITHOUT re-reading y (papc_lingather_bwd_pp_f32) -------------------------------------------------------------------------
+// dz arrives MASKED (p = dz where the layer's ReLU is open: papc_bwd_red.store_masked on the dX launch that wrote it), so the only per-row
+// quantity left is p itself; everything the BatchNorm backward takes from y[m] = P[j] + W_x d_m + b is linear in the per-point moments of the
+// list entries' (w, d) -- pmom, made with the lists -- and in P[j]:
+//   G[j]      = sc S1 - kB (w_j (P[j] + b - mu) + W_x D_j) - kA w_j
+//   dW_x[c,t] = sum_j [ sc sum_{m in j} p d_t - kB ((P[j] + b - mu)_c D_j[t] + sum_s W_x[c,s] M2_j[s,t]) - kA D_j[t] ]
+// One [rows, C] stream gathered instead of two.  Measured by elimination (tools/probe/r06_lg_pp_variants.sh, round 6) the kernel is NOT its
+// bytes: rows in list order instead of gathered made 50 -> 46 us, and of the first version's 50 us the entry loads cost 19, the row loads 16, the
+// empty skeleton (launch, range, constants, tail) 15.  Hence the geometry: ONE point per wave, the whole wave on one row at a time (lane = C / 64
+// channels), so range, row numbers, d and the moments are WAVE-UNIFORM; a list's entries arrive in one coalesced vector load (lane u = entry u)
+// and are handed round by readlane (scalar loads per entry -- the scalar cache -- were the 19 us); U row loads in flight for U x C/64 vector
+// registers; no barrier ahead of the gathers (the per-channel constants sit in the lane's own registers); 8 waves per SIMD.  Eight waves =
+// eight points per workgroup, their finished dW_x shares added in wave order.
+struct LgPpExtra { const float *P, *w, *bias; const float4 *pmom; int ldw, xcol0; };
+constexpr int LGP_T = 64 * LGL_PPW;
+
+template <int VEC, int U>
+__global__ __launch_bounds__(LGP_T) void lingather_bwd_pp_kernel(LinGatherArgs a, LgPpExtra e, const int32_t *__restrict__ prange,
+                                                                 const int32_t *__restrict__ prow, const float4 *__restrict__ pmeta, int64_t BN)
+{
+    __shared__ float red[LGL_PPW][3][64 * VEC];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = lane * VEC;
+    const DySrc &d = a.d;
+    float sc[VEC], kA[VEC], kB[VEC], boff[VEC], w0[VEC], w1[VEC], w2[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float s_ = d.scale[c + v], e2 = d.c2[c + v] * d.invstd[c + v];
+        sc[v] = s_; kA[v] = s_ * d.c1[c + v]; kB[v] = s_ * e2;
+        boff[v] = (e.bias ? e.bias[c + v] : 0.f) - d.mean[c + v];
+        const float *wp = e.w + (int64_t)(c + v) * e.ldw + e.xcol0;
+        w0[v] = wp[0]; w1[v] = wp[1]; w2[v] = wp[2];
+    }
+    float at[3][VEC];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) at[t][v] = 0.f;
+    const int64_t pt = (int64_t)blockIdx.x * LGL_PPW + wave;      // (wave-uniform)
+    if (pt < BN) {
+        const int rs = prange[2 * pt], re = prange[2 * pt + 1];
+        const float4 mo = e.pmom[3 * pt], m1 = e.pmom[3 * pt + 1], m2 = e.pmom[3 * pt + 2];      // w_j, D_j | M2 00 01 02 11 | 12 22
+        float Pv[VEC], acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { Pv[v] = e.P[pt * a.C + c + v]; acc[v] = 0.f; }
+        for (int base = rs; base < re; base += 64) {
+            const int nn = min(64, re - base);
+            int rowv = 0;
+            float ex = 0.f, ey = 0.f, ez = 0.f;
+            if (lane < nn) {
+                rowv = prow[base + lane];
+                const float4 t4 = pmeta[base + lane];
+                ex = t4.x; ey = t4.y; ez = t4.z;
+            }
+            for (int u0 = 0; u0 < nn; u0 += U) {
+                int m[U];
+                float dx[U], dy[U], dzc[U];
+                float vz[U][VEC];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int uu = min(u0 + u, nn - 1);
+                    m[u] = __builtin_amdgcn_readlane(rowv, uu);
+                    dx[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), uu));
+                    dy[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ey), uu));
+                    dzc[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez), uu));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float *src = d.dz + (int64_t)m[u] * a.C + c;
+                    if constexpr (VEC == 4) { const float4 t4 = ld4(src); vz[u][0] = t4.x; vz[u][1] = t4.y; vz[u][2] = t4.z; vz[u][3] = t4.w; }
+                    else if constexpr (VEC == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(src); vz[u][0] = t2.x; vz[u][1] = t2.y; }
+                    else vz[u][0] = src[0];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (u0 + u >= nn) continue;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float g = vz[u][v];
+                        acc[v] += g;
+                        at[0][v] = fmaf(g, dx[u], at[0][v]); at[1][v] = fmaf(g, dy[u], at[1][v]); at[2][v] = fmaf(g, dzc[u], at[2][v]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float pb = Pv[v] + boff[v];                                                             // P[j] + b - mu
+            const float yv = fmaf(w2[v], mo.w, fmaf(w1[v], mo.z, fmaf(w0[v], mo.y, mo.x * pb)));           // sum_m w (y[m] - mu)
+            a.G[pt * a.C + c + v] = fmaf(sc[v], acc[v], -fmaf(kB[v], yv, kA[v] * mo.x));
+            // the point's finished share of dW_x: column t of W_x M2_j is (w0 M2[0][t] + w1 M2[1][t] + w2 M2[2][t])
+            const float q0 = fmaf(w2[v], m1.z, fmaf(w1[v], m1.y, fmaf(w0[v], m1.x, pb * mo.y)));
+            const float q1 = fmaf(w2[v], m2.x, fmaf(w1[v], m1.w, fmaf(w0[v], m1.y, pb * mo.z)));
+            const float q2 = fmaf(w2[v], m2.y, fmaf(w1[v], m2.x, fmaf(w0[v], m1.z, pb * mo.w)));
+            at[0][v] = fmaf(sc[v], at[0][v], -fmaf(kB[v], q0, kA[v] * mo.y));
+            at[1][v] = fmaf(sc[v], at[1][v], -fmaf(kB[v], q1, kA[v] * mo.z));
+            at[2][v] = fmaf(sc[v], at[2][v], -fmaf(kB[v], q2, kA[v] * mo.w));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[wave][t][lane * VEC + v] = at[t][v];
+    __syncthreads();
+    float *out = a.dwx + (int64_t)blockIdx.x * a.C * 3;
+    for (int t = threadIdx.x; t < a.C * 3; t += LGP_T) {       // (channel, coordinate): the waves' shares in wave order
+        const int ch = t / 3, k = t - ch * 3;
+        float sA = 0.f;
+#pragma unroll
+        for (int w = 0; w < LGL_PPW; ++w) sA += red[w][k][ch];
+        out[t] = sA;
+    }
+}
+
 }  // namespace papc
 
 using namespace papc;
@@ -483,8 +628,14 @@ int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, con
     return check_launch("papc_lingather_fwd_f32");
 }
 
-static int lgl_ppw() { const int v = knob(KNOB_LGL_VARIANT); return v == 2 ? 16 : LGL_PPW; }
-int papc_lingather_list_parts(int64_t BN) { return (int)((BN + lgl_ppw() - 1) / lgl_ppw()); }
+int papc_lingather_list_parts(int64_t BN) { return (int)((BN + LGL_PPW - 1) / LGL_PPW); }
+
+static bool lg_lists_usable(const papc_group_src *g, int C);
+// the backward that gathers dz alone: the lists with their per-point moments, 32-bit byte offsets into dz, the constants table of 64 channel quads
+static bool lg_pp_usable(const papc_group_src *g, int B, int C)
+{
+    return lg_lists_usable(g, C) && g->plists->pmom && (C == 64 || C == 128 || C == 256) && knob(KNOB_LG_PP) != 0;
+}
 
 static bool lg_lists_usable(const papc_group_src *g, int C)
 {
@@ -493,6 +644,7 @@ static bool lg_lists_usable(const papc_group_src *g, int C)
 }
 
 int papc_lingather_bwd_lists_ok(const papc_group_src *grp, int C) { return grp && lg_lists_usable(grp, C) ? 1 : 0; }
+int papc_lingather_bwd_pp_ok(const papc_group_src *grp, int B, int C) { return grp && lg_pp_usable(grp, B, C) ? 1 : 0; }
 
 int papc_lingather_bwd_parts(const papc_group_src *grp, int B, int C)
 {
@@ -501,7 +653,8 @@ int papc_lingather_bwd_parts(const papc_group_src *grp, int B, int C)
     return lg_lists_usable(grp, C) ? papc_lingather_list_parts((int64_t)B * grp->N) : papc_lingather_parts(M);
 }
 
-int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start, int32_t *prange, int32_t *prow, float *pmeta, papc_stream_t stream)
+int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start, int32_t *prange, int32_t *prow, float *pmeta, float *pmom,
+                         papc_stream_t stream)
 {
     int rc = lg_check(grp, B, 4, "papc_point_lists_f32");
     if (rc) return rc;
@@ -509,7 +662,7 @@ int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start,
     PAPC_REQUIRE(!grp->cidx == !start, PAPC_E_INVALID, "papc_point_lists_f32: a compacted grouping needs start, a padded one must not pass it");
     PAPC_REQUIRE(!grp->cidx || grp->wstat, PAPC_E_INVALID, "papc_point_lists_f32: a compacted grouping needs its row weights (grp->wstat = wrow)");
     PAPC_REQUIRE(grp->N <= 8192, PAPC_E_UNSUPPORTED, "papc_point_lists_f32: N=%d > 8192 source points per cloud", grp->N);
-    PAPC_REQUIRE(aligned16(pmeta), PAPC_E_INVALID, "papc_point_lists_f32: pmeta must be 16-byte aligned");
+    PAPC_REQUIRE(aligned16(pmeta) && (!pmom || aligned16(pmom)), PAPC_E_INVALID, "papc_point_lists_f32: pmeta / pmom must be 16-byte aligned");
     PlArgs a;
     memset(&a, 0, sizeof(a));
     a.xyz = grp->xyz; a.sb = grp->sb; a.sn = grp->sn; a.sc = grp->sc; a.new_xyz = grp->new_xyz; a.idx = grp->idx; a.cidx = grp->cidx; a.start = start;
@@ -519,7 +672,42 @@ int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start,
     ProfScope prof(PAPC_K_GROUP, st);
     const int W = std::max(1, std::min(PL_MAXW, 16384 / grp->N));          // waves per cloud: W cursor rows of N ints in LDS (<= 64 KB)
     hipLaunchKernelGGL(point_lists_kernel, dim3((unsigned)B), dim3(64 * W), (size_t)W * grp->N * sizeof(int), st, a, W);
-    return check_launch("papc_point_lists_f32");
+    rc = check_launch("papc_point_lists_f32");
+    if (rc || !pmom) return rc;
+    const int64_t BN = (int64_t)B * grp->N;
+    hipLaunchKernelGGL(point_moments_kernel, dim3((unsigned)((BN * 8 + 255) / 256)), dim3(256), 0, st, prange, reinterpret_cast<const float4 *>(pmeta),
+                       reinterpret_cast<float4 *>(pmom), BN);
+    return check_launch("papc_point_lists_f32 (moments)");
+}
+
+int papc_lingather_bwd_pp_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, const float *P, const float *w, int ldw, int xcol0,
+                              const float *bias, float *G, float *dwx_partial, papc_stream_t stream)
+{
+    int rc = lg_check(grp, B, C, "papc_lingather_bwd_pp_f32");
+    if (rc) return rc;
+    PAPC_REQUIRE(dy && dy->dz_mode == PAPC_DZ_DENSE && dy->dz && dy->mean && dy->invstd && dy->scale && dy->c1 && dy->c2, PAPC_E_INVALID,
+                 "papc_lingather_bwd_pp_f32: needs a dense (masked) dZ source with its BatchNorm-backward constants");
+    PAPC_REQUIRE(P && w && G && dwx_partial && ldw >= xcol0 + 3 && xcol0 >= 0, PAPC_E_INVALID, "papc_lingather_bwd_pp_f32: null pointer / weight columns");
+    PAPC_REQUIRE(papc_lingather_bwd_pp_ok(grp, B, C), PAPC_E_UNSUPPORTED, "papc_lingather_bwd_pp_f32: needs the grouping's point lists WITH their moments "
+                 "(papc_point_lists_f32, pmom) in the layout the stack runs and C in {64, 128, 256} (papc_lingather_bwd_pp_ok)");
+    PAPC_REQUIRE(aligned16(G) && aligned16(dy->dz) && aligned16(P) && (!bias || aligned16(bias)), PAPC_E_INVALID, "papc_lingather_bwd_pp_f32: 16-byte alignment");
+    LinGatherArgs a;
+    memset(&a, 0, sizeof(a));
+    lg_fill(a, grp, B, C);
+    a.d.dz = dy->dz; a.d.mean = dy->mean; a.d.invstd = dy->invstd; a.d.scale = dy->scale; a.d.c1 = dy->c1; a.d.c2 = dy->c2; a.d.C = C;
+    a.G = G; a.dwx = dwx_partial;
+    const papc_point_lists &pl = *grp->plists;
+    LgPpExtra e{P, w, bias, reinterpret_cast<const float4 *>(pl.pmom), ldw, xcol0};
+    const int64_t BN = (int64_t)B * grp->N;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PAPC_K_BWD_DW, st);
+    const dim3 grid((unsigned)papc_lingather_list_parts(BN));
+    const float4 *pm = reinterpret_cast<const float4 *>(pl.pmeta);
+    // (U = 8 rows in flight per wave; 6 / 12 / 16 and two points per wave measured the same +- 1 us on SA2 of the SSG classifier, round 6)
+    if (C == 64) hipLaunchKernelGGL((lingather_bwd_pp_kernel<1, 8>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN);
+    else if (C == 128) hipLaunchKernelGGL((lingather_bwd_pp_kernel<2, 8>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN);
+    else hipLaunchKernelGGL((lingather_bwd_pp_kernel<4, 8>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN);
+    return check_launch("papc_lingather_bwd_pp_f32");
 }
 
 int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int B, int C, float *G, float *dwx_partial, papc_stream_t stream)
@@ -548,7 +736,6 @@ int papc_lingather_bwd_f32(const papc_bwd_dy *dy, const papc_group_src *grp, int
         const int var = knob(KNOB_LGL_VARIANT);
         const float4 *pm = reinterpret_cast<const float4 *>(pl.pmeta);
         if (a.cidx && var == 1) hipLaunchKernelGGL((lingather_bwd_lists_kernel<true, 2, 8>), dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, pm, BN);
-        else if (a.cidx && var == 2) hipLaunchKernelGGL((lingather_bwd_lists_kernel<true, 4, 16>), dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, pm, BN);
         else if (a.cidx && var == 3) hipLaunchKernelGGL((lingather_bwd_lists_kernel<true, 8, 8>), dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, pm, BN);
         else if (a.cidx)
             hipLaunchKernelGGL(lingather_bwd_lists_kernel<true>, dim3(nwg), dim3(LG_T), 0, st, a, pl.prange, pl.prow, reinterpret_cast<const float4 *>(pl.pmeta), BN);

@@ -17,6 +17,7 @@ enum { EPI_STORE = 0, EPI_SCATTER = 1, EPI_STORE_RED = 2, EPI_STORE_GMAX = 3, EP
 // RedSrc::y = xc [M][4], RedSrc::scale = the folded layer wf [Nout][4]; GemmArgs::stats = partial [parts][Nout][4] (T0, T1, T2, S).
 struct RedSrc {
     const float *y; const float *mean, *invstd, *scale, *shift;  // previous layer: pre-BN output [M,Nout] and BN constants
+    int masked;     // EPI_STORE_RED: store p (the ReLU-masked dX the sums are formed from) instead of dX (papc_bwd_red.store_masked)
 };
 
 struct ScatterDst {

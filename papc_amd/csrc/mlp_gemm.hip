@@ -497,8 +497,8 @@ __global__ __launch_bounds__((1 + WS) * WGM * WGN * 64, WS ? (1 + WS) : WGM * WG
                                     const int ro = (r & 3) + 8 * (r >> 2);
                                     if (full || rb + ro < p.M) {
                                         const float v = acc[wm][wn][r] + biasv[wn];   // (bias: the A_MAXCAT dX only, else 0)
-                                        yp[(int64_t)ro * p.ldy] = v;
                                         const float pp = fmaf(rsc[wn], yv[wi][r], rsh[wn]) > 0.f ? v : 0.f;
+                                        yp[(int64_t)ro * p.ldy] = p.rd.masked ? pp : v;     // (masked: the value the sums are formed from)
                                         s1[wn] += pp;
                                         s2[wn] = fmaf(pp, (yv[wi][r] - rmu[wn]) * ris[wn], s2[wn]);
                                     }
@@ -1146,13 +1146,13 @@ int papc_mlp_bwd_dx_f32(const papc_bwd_dy *dy, const float *wt, int64_t M, int C
         PAPC_REQUIRE(next_red->y && next_red->mean && next_red->invstd && next_red->scale && next_red->shift && next_red->red_partial,
                      PAPC_E_INVALID, "papc_mlp_bwd_dx_f32: null pointer in next_red");
         p.rd.y = next_red->y; p.rd.mean = next_red->mean; p.rd.invstd = next_red->invstd; p.rd.scale = next_red->scale;
-        p.rd.shift = next_red->shift; p.stats = next_red->red_partial;
+        p.rd.shift = next_red->shift; p.stats = next_red->red_partial; p.rd.masked = next_red->store_masked ? 1 : 0;
     }
     // opt-in (PAPC_GEMM_TL=1): measured on MI355X the transposed epilogue itself is 30-40 % shorter, but the kernel's load-issue
     // phase grows by more (9140-9180 vs 9220-9260 clouds/s end to end), so the column-lane epilogue stays the default
     const int tl_on = knob(KNOB_GEMM_TL);
     // (with the fused BN-backward sums only the 64-column tile has the registers for the 32 per-lane accumulators)
-    p.tl = tl_on && !scatter && dx && aligned16(dx) && Cin % 4 == 0 && (!next_red || (aligned16(next_red->y) && Cin <= 64));
+    p.tl = tl_on && !scatter && dx && aligned16(dx) && Cin % 4 == 0 && (!next_red || (aligned16(next_red->y) && Cin <= 64 && !next_red->store_masked));
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DX, st);
     if (next_red) {
@@ -1216,7 +1216,7 @@ int papc_mlp_bwd_dx_max_f32(const float *psel, const int32_t *argmax, int K, con
         PAPC_REQUIRE(next_red->y && next_red->mean && next_red->invstd && next_red->scale && next_red->shift && next_red->red_partial,
                      PAPC_E_INVALID, "papc_mlp_bwd_dx_max_f32: null pointer in next_red");
         p.rd.y = next_red->y; p.rd.mean = next_red->mean; p.rd.invstd = next_red->invstd; p.rd.scale = next_red->scale;
-        p.rd.shift = next_red->shift; p.stats = next_red->red_partial;
+        p.rd.shift = next_red->shift; p.stats = next_red->red_partial; p.rd.masked = next_red->store_masked ? 1 : 0;
     }
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_BWD_DX, st);

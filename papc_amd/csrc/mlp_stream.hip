@@ -600,10 +600,16 @@ __global__ __launch_bounds__(NWT * 64, NWT / 4) void stream_kernel(GemmArgs p, S
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[wn][r] + biasv[wn];
-                    yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = v;
                     const float pp = fmaf(rsc[wn], yv[r], rsh[wn]) > 0.f ? v : 0.f;
+                    // (masked: the value the sums are formed from, papc_bwd_red.store_masked.  The compacted flavours ALWAYS store it: every consumer
+                    // of a dX applies the mask itself, so the two are interchangeable, and these flavours have no register left for the choice)
+                    if constexpr (CP) yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = pp;
+                    else yp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldy] = v;      // (a masked store of the padded layout goes to the tiled kernel: stream_go)
                     s1[wn] += pp;
                     s2[wn] = fmaf(pp, (yv[r] - rmu[wn]) * ris[wn], s2[wn]);
+                    // (the stored value now comes out of a select: without a fence the scheduler forms all sixteen of them ahead of the stores and this
+                    // flavour -- at its register limit -- spills; four rows at a time keep the temporaries at four)
+                    if constexpr (CP) { if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
                 }
                 }
             } else {
@@ -848,6 +854,7 @@ static int stream_go(const GemmArgs &p, const StreamGeo &geo, hipStream_t st)
     gx = std::min(gx, std::max(1, (geo.n_units + 7) / 8));
     if (gx > p.parts) gx = p.parts;
     dim3 grid((unsigned)gx, (unsigned)ncb);
+    if constexpr (!CP && EPI == EPI_STORE_RED) { if (p.rd.masked) return 0; }      // (only the compacted flavours store the masked value; a select in the others spills)
     if constexpr (CP) {
         if (!knob(KNOB_STREAM_ASM)) return 0;
         if constexpr (PS) {

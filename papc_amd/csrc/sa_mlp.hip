@@ -57,6 +57,7 @@ struct SavedPtrs {
     int32_t *argmax;                    // [G, c_L]
     float *gbuf_f;                      // [2, G, c_L]: per-group max | min of the raw output; [0] becomes ysel (fused / ragged max)
     float *xc; double *gram; float *wf; // coordinates-only first layer: grouped coordinates [M, 4] (unless handed in), moments [16], folded layer [c_0, 4]
+    float *P;                           // gather-add first layer: P = feats W_f^T [B * N, c_0] (the list backward without y needs it again)
 };
 struct FwdPtrs {
     float *stats;                       // [max parts + corr rows, 2, max c]
@@ -133,6 +134,7 @@ static size_t layout_saved(const papc_sa_plan &p, void *base, SavedPtrs &s)
         s.gram = c.take<double>(16);
         s.wf = c.take<float>(4 * (size_t)p.d.cout[0]);
     }
+    if (p.lin0) s.P = c.take<float>((size_t)p.d.B * p.d.N * p.d.cout[0]);      // (last: the offsets ahead of it are part of papc_sa_plan)
     return c.off;
 }
 
@@ -147,10 +149,7 @@ static size_t layout_fwd(const papc_sa_plan &p, void *base, FwdPtrs &f)
     const int rows = std::max(papc_mlp_gemm_parts(M), p.lin0 ? papc_lingather_parts(M) : 0) + (p.compact ? papc_compact_corr_parts() : 0);
     f.stats = c.take<float>((size_t)rows * 2 * cmax * L);          // one region per layer: a layer's finalize may still read while the next GEMM writes
     if (p.gmax) f.gbuf_i = c.take<int32_t>(2 * (size_t)G * p.d.cout[L - 1]);
-    if (p.lin0) {
-        f.P = c.take<float>((size_t)p.d.B * p.d.N * p.d.cout[0]);
-        f.wfeat = c.take<float>((size_t)p.d.cout[0] * p.d.D);
-    }
+    if (p.lin0) f.wfeat = c.take<float>((size_t)p.d.cout[0] * p.d.D);     // (P itself lives in `saved`: the backward reads it again)
     if (p.xyz1) f.gpart = c.take<double>((size_t)papc_xyz_parts(M) * 16 + 16);
     return c.off;
 }
@@ -595,9 +594,9 @@ int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_
             const int fcol0 = d.xyz_first ? 3 : 0;
             SA_CALL(papc_copy2d_f32(ly.w + fcol0, cin, f.wfeat, d.D, cout, d.D, 0, st));
             const int64_t BN = (int64_t)d.B * d.N;
-            SA_CALL(papc_mlp_gemm_f32(A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, f.wfeat, nullptr, BN, d.D, cout, f.P, nullptr, nullptr, st));
+            SA_CALL(papc_mlp_gemm_f32(A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, f.wfeat, nullptr, BN, d.D, cout, s.P, nullptr, nullptr, st));
             parts_l = papc_lingather_parts(M);
-            SA_CALL(papc_lingather_fwd_f32(f.P, &grp, d.B, ly.w, cin, d.xyz_first ? 0 : d.D, ly.b, cout, y, stats, st));
+            SA_CALL(papc_lingather_fwd_f32(s.P, &grp, d.B, ly.w, cin, d.xyz_first ? 0 : d.D, ly.b, cout, y, stats, st));
         } else if (l == 0) {
             SA_CALL(papc_mlp_gemm_f32(A_GROUP_, nullptr, 0, &grp, nullptr, nullptr, ly.w, ly.b, M, cin, cout, y, stats, gm_ref, st));
         } else if (p.compact) {
@@ -674,6 +673,7 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
     papc_reduce_job jobs[PAPC_SA_MAX_LAYERS];
     int n_jobs = 0;
     bool xyz_fused = false;
+    bool dz0_masked = false;      // the dX launch of layer 1 stored the gather-add layer's dz with its ReLU mask applied (papc_bwd_red.store_masked)
     const float *dz = nullptr;
     const float *fused_red = nullptr;
     int flip = 0;
@@ -728,7 +728,11 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
             const int parts_l = papc_lingather_bwd_parts(&grp, d.B, cout);
             // (with the grouping's point lists every row of G is written in a fixed summation order: no atomics, nothing to pre-zero)
             if (!papc_lingather_bwd_lists_ok(&grp, cout)) SA_CALL(papc_fill_f32(b.Gs, BN * cout, 0.f, st));
-            SA_CALL(papc_lingather_bwd_f32(&dy, &grp, d.B, cout, b.Gs, b.dwx_part, st));
+            // (dz masked by the dX launch above + the point lists: the backward that gathers dz alone -- y's share comes from P and the lists' moments)
+            if (dz0_masked && papc_lingather_bwd_pp_ok(&grp, d.B, cout))
+                SA_CALL(papc_lingather_bwd_pp_f32(&dy, &grp, d.B, cout, s.P, ly.w, cin, d.xyz_first ? 0 : d.D, ly.b, b.Gs, b.dwx_part, st));
+            else
+                SA_CALL(papc_lingather_bwd_f32(&dy, &grp, d.B, cout, b.Gs, b.dwx_part, st));
             const int fcol0 = d.xyz_first ? 3 : 0, xcol0 = d.xyz_first ? 0 : d.D;
             float *dw = gr->dw[l];
             const int acc = acc_w ? 1 : 0;
@@ -808,6 +812,11 @@ int papc_sa_mlp_bwd(const papc_sa_plan *plan, const papc_sa_io *io, const papc_s
                 nr.y = s.y[l - 1]; nr.mean = pc; nr.invstd = pc + cin; nr.scale = pc + 2 * cin; nr.shift = pc + 3 * cin;
                 float *fr = b.fused_red[l & 1];
                 nr.red_partial = fr;
+                nr.store_masked = 0;
+                if (l == 1 && p.lin0 && papc_lingather_bwd_pp_ok(&grp, d.B, p.d.cout[0])) {
+                    nr.store_masked = 1;      // the gather-add layer below then gathers dz alone (papc_lingather_bwd_pp_f32)
+                    dz0_masked = true;
+                }
                 nr_ref = &nr;
                 fused_red = fr;
             }

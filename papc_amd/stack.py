@@ -108,7 +108,8 @@ def _fill_io(io, spec, xyz, new_xyz, feats, idx, x_rows, params, bn_buffers, kee
         io.compact = ctypes.pointer(src)
     pl = getattr(spec, "plists", None)
     if pl is not None:          # the grouping's point lists (compact.point_lists): deterministic gather-add backward
-        src = _lib.PointLists(pl.prange.data_ptr(), pl.prow.data_ptr(), pl.pmeta.data_ptr(), int(pl.compact))
+        src = _lib.PointLists(pl.prange.data_ptr(), pl.prow.data_ptr(), pl.pmeta.data_ptr(), int(pl.compact),
+                              pl.pmom.data_ptr() if getattr(pl, "pmom", None) is not None else None)
         keep.append(src)
         keep.append(pl)
         io.plists = ctypes.addressof(src)

@@ -263,6 +263,16 @@ def test_point_lists_match_numpy(dev, B, N, S, K, radius, compact):
         seen += b_ - a
     assert seen == int(((rows_pt >= 0) & (rows_pt < N)).sum())          # every valid row in exactly one list
     assert pl.compact == compact
+    # the lists' per-point moments (pmom: sum w | sum w d | sum w d d^T as 00, 01, 02, 11, 12, 22 | 0, 0), what the backward without y reads
+    mom = pl.pmom.cpu().numpy()
+    assert mom.shape == (B * N, 12) and not mom[:, 10:].any()
+    want = np.zeros((B * N, 10))
+    for q in range(B * N):
+        e = pmeta[prange[q, 0]:prange[q, 1]].astype(np.float64)
+        wq, dq = e[:, 3], e[:, :3]
+        m2 = np.einsum("e,es,et->st", wq, dq, dq)
+        want[q] = [wq.sum(), *(wq[:, None] * dq).sum(0), m2[0, 0], m2[0, 1], m2[0, 2], m2[1, 1], m2[1, 2], m2[2, 2]]
+    assert np.abs(mom[:, :10] - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
 
 
 def test_point_lists_with_repeated_indices_inside_a_step(dev):
@@ -440,3 +450,48 @@ def test_list_backward_other_first_layer_widths(dev, c0):
         if i % 4 != 1:
             assert_close(a, b, 2e-5, "c0 = %d, list vs atomic backward: gradient %d" % (c0, i), elem=1.0)
     assert_close(f1, fa, 2e-5, "c0 = %d, list vs atomic backward: dfeats" % c0, elem=1.0)
+
+
+@pytest.mark.parametrize("compact,c0", [(True, 128), (False, 128), (False, 64), (False, 256)])
+def test_list_backward_without_y_equals_the_two_stream_list_backward(dev, compact, c0):
+    """papc_lingather_bwd_pp_f32 (the default where the point lists exist): the dX launch above stores dz already masked (papc_bwd_red.store_masked)
+    and the gather-add backward gathers that ONE stream -- y's share of the BatchNorm backward comes from P[j] and the lists' per-point moments
+    (sum w, sum w d, sum w d d^T).  Against the list backward that gathers y and dz (PAPC_LG_PP=0): every gradient of an SA2-shaped stack equal to
+    2e-5 (the closed form does not re-read the forward's own rounding of y), bit-reproducible over two runs, on both row layouts and for the three
+    first-layer widths the kernel is built for (one, two and four channels per lane)."""
+    lib = _lib.load()
+
+    def run(pp):
+        old = _lib.ctypes.c_int(0)
+        _lib.check(lib.papc_knob_get(b"PAPC_LG_PP", _lib.ctypes.byref(old)), "papc_knob_get")
+        _lib.check(lib.papc_knob_set(b"PAPC_LG_PP", 1 if pp else 0), "papc_knob_set")
+        try:
+            N, S, K, D, B = 512, 128, 64, 128, 8
+            xyz, new_xyz, idx = _lists(dev, B, N, S, K, 0.4, 12)
+            rng = np.random.default_rng(12)
+            feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev).requires_grad_(True)
+            ws = seeded_weights([D + 3, c0, 128, 256], 61)
+            params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+            spec = StackSpec(B, N, S, K, D, True)
+            cp = C.plan(idx) if compact else None
+            spec.compact = cp
+            spec.plists = C.point_lists(xyz, new_xyz, idx, cp)
+            out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+            assert (out.grad_fn.compact is not None) == compact
+            out.backward(torch.from_numpy(np.random.default_rng(8).normal(size=tuple(out.shape)).astype(np.float32)).to(dev))
+            torch.cuda.synchronize()
+            return [p.grad.cpu().numpy() for p in params], feats.grad.cpu().numpy()
+        finally:
+            _lib.check(lib.papc_knob_set(b"PAPC_LG_PP", old.value), "papc_knob_set")
+
+    g0, f0 = run(False)
+    g1, f1 = run(True)
+    g2, f2 = run(True)
+    assert all(np.array_equal(a, b) for a, b in zip(g1, g2)) and np.array_equal(f1, f2)
+    names = ["w", "b", "gamma", "beta"]
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        if i % 4 != 1:
+            assert_close(a, b, 2e-5, "list backward without y vs with y: d%s layer %d" % (names[i % 4], i // 4), elem=1.0)
+        if i >= 4:      # layers 2 and 3 do not depend on how layer 1's backward is formed: the masked store changes nothing they read
+            assert np.array_equal(a, b), "masked dz store changed gradient %d" % i
+    assert_close(f1, f0, 2e-5, "list backward without y vs with y: dfeats", elem=1.0)
