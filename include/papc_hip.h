@@ -447,6 +447,8 @@ typedef struct papc_sa_io {
     void *saved, *scratch;
     const papc_point_lists *plists;       /* optional: point lists of idx (papc_point_lists_f32), used by the gather-add first layer's backward when they
                                              index the row layout the stack runs (plists->compact == plan.compact) */
+    const float *wfeat;                   /* optional: the first layer's feature block W_f [c_1, D], contiguous, prepared by the caller for THIS forward
+                                             (papc_transpose_batch_ld_f32 with copy = 1); NULL: a gather-add first layer copies it out itself (one launch) */
 } papc_sa_io;
 typedef struct papc_sa_plan {
     papc_sa_desc d;
@@ -916,6 +918,11 @@ int papc_pg_fold_f32(const papc_pg_fold_job *jobs, int count, papc_stream_t stre
 /* count <= 8 row-major fp32 matrices transposed in one launch: dst[i] [cols[i], rows[i]] = src[i] [rows[i], cols[i]]^T.  The four
  * arrays are HOST arrays (read during the call); the matrices are device memory.  Used for the W^T operands of a stack's dX GEMMs. */
 int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream);
+/* The same launch with a source row stride per matrix (src_ld, NULL: cols) and, where copy[i] != 0, a plain copy instead of a transpose:
+ * dst[i] [rows[i], cols[i]] = the block itself -- a column slice of a wider matrix made contiguous.  A training step uses it to prepare the feature
+ * block W_f [Cout, D] of a gather-add first layer (papc_sa_io.wfeat) in the launch that transposes the step's weights. */
+int papc_transpose_batch_ld_f32(const float *const *src, const int *src_ld, float *const *dst, const int *rows, const int *cols, const int *copy, int count,
+                                papc_stream_t stream);
 
 /* Small data-movement entry points, so that a training step launches nothing but this library's kernels (the
  * reference's layers interleave paddle.zeros / concat / slicing with the math, pointnet2_basic_layers.py:151,170-173):

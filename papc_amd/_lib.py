@@ -172,6 +172,7 @@ SIGNATURES = {
     "papc_pg_final_groups_f32": (c_i, [c_p, c_i, c_l, c_i, c_p, c_p, c_f, c_f] + [c_p] * 10 + [c_l, c_i, c_p, c_p, c_p, c_p]),
     "papc_pg_fold_f32": (c_i, [c_p, c_i, c_p]),
     "papc_transpose_batch_f32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p]),
+    "papc_transpose_batch_ld_f32": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "papc_rotate_nms_f32": (c_i, [c_p, c_i, c_f, c_p, c_p, c_p, ctypes.c_size_t, c_p]),
     "papc_rotate_iou_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "papc_rbbox_iou_f32": (c_i, [c_p, c_p, c_p, c_f, c_i, c_i, c_p, c_p]),

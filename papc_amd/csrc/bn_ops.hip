@@ -25,22 +25,29 @@ template <> struct Vec<1> {
 
 // this lane's share (rows tl, tl + 64, ...) of the [n_tiles][2][C] partial rows of channel c, summed in row order; the loads of 8
 // rows are issued before the first add (the rows are a dependent chain of ~0.5 us loads otherwise)
-__device__ __forceinline__ void sum_partial_rows(const float *__restrict__ part, int n_tiles, int C, int c, int tl, double &s1, double &s2)
+template <int D>
+__device__ __forceinline__ void sum_partial_rows_d(const float *__restrict__ part, int n_tiles, int C, int c, int tl, double &s1, double &s2)
 {
-    for (int t0 = tl; t0 < n_tiles; t0 += 64 * 8) {
-        float a[8], b[8];
+    for (int t0 = tl; t0 < n_tiles; t0 += 64 * D) {
+        float a[D], b[D];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < D; ++j) {
             const int t = t0 + 64 * j;
             const int64_t o = (int64_t)(t < n_tiles ? t : t0) * 2 * C + c;
             a[j] = part[o];
             b[j] = part[o + C];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < D; ++j) {
             if (t0 + 64 * j < n_tiles) { s1 += (double)a[j]; s2 += (double)b[j]; }
         }
     }
+}
+// (the same sums in the same order at either depth; beyond 512 rows -- the gather-add layer's 2048 -- sixteen rows in flight halve the round trips)
+__device__ __forceinline__ void sum_partial_rows(const float *__restrict__ part, int n_tiles, int C, int c, int tl, double &s1, double &s2)
+{
+    if (n_tiles > 512) sum_partial_rows_d<16>(part, n_tiles, C, c, tl, s1, s2);
+    else sum_partial_rows_d<8>(part, n_tiles, C, c, tl, s1, s2);
 }
 
 // lane l of a wave holds the double of part-lane l: the sum over the 64 part-lanes in a FIXED shape, left in lane 0 -- groups of four
@@ -669,6 +676,7 @@ struct TransposeBatch {
     const float *src[8];
     float *dst[8];
     int rows[8], cols[8];
+    int ld[8], copy[8];      // source row stride; copy != 0: dst [rows, cols] = the block itself (a column slice made contiguous), not its transpose
 };
 
 __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch t)
@@ -685,8 +693,11 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(TransposeBatch t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r0 + ty + 8 * i, c = c0 + tx;
-            tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+            const float v = (r < rows && c < cols) ? src[(int64_t)r * t.ld[m] + c] : 0.f;
+            tile[ty + 8 * i][tx] = v;
+            if (t.copy[m] && r < rows && c < cols) dst[(int64_t)r * cols + c] = v;
         }
+        if (t.copy[m]) continue;          // (uniform per job)
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1134,6 +1145,12 @@ int papc_bn_max_prep_f32(const float *gout, const float *ysel, const float *scal
 
 int papc_transpose_batch_f32(const float *const *src, float *const *dst, const int *rows, const int *cols, int count, papc_stream_t stream)
 {
+    return papc_transpose_batch_ld_f32(src, nullptr, dst, rows, cols, nullptr, count, stream);
+}
+
+int papc_transpose_batch_ld_f32(const float *const *src, const int *src_ld, float *const *dst, const int *rows, const int *cols, const int *copy, int count,
+                                papc_stream_t stream)
+{
     PAPC_REQUIRE(src && dst && rows && cols, PAPC_E_INVALID, "papc_transpose_batch_f32: null pointer");
     PAPC_REQUIRE(count >= 1 && count <= 8, PAPC_E_INVALID, "papc_transpose_batch_f32: count=%d not in [1, 8]", count);
     TransposeBatch t{};
@@ -1141,6 +1158,8 @@ int papc_transpose_batch_f32(const float *const *src, float *const *dst, const i
     for (int i = 0; i < count; ++i) {
         PAPC_REQUIRE(src[i] && dst[i] && rows[i] >= 1 && cols[i] >= 1, PAPC_E_INVALID, "papc_transpose_batch_f32: bad entry %d", i);
         t.src[i] = src[i]; t.dst[i] = dst[i]; t.rows[i] = rows[i]; t.cols[i] = cols[i];
+        t.ld[i] = src_ld ? src_ld[i] : cols[i]; t.copy[i] = copy ? copy[i] : 0;
+        PAPC_REQUIRE(t.ld[i] >= cols[i], PAPC_E_INVALID, "papc_transpose_batch_f32: entry %d: row stride shorter than a row", i);
         max_tiles = std::max(max_tiles, (int)(cdiv(rows[i], 32) * cdiv(cols[i], 32)));
     }
     hipStream_t st = as_stream(stream);

@@ -592,9 +592,13 @@ int papc_sa_mlp_fwd(const papc_sa_plan *plan, const papc_sa_io *io, papc_stream_
         } else if (l == 0 && p.lin0) {
             // W_f feats_j depends on the source point only: one [B*N, D] x [D, cout] product on the feature block of the weight, then a gather-add
             const int fcol0 = d.xyz_first ? 3 : 0;
-            SA_CALL(papc_copy2d_f32(ly.w + fcol0, cin, f.wfeat, d.D, cout, d.D, 0, st));
+            const float *wfeat = io->wfeat;       // (the caller's copy, made with the step's weight transposes: one launch less on the chain)
+            if (!wfeat) {
+                SA_CALL(papc_copy2d_f32(ly.w + fcol0, cin, f.wfeat, d.D, cout, d.D, 0, st));
+                wfeat = f.wfeat;
+            }
             const int64_t BN = (int64_t)d.B * d.N;
-            SA_CALL(papc_mlp_gemm_f32(A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, f.wfeat, nullptr, BN, d.D, cout, s.P, nullptr, nullptr, st));
+            SA_CALL(papc_mlp_gemm_f32(A_PLAIN_, io->feats, d.D, nullptr, nullptr, nullptr, wfeat, nullptr, BN, d.D, cout, s.P, nullptr, nullptr, st));
             parts_l = papc_lingather_parts(M);
             SA_CALL(papc_lingather_fwd_f32(s.P, &grp, d.B, ly.w, cin, d.xyz_first ? 0 : d.D, ly.b, cout, y, stats, st));
         } else if (l == 0) {

@@ -93,24 +93,39 @@ def _dw_rows_per_chunk(M, cout, cin, min_rows=256):
 # stale transpose can never be picked up.
 
 
-def precompute_wt(weights):
+def precompute_wt(weights, feat_blocks=()):
     """weights: conv / linear weights [Cout, Cin(, 1...)] whose [Cin, Cout] transposes the coming backward passes will need.
-    Returns the table {weight.data_ptr(): W^T tensor} to pass on as ``StackSpec.wt_table`` for this forward pass only."""
+    ``feat_blocks``: (weight [Cout, D + 3(, 1...)], xyz_first) of stacks whose first layer may run as a gather-add: the feature block -- columns
+    3.. of an SSG layer's weight (coordinates first), ..D of an MSG branch's -- is made contiguous in the same launch (key
+    ``("f", weight.data_ptr())``, value ``(block, xyz_first)``): the copy the stack's forward otherwise launches itself.
+    Returns the table {weight.data_ptr(): W^T tensor, ...} to pass on as ``StackSpec.wt_table`` for this forward pass only."""
     lib = _lib.load()
     st = stream_ptr()
     table = {}
-    ws = [w for w in weights if w.is_cuda and w.is_contiguous() and w.dtype == torch.float32]
-    for g0 in range(0, len(ws), 8):
-        grp_w = ws[g0:g0 + 8]
-        n = len(grp_w)
-        srcs, dsts, rws, cls = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
-        for i, w in enumerate(grp_w):
+    ok = lambda w: w.is_cuda and w.is_contiguous() and w.dtype == torch.float32      # noqa: E731
+    jobs = []        # (src pointer, source row stride, destination, rows, cols, copy)
+    for w in weights:
+        if ok(w):
             cout = w.shape[0]
             cin = w.numel() // cout
             t = torch.empty(cin, cout, device=w.device, dtype=torch.float32)
             table[w.data_ptr()] = t
-            srcs[i], dsts[i], rws[i], cls[i] = w.data_ptr(), t.data_ptr(), cout, cin
-        check(lib.papc_transpose_batch_f32(srcs, dsts, rws, cls, n, st), "papc_transpose_batch_f32")
+            jobs.append((w.data_ptr(), cin, t, cout, cin, 0))
+    for w, xyz_first in feat_blocks:
+        cout = w.shape[0]
+        cin = w.numel() // cout
+        if ok(w) and cin > 3:
+            t = torch.empty(cout, cin - 3, device=w.device, dtype=torch.float32)
+            table[("f", w.data_ptr())] = (t, bool(xyz_first))
+            jobs.append((w.data_ptr() + (12 if xyz_first else 0), cin, t, cout, cin - 3, 1))
+    for g0 in range(0, len(jobs), 8):
+        grp = jobs[g0:g0 + 8]
+        n = len(grp)
+        srcs, dsts = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        lds, rws, cls, cps = (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)(), (ctypes.c_int * n)()
+        for i, (src, ld, t, rows, cols, cp) in enumerate(grp):
+            srcs[i], lds[i], dsts[i], rws[i], cls[i], cps[i] = src, ld, t.data_ptr(), rows, cols, cp
+        check(lib.papc_transpose_batch_ld_f32(srcs, lds, dsts, rws, cls, cps, n, st), "papc_transpose_batch_ld_f32")
     return table
 
 

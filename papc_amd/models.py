@@ -137,7 +137,7 @@ class PointNet2_SSG_Clas(nn.Module, _ClasHead):
             ws = [c.weight for c in list(self.sa1.mlp_convs)[1:]] + [c.weight for c in self.sa2.mlp_convs]   # (SA2's first layer: the feature block of its W^T, gather-add backward)
             if not (smallm.takes_group_all(B, self.sa2.npoint, [c.weight.shape[0] for c in self.sa3.mlp_convs])):
                 ws += [c.weight for c in self.sa3.mlp_convs]    # (the planes path builds its own W^T planes: nothing to transpose for it)
-            wt = precompute_wt(ws)
+            wt = precompute_wt(ws, feat_blocks=[(self.sa2.mlp_convs[0].weight, True)])      # (SA2's gather-add first layer: its feature block, contiguous)
         l1_xyz, l1_points = self.sa1(xyz, norm, s[0], sampled=pl[0], wt_table=wt)
         if after_sa1 is not None:
             after_sa1()

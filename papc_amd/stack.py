@@ -41,7 +41,7 @@ class SaIo(ctypes.Structure):
     """papc_sa_io"""
     _fields_ = [("xyz", c_p), ("sb", c_l), ("sn", c_l), ("sc", c_l), ("new_xyz", c_p), ("feats", c_p), ("idx", c_p), ("x_rows", c_p),
                 ("xc", c_p), ("xc_gram", c_p), ("compact", ctypes.POINTER(CompactSrc)), ("consts3", c_p), ("consts3_ld", c_i),
-                ("layer", SaLayer * MAXL), ("out", c_p), ("saved", c_p), ("scratch", c_p), ("plists", c_p)]
+                ("layer", SaLayer * MAXL), ("out", c_p), ("saved", c_p), ("scratch", c_p), ("plists", c_p), ("wfeat", c_p)]
 
 
 class SaPlan(ctypes.Structure):
@@ -113,6 +113,14 @@ def _fill_io(io, spec, xyz, new_xyz, feats, idx, x_rows, params, bn_buffers, kee
         keep.append(src)
         keep.append(pl)
         io.plists = ctypes.addressof(src)
+    wtab = getattr(spec, "wt_table", None)
+    if wtab is not None and feats is not None and L >= 1:
+        # the first layer's feature block, made contiguous for THIS forward by mlp.precompute_wt(feat_blocks=...): shape-checked, like the transposes
+        ent = wtab.get(("f", params[0].data_ptr()))
+        cin0 = params[0].numel() // params[0].shape[0]
+        if ent is not None and ent[1] == bool(spec.xyz_first) and tuple(ent[0].shape) == (params[0].shape[0], cin0 - 3) and cin0 - 3 == spec.D:
+            io.wfeat = ent[0].data_ptr()
+            keep.append(ent[0])
     c3 = _consts3(params[0].device)
     keep.append(c3)
     io.consts3, io.consts3_ld = c3.data_ptr(), c3.shape[1]

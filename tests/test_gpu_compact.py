@@ -495,3 +495,50 @@ def test_list_backward_without_y_equals_the_two_stream_list_backward(dev, compac
         if i >= 4:      # layers 2 and 3 do not depend on how layer 1's backward is formed: the masked store changes nothing they read
             assert np.array_equal(a, b), "masked dz store changed gradient %d" % i
     assert_close(f1, f0, 2e-5, "list backward without y vs with y: dfeats", elem=1.0)
+
+
+@pytest.mark.parametrize("xyz_first", [True, False])
+def test_feature_block_prepared_with_the_weight_transposes_changes_nothing(dev, xyz_first):
+    """mlp.precompute_wt(feat_blocks=...): the gather-add first layer's feature block W_f made contiguous in the launch that transposes the step's
+    weights (papc_transpose_batch_ld_f32, copy = 1 -> papc_sa_io.wfeat) instead of by a launch of the stack's own.  Same bits out and in every
+    gradient, for both column orders (SSG: coordinates first; MSG: features first); a block of the wrong order is ignored."""
+    from papc_amd.mlp import precompute_wt
+    N, S, K, D, B = 512, 128, 64, 128, 8          # (fewer clouds run padded, i.e. on the float-atomic backward: no two runs alike)
+    xyz, new_xyz, idx = _lists(dev, B, N, S, K, 0.4, 21)
+    rng = np.random.default_rng(21)
+    fe = rng.normal(size=(B, N, D)).astype(np.float32)
+    ws = seeded_weights([D + 3, 128, 128, 256], 77)
+    gout = None
+
+    def run(table_order, poison=False):
+        nonlocal gout
+        feats = torch.from_numpy(fe).to(dev).requires_grad_(True)
+        params = [torch.from_numpy(a).to(dev).requires_grad_(True) for tup in ws for a in tup]
+        spec = StackSpec(B, N, S, K, D, xyz_first)
+        cp = C.plan(idx)
+        spec.compact = cp
+        spec.plists = C.point_lists(xyz, new_xyz, idx, cp)
+        spec.wt_table = precompute_wt([params[4], params[8]])      # (the reference run: the transposes alone)
+        if table_order is not None:
+            spec.wt_table = precompute_wt([params[4], params[8]], feat_blocks=[(params[0], table_order)])
+            blk, order = spec.wt_table[("f", params[0].data_ptr())]
+            want = params[0].detach()[:, 3:] if table_order else params[0].detach()[:, :D]
+            torch.cuda.synchronize()
+            assert order == table_order and torch.equal(blk, want)
+            if poison:
+                blk.zero_()
+        out = shared_mlp_max(spec, None, xyz, new_xyz, feats, idx, params)
+        assert out.grad_fn.compact is not None
+        if gout is None:
+            gout = torch.from_numpy(np.random.default_rng(5).normal(size=tuple(out.shape)).astype(np.float32)).to(dev)
+        out.backward(gout)
+        torch.cuda.synchronize()
+        return out.detach().cpu().numpy(), [p.grad.cpu().numpy() for p in params], feats.grad.cpu().numpy()
+
+    o0, g0, f0 = run(None)
+    for order in (xyz_first, not xyz_first):        # the right block is used, the wrong one ignored: the same bits either way
+        o1, g1, f1 = run(order)
+        assert np.array_equal(o0, o1) and np.array_equal(f0, f1) and all(np.array_equal(a, b) for a, b in zip(g0, g1))
+    # ... and it IS the prepared block the forward multiplies by: zeroed, the output moves; a zeroed block of the other order moves nothing
+    assert not np.array_equal(o0, run(xyz_first, poison=True)[0])
+    assert np.array_equal(o0, run(not xyz_first, poison=True)[0])
