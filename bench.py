@@ -81,7 +81,8 @@ def moved_work(B, N, plans, rows_sa2=None):
                coordinates (16 B / row) instead of 4 c_1 B / row, its dX is folded into four sums per channel instead of stored (xyz_fuse),
                there is no first-layer dW pass
       nostore  the max-pooled last layer never writes its [M, c_3] output; its dX / dW read the layer's INPUT instead
-      lin0     gather-add first layer: the D-wide product runs on the B*N source points; the row-sum backward is a dW-family launch
+      lin0     gather-add first layer: the D-wide product runs on the B*N source points; the row-sum backward is a dW-family launch (over the
+               compacted stack's point lists it reads the masked dz rows only, not y: round 6)
       compact  distinct neighbours only: every row count below is the physical one
       planes   few-row stacks on the planes path: operands are three bf16 planes (6 B / element), outputs fp32
     Fused epilogue operands (the BN-backward sums' second read of y_(l-1)) are counted, L2-resident weights are not."""
@@ -114,7 +115,12 @@ def moved_work(B, N, plans, rows_sa2=None):
                 fam[K_BWD_DX][0] += 2.0 * src_pts * D * cout
                 fam[K_BWD_DX][1] += 4.0 * src_pts * (D + cout)
                 fam[K_BWD_DW][0] += 2.0 * src_pts * D * cout + 6.0 * R * cout
-                fam[K_BWD_DW][1] += 8.0 * R * cout + 12.0 * src_pts * cout + 4.0 * src_pts * (D + cout)
+                # the row-sum backward: y and dz rows (the atomic / two-stream list kernels) -- or, over the point lists with their moments, the
+                # masked dz rows alone + 20 B per list entry + P and 48 B of moments per source point (papc_lingather_bwd_pp_f32)
+                one_stream = bool(fl.get("compact")) and cout in (64, 128, 256) and os.environ.get("PAPC_LG_PP", "1") != "0" \
+                    and os.environ.get("PAPC_LG_LISTS", "1") != "0" and os.environ.get("PAPC_POINT_LISTS", "1") != "0"
+                rows_read = (4.0 * R * cout + 20.0 * R + src_pts * (4.0 * cout + 48.0)) if one_stream else 8.0 * R * cout
+                fam[K_BWD_DW][1] += rows_read + 12.0 * src_pts * cout + 4.0 * src_pts * (D + cout)
                 continue
             fam[K_MLP_GEMM][0] += 2.0 * R * cin * cout
             fam[K_MLP_GEMM][1] += in_bytes + (R * cout * 4.0 if stored else 0.0)

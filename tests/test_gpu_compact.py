@@ -452,13 +452,14 @@ def test_list_backward_other_first_layer_widths(dev, c0):
     assert_close(f1, fa, 2e-5, "c0 = %d, list vs atomic backward: dfeats" % c0, elem=1.0)
 
 
-@pytest.mark.parametrize("compact,c0", [(True, 128), (False, 128), (False, 64), (False, 256)])
-def test_list_backward_without_y_equals_the_two_stream_list_backward(dev, compact, c0):
+@pytest.mark.parametrize("compact,c0,radius", [(True, 128, 0.4), (False, 128, 0.4), (False, 64, 0.4), (False, 256, 0.4), (True, 128, 0.1), (False, 128, 0.1)])
+def test_list_backward_without_y_equals_the_two_stream_list_backward(dev, compact, c0, radius):
     """papc_lingather_bwd_pp_f32 (the default where the point lists exist): the dX launch above stores dz already masked (papc_bwd_red.store_masked)
     and the gather-add backward gathers that ONE stream -- y's share of the BatchNorm backward comes from P[j] and the lists' per-point moments
     (sum w, sum w d, sum w d d^T).  Against the list backward that gathers y and dz (PAPC_LG_PP=0): every gradient of an SA2-shaped stack equal to
     2e-5 (the closed form does not re-read the forward's own rounding of y), bit-reproducible over two runs, on both row layouts and for the three
-    first-layer widths the kernel is built for (one, two and four channels per lane)."""
+    first-layer widths the kernel is built for (one, two and four channels per lane); radius 0.1: most source points in no group at all (empty
+    lists: their G rows must come out as exact zeros) and groups that are mostly padding copies."""
     lib = _lib.load()
 
     def run(pp):
@@ -467,7 +468,7 @@ def test_list_backward_without_y_equals_the_two_stream_list_backward(dev, compac
         _lib.check(lib.papc_knob_set(b"PAPC_LG_PP", 1 if pp else 0), "papc_knob_set")
         try:
             N, S, K, D, B = 512, 128, 64, 128, 8
-            xyz, new_xyz, idx = _lists(dev, B, N, S, K, 0.4, 12)
+            xyz, new_xyz, idx = _lists(dev, B, N, S, K, radius, 12)
             rng = np.random.default_rng(12)
             feats = torch.from_numpy(rng.normal(size=(B, N, D)).astype(np.float32)).to(dev).requires_grad_(True)
             ws = seeded_weights([D + 3, c0, 128, 256], 61)
@@ -495,6 +496,13 @@ def test_list_backward_without_y_equals_the_two_stream_list_backward(dev, compac
         if i >= 4:      # layers 2 and 3 do not depend on how layer 1's backward is formed: the masked store changes nothing they read
             assert np.array_equal(a, b), "masked dz store changed gradient %d" % i
     assert_close(f1, f0, 2e-5, "list backward without y vs with y: dfeats", elem=1.0)
+    if radius < 0.2:      # points no group gathered: zero gradient, exactly
+        iq = _lists(dev, 8, 512, 128, 64, radius, 12)[2].cpu().numpy()
+        used = np.zeros((8, 512), bool)
+        for b_ in range(8):
+            v = iq[b_][(iq[b_] >= 0) & (iq[b_] < 512)]
+            used[b_, v] = True
+        assert (~used).sum() > 100 and not f1[~used].any()
 
 
 @pytest.mark.parametrize("xyz_first", [True, False])
