@@ -145,8 +145,10 @@ int papc_three_interpolate_bwd_first3_f32(const float *grad_out, const float *we
  * inverse of the ball-query lists.  Weight-independent like the lists themselves, so a training loop builds them with the sampling pyramid of the
  * next batch; with them the gather-add first layer's backward sums a point's rows in FIXED order (no float atomics: bit-reproducible gradients, no
  * pre-zeroed G).  prange [B*N][2] = (first entry, one past the last) into prow / pmeta; prow [cap] physical row per entry; pmeta [cap][4] per entry:
- * xyz_j - centre (3 floats) and the row's multiplicity weight (1 for a padded grouping).  cap = rows of the grouping (G * K, rounded up to 128 for
- * a compacted one).  `compact` says which row numbering the lists index: 1 = the compacted layout of papc_compact_plan_f32, 0 = the padded
+ * xyz_j - centre (3 floats) and the entry's weight: a compacted grouping's row weight (papc_compact_plan_f32: wrow); for a padded grouping 1 --
+ * except that a group's padding copies of its first neighbour (rows with identical input, hence identical gradients) are ONE entry, the first
+ * copy's row with weight = their number: both list backwards multiply the row's contribution by it.  cap = rows of the grouping (G * K, rounded up
+ * to 128 for a compacted one).  `compact` says which row numbering the lists index: 1 = the compacted layout of papc_compact_plan_f32, 0 = the padded
  * [B,S,K] lists; a consumer whose stack runs the other layout ignores the lists (and takes the atomic path). */
 typedef struct papc_point_lists {
     const int32_t *prange;

@@ -71,11 +71,13 @@ class PointLists:
         return (self.prange, self.prow, self.pmeta)
 
 
-# "0": never (the float-atomic backward everywhere); "1" (default): for compacted stacks; "2": for padded ones too.  Measured on MI355X (round 6,
-# SA2 of the SSG classifier): compacted 76.7 + 5.5 (atomics + the fill of G) -> 62 us; PADDED 0.41 ms SLOWER per step -- the ball query's padding
-# copies all sit in the list of their group's first neighbour (lists of hundreds of rows on one wave) where the atomic kernel pre-sums them per
-# group in a register.  The padded layout therefore keeps the atomic kernel.
-LISTS = int(os.environ.get("PAPC_POINT_LISTS", "1"))
+# "0": never (the float-atomic backward everywhere); "1": for compacted stacks only; "2" (default): for padded ones too.  Measured on MI355X (round 6,
+# SA2 of the SSG classifier): compacted 76.7 + 5.5 (atomics + the fill of G) -> 62 us (lists) -> 41 us (lists, dz alone: papc_lingather_bwd_pp_f32).
+# PADDED: with one entry per row the step was 0.41 ms SLOWER (every padding copy of a group's first neighbour sits in that one point's list: hundreds
+# of rows on one wave, where the atomic kernel pre-sums them per group in a register); since the builder makes a group's copies ONE weighted entry
+# (identical rows, identical gradients) the kernel takes 33 us against 85 + 5.5 and the padded step is 0-10 us faster -- the builder's time on the
+# sampling stream eats most of it -- but, like the compacted one, free of float atomics: bit-reproducible.  Config 3: 5.56 -> 5.58 ms.
+LISTS = int(os.environ.get("PAPC_POINT_LISTS", "2"))
 MAX_LIST_POINTS = 8192                                      # source points per cloud the list builder holds in LDS
 
 

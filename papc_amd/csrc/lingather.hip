@@ -236,6 +236,10 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_kernel(LinGatherArgs a)
 // takes the next slot of its point's list, so every list is ascending in the row index -- a FIXED summation order for the backward below.
 // Within a step the ball query's structure makes the slots unique except for the padding copies of the group's first neighbour (one ballot ranks
 // them); any other repeated index inside a step (a caller's own lists) is detected after the LDS atomics and ranked by a 64-step lane sweep.
+// PADDED layout: a group's padding copies (rows k > 0 that repeat its first neighbour) are rows with identical input, hence identical
+// activations and identical gradients -- the first-maximum rule hands the max-pool's gradient to row 0, never to a copy -- so they enter the
+// first neighbour's list as ONE entry: the first copy's row with weight = their number (pmeta.w; 1 for every other entry).  Without that a point
+// that is the first neighbour of a few groups owns a list of hundreds of rows, walked by one wave.
 struct PlArgs {
     const float *xyz; int64_t sb, sn, sc;
     const float *new_xyz;
@@ -264,14 +268,23 @@ __global__ __launch_bounds__(64 * PL_MAXW) void point_lists_kernel(PlArgs a, int
     const int wg0 = min(g1, g0 + wave * gper), wg1 = min(g1, wg0 + gper);      // this wave's groups
     auto row_of = [&](int g) { return cp ? (g == a.G ? a.rows_dev[0] : a.start[g]) : g * a.K; };
     const int r0 = row_of(g0);
-    for (int e = tid; e < W * a.N; e += NT) cw[e] = 0;
+    int *gflag = cw + W * a.N;                     // [S] padded layout: the group's padding copies have been counted
+    for (int e = tid; e < W * a.N + (cp ? 0 : a.S); e += NT) cw[e] = 0;
     __syncthreads();
     if (wave < W) {
         int *cnt = cw + wave * a.N;
         const int m0 = row_of(wg0), m1 = row_of(wg1);
         for (int m = m0 + lane; m < m1; m += 64) {
             const int j = src[m];
-            if (j >= 0 && j < a.N) atomicAdd(&cnt[j], 1);
+            if (j < 0 || j >= a.N) continue;
+            bool copy = false;
+            int gl = 0;
+            if (!cp) {                             // PADDED layout: a group's copies of its first neighbour (identical rows, identical gradients) are ONE entry
+                gl = m / a.K - g0;
+                const int k = m - (g0 + gl) * a.K;
+                copy = k > 0 && j == src[m - k];
+            }
+            if (!copy || atomicExch(&gflag[gl], 1) == 0) atomicAdd(&cnt[j], 1);
         }
     }
     __syncthreads();
@@ -309,6 +322,7 @@ __global__ __launch_bounds__(64 * PL_MAXW) void point_lists_kernel(PlArgs a, int
         const int n = cp ? ((g == a.G - 1 ? a.rows_dev[0] : a.start[g + 1]) - s) : a.K;
         const int first = src[s];
         const float cx = a.new_xyz[(int64_t)g * 3], cy = a.new_xyz[(int64_t)g * 3 + 1], cz = a.new_xyz[(int64_t)g * 3 + 2];
+        int ncopy = 0, mcopy = 0;                  // padded layout: the group's padding copies, the first of them
         for (int k0 = 0; k0 < n; k0 += 64) {
             const int k = k0 + lane;
             const bool in = k < n;
@@ -331,18 +345,29 @@ __global__ __launch_bounds__(64 * PL_MAXW) void point_lists_kernel(PlArgs a, int
                 if (uniq) pos = base + rank;
             }
             const unsigned long long cm = __ballot(copy);
-            if (cm) {
+            if (cm && cp) {
                 const int leader = __ffsll((long long)cm) - 1;
                 int base = 0;
                 if (lane == leader) base = atomicAdd(&cur[first], __popcll(cm));
                 base = __builtin_amdgcn_readlane(base, leader);
                 if (copy) pos = base + __popcll(cm & lt);
+            } else if (cm) {                       // (padded: counted here, ONE weighted entry behind the group's rows)
+                if (!ncopy) mcopy = s + k0 + (__ffsll((long long)cm) - 1);
+                ncopy += __popcll(cm);
             }
-            if (valid) {
+            if (valid && (cp || !copy)) {
                 const float *q = a.xyz + (int64_t)b * a.sb + (int64_t)p * a.sn;
                 a.prow[pos] = m;
                 a.pmeta[pos] = make_float4(q[0] - cx, q[a.sc] - cy, q[2 * a.sc] - cz, a.wrow ? a.wrow[m] : 1.f);
             }
+        }
+        if (ncopy && lane == 0) {
+            // the copies are rows with the first neighbour's input: identical activations, identical gradients (the first-maximum rule sends
+            // the max-pool's gradient to row 0, never to a copy) -- the entry stands for all of them with weight = their number
+            const int pos = atomicAdd(&cur[first], 1);
+            const float *q = a.xyz + (int64_t)b * a.sb + (int64_t)first * a.sn;
+            a.prow[pos] = mcopy;
+            a.pmeta[pos] = make_float4(q[0] - cx, q[a.sc] - cy, q[2 * a.sc] - cz, (float)ncopy);
         }
     }
 }
@@ -404,6 +429,7 @@ __global__ __launch_bounds__(LG_T) void lingather_bwd_lists_kernel(LinGatherArgs
                 g.y = gval(vy[u].y, vz[u].y, ksc.y, ksh.y, kmu.y, kA.y, kB.y, mt[u].w);
                 g.z = gval(vy[u].z, vz[u].z, ksc.z, ksh.z, kmu.z, kA.z, kB.z, mt[u].w);
                 g.w = gval(vy[u].w, vz[u].w, ksc.w, ksh.w, kmu.w, kA.w, kB.w, mt[u].w);
+                if (!CP) { g.x *= mt[u].w; g.y *= mt[u].w; g.z *= mt[u].w; g.w *= mt[u].w; }      // (padded: an entry may stand for a group's copies; 1 otherwise)
                 acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
                 a0.x = fmaf(g.x, mt[u].x, a0.x); a0.y = fmaf(g.y, mt[u].x, a0.y); a0.z = fmaf(g.z, mt[u].x, a0.z); a0.w = fmaf(g.w, mt[u].x, a0.w);
                 a1.x = fmaf(g.x, mt[u].y, a1.x); a1.y = fmaf(g.y, mt[u].y, a1.y); a1.z = fmaf(g.z, mt[u].y, a1.z); a1.w = fmaf(g.w, mt[u].y, a1.w);
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(256) void point_moments_kernel(const int32_t *__res
 struct LgPpExtra { const float *P, *w, *bias; const float4 *pmom; int ldw, xcol0; };
 constexpr int LGP_T = 64 * LGL_PPW;
 
-template <int VEC, int U>
+template <int VEC, int U, bool WEIGHTED>
 __global__ __launch_bounds__(LGP_T) void lingather_bwd_pp_kernel(LinGatherArgs a, LgPpExtra e, const int32_t *__restrict__ prange,
                                                                  const int32_t *__restrict__ prow, const float4 *__restrict__ pmeta, int64_t BN)
 {
@@ -510,15 +536,16 @@ __global__ __launch_bounds__(LGP_T) void lingather_bwd_pp_kernel(LinGatherArgs a
         for (int base = rs; base < re; base += 64) {
             const int nn = min(64, re - base);
             int rowv = 0;
-            float ex = 0.f, ey = 0.f, ez = 0.f;
+            float ex = 0.f, ey = 0.f, ez = 0.f, ew = 1.f;      // (WEIGHTED -- the padded layout: an entry may stand for a group's padding copies)
             if (lane < nn) {
                 rowv = prow[base + lane];
                 const float4 t4 = pmeta[base + lane];
                 ex = t4.x; ey = t4.y; ez = t4.z;
+                if (WEIGHTED) ew = t4.w;
             }
             for (int u0 = 0; u0 < nn; u0 += U) {
                 int m[U];
-                float dx[U], dy[U], dzc[U];
+                float dx[U], dy[U], dzc[U], wu[U];
                 float vz[U][VEC];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -527,6 +554,7 @@ __global__ __launch_bounds__(LGP_T) void lingather_bwd_pp_kernel(LinGatherArgs a
                     dx[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), uu));
                     dy[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ey), uu));
                     dzc[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ez), uu));
+                    wu[u] = WEIGHTED ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ew), uu)) : 1.f;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(LGP_T) void lingather_bwd_pp_kernel(LinGatherArgs a
                     if (u0 + u >= nn) continue;
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        const float g = vz[u][v];
+                        const float g = WEIGHTED ? vz[u][v] * wu[u] : vz[u][v];
                         acc[v] += g;
                         at[0][v] = fmaf(g, dx[u], at[0][v]); at[1][v] = fmaf(g, dy[u], at[1][v]); at[2][v] = fmaf(g, dzc[u], at[2][v]);
                     }
@@ -671,7 +699,11 @@ int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start,
     hipStream_t st = as_stream(stream);
     ProfScope prof(PAPC_K_GROUP, st);
     const int W = std::max(1, std::min(PL_MAXW, 16384 / grp->N));          // waves per cloud: W cursor rows of N ints in LDS (<= 64 KB)
-    hipLaunchKernelGGL(point_lists_kernel, dim3((unsigned)B), dim3(64 * W), (size_t)W * grp->N * sizeof(int), st, a, W);
+    const size_t lds = ((size_t)W * grp->N + (grp->cidx ? 0 : grp->S)) * sizeof(int);      // cursor rows + (padded layout) one flag per group
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(point_lists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("papc_point_lists_f32: hipFuncSetAttribute");
+    PAPC_REQUIRE(lds <= 150 * 1024, PAPC_E_UNSUPPORTED, "papc_point_lists_f32: N=%d S=%d do not fit the builder's LDS", grp->N, grp->S);
+    hipLaunchKernelGGL(point_lists_kernel, dim3((unsigned)B), dim3(64 * W), lds, st, a, W);
     rc = check_launch("papc_point_lists_f32");
     if (rc || !pmom) return rc;
     const int64_t BN = (int64_t)B * grp->N;
@@ -704,9 +736,12 @@ int papc_lingather_bwd_pp_f32(const papc_bwd_dy *dy, const papc_group_src *grp, 
     const dim3 grid((unsigned)papc_lingather_list_parts(BN));
     const float4 *pm = reinterpret_cast<const float4 *>(pl.pmeta);
     // (U = 8 rows in flight per wave; 6 / 12 / 16 and two points per wave measured the same +- 1 us on SA2 of the SSG classifier, round 6)
-    if (C == 64) hipLaunchKernelGGL((lingather_bwd_pp_kernel<1, 8>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN);
-    else if (C == 128) hipLaunchKernelGGL((lingather_bwd_pp_kernel<2, 8>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN);
-    else hipLaunchKernelGGL((lingather_bwd_pp_kernel<4, 8>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN);
+#define PAPC_LGP_GO(VEC) do { if (a.cidx) hipLaunchKernelGGL((lingather_bwd_pp_kernel<VEC, 8, false>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN); \
+                              else hipLaunchKernelGGL((lingather_bwd_pp_kernel<VEC, 8, true>), grid, dim3(LGP_T), 0, st, a, e, pl.prange, pl.prow, pm, BN); } while (0)
+    if (C == 64) PAPC_LGP_GO(1);
+    else if (C == 128) PAPC_LGP_GO(2);
+    else PAPC_LGP_GO(4);
+#undef PAPC_LGP_GO
     return check_launch("papc_lingather_bwd_pp_f32");
 }
 

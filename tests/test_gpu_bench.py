@@ -88,6 +88,21 @@ def test_training_run_is_bit_reproducible_at_the_reference_learning_rate(tmp_pat
         assert np.array_equal(r["grad"], a["grad"]), name
 
 
+def test_training_run_on_the_padded_stack_is_bit_reproducible_too(tmp_path):
+    """PAPC_COMPACT=0 -- the layout clouds with few padding copies (ShapeNet-like surfaces) keep: since the list builder makes a group's padding
+    copies one weighted entry, the padded stack's gather-add backward runs over the point lists as well (compact.LISTS == 2), so this layout has no
+    float atomics left either: two runs of the timed structure end in the same bits."""
+    env = {"PAPC_COMPACT": "0"}
+    a, _ = _bench(tmp_path, "pad_a", "1e-3", env_extra=env)
+    b, _ = _bench(tmp_path, "pad_b", "1e-3", env_extra=env)
+    assert int(a["graph"]) == 1
+    assert np.array_equal(a["loss"], b["loss"]) and np.array_equal(a["params"], b["params"]) and np.array_equal(a["grad"], b["grad"])
+    # ... and the float-atomic kernel (PAPC_POINT_LISTS=1: lists for compacted stacks only) walks the same trajectory to the accuracy its
+    # summation-order noise allows after these few steps at this learning rate
+    c, _ = _bench(tmp_path, "pad_c", "1e-3", env_extra={"PAPC_COMPACT": "0", "PAPC_POINT_LISTS": "1"})
+    assert float(np.max(np.abs(c["loss"] - a["loss"]))) <= 5e-2 * float(np.max(np.abs(a["loss"])))
+
+
 def test_side_graph_survives_a_main_stream_stall(tmp_path):
     """Round-5 review: the sampling graph's device-side gate gave up after ~35 ms and "started anyway", after which every later pyramid ran one
     gate early and could overwrite a plan under the previous step's backward.  Now (i) the gate counts openings, so a give-up cannot shift the

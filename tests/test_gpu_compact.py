@@ -155,11 +155,13 @@ def test_auto_policy_measures_once(dev):
     sparse = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 256], False).to(dev)
     assert len(sparse.sample(x, st)) == 12 and sparse._compact_on is True       # compact plan + point lists
     full = PointNetSetAbstraction(128, 3.0, 64, 131, [128, 128, 256], False).to(dev)      # radius covers the cloud: every list is full
-    assert len(full.sample(x, st)) == 2 and full._compact_on is False           # padded: no point lists either (compact.LISTS == 1)
+    assert len(full.sample(x, st)) == 5 and full._compact_on is False           # padded, with its point lists (compact.LISTS == 2: padded stacks too)
     sparse.eval()
     assert len(sparse.sample(x, st)) == 9                                        # no backward will follow: no lists
+    full.eval()
+    assert len(full.sample(x, st)) == 2
     other = PointNetSetAbstraction(128, 0.4, 64, 131, [128, 128, 128], False).to(dev)     # widths without a compacted flavour
-    assert len(other.sample(x, st)) == 2 and other._compact_on is None
+    assert len(other.sample(x, st)) == 5 and other._compact_on is None
 
 
 def test_weighted_statistics_equal_the_correction_launches(dev, monkeypatch):
@@ -200,6 +202,21 @@ def test_streamed_psel_is_bit_identical(dev, monkeypatch):
         elif i % 4 != 1:  # the gather-add first layer sums its rows with float atomics: same numbers, not the same bits run to run
             assert_close(a, b, 2e-5, "streamed psel: gradient %d" % i)
     assert_close(res["1"][1], res["0"][1], 2e-5, "streamed psel: dfeats")
+
+
+def _collapse_copies(ii, N):
+    """padded layout as the list builder sees it: a group's padding copies of its first neighbour (rows k > 0 repeating idx[g, 0]) are ONE entry --
+    the first copy's row with weight = their number; the others are in no list (point index -1 here)"""
+    B, S, K = ii.shape
+    flat = ii.reshape(B * S, K).astype(np.int64)
+    rows_pt = flat.copy()
+    w = np.ones((B * S, K), np.float32)
+    for g in range(B * S):
+        cp = np.nonzero((flat[g, 1:] == flat[g, 0]) & (flat[g, 0] >= 0) & (flat[g, 0] < N))[0] + 1
+        if len(cp):
+            rows_pt[g, cp[1:]] = -1
+            w[g, cp[0]] = len(cp)
+    return rows_pt.reshape(-1), np.repeat(np.arange(B * S), K), w.reshape(-1)
 
 
 def _numpy_lists(B, N, S, K, xyz, new_xyz, rows_pt, rows_grp, w):
@@ -246,9 +263,7 @@ def test_point_lists_match_numpy(dev, B, N, S, K, radius, compact):
         rows_grp = np.repeat(cp.seg_grp.cpu().numpy()[:rows // 8], 8).astype(np.int64)
         w = cp.wrow.cpu().numpy()[:rows]
     else:
-        rows_pt = idx.cpu().numpy().reshape(-1).astype(np.int64)
-        rows_grp = np.repeat(np.arange(B * S), K)
-        w = np.ones(len(rows_pt), np.float32)
+        rows_pt, rows_grp, w = _collapse_copies(idx.cpu().numpy(), N)
     prange, key, rws, meta = _numpy_lists(B, N, S, K, xyz.cpu().numpy(), new_xyz.cpu().numpy(), rows_pt, rows_grp, w)
     got_range = pl.prange.cpu().numpy()
     assert np.array_equal(got_range, prange)
@@ -261,7 +276,7 @@ def test_point_lists_match_numpy(dev, B, N, S, K, radius, compact):
         for e, r in zip(range(a, b_), want):
             assert tuple(pmeta[e]) == tuple(np.float32(v) for v in meta[int(r)]), (q, r)
         seen += b_ - a
-    assert seen == int(((rows_pt >= 0) & (rows_pt < N)).sum())          # every valid row in exactly one list
+    assert seen == int(((rows_pt >= 0) & (rows_pt < N)).sum())          # every valid row (padded: every distinct row + one entry per group's copies) in exactly one list
     assert pl.compact == compact
     # the lists' per-point moments (pmom: sum w | sum w d | sum w d d^T as 00, 01, 02, 11, 12, 22 | 0, 0), what the backward without y reads
     mom = pl.pmom.cpu().numpy()
@@ -288,14 +303,14 @@ def test_point_lists_with_repeated_indices_inside_a_step(dev):
     new_xyz = torch.from_numpy(rng.normal(size=(B, S, 3)).astype(np.float32)).to(dev)
     pl = C.point_lists(xyz, new_xyz, idx, None)
     torch.cuda.synchronize()
-    rows_pt = ii.reshape(-1).astype(np.int64)
-    prange, key, rws, meta = _numpy_lists(B, N, S, K, xyz.cpu().numpy(), new_xyz.cpu().numpy(), rows_pt, np.repeat(np.arange(B * S), K),
-                                          np.ones(len(rows_pt), np.float32))
+    rows_pt, rows_grp, w = _collapse_copies(ii, N)      # (repeats of a group's FIRST index are its padding copies: one weighted entry)
+    prange, key, rws, meta = _numpy_lists(B, N, S, K, xyz.cpu().numpy(), new_xyz.cpu().numpy(), rows_pt, rows_grp, w)
     assert np.array_equal(pl.prange.cpu().numpy(), prange)
-    prow = pl.prow.cpu().numpy()
+    prow, pmeta = pl.prow.cpu().numpy(), pl.pmeta.cpu().numpy()
     for q in range(B * N):
         a, b_ = prange[q]
         assert np.array_equal(prow[a:b_], rws[key == q]), q
+        assert np.array_equal(pmeta[a:b_, 3], w[rws[key == q]]), q
 
 
 @pytest.mark.parametrize("compact", [True, False])
