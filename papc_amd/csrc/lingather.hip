@@ -253,7 +253,7 @@ struct PlArgs {
 // W waves per cloud, each owning a contiguous chunk of the cloud's groups and its own cursor row cw[w][.] in LDS: the serial walk (the LDS cursor
 // chain of step (3)) is S / W groups long instead of S, and a point's list is the concatenation of the waves' pieces in wave order -- still
 // ascending in the row index.
-constexpr int PL_MAXW = 8;
+constexpr int PL_MAXW = 16;
 
 __global__ __launch_bounds__(64 * PL_MAXW) void point_lists_kernel(PlArgs a, int W)
 {
