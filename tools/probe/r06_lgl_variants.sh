@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06_lgl
 mkdir -p $O
 for v in 0 1 2 3; do
-PAPC_LGL_VARIANT=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/v$v -o run -- python bench.py --no-cpu-baseline --no-padded-leg --steps 30 --warmup 5 --diag-fixed-plan > $O/v$v.log 2>&1
+PAPC_LG_PP=0 PAPC_LGL_VARIANT=$v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/v$v -o run -- python bench.py --no-cpu-baseline --no-padded-leg --steps 30 --warmup 5 --diag-fixed-plan > $O/v$v.log 2>&1
 f=$(find $O/v$v -name "*kernel_stats.csv" | head -1)
 python - "$f" $v <<'PY'
 import csv,sys
