@@ -748,7 +748,7 @@ int papc_lingather_list_parts(int64_t BN);
 int papc_lingather_bwd_parts(const papc_group_src *grp, int B, int C);
 int papc_lingather_bwd_lists_ok(const papc_group_src *grp, int C);     /* 1: papc_lingather_bwd_f32 will take the point-list path (G need not be zeroed) */
 /* Build the point lists of a grouping: grp gives xyz / new_xyz / idx / N / S / K and, for a compacted grouping, cidx / seg_grp / rows_dev / wstat
- * (= wrow) plus `start` [G + 1] (papc_compact_plan_f32); start == NULL: the padded lists.  One wave per cloud walks its groups in order, so every
+ * (= wrow) plus `start` [G + 1] (papc_compact_plan_f32); start == NULL: the padded lists.  One workgroup per cloud, its waves walking runs of the cloud's groups in order, so every
  * list is ascending in the row index.  Entries whose index is outside [0, N) (the no-hit sentinel) are in no list.  N <= 8192.
  * pmom (may be NULL): [B*N][12], the lists' per-point moments (papc_point_lists.pmom; a second small launch, one lane per point in list order). */
 int papc_point_lists_f32(const papc_group_src *grp, int B, const int32_t *start, int32_t *prange, int32_t *prow, float *pmeta, float *pmom,

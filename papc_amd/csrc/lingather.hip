@@ -659,8 +659,8 @@ int papc_lingather_fwd_f32(const float *P, const papc_group_src *grp, int B, con
 int papc_lingather_list_parts(int64_t BN) { return (int)((BN + LGL_PPW - 1) / LGL_PPW); }
 
 static bool lg_lists_usable(const papc_group_src *g, int C);
-// the backward that gathers dz alone: the lists with their per-point moments, 32-bit byte offsets into dz, the constants table of 64 channel quads
-static bool lg_pp_usable(const papc_group_src *g, int B, int C)
+// the backward that gathers dz alone: the lists with their per-point moments, a first-layer width the kernel is built for (C / 64 channels per lane)
+static bool lg_pp_usable(const papc_group_src *g, int /*B: no size limit of its own*/, int C)
 {
     return lg_lists_usable(g, C) && g->plists->pmom && (C == 64 || C == 128 || C == 256) && knob(KNOB_LG_PP) != 0;
 }
